@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Regenerate the golden fixtures under tests/golden/ from the COMPILED REFERENCE.
+
+Run in the build container only (needs /root/reference):
+    make -C oracle ref && python tests/golden/make_golden.py
+
+What it stores (data only: inputs + the reference's outputs; no reference source text):
+  kat.jsonl                         known answers printed by oracle/_ref/ref_kat (hash, sizing, tai,
+                                    NT2int, and the ReadscanTest.cpp cases replayed through the
+                                    reference's ReadScanner::scanInputRead with a fake Bloom)
+  <case>/reads.f[aq].gz             seeded synthetic input (faucet_amd/synth.py)
+  <case>/case.json                  CLI arguments + counters parsed from the reference's stdout
+  <case>/out.bloom.gz               <prefix>.bloom        (raw bit array, utils/Bloom.cpp:571-578)
+  <case>/out.junctions.gz           <prefix>.junctions    (utils/JunctionMap.cpp:579-596)
+  <case>/out.short_pair_filter.gz, out.long_pair_filter.gz   (paired-end case only)
+"""
+import gzip
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from faucet_amd import synth  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "faucet_ref")
+REF_KAT = os.path.join(ROOT, "oracle", "_ref", "ref_kat")
+
+COUNTERS = {
+    "distinct_junctions": r"Distinct junctions: (\d+)",
+    "nb_jcheck_kmer": r"Number of kmers that we j-checked: (\d+)",
+    "nb_no_juncs": r"Number of reads with no junctions: (\d+)",
+    "nb_processed": r"Number of processed kmers: (\d+)",
+    "nb_skipped": r"Number of skipped kmers: (\d+)",
+    "reads_no_errors": r"Reads without errors: (\d+)",
+    "bits_per_kmer": r"Bits per kmer: (\d+)",
+    "n_hash": r"Number of hash functions: (\d+)",
+    "p1": r"p1 estimated as ([0-9.eE+-]+)",
+    "empty_count": r"Empty count: (\d+)",
+    "not_empty_count": r"not empty count: (\d+)",
+}
+
+
+def gz_write(path, data: bytes):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(data)
+
+
+def ragged_fasta(path, reads, lens, extra_lines=()):
+    with open(path, "wb") as f:
+        for i in range(reads.shape[0]):
+            f.write(b">r%d\n" % i)
+            f.write(reads[i, : lens[i]].tobytes())
+            f.write(b"\n")
+        for ln in extra_lines:
+            f.write(ln)
+
+
+def run_case(name, reads_path, fastq, args, tolerate_crash=False):
+    out = os.path.join(HERE, name)
+    os.makedirs(out, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "reads.fq" if fastq else "reads.fa")
+        shutil.copy(reads_path, inp)
+        cmd = [REF_BIN, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", os.path.join(td, "out")] + args
+        p = subprocess.run(["stdbuf", "-o0"] + cmd, capture_output=True, text=True, errors="replace")
+        if p.returncode != 0 and not tolerate_crash:
+            raise RuntimeError(f"{name}: reference exit {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}")
+        text = p.stdout
+        counters = {}
+        for key, pat in COUNTERS.items():
+            m = re.findall(pat, text)
+            if m:
+                counters[key] = m[0] if key == "p1" else int(m[0])
+        # the load pass prints "Reads processed"/"Unambiguous reads" first, the scan pass second
+        rp = re.findall(r"Reads processed: (\d+)", text)
+        ur = re.findall(r"Unambiguous reads: (\d+)", text)
+        counters["load_reads_processed"], counters["scan_reads_processed"] = int(rp[0]), int(rp[1])
+        counters["load_unambiguous"], counters["scan_unambiguous"] = int(ur[0]), int(ur[1])
+        w = re.findall(r"Weights after load: ([0-9.]+), ([0-9.]+)", text)
+        counters["weights_after_load"] = [w[0][0], w[0][1]]
+        with open(inp, "rb") as f:
+            gz_write(os.path.join(out, os.path.basename(inp) + ".gz"), f.read())
+        for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+            fp = os.path.join(td, "out." + ext)
+            if os.path.exists(fp):
+                with open(fp, "rb") as f:
+                    gz_write(os.path.join(out, "out." + ext + ".gz"), f.read())
+        with open(os.path.join(out, "case.json"), "w") as f:
+            json.dump({"name": name, "fastq": fastq, "args": args, "ref_exit": p.returncode, "counters": counters}, f, indent=1)
+            f.write("\n")
+    print(name, counters)
+
+
+def main():
+    kat = subprocess.run([REF_KAT], capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(HERE, "kat.jsonl"), "w") as f:
+        for line in kat.splitlines():
+            if line.startswith('{"kat"'):
+                json.loads(line)
+                f.write(line + "\n")
+
+    with tempfile.TemporaryDirectory() as td:
+        # config 1 of BASELINE.json: 1k x 100 bp fasta, k=21, E=1e5 (S=2e4)
+        g = synth.make_genome(4000, 1)
+        r = synth.make_reads(g, 1000, 100, 0.01, 1)
+        p = os.path.join(td, "c1.fa")
+        synth.write_fasta(p, r)
+        run_case("c1_k21", p, False, ["-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "100000",
+                                      "-singletons", "20000", "--no_cleaning"])
+
+        # ragged lengths, N / lower-case / CR characters, a trailing blank line, planted repeats, k=31
+        g = synth.make_genome(6000, 7, repeats=4, repeat_len=300)
+        r = synth.make_reads(g, 1200, 120, 0.01, 8, n_rate=0.002)
+        rng = np.random.default_rng(9)
+        lens = rng.integers(20, 121, size=r.shape[0])
+        lens[rng.random(r.shape[0]) < 0.5] = 120
+        r[5, 40] = ord("a")
+        r[6, 10:14] = ord("N")
+        r[7, 119] = ord("\r")
+        lens[7] = 120
+        lens[8] = 0
+        p = os.path.join(td, "rag.fa")
+        ragged_fasta(p, r, lens, extra_lines=[b"\n"])
+        run_case("ragged_k31", p, False, ["-size_kmer", "31", "-max_read_length", "120", "-estimated_kmers", "100000",
+                                          "-singletons", "20000", "--no_cleaning"])
+
+        # S/E = 0.5 -> the reference's own sizing gives 2 hash functions (config 5's filter shape), 150 bp, 5 % errors
+        g = synth.make_genome(8000, 11)
+        r = synth.make_reads(g, 1500, 150, 0.05, 12)
+        p = os.path.join(td, "h2.fa")
+        synth.write_fasta(p, r)
+        run_case("twohash_k31_L150", p, False, ["-size_kmer", "31", "-max_read_length", "150", "-estimated_kmers", "200000",
+                                                "-singletons", "100000", "--no_cleaning", "--two_hash"])
+
+        # j = 2, short spacer so the spacer rule fires, small k
+        g = synth.make_genome(3000, 21, repeats=3, repeat_len=120)
+        r = synth.make_reads(g, 800, 150, 0.005, 22)
+        p = os.path.join(td, "j2.fa")
+        synth.write_fasta(p, r)
+        run_case("j2_spacer20_k15", p, False, ["-size_kmer", "15", "-max_read_length", "150", "-estimated_kmers", "50000",
+                                               "-singletons", "10000", "-j", "2", "-max_spacer_dist", "20", "--no_cleaning"])
+
+        # j = 0
+        run_case("j0_k15", p, False, ["-size_kmer", "15", "-max_read_length", "150", "-estimated_kmers", "50000",
+                                      "-singletons", "10000", "-j", "0", "--no_cleaning"])
+
+        # paired-end interleaved fastq (config 3 shape), with cleaning on: pair filters are written before Stage 3
+        g = synth.make_genome(5000, 31, repeats=3, repeat_len=200)
+        r = synth.make_pairs(g, 600, 100, 300, 30, 0.01, 32)
+        p = os.path.join(td, "pe.fq")
+        synth.write_fastq(p, r)
+        run_case("pe_fastq_k21", p, True, ["-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "100000",
+                                           "-singletons", "20000", "--fastq", "--paired_ends"], tolerate_crash=True)
+
+
+if __name__ == "__main__":
+    main()
