@@ -1,0 +1,105 @@
+"""ctypes loader for libfaucet_gpu.so (the C ABI of include/faucet_gpu.h).
+
+Fails loudly: if the shared library is missing or does not export the ABI there is no fallback of any kind.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfaucet_gpu.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_CAPACITY, ERR_NOMEM = range(6)
+BLOO1, BLOO2 = 0, 1
+FLAG_PROFILE = 1
+TABLE_ENTRY_BYTES = 32
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("j", C.c_int32), ("max_spacer_dist", C.c_int32), ("n_hash", C.c_int32),
+                ("tai", C.c_uint64), ("device", C.c_int32), ("flags", C.c_int32), ("junction_capacity", C.c_uint64),
+                ("max_batch_bases", C.c_uint64), ("stream", C.c_void_p), ("walk_window_span", C.c_uint64)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("on_device", C.c_int32)]
+
+
+class LoadStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("reads_processed", "unambiguous_reads", "kmers", "to_bloo2")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class ScanStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("reads_processed", "unambiguous_reads", "reads_no_errors", "nb_jcheck_kmer", "nb_no_juncs",
+                                          "nb_processed", "nb_skipped", "n_junctions", "kmers", "walk_windows", "walk_followers",
+                                          "walk_max_cluster")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+# every symbol include/faucet_gpu.h declares: (restype, argtypes)
+_u64, _i32, _vp, _f32, _f64 = C.c_uint64, C.c_int32, C.c_void_p, C.c_float, C.c_double
+_P = C.POINTER
+SIGNATURES = {
+    "fgpu_abi_version": (C.c_int, []),
+    "fgpu_device_count": (C.c_int, []),
+    "fgpu_create": (C.c_int, [_P(Params), _P(_vp)]),
+    "fgpu_destroy": (None, [_vp]),
+    "fgpu_last_error": (C.c_char_p, [_vp]),
+    "fgpu_synchronize": (C.c_int, [_vp]),
+    "fgpu_solve_p1": (_f64, [_u64, _u64, _f32, _P(_i32)]),
+    "fgpu_bloom_tai": (_u64, [_u64]),
+    "fgpu_size_optimal": (None, [_u64, _f32, _P(_i32), _P(_u64), _P(_i32)]),
+    "fgpu_size_two_hash": (None, [_u64, _f32, _P(_i32), _P(_u64), _P(_i32)]),
+    "fgpu_load_begin": (C.c_int, [_vp, C.c_int]),
+    "fgpu_load_batch": (C.c_int, [_vp, _P(Reads)]),
+    "fgpu_load_end": (C.c_int, [_vp, _P(LoadStats)]),
+    "fgpu_presence_batch": (C.c_int, [_vp, _P(Reads)]),
+    "fgpu_bloom_download": (C.c_int, [_vp, C.c_int, _vp, _u64]),
+    "fgpu_bloom_upload": (C.c_int, [_vp, C.c_int, _vp, _u64]),
+    "fgpu_bloom_weight": (C.c_int, [_vp, C.c_int, _P(_f32)]),
+    "fgpu_bloom_devptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(_u64)]),
+    "fgpu_bitmap_or": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "fgpu_scan_begin": (C.c_int, [_vp]),
+    "fgpu_scan_batch": (C.c_int, [_vp, _P(Reads)]),
+    "fgpu_scan_end": (C.c_int, [_vp, _P(ScanStats)]),
+    "fgpu_scan_junction_count": (C.c_int, [_vp, _P(_u64)]),
+    "fgpu_scan_download_junctions": (C.c_int, [_vp, _vp, _vp, _u64, _P(_u64)]),
+    "fgpu_scan_table_entries": (C.c_int, [_vp, _P(_u64)]),
+    "fgpu_scan_export_table": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
+    "fgpu_scan_import_table": (C.c_int, [_vp, _vp, _u64, _P(ScanStats)]),
+    "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
+    "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
+    "fgpu_kernel_times": (C.c_int, [_vp, _P(KernelTime), C.c_int]),
+    "fgpu_kernel_times_reset": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it is missing or incomplete — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m faucet_amd.build` (hipcc, gfx950). "
+                           "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fgpu_abi_version() != 1:
+        raise RuntimeError("libfaucet_gpu.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference interface for the hot path, on top of the C ABI.
+
+Names follow the reference so that the parity tests read like its own:
+
+    Bloom.create_bloom_filter_optimal / create_bloom_filter_2_hash     utils/Bloom.cpp:206-247
+    load_two_filters(bloo1, bloo2, reads)                               utils/Bloom.cpp:267-350
+    ReadScanner(...).scanReads(reads) / printScanSummary fields         src/ReadScanner.cpp:19-27,284-359
+    JunctionMap.writeToFile                                             utils/JunctionMap.cpp:579-596
+
+All compute runs in libfaucet_gpu.so on the MI355X; nothing here computes k-mers, hashes or junctions on the
+host, and nothing falls back to a CPU path: without the library or without a gfx950 device the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class FaucetGpuError(RuntimeError):
+    pass
+
+
+def _check(rc, ctx=None):
+    if rc != L.OK:
+        msg = L.load().fgpu_last_error(ctx).decode(errors="replace") if ctx is not None else L.load().fgpu_last_error(None).decode()
+        raise FaucetGpuError(f"libfaucet_gpu error {rc}: {msg}")
+
+
+# ---- sizing (src/Faucet.cpp:197-219) --------------------------------------------------------------
+def solve_p1(estimated_kmers: int, singletons: int, fp: float = 0.04) -> float:
+    it = C.c_int32(0)
+    p1 = L.load().fgpu_solve_p1(estimated_kmers, singletons, C.c_float(fp), C.byref(it))
+    if p1 < 0:
+        raise ValueError("p1 solver: root not bracketed (singletons must be > 0 and < estimated_kmers)")
+    return p1
+
+
+def size_optimal(estimated: int, fp: float):
+    b, t, h = C.c_int32(), C.c_uint64(), C.c_int32()
+    L.load().fgpu_size_optimal(estimated, C.c_float(fp), C.byref(b), C.byref(t), C.byref(h))
+    return b.value, t.value, h.value
+
+
+def size_two_hash(estimated: int, fp: float):
+    b, t, h = C.c_int32(), C.c_uint64(), C.c_int32()
+    L.load().fgpu_size_two_hash(estimated, C.c_float(fp), C.byref(b), C.byref(t), C.byref(h))
+    return b.value, t.value, h.value
+
+
+def load_filter_shape(estimated_kmers: int, singletons: int, fp: float = 0.04):
+    """(tai, n_hash) of bloo1/bloo2 as getBloomFilterFromReads sizes them (src/Faucet.cpp:204-219)."""
+    p1 = solve_p1(estimated_kmers, singletons, fp)
+    _, tai, nh = size_optimal(estimated_kmers, np.float32(p1))
+    return tai, nh
+
+
+# ---- read batches -----------------------------------------------------------------------------------
+class ReadBatch:
+    """Sequence lines in file order.  Host numpy arrays or device pointers (e.g. torch tensors' data_ptr())."""
+
+    def __init__(self, bases, offsets, n_reads=None, on_device=False, keepalive=None):
+        self.on_device = bool(on_device)
+        self._keep = (bases, offsets, keepalive)
+        if on_device:
+            self.bases_ptr, self.offsets_ptr = int(bases), int(offsets)
+            self.n_reads = int(n_reads)
+        else:
+            self.bases = np.ascontiguousarray(bases, dtype=np.uint8)
+            self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            self.bases_ptr = self.bases.ctypes.data
+            self.offsets_ptr = self.offsets.ctypes.data
+            self.n_reads = len(self.offsets) - 1
+
+    @classmethod
+    def from_lines(cls, lines):
+        offs = np.zeros(len(lines) + 1, dtype=np.uint64)
+        if lines:
+            offs[1:] = np.cumsum([len(x) for x in lines], dtype=np.uint64)
+        data = b"".join(lines)
+        bases = np.frombuffer(data, dtype=np.uint8).copy() if data else np.zeros(1, np.uint8)
+        return cls(bases, offs)
+
+    @classmethod
+    def from_matrix(cls, mat: np.ndarray):
+        n, ln = mat.shape
+        return cls(np.ascontiguousarray(mat).reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(ln))
+
+    def c_struct(self):
+        return L.Reads(self.bases_ptr, self.offsets_ptr, self.n_reads, int(self.on_device))
+
+
+JUNC_DTYPE = np.dtype([("cov", np.uint8, 4), ("dist", np.uint8, 5), ("linked", np.uint8, 5)])
+
+
+class Context:
+    """One fgpu_ctx: one MI355X, one pair of load filters, one junction map."""
+
+    def __init__(self, k, tai, n_hash, j=1, max_spacer_dist=100, device=0, profile=False, junction_capacity=0,
+                 max_batch_bases=0, stream=None, walk_window_span=0):
+        self.lib = L.load()
+        p = L.Params(k, j, max_spacer_dist, n_hash, tai, device, L.FLAG_PROFILE if profile else 0, junction_capacity,
+                     max_batch_bases, stream, walk_window_span)
+        h = C.c_void_p()
+        _check(self.lib.fgpu_create(C.byref(p), C.byref(h)))
+        self.h = h
+        self.k, self.tai, self.n_hash, self.j = k, tai, n_hash, j
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _c(self, rc):
+        _check(rc, self.h)
+
+    # pass 1
+    def load_begin(self, keep_carry=False):
+        self._c(self.lib.fgpu_load_begin(self.h, int(keep_carry)))
+
+    def load_batch(self, batch: ReadBatch):
+        s = batch.c_struct()
+        self._c(self.lib.fgpu_load_batch(self.h, C.byref(s)))
+
+    def presence_batch(self, batch: ReadBatch):
+        s = batch.c_struct()
+        self._c(self.lib.fgpu_presence_batch(self.h, C.byref(s)))
+
+    def load_end(self) -> dict:
+        st = L.LoadStats()
+        self._c(self.lib.fgpu_load_end(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def bloom_download(self, which=L.BLOO2) -> np.ndarray:
+        out = np.empty(self.tai // 8, dtype=np.uint8)
+        self._c(self.lib.fgpu_bloom_download(self.h, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def bloom_upload(self, which, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        self._c(self.lib.fgpu_bloom_upload(self.h, which, data.ctypes.data, data.nbytes))
+
+    def bloom_weight(self, which=L.BLOO2) -> float:
+        w = C.c_float()
+        self._c(self.lib.fgpu_bloom_weight(self.h, which, C.byref(w)))
+        return w.value
+
+    def bloom_devptr(self, which):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._c(self.lib.fgpu_bloom_devptr(self.h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bitmap_or(self, dst_ptr, src_ptr, nbytes):
+        self._c(self.lib.fgpu_bitmap_or(self.h, dst_ptr, src_ptr, nbytes))
+
+    # pass 2
+    def scan_begin(self):
+        self._c(self.lib.fgpu_scan_begin(self.h))
+
+    def scan_batch(self, batch: ReadBatch):
+        s = batch.c_struct()
+        self._c(self.lib.fgpu_scan_batch(self.h, C.byref(s)))
+
+    def scan_end(self) -> dict:
+        st = L.ScanStats()
+        self._c(self.lib.fgpu_scan_end(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def junctions(self):
+        """(keys uint64[n], records[n]) in creation order."""
+        n = C.c_uint64()
+        self._c(self.lib.fgpu_scan_junction_count(self.h, C.byref(n)))
+        keys = np.zeros(max(n.value, 1), dtype=np.uint64)
+        recs = np.zeros(max(n.value, 1), dtype=JUNC_DTYPE)
+        got = C.c_uint64()
+        self._c(self.lib.fgpu_scan_download_junctions(self.h, keys.ctypes.data, recs.ctypes.data, len(keys), C.byref(got)))
+        return keys[: got.value], recs[: got.value]
+
+    def table_entries(self) -> int:
+        n = C.c_uint64()
+        self._c(self.lib.fgpu_scan_table_entries(self.h, C.byref(n)))
+        return n.value
+
+    def export_table(self, dev_ptr, nbytes) -> int:
+        n = C.c_uint64()
+        self._c(self.lib.fgpu_scan_export_table(self.h, dev_ptr, nbytes, C.byref(n)))
+        return n.value
+
+    def import_table(self, dev_ptr, n_entries, carried: dict = None):
+        st = None
+        if carried is not None:
+            st = L.ScanStats(**{k: int(v) for k, v in carried.items()})
+        self._c(self.lib.fgpu_scan_import_table(self.h, dev_ptr, n_entries, C.byref(st) if st is not None else None))
+
+    # probes / profiling
+    def probe_hash(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        n = len(kmers)
+        c, a, b = (np.zeros(n, np.uint64) for _ in range(3))
+        self._c(self.lib.fgpu_probe_hash(self.h, kmers.ctypes.data, n, c.ctypes.data, a.ctypes.data, b.ctypes.data))
+        return c, a, b
+
+    def probe_contains(self, which, canon):
+        canon = np.ascontiguousarray(canon, dtype=np.uint64)
+        out = np.zeros(len(canon), np.uint8)
+        self._c(self.lib.fgpu_probe_contains(self.h, which, canon.ctypes.data, len(canon), out.ctypes.data))
+        return out.astype(bool)
+
+    def synchronize(self):
+        self._c(self.lib.fgpu_synchronize(self.h))
+
+    def kernel_times(self) -> dict:
+        arr = (L.KernelTime * 64)()
+        n = self.lib.fgpu_kernel_times(self.h, arr, 64)
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n, 64))}
+
+    def kernel_times_reset(self):
+        self._c(self.lib.fgpu_kernel_times_reset(self.h))
+
+
+# ---- reference-shaped front end -------------------------------------------------------------------------------------
+class Bloom:
+    """Handle on one of the two load filters of a Context (utils/Bloom.h: tai, n_hash_func, blooma)."""
+
+    def __init__(self, ctx: Context, which: int):
+        self.ctx, self.which = ctx, which
+        self.tai, self.n_hash_func = ctx.tai, ctx.n_hash
+
+    def weight(self) -> float:                       # Bloom::weight
+        return self.ctx.bloom_weight(self.which)
+
+    def blooma(self) -> np.ndarray:                  # the raw bit array
+        return self.ctx.bloom_download(self.which)
+
+    def dump(self, path: str):                       # Bloom::dump (utils/Bloom.cpp:571-578)
+        self.blooma().tofile(path)
+
+    def load(self, path: str):                       # Bloom::load (utils/Bloom.cpp:580-587)
+        self.ctx.bloom_upload(self.which, np.fromfile(path, dtype=np.uint8, count=self.tai // 8))
+
+    def oldContains(self, canon_kmers):              # Bloom::oldContains (utils/Bloom.h:162-173), batched
+        return self.ctx.probe_contains(self.which, canon_kmers)
+
+
+def load_two_filters(bloo1: Bloom, bloo2: Bloom, batches) -> dict:
+    """load_two_filters (utils/Bloom.cpp:267-350): `batches` is an iterable of ReadBatch in file order."""
+    ctx = bloo1.ctx
+    assert bloo2.ctx is ctx and bloo1.which == L.BLOO1 and bloo2.which == L.BLOO2
+    ctx.load_begin()
+    for b in batches:
+        ctx.load_batch(b)
+    return ctx.load_end()
+
+
+class ReadScanner:
+    """ReadScanner (src/ReadScanner.h:30-92) on the device junction map of a Context."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.stats = None
+
+    def scanReads(self, batches):                    # src/ReadScanner.cpp:284-359
+        self.ctx.scan_begin()
+        for b in batches:
+            self.ctx.scan_batch(b)
+        self.stats = self.ctx.scan_end()
+        return self.stats
+
+    def junctions(self):
+        return self.ctx.junctions()
+
+
+_DEC = np.frombuffer(b"ACTG", dtype=np.uint8)
+
+
+def print_kmer(kmer: int, k: int) -> str:            # print_kmer / code2seq (utils/Kmer.cpp:217)
+    return "".join(chr(_DEC[(int(kmer) >> (2 * (k - 1 - i))) & 3]) for i in range(k))
+
+
+def junction_lines(keys, recs, k):
+    """The `.junctions` line of every record (Junction::toString, utils/Junction.cpp:74-89)."""
+    out = []
+    for key, r in zip(keys, recs):
+        cv = [int(x) for x in r["cov"]]
+        out.append("%s %s  %s  %s " % (print_kmer(int(key), k), " ".join(str(int(x)) for x in r["dist"]),
+                                       " ".join(str(x) for x in cv + [sum(cv)]), " ".join(str(int(x)) for x in r["linked"])))
+    return out

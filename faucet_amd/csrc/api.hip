@@ -1,0 +1,469 @@
+// api.hip — the extern "C" entry points of include/faucet_gpu.h.
+//
+// Thin: argument checks, state machine (idle -> loading -> idle -> scanning -> idle), buffer management and the
+// order in which the stages of pack.hip / load.hip / scan_pure.hip / scan_walk.hip are put on the stream.
+// There is no CPU path in this library: with no usable gfx950 device fgpu_create fails with FGPU_ERR_HIP.
+#include <algorithm>
+#include <string>
+
+#include "fgpu_ctx.h"
+
+int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries, uint64_t* d_stamps, uint64_t* n_entries);
+int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n);
+int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* recs_host, uint64_t cap, uint64_t* n_out);
+
+static std::string g_create_error;
+
+// ---- helpers declared in fgpu_ctx.h ---------------------------------------------------------------------------
+int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes) {
+    if (b->bytes >= bytes && b->p) return FGPU_OK;
+    if (b->p) {
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(hipFree(b->p));
+        b->p = nullptr;
+        b->bytes = 0;
+    } else {
+        ctx->owned.push_back(b);
+    }
+    uint64_t want = bytes + bytes / 8 + 256;   // head room so that slightly larger batches do not reallocate
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e);
+        b->p = nullptr;
+        return FGPU_ERR_NOMEM;
+    }
+    b->bytes = want;
+    return FGPU_OK;
+}
+
+int fgpu_prof_begin(fgpu_ctx* ctx, const char* name) {
+    if (!ctx->profile) return -1;
+    int idx = -1;
+    for (size_t i = 0; i < ctx->kstats.size(); i++)
+        if (ctx->kstats[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) {
+        KernelStat ks;
+        ks.name = name;
+        ctx->kstats.push_back(ks);
+        idx = (int)ctx->kstats.size() - 1;
+    }
+    PendingEvent pe;
+    pe.stat = idx;
+    if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) return -1;
+    hipEventRecord(pe.a, ctx->stream);
+    ctx->pending_events.push_back(pe);
+    return (int)ctx->pending_events.size() - 1;
+}
+
+void fgpu_prof_end(fgpu_ctx* ctx, int token) {
+    if (token < 0) return;
+    hipEventRecord(ctx->pending_events[token].b, ctx->stream);
+}
+
+int fgpu_prof_collect(fgpu_ctx* ctx) {
+    if (ctx->pending_events.empty()) return FGPU_OK;
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    for (PendingEvent& pe : ctx->pending_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            ctx->kstats[pe.stat].launches++;
+            ctx->kstats[pe.stat].total_ms += ms;
+        }
+        hipEventDestroy(pe.a);
+        hipEventDestroy(pe.b);
+    }
+    ctx->pending_events.clear();
+    return FGPU_OK;
+}
+
+static int check_errors(fgpu_ctx* ctx) {
+    // device-side error flags (table overflow) are surfaced at the synchronising calls
+    if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
+    if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
+    return FGPU_OK;
+}
+
+static int pull_counters(fgpu_ctx* ctx) {
+    FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return check_errors(ctx);
+}
+
+static bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+
+extern "C" {
+
+int fgpu_abi_version(void) { return FGPU_ABI_VERSION; }
+
+int fgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::string(prop.gcnArchName).rfind("gfx950", 0) == 0) usable++;
+    }
+    return usable;
+}
+
+const char* fgpu_last_error(const fgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
+    if (!p || !out) return FGPU_ERR_ARG;
+    *out = nullptr;
+    if (p->k < 1 || p->k > 31) { g_create_error = "k must be in 1..31"; return FGPU_ERR_ARG; }
+    if (p->j < 0 || p->j > 8) { g_create_error = "j must be in 0..8"; return FGPU_ERR_ARG; }
+    if (p->n_hash < 1 || p->n_hash > 10) { g_create_error = "n_hash must be in 1..10"; return FGPU_ERR_ARG; }
+    if (!is_pow2(p->tai) || p->tai < 128) { g_create_error = "tai must be a power of two >= 128"; return FGPU_ERR_ARG; }
+    if (p->max_spacer_dist < 1) { g_create_error = "max_spacer_dist must be >= 1"; return FGPU_ERR_ARG; }
+    if (p->junction_capacity && !is_pow2(p->junction_capacity)) { g_create_error = "junction_capacity must be a power of two"; return FGPU_ERR_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_create_error = std::string("no HIP device: ") + (e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return FGPU_ERR_HIP;
+    }
+    if (p->device < 0 || p->device >= ndev) { g_create_error = "device ordinal out of range"; return FGPU_ERR_ARG; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, p->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return FGPU_ERR_HIP; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return FGPU_ERR_HIP;
+    }
+    if ((e = hipSetDevice(p->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return FGPU_ERR_HIP; }
+
+    fgpu_ctx* ctx = new fgpu_ctx();
+    ctx->prm = *p;
+    if (!ctx->prm.junction_capacity) ctx->prm.junction_capacity = 1ULL << 24;
+    if (!ctx->prm.max_batch_bases) ctx->prm.max_batch_bases = 1ULL << 30;
+    ctx->fd.k = p->k;
+    ctx->fd.j = p->j;
+    ctx->fd.n_hash = p->n_hash;
+    ctx->fd.max_spacer = p->max_spacer_dist;
+    ctx->fd.kmask = (1ULL << (2 * p->k)) - 1;
+    ctx->fd.tai_mask = p->tai - 1;
+    ctx->profile = (p->flags & FGPU_FLAG_PROFILE) != 0;
+    ctx->bloom_bytes = p->tai / 8;
+    memset(&ctx->load_stats, 0, sizeof(ctx->load_stats));
+    memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
+    int rc = FGPU_OK;
+    auto fail = [&](const char* what, hipError_t he) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(he);
+        rc = FGPU_ERR_HIP;
+    };
+    if (p->stream) {
+        ctx->stream = (hipStream_t)p->stream;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
+        ctx->own_stream = true;
+    }
+    if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
+    if (!rc && (e = hipMalloc(&ctx->bloo1_new, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1_new", e);
+    if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
+    if (!rc && (e = hipMalloc(&ctx->counters, sizeof(DevCounters))) != hipSuccess) fail("hipMalloc counters", e);
+    if (!rc && (e = hipHostMalloc(&ctx->counters_host, sizeof(DevCounters))) != hipSuccess) fail("hipHostMalloc", e);
+    if (!rc) {
+        memset(ctx->counters_host, 0, sizeof(DevCounters));
+        hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream);
+        hipMemsetAsync(ctx->bloo1_new, 0, ctx->bloom_bytes, ctx->stream);
+        hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream);
+        hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) fail("initial memset", e);
+    }
+    if (rc) {
+        fgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return FGPU_OK;
+}
+
+void fgpu_destroy(fgpu_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
+    for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
+    void* ptrs[] = {ctx->bloo1, ctx->bloo1_new, ctx->bloo2, ctx->first, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->wkeys, ctx->wowner,
+                    ctx->wslots, ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_members, ctx->counters,
+                    ctx->wdesc};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (ctx->counters_host) hipHostFree(ctx->counters_host);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int fgpu_synchronize(fgpu_ctx* ctx) {
+    if (!ctx) return FGPU_ERR_ARG;
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+// ---- pass 1 --------------------------------------------------------------------------------------------------
+int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "load_begin while another pass is open"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (!ctx->first) {
+        hipError_t e = hipMalloc(&ctx->first, ctx->prm.tai * 4);
+        if (e != hipSuccess) {
+            ctx->err = std::string("hipMalloc of the first-set-time array (4 bytes per Bloom bit) failed: ") + hipGetErrorString(e);
+            ctx->first = nullptr;
+            return FGPU_ERR_NOMEM;
+        }
+    }
+    FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
+    if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(ctx->bloo1_new, ctx->bloo1, ctx->bloom_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
+    memset(&ctx->load_stats, 0, sizeof(ctx->load_stats));
+    ctx->phase = 1;
+    return FGPU_OK;
+}
+
+static int check_reads(fgpu_ctx* ctx, const fgpu_reads* r) {
+    if (!r || (r->n_reads && (!r->bases || !r->offsets))) { ctx->err = "null read batch"; return FGPU_ERR_ARG; }
+    return FGPU_OK;
+}
+
+int fgpu_load_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 1) { ctx->err = "load_batch outside load_begin/load_end"; return FGPU_ERR_STATE; }
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if ((rc = fgpu_stage_pack(ctx, reads))) return rc;
+    if ((rc = fgpu_stage_load(ctx))) return rc;
+    ctx->load_stats.reads_processed += reads->n_reads;
+    if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));   // caller may reuse its host buffers
+    return FGPU_OK;
+}
+
+int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "presence_batch while a pass is open"; return FGPU_ERR_STATE; }
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if ((rc = fgpu_stage_pack(ctx, reads))) return rc;
+    if ((rc = fgpu_stage_presence(ctx))) return rc;
+    if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 1) { ctx->err = "load_end without load_begin"; return FGPU_ERR_STATE; }
+    int rc = pull_counters(ctx);
+    ctx->phase = 0;
+    if (rc) return rc;
+    ctx->load_stats.kmers = ctx->counters_host->kmers;
+    ctx->load_stats.to_bloo2 = ctx->counters_host->to_bloo2;
+    ctx->load_stats.unambiguous_reads = ctx->counters_host->segments;
+    if (stats) *stats = ctx->load_stats;
+    return FGPU_OK;
+}
+
+static uint32_t* bloom_ptr(fgpu_ctx* ctx, int which) { return which == FGPU_BLOO1 ? ctx->bloo1 : which == FGPU_BLOO2 ? ctx->bloo2 : nullptr; }
+
+int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes) {
+    if (!ctx || !host_out || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    FGPU_HIP(hipMemcpyAsync(host_out, bloom_ptr(ctx, which), nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t nbytes) {
+    if (!ctx || !host_in || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    FGPU_HIP(hipMemcpyAsync(bloom_ptr(ctx, which), host_in, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+int fgpu_bloom_weight(fgpu_ctx* ctx, int which, float* weight) {
+    if (!ctx || !weight || !bloom_ptr(ctx, which)) return FGPU_ERR_ARG;
+    FGPU_HIP(hipMemsetAsync(&ctx->counters->pad, 0, 8, ctx->stream));
+    int rc = fgpu_util_popcount(ctx, bloom_ptr(ctx, which), ctx->bloom_bytes, &ctx->counters->pad);
+    if (rc) return rc;
+    FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->pad, &ctx->counters->pad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    *weight = (float)(long)ctx->counters_host->pad / (float)ctx->prm.tai;   // Bloom::weight: (float)weight/(float)tai
+    return FGPU_OK;
+}
+
+int fgpu_bloom_devptr(fgpu_ctx* ctx, int which, void** dptr, uint64_t* nbytes) {
+    if (!ctx || !dptr || !bloom_ptr(ctx, which)) return FGPU_ERR_ARG;
+    *dptr = bloom_ptr(ctx, which);
+    if (nbytes) *nbytes = ctx->bloom_bytes;
+    return FGPU_OK;
+}
+
+int fgpu_bitmap_or(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t nbytes) {
+    if (!ctx || !dst_dev || !src_dev || (nbytes & 15)) return FGPU_ERR_ARG;
+    return fgpu_util_or(ctx, dst_dev, src_dev, nbytes);
+}
+
+// ---- pass 2 --------------------------------------------------------------------------------------------------
+int fgpu_scan_begin(fgpu_ctx* ctx) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "scan_begin while another pass is open"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    int rc = fgpu_scan_alloc(ctx);
+    if (rc) return rc;
+    if ((rc = fgpu_scan_reset(ctx))) return rc;
+    FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
+    memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
+    memset(ctx->counters_host, 0, sizeof(DevCounters));
+    ctx->scan_windows = 0;
+    ctx->scan_pieces_seen = 0;
+    ctx->scan_piece_base = 0;
+    ctx->scan_imported = 0;
+    ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), FGPU_MAX_SPAN)
+                                                 : (1ULL << 17);
+    ctx->adapt_followers = 0;
+    ctx->adapt_pieces = 0;
+    ctx->phase = 2;
+    return FGPU_OK;
+}
+
+int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "scan_batch outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if ((rc = fgpu_stage_pack(ctx, reads))) return rc;
+    uint64_t n_pieces = 0;
+    if ((rc = fgpu_stage_scan_pure(ctx, &n_pieces))) return rc;
+    if ((rc = check_errors(ctx))) return rc;
+    // adapt the scheduling window to the data: keep the share of pieces that had to queue behind an earlier
+    // piece of their cluster small (the counters were just pulled by the pure stage's only synchronisation)
+    {
+        const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
+        const uint64_t p = ctx->scan_pieces_seen - n_pieces - ctx->adapt_pieces;
+        if (p > 0 && !ctx->prm.walk_window_span) {
+            if (f * 8 > p && ctx->window_span > 4096) ctx->window_span /= 2;
+            else if (f * 64 < p && ctx->window_span < FGPU_MAX_SPAN / 2) ctx->window_span *= 2;
+        }
+        ctx->adapt_followers = ctx->counters_host->followers;
+        ctx->adapt_pieces = ctx->scan_pieces_seen - n_pieces;
+    }
+    if ((rc = fgpu_stage_scan_walk(ctx, n_pieces))) return rc;
+    ctx->scan_stats.reads_processed += reads->n_reads;
+    if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "scan_end without scan_begin"; return FGPU_ERR_STATE; }
+    int rc = pull_counters(ctx);
+    ctx->phase = 0;
+    if (rc) return rc;
+    const DevCounters& c = *ctx->counters_host;
+    fgpu_scan_stats& s = ctx->scan_stats;
+    s.unambiguous_reads = c.segments + ctx->carried.unambiguous_reads;
+    s.reads_no_errors = c.pieces + ctx->carried.reads_no_errors;
+    s.nb_jcheck_kmer = c.nb_jcheck + ctx->carried.nb_jcheck_kmer;
+    s.nb_no_juncs = c.nb_no_juncs + ctx->carried.nb_no_juncs;
+    s.nb_processed = c.nb_processed + ctx->carried.nb_processed;
+    s.nb_skipped = c.nb_skipped + ctx->carried.nb_skipped;
+    s.n_junctions = c.n_junctions + ctx->scan_imported;
+    s.kmers = c.kmers + ctx->carried.kmers;
+    s.reads_processed += ctx->carried.reads_processed;
+    s.walk_windows = ctx->scan_windows;
+    s.walk_followers = c.followers;
+    s.walk_max_cluster = c.max_cluster;
+    memset(&ctx->carried, 0, sizeof(ctx->carried));
+    if (stats) *stats = s;
+    return FGPU_OK;
+}
+
+int fgpu_scan_junction_count(fgpu_ctx* ctx, uint64_t* n) {
+    if (!ctx || !n) return FGPU_ERR_ARG;
+    return fgpu_scan_download_impl(ctx, nullptr, nullptr, 0, n);
+}
+
+int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* recs, uint64_t cap, uint64_t* n_out) {
+    if (!ctx || !keys || !recs || !n_out) return FGPU_ERR_ARG;
+    if (!ctx->jkeys) { *n_out = 0; return FGPU_OK; }
+    return fgpu_scan_download_impl(ctx, keys, recs, cap, n_out);
+}
+
+int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries) { return fgpu_scan_junction_count(ctx, n_entries); }
+
+int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries) {
+    if (!ctx || !dev_buf || !n_entries) return FGPU_ERR_ARG;
+    uint64_t n = 0;
+    int rc = fgpu_scan_junction_count(ctx, &n);
+    if (rc) return rc;
+    if (buf_bytes < n * FGPU_TABLE_ENTRY_BYTES) { ctx->err = "export buffer too small"; return FGPU_ERR_CAPACITY; }
+    if ((rc = fgpu_ensure(ctx, &ctx->export_stamps, n * 8 + 8))) return rc;
+    return fgpu_scan_export_impl(ctx, dev_buf, n, (uint64_t*)ctx->export_stamps.p, n_entries);
+}
+
+int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries, const fgpu_scan_stats* carried) {
+    if (!ctx || (n_entries && !dev_buf)) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "import_table outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    int rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
+    if (rc) return rc;
+    ctx->scan_imported += n_entries;
+    if (carried) ctx->carried = *carried;
+    // creation stamps of this shard must sort after everything imported
+    ctx->scan_piece_base = std::max<uint64_t>(ctx->scan_piece_base, carried ? carried->reads_no_errors : 0);
+    return FGPU_OK;
+}
+
+// ---- probes ----------------------------------------------------------------------------------------------------
+int fgpu_probe_hash(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, uint64_t* canon_out, uint64_t* hA_out, uint64_t* hB_out) {
+    if (!ctx || !kmers_host || !canon_out || !hA_out || !hB_out) return FGPU_ERR_ARG;
+    if (!n) return FGPU_OK;
+    DevBuf& b = ctx->probe_buf;
+    int rc = fgpu_ensure(ctx, &b, n * 32);
+    if (rc) return rc;
+    uint64_t* d = (uint64_t*)b.p;
+    FGPU_HIP(hipMemcpyAsync(d, kmers_host, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = fgpu_util_probe_hash(ctx, d, n, d + n, d + 2 * n, d + 3 * n))) return rc;
+    FGPU_HIP(hipMemcpyAsync(canon_out, d + n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(hA_out, d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(hB_out, d + 3 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+int fgpu_probe_contains(fgpu_ctx* ctx, int which, const uint64_t* canon_host, uint64_t n, uint8_t* out) {
+    if (!ctx || !canon_host || !out || !bloom_ptr(ctx, which)) return FGPU_ERR_ARG;
+    if (!n) return FGPU_OK;
+    DevBuf& b = ctx->probe_buf;
+    int rc = fgpu_ensure(ctx, &b, n * 16);
+    if (rc) return rc;
+    uint64_t* d = (uint64_t*)b.p;
+    FGPU_HIP(hipMemcpyAsync(d, canon_host, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = fgpu_util_probe_contains(ctx, bloom_ptr(ctx, which), d, n, (unsigned char*)(d + n)))) return rc;
+    FGPU_HIP(hipMemcpyAsync(out, d + n, n, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------------------
+int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap) {
+    if (!ctx) return 0;
+    if (fgpu_prof_collect(ctx) != FGPU_OK) return 0;
+    int n = (int)ctx->kstats.size();
+    for (int i = 0; i < n && i < cap && out; i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, ctx->kstats[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = ctx->kstats[i].launches;
+        out[i].total_ms = ctx->kstats[i].total_ms;
+    }
+    return n;
+}
+
+int fgpu_kernel_times_reset(fgpu_ctx* ctx) {
+    if (!ctx) return FGPU_ERR_ARG;
+    int rc = fgpu_prof_collect(ctx);
+    ctx->kstats.clear();
+    return rc;
+}
+
+}  // extern "C"

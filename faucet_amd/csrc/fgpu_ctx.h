@@ -1,0 +1,170 @@
+// fgpu_ctx.h — host-side context of libfaucet_gpu.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/faucet_gpu.h"
+#include "fgpu_device.h"
+
+// every per-position plane / code array carries this many padding words past ceil(T/64): kernels run
+// whole 256-thread blocks and funnel-read one word ahead
+#define FGPU_PADW 8
+#define FGPU_MAX_SPAN (1ULL << 20)   // largest scheduling window of the ordered walk, in stream positions
+
+// A growable device buffer (hipMalloc'd; freed with the context).
+struct DevBuf {
+    void*    p = nullptr;
+    uint64_t bytes = 0;
+};
+
+// Everything one batch of reads turns into on the device ("data layout in HBM").
+struct BatchBufs {
+    DevBuf in_bases, in_offsets;   // staging when the caller hands over host pointers
+    DevBuf codes, bad;             // normalized stream: 2-bit codes, bad-position mask
+    DevBuf readflag;               // 1 byte per read: has interior non-ACGT characters
+    DevBuf pending;                // pass 1: occurrences that need the first-set-time test
+    // pass 2 planes (1 bit per stream position, LSB first)
+    DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
+    DevBuf ps_prefix;              // exclusive prefix of popcount(ps) per 64-bit word (uint32)
+    DevBuf pieces;                 // uint2 {start position, windows} per valid piece, in stream order
+    uint64_t T = 0;                // stream length = bases + n_reads
+    uint64_t n_words = 0;          // ceil(T / 64)
+    uint64_t n_reads = 0;
+};
+
+struct KernelStat {
+    std::string name;
+    uint64_t launches = 0;
+    double total_ms = 0;
+};
+
+struct PendingEvent {
+    int stat;
+    hipEvent_t a, b;
+};
+
+// counters that kernels bump (one device struct, zeroed at *_begin)
+struct DevCounters {
+    unsigned long long kmers;
+    unsigned long long to_bloo2;
+    unsigned long long segments;        // unambiguous segments counted by the current pass
+    unsigned long long pieces;
+    unsigned long long nb_jcheck;
+    unsigned long long nb_no_juncs;
+    unsigned long long nb_processed;
+    unsigned long long nb_skipped;
+    unsigned long long n_junctions;     // oriented junction records created
+    unsigned long long table_slots_used;
+    unsigned long long followers;
+    unsigned long long max_cluster;
+    unsigned long long error_flags;     // bit 0: junction table full, bit 1: window table full
+    unsigned long long max_read_len;    // longest read of the batches packed so far (bounds how far a piece reaches)
+    unsigned long long wt_used;         // slots claimed in the window table during the current window
+    unsigned long long pad;
+};
+
+struct fgpu_ctx {
+    fgpu_params prm;
+    FdParams fd;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // pass 1 state
+    uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
+    uint32_t* bloo1_new = nullptr;   // carry_old | bits set during the current batch
+    uint32_t* bloo2 = nullptr;
+    uint32_t* first = nullptr;       // first-set time per Bloom bit, 4*tai bytes (allocated at load_begin)
+    uint64_t bloom_bytes = 0;
+    int phase = 0;                   // 0 idle, 1 loading, 2 scanning
+
+    // pass 2 state: junction table (open addressing on the canonical k-mer)
+    uint64_t jcap = 0;               // slots (power of two)
+    uint64_t* jkeys = nullptr;       // canon | present bits in 63,62 ; EMPTY = ~0
+    uint8_t* jrecs = nullptr;        // [slot][orient] 16-byte records
+    uint64_t* jstamps = nullptr;     // [slot][orient] creation stamp
+    // window table (candidate keys of the window being walked)
+    uint64_t wcap = 0;
+    uint64_t* wkeys = nullptr;
+    uint32_t* wowner = nullptr;
+    uint32_t* wslots = nullptr;      // list of claimed slots, for the sparse clear
+    uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
+    // union-find / cluster scratch (per window)
+    uint32_t wmax = 0;               // max pieces per window
+    uint32_t* uf_parent = nullptr;
+    uint32_t* cl_count = nullptr;
+    uint32_t* cl_offset = nullptr;
+    uint32_t* cl_fill = nullptr;
+    uint32_t* cl_members = nullptr;
+    void* wdesc = nullptr;           // device WinDesc of the window in flight
+    uint64_t window_span = 1ULL << 17;   // adaptive: stream positions per scheduling window
+    uint64_t max_piece_span = 0;     // longest read of the current batch (+k): how far a piece may reach past its window
+    uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
+    uint64_t scan_imported = 0;      // junction records imported from a previous shard
+
+    DevCounters* counters = nullptr;      // device
+    DevCounters* counters_host = nullptr; // pinned host mirror
+
+    fgpu_load_stats load_stats;
+    fgpu_scan_stats scan_stats;
+    uint64_t scan_windows = 0;
+    uint64_t scan_pieces_seen = 0;   // pieces counted by previous batches of this scan
+
+    uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
+    fgpu_scan_stats carried = {};    // counters handed over by the previous shard (multi-GPU)
+
+    BatchBufs bb;
+    DevBuf probe_buf, export_stamps;
+    std::vector<DevBuf*> owned;
+
+    // profiling
+    bool profile = false;
+    std::vector<KernelStat> kstats;
+    std::vector<PendingEvent> pending_events;
+};
+
+#define FGPU_HIP(call)                                                                               \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            char b__[512];                                                                           \
+            snprintf(b__, sizeof(b__), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            ctx->err = b__;                                                                          \
+            return FGPU_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes);
+int fgpu_prof_begin(fgpu_ctx* ctx, const char* name);
+void fgpu_prof_end(fgpu_ctx* ctx, int token);
+int fgpu_prof_collect(fgpu_ctx* ctx);
+
+// Launch helper: brackets the launch with HIP events on ctx->stream when profiling is on.
+#define FGPU_LAUNCH(name, kernel, grid, block, ...)                                        \
+    do {                                                                                   \
+        int tok__ = fgpu_prof_begin(ctx, name);                                            \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, ctx->stream, __VA_ARGS__);  \
+        fgpu_prof_end(ctx, tok__);                                                         \
+        FGPU_HIP(hipGetLastError());                                                       \
+    } while (0)
+
+static inline unsigned fgpu_blocks(uint64_t n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// stage entry points implemented in the .hip files
+int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);
+int fgpu_stage_load(fgpu_ctx* ctx);
+int fgpu_stage_presence(fgpu_ctx* ctx);
+int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
+int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
+int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);
+int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out);
+int fgpu_util_or(fgpu_ctx* ctx, void* dst, const void* src, uint64_t nbytes);
+int fgpu_util_probe_hash(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t* d_canon, uint64_t* d_hA, uint64_t* d_hB);
+int fgpu_util_probe_contains(fgpu_ctx* ctx, const uint32_t* bloom, const uint64_t* d_canon, uint64_t n, unsigned char* d_out);
+int fgpu_scan_alloc(fgpu_ctx* ctx);
+int fgpu_scan_reset(fgpu_ctx* ctx);

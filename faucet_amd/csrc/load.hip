@@ -1,0 +1,233 @@
+// load.hip — pass 1: the two-filter Bloom load, exact and order-free.
+//
+// Replaces the loop body of load_two_filters (utils/Bloom.cpp:289-299):
+//     for every k-mer window, in processing order:
+//         if (bloo1->contains(hA,hB)) bloo2->add(hA,hB); else bloo1->add(hA,hB);
+//
+// Exact parallel form.  Because an occurrence either finds all of its bits set or
+// sets them all, bloo1 before time t is the OR of the bits of all occurrences < t.  Hence
+//     occurrence t goes to bloo2  <=>  every one of its bits was first set at a time < t.
+// Per batch:
+//   k_load_mark   (all windows)     test the carried-in bitmap (bloo1 as it stood before this batch).
+//                                   All bits set  -> the occurrence certainly goes to bloo2: set its bits there.
+//                                   Otherwise     -> atomicMin(first[bit], t) for the bits not yet in the carry,
+//                                                    OR them into the next carry, flag the occurrence as pending.
+//   k_load_resolve (pending only)   bit is "set before t" iff it is in the carry or first[bit] < t;
+//                                   all bits set before t -> bloo2.
+//   then carry := next carry (D2D copy).
+// t is the stream position (pack.hip makes position order == processing order); times are batch-local
+// because a bit that is still 0 in the carry has first[bit] == 0xFFFFFFFF at batch start.
+//
+// Roofline: HBM/Infinity-Cache random access.  Algorithmic bytes per k-mer:
+//   L/(L-k+1) bytes of bases + 64 B * n_hash (test-and-set on bloo1) + 64 B * rho * n_hash (set on bloo2).
+#include "fgpu_ctx.h"
+
+namespace {
+
+// lanes = consecutive stream positions; one wave covers one 64-position word of every plane
+__global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
+                                                   uint64_t T, FdParams fp, const uint32_t* __restrict__ carry,
+                                                   uint32_t* carry_next, uint32_t* bloo2, uint32_t* first,
+                                                   uint64_t* __restrict__ pending, DevCounters* cnt) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = p < T && fd_window_ok(bad, p, fp.k);
+    bool pend = false, hit = false;
+    if (ok) {
+        uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
+        uint64_t hA, hB;
+        fd_hash_pair(canon, fp.tai_mask, hA, hB);
+        // gather the carried-in bits of all n_hash positions first (independent loads in flight)
+        uint32_t missing = 0;
+        uint64_t h = hA;
+        for (int i = 0; i < fp.n_hash; i++) {
+            if (!((carry[h >> 5] >> (h & 31)) & 1u)) missing |= 1u << i;
+            h = (h + hB) & fp.tai_mask;
+        }
+        if (!missing) {
+            hit = true;
+            fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+        } else {
+            pend = true;
+            h = hA;
+            for (int i = 0; i < fp.n_hash; i++) {
+                if (missing & (1u << i)) {
+                    atomicMin(&first[h], (uint32_t)p);
+                    uint32_t bit = 1u << (h & 31);
+                    if (!(carry_next[h >> 5] & bit)) atomicOr(&carry_next[h >> 5], bit);
+                }
+                h = (h + hB) & fp.tai_mask;
+            }
+        }
+    }
+    uint64_t pm = __ballot(pend);
+    uint64_t okm = __ballot(ok);
+    uint64_t hm = __ballot(hit);
+    if (fd_lane() == 0) {
+        if (p < ((T + 63) & ~63ULL)) pending[p >> 6] = pm;
+        if (okm) atomicAdd(&cnt->kmers, (unsigned long long)__popcll(okm));
+        if (hm) atomicAdd(&cnt->to_bloo2, (unsigned long long)__popcll(hm));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, FdParams fp,
+                                                      const uint32_t* __restrict__ carry, uint32_t* bloo2,
+                                                      const uint32_t* __restrict__ first,
+                                                      const uint64_t* __restrict__ pending, DevCounters* cnt) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pass = false;
+    if (p < T && ((pending[p >> 6] >> (p & 63)) & 1ULL)) {
+        uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
+        uint64_t hA, hB;
+        fd_hash_pair(canon, fp.tai_mask, hA, hB);
+        pass = true;
+        uint64_t h = hA;
+        for (int i = 0; i < fp.n_hash; i++) {
+            bool before = ((carry[h >> 5] >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
+            if (!before) { pass = false; break; }
+            h = (h + hB) & fp.tai_mask;
+        }
+        if (pass) fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+    }
+    uint64_t m = __ballot(pass);
+    if (fd_lane() == 0 && m) atomicAdd(&cnt->to_bloo2, (unsigned long long)__popcll(m));
+}
+
+// multi-GPU helper: OR the bits of every k-mer into a bitmap, no ordering
+__global__ void __launch_bounds__(256) k_presence(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
+                                                  uint64_t T, FdParams fp, uint32_t* bitmap, DevCounters* cnt) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = p < T && fd_window_ok(bad, p, fp.k);
+    if (ok) {
+        uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
+        uint64_t hA, hB;
+        fd_hash_pair(canon, fp.tai_mask, hA, hB);
+        fd_bloom_set(bitmap, hA, hB, fp.tai_mask, fp.n_hash);
+    }
+    uint64_t okm = __ballot(ok);
+    if (fd_lane() == 0 && okm) atomicAdd(&cnt->kmers, (unsigned long long)__popcll(okm));
+}
+
+// unambiguous segments of length >= minlen (utils/Kmer.cpp:77; ReadScanner.cpp:268): one count per
+// segment start whose run of good positions is long enough
+__global__ void __launch_bounds__(256) k_count_segments(const uint64_t* __restrict__ bad, uint64_t T, int minlen,
+                                                        unsigned long long* out) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool counted = false;
+    if (p < T) {
+        bool isbad = (bad[p >> 6] >> (p & 63)) & 1ULL;
+        bool prevbad = p == 0 ? true : ((bad[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ULL);
+        if (!isbad && prevbad) {
+            // length of the good run starting at p (bad padding past T terminates the scan)
+            uint64_t q = p;
+            int len = 0;
+            while (len < minlen) {
+                uint64_t v = fd_bits_at(bad, q);
+                if (v) { len += __builtin_ctzll(v); break; }
+                len += 64;
+                q += 64;
+            }
+            counted = len >= minlen;
+        }
+    }
+    uint64_t m = __ballot(counted);
+    if (fd_lane() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+__global__ void __launch_bounds__(256) k_popcount(const uint4* __restrict__ words, uint64_t n16, unsigned long long* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (; i < n16; i += stride) {
+        uint4 v = words[i];
+        acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (fd_lane() == 0 && acc) atomicAdd(out, acc);
+}
+
+__global__ void __launch_bounds__(256) k_bitmap_or(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t n16) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) {
+        uint4 a = dst[i], b = src[i];
+        a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+        dst[i] = a;
+    }
+}
+
+__global__ void k_probe_hash(const uint64_t* __restrict__ kmers, uint64_t n, FdParams fp, uint64_t* canon, uint64_t* hA, uint64_t* hB) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t c = fd_canon(kmers[i], fp.k);
+    uint64_t a, b;
+    fd_hash_pair(c, fp.tai_mask, a, b);
+    canon[i] = c;
+    hA[i] = a;
+    hB[i] = b;
+}
+
+__global__ void k_probe_contains(const uint32_t* __restrict__ bloom, const uint64_t* __restrict__ canon, uint64_t n, FdParams fp,
+                                 unsigned char* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = fd_bloom_contains_canon(bloom, canon[i], fp.tai_mask, fp.n_hash) ? 1 : 0;
+}
+
+}  // namespace
+
+int fgpu_stage_load(fgpu_ctx* ctx) {
+    BatchBufs& bb = ctx->bb;
+    if (bb.T == 0) return FGPU_OK;
+    int rc = fgpu_ensure(ctx, &bb.pending, (bb.n_words + FGPU_PADW) * 8);
+    if (rc) return rc;
+    const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
+    if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
+    FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd,
+                (const uint32_t*)ctx->bloo1, ctx->bloo1_new, ctx->bloo2, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
+    FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, ctx->fd, (const uint32_t*)ctx->bloo1,
+                ctx->bloo2, (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
+    int tok = fgpu_prof_begin(ctx, "carry_copy");
+    hipError_t e = hipMemcpyAsync(ctx->bloo1, ctx->bloo1_new, ctx->bloom_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    fgpu_prof_end(ctx, tok);
+    FGPU_HIP(e);
+    return FGPU_OK;
+}
+
+int fgpu_stage_presence(fgpu_ctx* ctx) {
+    BatchBufs& bb = ctx->bb;
+    if (bb.T == 0) return FGPU_OK;
+    const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
+    int rc;
+    if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
+    FGPU_LAUNCH("presence", k_presence, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd, ctx->bloo1,
+                ctx->counters);
+    return FGPU_OK;
+}
+
+// ---- small utilities used by api.hip and scan_pure.hip --------------------------------------------
+int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen) {
+    BatchBufs& bb = ctx->bb;
+    FGPU_LAUNCH("count_segments", k_count_segments, fgpu_blocks(bb.n_words * 64, 256), 256, (const uint64_t*)bb.bad.p, bb.T, minlen,
+                &ctx->counters->segments);
+    return FGPU_OK;
+}
+
+int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out) {
+    FGPU_LAUNCH("popcount", k_popcount, 1024, 256, (const uint4*)dev, nbytes / 16, dev_out);
+    return FGPU_OK;
+}
+
+int fgpu_util_or(fgpu_ctx* ctx, void* dst, const void* src, uint64_t nbytes) {
+    FGPU_LAUNCH("bitmap_or", k_bitmap_or, 2048, 256, (uint4*)dst, (const uint4*)src, nbytes / 16);
+    return FGPU_OK;
+}
+
+int fgpu_util_probe_hash(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t* d_canon, uint64_t* d_hA, uint64_t* d_hB) {
+    FGPU_LAUNCH("probe_hash", k_probe_hash, fgpu_blocks(n, 256), 256, d_kmers, n, ctx->fd, d_canon, d_hA, d_hB);
+    return FGPU_OK;
+}
+
+int fgpu_util_probe_contains(fgpu_ctx* ctx, const uint32_t* bloom, const uint64_t* d_canon, uint64_t n, unsigned char* d_out) {
+    FGPU_LAUNCH("probe_contains", k_probe_contains, fgpu_blocks(n, 256), 256, bloom, d_canon, n, ctx->fd, d_out);
+    return FGPU_OK;
+}

@@ -1,0 +1,277 @@
+// scan_pure.hip — pass 2, the part that is a pure function of (reads, bloo2).
+//
+// Replaces, for every position of the batch at once:
+//   ReadScanner::getValidReads   (src/ReadScanner.cpp:233-257)  one oldContains(canon) per window; maximal runs of
+//                                >= k present windows become "valid pieces" (the strings scan_forward walks)
+//   scanInputRead's length gate  (src/ReadScanner.cpp:268)      segment length >= k + 2j + 1
+//   ReadScanner::testForJunction (src/ReadScanner.cpp:36-56)    for nt != real extension: if oldContains(canon(ext))
+//                                { NbJCheckKmer++; if jcheck(ext) return true; }
+//   JChecker::jcheck(kmer_type)  (utils/JChecker.cpp:51-80)     is there a chain of j forward extensions in the filter
+//
+// Outputs, one bit per stream position (LSB-first words, written with one ballot per wave = coalesced 8-byte stores):
+//   valid  window at p is in bloo2            pm   window p belongs to a valid piece      ps   p is the first window of a piece
+//   ff/fb  testForJunction at (p, FORWARD) / (p, BACKWARD)
+//   cf0,cf1 / cb0,cb1  two bit-planes of the NbJCheckKmer increment (0..3) at (p, FORWARD) / (p, BACKWARD)
+// plus the piece list {start, windows} in stream (= processing) order.
+//
+// Roofline: random bit probes into bloo2 (Infinity-Cache / HBM); algorithmic bytes per k-mer:
+//   L/(L-k+1) B of bases + 64 B per bit test the reference semantics perform (validity, alternate extensions, jcheck).
+#include "fgpu_ctx.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_scan_valid(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
+                                                    uint64_t T, FdParams fp, const uint32_t* __restrict__ bloom,
+                                                    uint64_t* __restrict__ valid, DevCounters* cnt) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = p < T && fd_window_ok(bad, p, fp.k);
+    bool v = false;
+    if (ok) v = fd_bloom_contains_canon(bloom, fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, fp.n_hash);
+    uint64_t vm = __ballot(v);
+    uint64_t okm = __ballot(ok);
+    if (fd_lane() == 0) {
+        valid[p >> 6] = vm;   // grid is sized to whole words; padding words exist
+        if (okm) atomicAdd(&cnt->kmers, (unsigned long long)__popcll(okm));
+    }
+}
+
+// One thread per position; a thread that sits on the first window of a run of valid windows measures the
+// run, and if it is a piece (>= k windows, inside a long enough segment) publishes ps/pm.
+__global__ void __launch_bounds__(256) k_scan_pieces(const uint64_t* __restrict__ valid, const uint64_t* __restrict__ bad,
+                                                     uint64_t T, FdParams fp, int check_segment,
+                                                     unsigned long long* pm, uint64_t* __restrict__ ps, DevCounters* cnt) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool start = false;
+    if (p < T) {
+        bool v = (valid[p >> 6] >> (p & 63)) & 1ULL;
+        bool pv = p == 0 ? false : ((valid[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ULL);
+        if (v && !pv) {
+            // run length: first 0 bit at or after p
+            uint64_t q = p, len = 0;
+            for (;;) {
+                uint64_t bits = ~fd_bits_at(valid, q);
+                if (bits) { len += __builtin_ctzll(bits); break; }
+                len += 64;
+                q += 64;
+            }
+            bool piece = len >= (uint64_t)fp.k;
+            if (piece && check_segment) {
+                // the unambiguous segment around the run must have length >= k + 2j + 1 (ReadScanner.cpp:268)
+                uint64_t b = p;            // walk back to the segment start
+                while (b > 0 && !((bad[(b - 1) >> 6] >> ((b - 1) & 63)) & 1ULL)) b--;
+                uint64_t e = p;            // forward to the first bad position
+                for (;;) {
+                    uint64_t bits = fd_bits_at(bad, e);
+                    if (bits) { e += __builtin_ctzll(bits); break; }
+                    e += 64;
+                }
+                piece = (e - b) >= (uint64_t)(fp.k + 2 * fp.j + 1);
+            }
+            if (piece) {
+                start = true;
+                // pm bits p .. p+len-1
+                uint64_t a = p, z = p + len;
+                while (a < z) {
+                    uint64_t w = a >> 6;
+                    uint64_t hi = (w + 1) << 6;
+                    uint64_t upto = z < hi ? z : hi;
+                    int lo_b = (int)(a & 63), n_b = (int)(upto - a);
+                    unsigned long long m = (n_b == 64 ? ~0ULL : ((1ULL << n_b) - 1)) << lo_b;
+                    atomicOr(&pm[w], m);
+                    a = upto;
+                }
+            }
+        }
+    }
+    uint64_t sm = __ballot(start);
+    if (fd_lane() == 0) {
+        ps[p >> 6] = sm;
+        if (sm) atomicAdd(&cnt->pieces, (unsigned long long)__popcll(sm));
+    }
+}
+
+// exclusive prefix sum of popcount(ps[w]) over the words of the batch: three small kernels
+// (per-block sums, scan of the block sums by one block, apply).
+constexpr int SCAN_BLOCK = 1024;
+__global__ void __launch_bounds__(SCAN_BLOCK) k_prefix_block(const uint64_t* __restrict__ ps, uint64_t n_words,
+                                                             uint32_t* __restrict__ prefix, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint64_t w = (uint64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint32_t c = w < n_words ? (uint32_t)__popcll(ps[w]) : 0;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (w < n_words) prefix[w] = sh[threadIdx.x] - c;   // exclusive within the block
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_prefix_sums(uint32_t* block_sums, uint32_t n_blocks) {
+    // serial-over-chunks scan by one block; n_blocks is small (n_words / 1024)
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += SCAN_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t c = i < n_blocks ? block_sums[i] : 0;
+        sh[threadIdx.x] = c;
+        __syncthreads();
+        for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+            uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = carry + sh[threadIdx.x] - c;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry += sh[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_prefix_apply(uint32_t* __restrict__ prefix, const uint32_t* __restrict__ block_sums,
+                                                      uint64_t n_words) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_words) prefix[w] += block_sums[w / SCAN_BLOCK];
+}
+
+// piece list: thread on a piece start writes {start, windows} at its rank
+__global__ void __launch_bounds__(256) k_scan_piece_list(const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pm,
+                                                         const uint32_t* __restrict__ prefix, uint64_t T, uint2* __restrict__ pieces) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= T) return;
+    uint64_t word = ps[p >> 6];
+    if (!((word >> (p & 63)) & 1ULL)) return;
+    uint32_t rank = prefix[p >> 6] + (uint32_t)__popcll(word & ((1ULL << (p & 63)) - 1));
+    uint64_t q = p, len = 0;
+    for (;;) {   // run of pm bits; pieces are separated by at least one 0
+        uint64_t bits = ~fd_bits_at(pm, q);
+        if (bits) { len += __builtin_ctzll(bits); break; }
+        len += 64;
+        q += 64;
+    }
+    pieces[rank] = make_uint2((uint32_t)p, (uint32_t)len);
+}
+
+// JChecker::jcheck: depth-first search for one chain of j present extensions (same truth value as the
+// reference's level-by-level search; nothing else about it is observable).
+__device__ bool jcheck_dfs(uint64_t kmer, const FdParams& fp, const uint32_t* __restrict__ bloom) {
+    if (fp.j == 0) return true;
+    uint64_t stack_k[8];
+    int stack_nt[8];
+    int depth = 0;
+    stack_k[0] = kmer;
+    stack_nt[0] = 0;
+    const int J = fp.j < 8 ? fp.j : 8;
+    while (depth >= 0) {
+        if (stack_nt[depth] == 4) { depth--; continue; }
+        int nt = stack_nt[depth]++;
+        uint64_t e = ((stack_k[depth] << 2) | (uint64_t)nt) & fp.kmask;
+        if (fd_bloom_contains_canon(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
+            if (depth + 1 == J) return true;
+            depth++;
+            stack_k[depth] = e;
+            stack_nt[depth] = 0;
+        }
+    }
+    return false;
+}
+
+// testForJunction for the k-mer `key` (already oriented towards the extension) with real next base `real`
+__device__ __forceinline__ void test_for_junction(uint64_t key, int real, const FdParams& fp, const uint32_t* __restrict__ bloom,
+                                                  bool& flag, int& njc) {
+    flag = false;
+    njc = 0;
+    for (int nt = 0; nt < 4; nt++) {
+        if (nt == real) continue;
+        uint64_t e = ((key << 2) | (uint64_t)nt) & fp.kmask;
+        if (fd_bloom_contains_canon(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
+            njc++;
+            if (jcheck_dfs(e, fp, bloom)) { flag = true; return; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
+                                                    uint64_t T, FdParams fp, const uint32_t* __restrict__ bloom,
+                                                    uint64_t* __restrict__ ff, uint64_t* __restrict__ fb, uint64_t* __restrict__ cf0,
+                                                    uint64_t* __restrict__ cf1, uint64_t* __restrict__ cb0, uint64_t* __restrict__ cb1) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool f_f = false, f_b = false;
+    int c_f = 0, c_b = 0;
+    if (p < T) {
+        uint64_t wbits = fd_bits_at(pm, p == 0 ? 0 : p - 1);   // bit0 = pm[p-1], bit1 = pm[p], bit2 = pm[p+1]
+        bool here, prev, next;
+        if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
+        else { prev = wbits & 1; here = (wbits >> 1) & 1; next = (wbits >> 2) & 1; }
+        if (here && (prev || next)) {
+            uint64_t km = fd_kmer_at(codes, p, fp.k);
+            if (next) {   // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110)
+                test_for_junction(km, fd_base_at(codes, p + fp.k), fp, bloom, f_f, c_f);
+            }
+            if (prev) {   // facing backward: reverse complement, real extension = complement of the base before (:111-113)
+                test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, p - 1) ^ 2, fp, bloom, f_b, c_b);
+            }
+        }
+    }
+    uint64_t m_ff = __ballot(f_f), m_fb = __ballot(f_b);
+    uint64_t m_cf0 = __ballot(c_f & 1), m_cf1 = __ballot(c_f & 2), m_cb0 = __ballot(c_b & 1), m_cb1 = __ballot(c_b & 2);
+    if (fd_lane() == 0) {
+        uint64_t w = p >> 6;
+        ff[w] = m_ff; fb[w] = m_fb; cf0[w] = m_cf0; cf1[w] = m_cf1; cb0[w] = m_cb0; cb1[w] = m_cb1;
+    }
+}
+
+}  // namespace
+
+int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
+    BatchBufs& bb = ctx->bb;
+    *n_pieces = 0;
+    if (bb.T == 0) return FGPU_OK;
+    const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
+    int rc;
+    DevBuf* planes[] = {&bb.valid, &bb.pm, &bb.ps, &bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1, &bb.inF, &bb.inB};
+    for (DevBuf* b : planes)
+        if ((rc = fgpu_ensure(ctx, b, wb))) return rc;
+    if ((rc = fgpu_ensure(ctx, &bb.ps_prefix, (bb.n_words + FGPU_PADW + bb.n_words / SCAN_BLOCK + 2) * 4))) return rc;
+    // valid/pm/ps need zeroed padding (funnel reads run one word past the end); pm is built with atomicOr
+    FGPU_HIP(hipMemsetAsync(bb.valid.p, 0, wb, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(bb.pm.p, 0, wb, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(bb.ps.p, 0, wb, ctx->stream));
+
+    const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
+    if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k + 2 * ctx->fd.j + 1))) return rc;
+    FGPU_LAUNCH("scan_valid", k_scan_valid, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd,
+                (const uint32_t*)ctx->bloo2, (uint64_t*)bb.valid.p, ctx->counters);
+    const int check_segment = ctx->fd.k < 2 * ctx->fd.j + 2;   // otherwise a run of k windows already implies the length gate
+    FGPU_LAUNCH("scan_pieces", k_scan_pieces, grid, 256, (const uint64_t*)bb.valid.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd,
+                check_segment, (unsigned long long*)bb.pm.p, (uint64_t*)bb.ps.p, ctx->counters);
+    uint32_t* prefix = (uint32_t*)bb.ps_prefix.p;
+    uint32_t* block_sums = prefix + bb.n_words + FGPU_PADW;
+    const uint32_t nblk = fgpu_blocks(bb.n_words + 1, SCAN_BLOCK);
+    // one word more than the batch has, so that prefix[n_words] = number of pieces (rank queries at position T)
+    const uint64_t nw1 = bb.n_words + 1;
+    FGPU_LAUNCH("prefix_block", k_prefix_block, nblk, SCAN_BLOCK, (const uint64_t*)bb.ps.p, nw1, prefix, block_sums);
+    FGPU_LAUNCH("prefix_sums", k_prefix_sums, 1, SCAN_BLOCK, block_sums, nblk);
+    FGPU_LAUNCH("prefix_apply", k_prefix_apply, fgpu_blocks(nw1, 256), 256, prefix, (const uint32_t*)block_sums, nw1);
+    FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->max_piece_span = ctx->counters_host->max_read_len + 64;
+    const uint64_t np = ctx->counters_host->pieces - ctx->scan_pieces_seen;
+    ctx->scan_pieces_seen = ctx->counters_host->pieces;
+    *n_pieces = np;
+    if ((rc = fgpu_ensure(ctx, &bb.pieces, (np + 1) * sizeof(uint2)))) return rc;
+    if (np) {
+        FGPU_LAUNCH("piece_list", k_scan_piece_list, grid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
+                    (const uint32_t*)prefix, bb.T, (uint2*)bb.pieces.p);
+        FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.T, ctx->fd,
+                    (const uint32_t*)ctx->bloo2, (uint64_t*)bb.ff.p, (uint64_t*)bb.fb.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p,
+                    (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p);
+    }
+    return FGPU_OK;
+}

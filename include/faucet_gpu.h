@@ -1,0 +1,179 @@
+/*
+ * faucet_gpu.h — C ABI of libfaucet_gpu.so: Faucet's two-pass k-mer pipeline on MI355X (gfx950).
+ *
+ * The reference (Shamir-Lab/Faucet) has no plugin / FFI layer; this ABI cuts the two seams that
+ * SURVEY.md §8(b) names and is what a maintainer's `faucet` binary (or any other host language)
+ * binds.  Every entry point cites the reference interface it replaces.
+ *
+ *   pass 1   void load_two_filters(Bloom*, Bloom*, std::string, bool fastq, bool mercy)
+ *            utils/Bloom.h:294, utils/Bloom.cpp:267, caller src/Faucet.cpp:220
+ *   pass 2   void ReadScanner::scanReads(bool fastq, bool paired_ends, bool no_cleaning)
+ *            src/ReadScanner.cpp:284, constructed and called at src/Faucet.cpp:241-245
+ *   sizing   getBloomFilterFromReads / create_bloom_filter_optimal / _2_hash / Bloom::Bloom
+ *            src/Faucet.cpp:197-219, utils/Bloom.cpp:165-247
+ *
+ * Conventions: extern "C", opaque context, POD structs, caller-owned buffers with explicit sizes,
+ * int status (0 = ok), no exceptions / STL / torch types across the boundary.  One host thread
+ * drives one context; one context drives one HIP device.  Results are bit-identical to the
+ * reference CPU path (same Bloom bit array, same junction records).  There is no CPU fallback:
+ * every compute entry point returns FGPU_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef FAUCET_GPU_H
+#define FAUCET_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGPU_ABI_VERSION 1
+
+enum {
+    FGPU_OK = 0,
+    FGPU_ERR_ARG = 1,       /* bad parameter (k out of 1..31, tai not a power of two, ...) */
+    FGPU_ERR_HIP = 2,       /* HIP runtime error or no device; see fgpu_last_error() */
+    FGPU_ERR_STATE = 3,     /* call out of sequence (e.g. load_batch before load_begin) */
+    FGPU_ERR_CAPACITY = 4,  /* batch larger than max_batch_bases, junction table full, ... */
+    FGPU_ERR_NOMEM = 5
+};
+
+enum { FGPU_BLOO1 = 0, FGPU_BLOO2 = 1 };
+
+typedef struct fgpu_ctx fgpu_ctx;
+
+typedef struct {
+    int32_t  k;                 /* -size_kmer (src/Faucet.cpp:66), 1..31 */
+    int32_t  j;                 /* -j, default 1 (src/Faucet.h:15) */
+    int32_t  max_spacer_dist;   /* -max_spacer_dist, default 100 (src/Faucet.h:48) */
+    int32_t  n_hash;            /* hash functions of both load filters (utils/Bloom.cpp:243-244) */
+    uint64_t tai;               /* bits per load filter, power of two (utils/Bloom.cpp:173-175) */
+    int32_t  device;            /* HIP device ordinal */
+    int32_t  flags;             /* FGPU_FLAG_* */
+    uint64_t junction_capacity; /* slots of the device junction table, power of two; 0 = default */
+    uint64_t max_batch_bases;   /* largest batch (bases + one separator per read); 0 = default 2^30 */
+    void*    stream;            /* hipStream_t to run on, or NULL for a private stream */
+    uint64_t walk_window_span;  /* stream positions per scheduling window of the ordered walk; 0 = adaptive.
+                                 * Any value gives the same results (tests use small ones to force clusters). */
+} fgpu_params;
+
+#define FGPU_FLAG_PROFILE 1     /* bracket every kernel with HIP events (fgpu_kernel_times) */
+
+/* A batch of sequence lines in file order: read i = bases[offsets[i] .. offsets[i+1]).  Any byte
+ * may occur; everything except upper-case A C G T splits a read exactly as isValidNuc /
+ * getUnambiguousReads do (utils/Kmer.cpp:50-80).  offsets[0] need not be 0.
+ * on_device != 0: both pointers are device (HBM) pointers on params.device. */
+typedef struct {
+    const char*     bases;
+    const uint64_t* offsets;    /* n_reads + 1 entries */
+    uint64_t        n_reads;
+    int32_t         on_device;
+} fgpu_reads;
+
+typedef struct {
+    uint64_t reads_processed;    /* "Reads processed"   utils/Bloom.cpp:335,346 */
+    uint64_t unambiguous_reads;  /* "Unambiguous reads" utils/Bloom.cpp:287,347 */
+    uint64_t kmers;              /* iterations of the loop at utils/Bloom.cpp:289 — the unit N */
+    uint64_t to_bloo2;           /* occurrences routed to bloo2 (utils/Bloom.cpp:293) */
+} fgpu_load_stats;
+
+typedef struct {
+    uint64_t reads_processed;    /* src/ReadScanner.cpp:348 */
+    uint64_t unambiguous_reads;  /* :269 */
+    uint64_t reads_no_errors;    /* :276 */
+    uint64_t nb_jcheck_kmer;     /* :49  */
+    uint64_t nb_no_juncs;        /* :196 */
+    uint64_t nb_processed;       /* :83,:192 */
+    uint64_t nb_skipped;         /* :192 */
+    uint64_t n_junctions;        /* JunctionMap::getNumJunctions, utils/JunctionMap.cpp:598-600 */
+    uint64_t kmers;              /* windows inside unambiguous segments (same unit N as pass 1) */
+    /* diagnostics of the ordered walk (not in the reference) */
+    uint64_t walk_windows;       /* scheduling windows executed */
+    uint64_t walk_followers;     /* pieces that had to wait for an earlier piece of their cluster */
+    uint64_t walk_max_cluster;   /* largest dependency cluster seen */
+} fgpu_scan_stats;
+
+/* Junction record, field for field utils/Junction.h:10-18 (cov is private there). */
+typedef struct {
+    uint8_t cov[4];
+    uint8_t dist[5];
+    uint8_t linked[5];
+} fgpu_junction;
+
+/* ---- library / context ------------------------------------------------------------------- */
+int         fgpu_abi_version(void);
+/* Number of usable gfx950 devices (0 when there is none; never fails). */
+int         fgpu_device_count(void);
+int         fgpu_create(const fgpu_params* params, fgpu_ctx** out);
+void        fgpu_destroy(fgpu_ctx* ctx);
+const char* fgpu_last_error(const fgpu_ctx* ctx);   /* ctx may be NULL: last fgpu_create failure */
+int         fgpu_synchronize(fgpu_ctx* ctx);
+
+/* ---- filter sizing (host arithmetic only; replaces src/Faucet.cpp:197-219, Bloom.cpp:165-247) --- */
+/* p1 such that two filters at rate p1 give overall rate fp; <0 when the root is not bracketed
+ * (e.g. singletons == 0) — callers must treat that as an argument error. */
+double   fgpu_solve_p1(uint64_t estimated_kmers, uint64_t singletons, float fp, int32_t* iterations);
+uint64_t fgpu_bloom_tai(uint64_t requested_bits);                                  /* Bloom.cpp:173-178 */
+void     fgpu_size_optimal(uint64_t estimated, float fp, int32_t* bits_per_item, uint64_t* tai, int32_t* n_hash);
+void     fgpu_size_two_hash(uint64_t estimated, float fp, int32_t* bits_per_item, uint64_t* tai, int32_t* n_hash);
+
+/* ---- pass 1: Bloom load (replaces load_two_filters, utils/Bloom.cpp:267-350) ------------------- */
+/* Zero both filters (or keep bloo1's current content as the carried-in state when keep_carry != 0:
+ * multi-GPU shards start from the prefix-OR of the lower ranks' k-mer presence bitmaps). */
+int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry);
+/* Consume one batch, in file order.  Exact: occurrence t goes to bloo2 iff all its bits were set
+ * by occurrences < t, t following the reference's processing order. */
+int fgpu_load_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
+int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats);
+/* OR the bits of every k-mer of the batch into bloo1 with no ordering (presence bitmap; used by
+ * multi-GPU shards before the prefix-OR exchange).  Same unit counters as load_batch. */
+int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
+
+/* filters: raw bit arrays, tai/8 bytes, exactly the .bloom file body (utils/Bloom.cpp:571-587) */
+int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes);
+int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t nbytes);   /* -bloom_file restart */
+int fgpu_bloom_weight(fgpu_ctx* ctx, int which, float* weight);                             /* Bloom::weight, Bloom.cpp:191-203 */
+int fgpu_bloom_devptr(fgpu_ctx* ctx, int which, void** dptr, uint64_t* nbytes);
+/* dst |= src over nbytes (device pointers, nbytes multiple of 16): the local step of the
+ * prefix-OR / OR-allreduce that RCCL cannot express as a reduction op. */
+int fgpu_bitmap_or(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t nbytes);
+
+/* ---- pass 2: junction scan (replaces ReadScanner::scanReads, src/ReadScanner.cpp:284-359) ------- */
+/* Uses bloo2 as resident on the device (after fgpu_load_end or fgpu_bloom_upload). */
+int fgpu_scan_begin(fgpu_ctx* ctx);
+/* Pure stage + ordered walk for one batch, in file order. */
+int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
+int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
+/* Junction map after the scan, in CREATION order (inserting the records in this order into a
+ * std::unordered_map<kmer_type,Junction> reproduces the reference's dump order,
+ * utils/JunctionMap.cpp:588-593).  keys are the oriented k-mers (ReadKmer::getKmer). */
+int fgpu_scan_junction_count(fgpu_ctx* ctx, uint64_t* n);
+int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* recs, uint64_t cap, uint64_t* n_out);
+/* Multi-GPU hand-over of the ordered state between consecutive read shards: export on rank r
+ * (device buffer of fgpu_scan_table_bytes()), import on rank r+1 before its first scan_batch. */
+int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries);
+int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries);
+int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries, const fgpu_scan_stats* carried);
+#define FGPU_TABLE_ENTRY_BYTES 32
+
+/* ---- probes for tests (pure, no state change) ------------------------------------------------- */
+/* For each of n k-mers (2-bit encoded, utils/Kmer.cpp:82-88,410-425): canonical form and
+ * hA = oldHash(canon,0), hB = oldHash(canon,1) masked with tai-1 (utils/Bloom.h:134-145). */
+int fgpu_probe_hash(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, uint64_t* canon_out, uint64_t* hA_out, uint64_t* hB_out);
+/* Bloom::oldContains (utils/Bloom.h:162-173) of n canonical k-mers against filter `which`. */
+int fgpu_probe_contains(fgpu_ctx* ctx, int which, const uint64_t* canon_host, uint64_t n, uint8_t* out);
+
+/* ---- profiling --------------------------------------------------------------------------------- */
+typedef struct {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;       /* sum of HIP-event durations on the context's stream */
+} fgpu_kernel_time;
+/* Requires FGPU_FLAG_PROFILE.  Returns the number of distinct kernels; fills up to cap entries. */
+int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap);
+int fgpu_kernel_times_reset(fgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAUCET_GPU_H */

@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from faucet_amd import _lib as L
+from faucet_amd import api, synth
+from oracle import pyoracle as po
+from tests.golden_util import CASES, Case, kat
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_run(lines_or_batch, k, tai, nh, j=1, spacer=100):
+    bases, offs = lines_or_batch
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    lst = po.load_two_filters(b1, b2, bases, offs, k)
+    sc = po.Scanner(k, j, spacer, b2)
+    sc.scan_reads(bases, offs, paired_ends=False, no_cleaning=True)
+    return b1, b2, lst, sc
+
+
+def chunks(bases, offs, n_chunks):
+    """split a host batch into n_chunks ReadBatch objects at read boundaries"""
+    n = len(offs) - 1
+    cuts = np.linspace(0, n, n_chunks + 1).astype(int)
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out.append(api.ReadBatch(bases, offs[a:b + 1].copy()))
+    return out
+
+
+def test_library_is_the_hip_one():
+    assert L.load().fgpu_device_count() >= 1
+
+
+@pytest.mark.parametrize("d", kat("hash"), ids=lambda d: f"k{d['k']}")
+def test_hash_kat_on_device(d):
+    k, tai = d["k"], d["tai"]
+    ctx = api.Context(k, tai, 3)
+    kmers = np.array([int(e["fwd"], 16) for e in d["pos"]], dtype=np.uint64)
+    c, a, b = ctx.probe_hash(kmers)
+    assert list(c) == [min(int(e["fwd"], 16), int(e["rc"], 16)) for e in d["pos"]]
+    assert list(a) == [e["hA"] for e in d["pos"]]
+    assert list(b) == [e["hB"] for e in d["pos"]]
+    # the reverse complement hashes to the same canonical values
+    c2, a2, b2 = ctx.probe_hash(np.array([int(e["rc"], 16) for e in d["pos"]], dtype=np.uint64))
+    assert np.array_equal(c, c2) and np.array_equal(a, a2) and np.array_equal(b, b2)
+
+
+def test_hash_random_vs_oracle():
+    rng = np.random.default_rng(3)
+    for k, tai in ((31, 1 << 29), (21, 1 << 19), (5, 1 << 10), (15, 1 << 33)):
+        kmers = rng.integers(0, 1 << (2 * k), size=5000, dtype=np.uint64)
+        ctx = api.Context(k, tai, 3)
+        c, a, b = ctx.probe_hash(kmers)
+        lib = po.lib()
+        for i in range(0, 5000, 7):
+            cc = lib.fo_canon(int(kmers[i]), k)
+            assert int(c[i]) == cc
+            assert int(a[i]) == lib.fo_old_hash(cc, 0, tai) and int(b[i]) == lib.fo_old_hash(cc, 1, tai)
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("n_batches", [1, 3])
+def test_load_matches_reference_bloom(name, n_batches):
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, n_batches))
+    got2 = ctx.bloom_download(L.BLOO2)
+    assert np.array_equal(got2, c.bloom()), "bloo2 differs from the reference's .bloom file"
+    b1, b2, lst, _ = oracle_run((bases, offs), c.k, tai, nh, c.j, c.spacer)
+    assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    assert st["reads_processed"] == c.counters["load_reads_processed"]
+    assert st["unambiguous_reads"] == c.counters["load_unambiguous"]
+    assert st["kmers"] == lst.kmers and st["to_bloo2"] == lst.to_bloo2
+    w = c.counters["weights_after_load"]
+    assert f"{ctx.bloom_weight(L.BLOO1):f}" == w[0] and f"{ctx.bloom_weight(L.BLOO2):f}" == w[1]
+
+
+def _scan_and_compare(c, bases, offs, n_batches, span):
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer, walk_window_span=span)
+    ctx.bloom_upload(L.BLOO2, c.bloom())
+    sc = api.ReadScanner(ctx)
+    st = sc.scanReads(chunks(bases, offs, n_batches))
+    cn = c.counters
+    assert st["n_junctions"] == cn["distinct_junctions"]
+    assert st["nb_jcheck_kmer"] == cn["nb_jcheck_kmer"]
+    assert st["nb_no_juncs"] == cn["nb_no_juncs"]
+    assert st["nb_processed"] == cn["nb_processed"]
+    assert st["nb_skipped"] == cn["nb_skipped"]
+    assert st["reads_no_errors"] == cn["reads_no_errors"]
+    assert st["reads_processed"] == cn["scan_reads_processed"]
+    assert st["unambiguous_reads"] == cn["scan_unambiguous"]
+    keys, recs = sc.junctions()
+    got = api.junction_lines(keys, recs, c.k)
+    assert sorted(got) == sorted(c.junction_lines())
+    # creation order == the oracle's insertion order, so the same container gives the reference's dump order
+    b2 = po.Bloom(tai, nh)
+    b2.set_bits(c.bloom())
+    osc = po.Scanner(c.k, c.j, c.spacer, b2)
+    osc.scan_reads(bases, offs, paired_ends=False, no_cleaning=True)
+    okeys, orecs = osc.junctions("creation")
+    assert np.array_equal(keys, okeys)
+    assert got == po.junction_lines(okeys, orecs, c.k)
+    return st
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("n_batches,span", [(1, 0), (4, 0), (1, 256), (2, 4096), (1, 1 << 20)])
+def test_scan_matches_reference_junctions(name, n_batches, span):
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    _scan_and_compare(c, bases, offs, n_batches, span)
+
+
+def test_load_then_scan_end_to_end_on_device():
+    """bloo2 stays resident between the passes (no upload), as in the CLI."""
+    c = Case("c1_k21")
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh)
+    api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), [api.ReadBatch(bases, offs)])
+    sc = api.ReadScanner(ctx)
+    st = sc.scanReads([api.ReadBatch(bases, offs)])
+    keys, recs = sc.junctions()
+    assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
+    assert st["n_junctions"] == c.counters["distinct_junctions"]
+
+
+def _random_case(n_reads, L_, k, G, err, seed, n_rate=0.0, repeats=0):
+    g = synth.make_genome(G, seed, repeats=repeats, repeat_len=3 * k if repeats else 0)
+    r = synth.make_reads(g, n_reads, L_, err, seed + 1, n_rate=n_rate)
+    return po.reads_from_matrix(r)
+
+
+@pytest.mark.parametrize("n_reads,L_,k,G,err,E,S,j,n_rate,repeats", [
+    (20000, 100, 31, 40000, 0.01, 2_000_000, 400_000, 1, 0.0, 0),
+    (20000, 100, 31, 40000, 0.01, 2_000_000, 400_000, 1, 0.003, 5),
+    (6000, 150, 27, 20000, 0.03, 1_000_000, 500_000, 1, 0.0, 3),      # 2 hash functions, spacer rule reachable
+    (8000, 80, 15, 3000, 0.005, 300_000, 60_000, 0, 0.0, 2),          # tiny genome: heavy clustering
+    (5000, 250, 31, 30000, 0.01, 1_000_000, 200_000, 2, 0.001, 2),    # long reads, j = 2
+])
+def test_random_inputs_vs_oracle(n_reads, L_, k, G, err, E, S, j, n_rate, repeats):
+    bases, offs = _random_case(n_reads, L_, k, G, err, 1234 + n_reads, n_rate, repeats)
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, j, 100)
+    ctx = api.Context(k, tai, nh, j=j)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, 3))
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits())
+    assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    assert st["kmers"] == lst.kmers and st["to_bloo2"] == lst.to_bloo2 and st["unambiguous_reads"] == lst.unambiguous_reads
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, 2))
+    ost = osc.stats()
+    for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors",
+                "unambiguous_reads", "reads_processed"):
+        assert sst[key] == ost[key], key
+    keys, recs = sc.junctions()
+    okeys, orecs = osc.junctions("creation")
+    assert np.array_equal(keys, okeys)
+    assert np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
+    assert np.array_equal(recs["linked"], orecs["linked"])
+
+
+def test_empty_and_degenerate_batches():
+    ctx = api.Context(21, 1 << 19, 3)
+    ctx.load_begin()
+    ctx.load_batch(api.ReadBatch.from_lines([]))
+    ctx.load_batch(api.ReadBatch.from_lines([b"", b"", b"ACGT", b"NNNN"]))
+    st = ctx.load_end()
+    assert st["kmers"] == 0 and st["reads_processed"] == 4 and st["unambiguous_reads"] == 0
+    assert not ctx.bloom_download(L.BLOO2).any() and not ctx.bloom_download(L.BLOO1).any()
+    ctx.scan_begin()
+    ctx.scan_batch(api.ReadBatch.from_lines([b"", b"ACGT"]))
+    s = ctx.scan_end()
+    assert s["n_junctions"] == 0 and s["reads_processed"] == 2
+    keys, recs = ctx.junctions()
+    assert len(keys) == 0
+
+
+def test_state_machine_errors():
+    ctx = api.Context(21, 1 << 19, 3)
+    with pytest.raises(api.FaucetGpuError):
+        ctx.load_batch(api.ReadBatch.from_lines([b"ACGT"]))
+    ctx.load_begin()
+    with pytest.raises(api.FaucetGpuError):
+        ctx.scan_begin()
+    ctx.load_end()
+    with pytest.raises(api.FaucetGpuError):
+        api.Context(32, 1 << 19, 3)
+    with pytest.raises(api.FaucetGpuError):
+        api.Context(21, 1000, 3)
+
+
+def test_two_shard_load_prefix_or_is_exact():
+    """Multi-GPU pass 1 emulated with two contexts on one device: presence bitmaps, exclusive
+    prefix-OR as the carried-in state of the later shard, OR of the shards' bloo2."""
+    c = Case("ragged_k31")
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    parts = chunks(bases, offs, 2)
+    ctxs = [api.Context(c.k, tai, nh) for _ in parts]
+    for ctx, part in zip(ctxs, parts):
+        ctx.presence_batch(part)
+    p0, nbytes = ctxs[0].bloom_devptr(L.BLOO1)
+    p1, _ = ctxs[1].bloom_devptr(L.BLOO1)
+    pres0 = ctxs[0].bloom_download(L.BLOO1)
+    # rank 0 starts from nothing, rank 1 from rank 0's presence bitmap
+    ctxs[0].bloom_upload(L.BLOO1, np.zeros_like(pres0))
+    ctxs[1].bloom_upload(L.BLOO1, pres0)
+    for ctx, part in zip(ctxs, parts):
+        ctx.load_begin(keep_carry=True)
+        ctx.load_batch(part)
+        ctx.load_end()
+    q0, _ = ctxs[0].bloom_devptr(L.BLOO2)
+    q1, _ = ctxs[1].bloom_devptr(L.BLOO2)
+    ctxs[0].synchronize(); ctxs[1].synchronize()
+    ctxs[0].bitmap_or(q0, q1, nbytes)
+    assert np.array_equal(ctxs[0].bloom_download(L.BLOO2), c.bloom())
+
+
+def test_two_shard_scan_table_handover_is_exact():
+    import torch
+    c = Case("c1_k21")
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    parts = chunks(bases, offs, 2)
+    a = api.Context(c.k, tai, nh)
+    b = api.Context(c.k, tai, nh)
+    for ctx in (a, b):
+        ctx.bloom_upload(L.BLOO2, c.bloom())
+    a.scan_begin()
+    a.scan_batch(parts[0])
+    st_a = a.scan_end()
+    n = a.table_entries()
+    buf = torch.empty(max(n, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device="cuda")
+    assert a.export_table(buf.data_ptr(), buf.numel()) == n
+    torch.cuda.synchronize()
+    b.scan_begin()
+    b.import_table(buf.data_ptr(), n, carried=st_a)
+    b.scan_batch(parts[1])
+    st = b.scan_end()
+    cn = c.counters
+    assert st["n_junctions"] == cn["distinct_junctions"] and st["nb_processed"] == cn["nb_processed"]
+    assert st["nb_skipped"] == cn["nb_skipped"] and st["nb_no_juncs"] == cn["nb_no_juncs"]
+    assert st["reads_no_errors"] == cn["reads_no_errors"] and st["nb_jcheck_kmer"] == cn["nb_jcheck_kmer"]
+    keys, recs = b.junctions()
+    assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
