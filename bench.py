@@ -1,0 +1,363 @@
+#!/usr/bin/env python3
+"""bench.py — canonical k-mers/s (load+scan) of the MI355X path on BASELINE.json's config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (Bloom load pass + junction scan pass) over the whole synthetic read set,
+which is resident in HBM before the timed region starts.  N = 1: BASELINE.json configs[1] — 10 M synthetic
+100 bp reads, k = 31, -estimated_kmers 1e8 -singletons 2e7 (64 MiB filters, 3 hash functions).  N > 1: weak
+scaling — every rank holds 10 M reads of an N x 20 Mb genome and the filters are sized for N x 1e8 k-mers; reads
+are sharded in file order, the shards' k-mer presence bitmaps are exchanged for the exclusive prefix-OR, the
+shards' bloo2 are OR-all-reduced (RCCL all-gather + local OR kernel), the pure scan stage runs on every rank
+at once and the ordered junction walk is handed from rank to rank (table export -> send/recv -> import).
+
+The timed region of a step ends when the pass outputs are final in HOST memory: the bloo2 bit array and the
+junction records in creation order.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from faucet_amd import _lib as L  # noqa: E402
+from faucet_amd import api  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "canonical k-mers/s (load+scan) at k=31, 100bp reads; % HBM roofline"
+
+
+# ---------------------------------------------------------------------------------------------- synthetic data
+def make_genome(length, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    return acgt[torch.randint(0, 4, (length,), generator=g, device=device)]
+
+
+def make_reads(genome, n_reads, read_len, err, seed, device, chunk=1_000_000):
+    """(n_reads, read_len) uint8 ASCII in HBM: uniform placement, i.i.d. substitutions, half reverse-complemented
+    (same shape of data as faucet_amd/synth.py, generated on the device)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    G = genome.numel()
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    code[acgt.long()] = torch.arange(4, device=device)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
+    ar = torch.arange(read_len, device=device)
+    for lo in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - lo)
+        starts = torch.randint(0, G - read_len + 1, (n,), generator=g, device=device)
+        r = genome[starts[:, None] + ar[None, :]]
+        if err > 0:
+            m = torch.rand((n, read_len), generator=g, device=device) < err
+            shift = torch.randint(1, 4, (n, read_len), generator=g, device=device)
+            r = torch.where(m, acgt[(code[r.long()] + shift) & 3], r)
+        rc = torch.rand((n,), generator=g, device=device) < 0.5
+        r = torch.where(rc[:, None], comp[r.long()].flip(1), r)
+        out[lo:lo + n] = r
+    return out
+
+
+def device_batches(reads, batch_reads):
+    """ReadBatch views (device pointers) over consecutive row blocks of the read matrix"""
+    n, ln = reads.shape
+    offs = torch.arange(n + 1, dtype=torch.int64, device=reads.device) * ln
+    out = []
+    for lo in range(0, n, batch_reads):
+        hi = min(n, lo + batch_reads)
+        o = offs[lo:hi + 1]
+        out.append(api.ReadBatch(reads.data_ptr(), o.data_ptr(), n_reads=hi - lo, on_device=True, keepalive=(reads, offs, o)))
+    return out
+
+
+class DevView:
+    """zero-copy torch view of device memory owned by libfaucet_gpu (via __cuda_array_interface__)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def dev_tensor(ptr, nbytes, device):
+    return torch.as_tensor(DevView(ptr, nbytes), device=device)
+
+
+# ---------------------------------------------------------------------------------------------- one step
+def step_single(ctx, batches):
+    ctx.load_begin()
+    for b in batches:
+        ctx.load_batch(b)
+    lst = ctx.load_end()
+    bloo2 = ctx.bloom_download(L.BLOO2)             # pass-1 output final in host memory
+    ctx.scan_begin()
+    for b in batches:
+        ctx.scan_batch(b)
+    sst = ctx.scan_end()
+    keys, recs = ctx.junctions()                    # pass-2 output final in host memory (creation order)
+    return lst, sst, bloo2, keys, recs
+
+
+def step_multi(ctx, batches, rank, world, device, scratch):
+    nbytes = ctx.tai // 8
+    p1, _ = ctx.bloom_devptr(L.BLOO1)
+    p2, _ = ctx.bloom_devptr(L.BLOO2)
+    b1 = dev_tensor(p1, nbytes, device)
+    b2 = dev_tensor(p2, nbytes, device)
+    gathered = scratch["gathered"]
+    # presence bitmap of this shard -> exclusive prefix-OR over ranks = carried-in bloo1
+    ctx.load_begin()
+    ctx.load_end()                                  # zeroes both filters
+    for b in batches:
+        ctx.presence_batch(b)
+    ctx.synchronize()
+    dist.all_gather_into_tensor(gathered, b1)
+    b1.zero_()
+    torch.cuda.synchronize()
+    for q in range(rank):
+        ctx.bitmap_or(p1, gathered[q * nbytes:(q + 1) * nbytes].data_ptr(), nbytes)
+    ctx.load_begin(keep_carry=True)
+    for b in batches:
+        ctx.load_batch(b)
+    lst = ctx.load_end()
+    # OR-allreduce of bloo2 (RCCL has no OR op: all-gather + local OR kernel)
+    dist.all_gather_into_tensor(gathered, b2)
+    torch.cuda.synchronize()
+    for q in range(world):
+        if q != rank:
+            ctx.bitmap_or(p2, gathered[q * nbytes:(q + 1) * nbytes].data_ptr(), nbytes)
+    bloo2 = ctx.bloom_download(L.BLOO2) if rank == 0 else None
+    # scan: pure stage everywhere at once, ordered walk handed from rank to rank
+    ctx.scan_begin()
+    for b in batches:
+        ctx.scan_prepare(b)
+    hdr = torch.zeros(16, dtype=torch.int64, device=device)
+    names = [n for n, _ in L.ScanStats._fields_]
+    if rank > 0:
+        dist.recv(hdr, src=rank - 1)
+        h = hdr.cpu().tolist()
+        n_in = h[0]
+        buf = torch.empty(max(n_in, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=device)
+        dist.recv(buf, src=rank - 1)
+        torch.cuda.synchronize()
+        ctx.import_table(buf.data_ptr(), n_in, carried=dict(zip(names, h[1:1 + len(names)])))
+    ctx.scan_walk_prepared()
+    sst = ctx.scan_end()
+    keys = recs = None
+    if rank < world - 1:
+        n_out = ctx.table_entries()
+        buf = torch.empty(max(n_out, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=device)
+        ctx.export_table(buf.data_ptr(), buf.numel())
+        ctx.synchronize()
+        hdr[0] = n_out
+        hdr[1:1 + len(names)] = torch.tensor([sst[n] for n in names], dtype=torch.int64)
+        dist.send(hdr, dst=rank + 1)
+        dist.send(buf, dst=rank + 1)
+    else:
+        keys, recs = ctx.junctions()
+    return lst, sst, bloo2, keys, recs
+
+
+# ---------------------------------------------------------------------------------------------- CPU legs (oracle)
+def cpu_baseline(reads_host, k, tai, nh):
+    """The oracle ("port" of the reference's single-threaded path) timed on this host: load + scan of a bounded
+    sample with the SAME filter size as the GPU run.  Returns (k-mers/s, seconds, n_kmers)."""
+    from oracle import pyoracle as po
+    bases, offs = po.reads_from_matrix(reads_host)
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    t0 = time.perf_counter()
+    lst = po.load_two_filters(b1, b2, bases, offs, k)
+    sc = po.Scanner(k, 1, 100, b2)
+    sc.scan_reads(bases, offs)
+    dt = time.perf_counter() - t0
+    return lst.kmers / dt, dt, int(lst.kmers)
+
+
+def reference_bit_counts(k, read_len, err, coverage, bits_per_kmer_ratio, seed=77):
+    """Bit accesses per k-mer that the REFERENCE semantics perform (early exit and skipping included), counted by
+    the oracle on a scaled-down read set with the bench's coverage, error rate and filter bits per estimated k-mer.
+    Returns dict(T_load, T_valid, T_junc, rho)."""
+    from faucet_amd import synth
+    from oracle import pyoracle as po
+    tai = 1 << 24
+    E = int(tai / bits_per_kmer_ratio)
+    n_reads = int(E * 0.1)                  # bench: 1e7 reads for E = 1e8
+    G = int(n_reads * read_len / coverage)
+    g = synth.make_genome(G, seed)
+    r = synth.make_reads(g, n_reads, read_len, err, seed + 1)
+    bases, offs = po.reads_from_matrix(r)
+    b1, b2 = po.Bloom(tai, 3), po.Bloom(tai, 3)
+    lst = po.load_two_filters(b1, b2, bases, offs, k)
+    b2.reset_counters()
+    sc = po.Scanner(k, 1, 100, b2)
+    sc.scan_reads(bases, offs)
+    tests, _ = b2.counters()
+    tv = sc.bit_tests_valid()
+    n = lst.kmers
+    rho = lst.to_bloo2 / n
+    return {"T_load": 3 + 3 * rho, "T_valid": tv / n, "T_junc": (tests - tv) / n, "rho": rho, "sample_reads": n_reads, "sample_genome": G}
+
+
+# ---------------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--genome", type=int, default=20_000_000, help="genome bases per GPU")
+    ap.add_argument("--estimated-kmers", type=int, default=100_000_000, help="per GPU")
+    ap.add_argument("--singletons", type=int, default=20_000_000, help="per GPU")
+    ap.add_argument("--err", type=float, default=0.01)
+    ap.add_argument("--batch-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (cpu_baseline and reference bit counts)")
+    ap.add_argument("--profile-walk", action="store_true", help="time the per-window walk kernels individually")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch sees no GPU (there is no CPU fallback)")
+    if args.profile_walk:
+        os.environ["FGPU_PROFILE_WALK"] = "1"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    k, L_ = args.k, args.read_len
+    E, S = args.estimated_kmers * world, args.singletons * world
+    tai, nh = api.load_filter_shape(E, S)
+    genome = make_genome(args.genome * world, 2, device)
+    reads = make_reads(genome, args.reads, L_, args.err, 1000 + rank, device)
+    del genome
+    batches = device_batches(reads, args.batch_reads)
+    torch.cuda.synchronize()
+
+    ctx = api.Context(k, tai, nh, device=local_rank, profile=True)
+    scratch = {}
+    if world > 1:
+        scratch["gathered"] = torch.empty(world * (tai // 8), dtype=torch.uint8, device=device)
+
+    def one_step():
+        if world == 1:
+            return step_single(ctx, batches)
+        return step_multi(ctx, batches, rank, world, device, scratch)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    ctx.kernel_times_reset()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lst, sst, bloo2, keys, recs = out
+    kmers_local = lst["kmers"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        kk = torch.tensor([kmers_local], dtype=torch.int64, device=device)
+        dist.all_reduce(kk, op=dist.ReduceOp.SUM)
+        kmers_total = int(kk.item())
+    else:
+        kmers_total = kmers_local
+    ktimes = ctx.kernel_times()
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = kmers_total * args.steps / elapsed
+    res = {
+        "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{args.reads * world} synthetic {L_} bp reads ({args.reads} per GPU), k={k}, "
+                               f"estimated_kmers={E}, singletons={S}, genome {args.genome * world} bp, {args.err:.0%} substitutions; "
+                               f"filters 2 x {tai // 8 >> 20} MiB, {nh} hash functions",
+                   "reads_per_gpu": args.reads, "read_len": L_, "k": k, "tai": tai, "n_hash": nh, "batch_reads": args.batch_reads,
+                   "sharding": "reads in file order; prefix-OR(bloo1 presence) + OR-allreduce(bloo2); walk handed rank to rank" if world > 1 else "single GPU"},
+        "kmers_per_step": kmers_total,
+        "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
+                    "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
+                    "walk_max_cluster_rank0": int(sst["walk_max_cluster"])},
+        "kernel_ms_per_step_rank0": {n: round(ms / args.steps, 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
+    }
+
+    # ---- roofline of the dominant kernel, from HIP events recorded on the context's stream inside the timed region
+    T = None
+    if not args.no_cpu:
+        T = reference_bit_counts(k, L_, args.err, args.reads * L_ / args.genome, tai / E)
+    heavy = {n: v for n, v in ktimes.items() if n in ("pack", "load_mark", "load_resolve", "scan_valid", "scan_flags", "walk_stage")}
+    if heavy:
+        name = max(heavy, key=lambda n: heavy[n][1])
+        launches, total_ms = heavy[name]
+        kmers_per_launch = kmers_local * args.steps * (2 if name == "pack" else 1) / launches
+        base_bytes = L_ / (L_ - k + 1)
+        rho = lst["to_bloo2"] / max(kmers_local, 1)
+        per_kmer = {
+            "pack": base_bytes,                                  # each base read once per pass (1 B/base in HBM)
+            "load_mark": 64.0 * nh,                              # test-and-set of n_hash bits of bloo1
+            "load_resolve": 64.0 * nh * rho,                     # sets on bloo2 (rho = occurrences routed to bloo2 / N)
+            "scan_valid": 64.0 * (T["T_valid"] if T else nh),    # validity bit tests the reference performs (early exit)
+            "scan_flags": 64.0 * (T["T_junc"] if T else 0.0),    # alternate-extension + jcheck bit tests WITH the reference's skipping
+            "walk_stage": 0.0,
+        }[name]
+        avg_ms = total_ms / launches
+        achieved = per_kmer * kmers_per_launch / (avg_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                           "algorithmic_bytes_per_kmer": per_kmer, "kmers_per_launch": kmers_per_launch}
+    if T:
+        ab64 = 2 * L_ / (L_ - k + 1) + 64.0 * (T["T_load"] + T["T_valid"] + T["T_junc"])
+        res["pipeline_ab64"] = {"bytes_per_kmer": ab64, "achieved_GBps": ab64 * value / 1e9, "frac_of_hbm_peak": ab64 * value / 1e9 / HBM_PEAK_GBPS,
+                                "T_load": T["T_load"], "T_valid": T["T_valid"], "T_junc": T["T_junc"], "rho_sample": T["rho"],
+                                "rho_gpu_run": lst["to_bloo2"] / max(kmers_local, 1),
+                                "counted_on": f"oracle, {T['sample_reads']} reads of a {T['sample_genome']} bp genome (same coverage, error rate, bits per estimated k-mer)"}
+
+    # ---- CPU baseline beside it (N = 1 only): the oracle on this host's cores, 1 thread like the reference
+    if world == 1 and not args.no_cpu:
+        n_s = min(args.cpu_sample_reads, args.reads)
+        v, dt, nk = cpu_baseline(reads[:n_s].cpu().numpy(), k, tai, nh)
+        res["cpu_baseline"] = {"value": v, "unit": "k-mers/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n_s} of the {args.reads} reads ({nk} k-mers), same 2 x {tai // 8 >> 20} MiB filters; "
+                                         f"load+scan took {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+    print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

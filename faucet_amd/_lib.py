@@ -71,6 +71,8 @@ SIGNATURES = {
     "fgpu_bitmap_or": (C.c_int, [_vp, _vp, _vp, _u64]),
     "fgpu_scan_begin": (C.c_int, [_vp]),
     "fgpu_scan_batch": (C.c_int, [_vp, _P(Reads)]),
+    "fgpu_scan_prepare": (C.c_int, [_vp, _P(Reads)]),
+    "fgpu_scan_walk_prepared": (C.c_int, [_vp]),
     "fgpu_scan_end": (C.c_int, [_vp, _P(ScanStats)]),
     "fgpu_scan_junction_count": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_scan_download_junctions": (C.c_int, [_vp, _vp, _vp, _u64, _P(_u64)]),
@@ -94,6 +96,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m faucet_amd.build` (hipcc, gfx950). "
                            "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7.  If torch is going to be used in this
+    # process (bench.py, torch.distributed) it must be loaded FIRST so that our NEEDED libamdhip64.so.7 binds to
+    # the copy already mapped; two runtimes in one process leave the second one without a device.
+    if os.environ.get("FAUCET_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

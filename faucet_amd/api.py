@@ -166,6 +166,13 @@ class Context:
         s = batch.c_struct()
         self._c(self.lib.fgpu_scan_batch(self.h, C.byref(s)))
 
+    def scan_prepare(self, batch: ReadBatch):
+        s = batch.c_struct()
+        self._c(self.lib.fgpu_scan_prepare(self.h, C.byref(s)))
+
+    def scan_walk_prepared(self):
+        self._c(self.lib.fgpu_scan_walk_prepared(self.h))
+
     def scan_end(self) -> dict:
         st = L.ScanStats()
         self._c(self.lib.fgpu_scan_end(self.h, C.byref(st)))

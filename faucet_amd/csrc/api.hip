@@ -37,7 +37,7 @@ int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes) {
 }
 
 int fgpu_prof_begin(fgpu_ctx* ctx, const char* name) {
-    if (!ctx->profile) return -1;
+    if (!ctx->profile || ctx->prof_suppress) return -1;
     int idx = -1;
     for (size_t i = 0; i < ctx->kstats.size(); i++)
         if (ctx->kstats[i].name == name) { idx = (int)i; break; }
@@ -143,6 +143,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     ctx->fd.kmask = (1ULL << (2 * p->k)) - 1;
     ctx->fd.tai_mask = p->tai - 1;
     ctx->profile = (p->flags & FGPU_FLAG_PROFILE) != 0;
+    { const char* e = getenv("FGPU_PROFILE_WALK"); ctx->prof_walk_detail = e && e[0] == '1'; }
     ctx->bloom_bytes = p->tai / 8;
     memset(&ctx->load_stats, 0, sizeof(ctx->load_stats));
     memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
@@ -189,6 +190,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    for (BatchBufs* b : ctx->all_batches) delete b;
     delete ctx;
 }
 
@@ -322,36 +324,86 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
                                                  : (1ULL << 17);
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
+    ctx->walked_pieces = 0;
+    for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
+    ctx->prepared.clear();
+    ctx->cur = &ctx->bb_default;
     ctx->phase = 2;
     return FGPU_OK;
+}
+
+// Adapt the scheduling window to the data: keep the share of pieces that had to queue behind an earlier piece of
+// their cluster small.  counters_host must be fresh with respect to the walks issued so far.
+static void adapt_window(fgpu_ctx* ctx) {
+    const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
+    const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
+    if (p > 0 && !ctx->prm.walk_window_span) {
+        if (f * 8 > p && ctx->window_span > 4096) ctx->window_span /= 2;
+        else if (f * 64 < p && ctx->window_span < FGPU_MAX_SPAN / 2) ctx->window_span *= 2;
+    }
+    ctx->adapt_followers = ctx->counters_host->followers;
+    ctx->adapt_pieces = ctx->walked_pieces;
+}
+
+static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
+    ctx->cur = b;
+    int rc = fgpu_stage_pack(ctx, reads);
+    uint64_t n_pieces = 0;
+    if (!rc) rc = fgpu_stage_scan_pure(ctx, &n_pieces);   // ends with the batch's only synchronisation (piece count)
+    if (!rc) rc = check_errors(ctx);
+    if (!rc) ctx->scan_stats.reads_processed += reads->n_reads;
+    return rc;
 }
 
 int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_batch outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    if (!ctx->prepared.empty()) { ctx->err = "scan_batch while prepared batches are waiting: call fgpu_scan_walk_prepared first"; return FGPU_ERR_STATE; }
     int rc = check_reads(ctx, reads);
     if (rc) return rc;
     FGPU_HIP(hipSetDevice(ctx->prm.device));
-    if ((rc = fgpu_stage_pack(ctx, reads))) return rc;
-    uint64_t n_pieces = 0;
-    if ((rc = fgpu_stage_scan_pure(ctx, &n_pieces))) return rc;
-    if ((rc = check_errors(ctx))) return rc;
-    // adapt the scheduling window to the data: keep the share of pieces that had to queue behind an earlier
-    // piece of their cluster small (the counters were just pulled by the pure stage's only synchronisation)
-    {
-        const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
-        const uint64_t p = ctx->scan_pieces_seen - n_pieces - ctx->adapt_pieces;
-        if (p > 0 && !ctx->prm.walk_window_span) {
-            if (f * 8 > p && ctx->window_span > 4096) ctx->window_span /= 2;
-            else if (f * 64 < p && ctx->window_span < FGPU_MAX_SPAN / 2) ctx->window_span *= 2;
-        }
-        ctx->adapt_followers = ctx->counters_host->followers;
-        ctx->adapt_pieces = ctx->scan_pieces_seen - n_pieces;
-    }
-    if ((rc = fgpu_stage_scan_walk(ctx, n_pieces))) return rc;
-    ctx->scan_stats.reads_processed += reads->n_reads;
-    if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = scan_pure_into(ctx, &ctx->bb_default, reads))) return rc;
+    adapt_window(ctx);   // the pure stage's synchronisation just refreshed the counters
+    if ((rc = fgpu_stage_scan_walk(ctx, ctx->cur->n_pieces))) return rc;
+    ctx->walked_pieces += ctx->cur->n_pieces;
     return FGPU_OK;
+}
+
+int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "scan_prepare outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    int rc = check_reads(ctx, reads);
+    if (rc) return rc;
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    BatchBufs* b;
+    if (!ctx->pool.empty()) { b = ctx->pool.back(); ctx->pool.pop_back(); }
+    else { b = new BatchBufs(); ctx->all_batches.push_back(b); }
+    rc = scan_pure_into(ctx, b, reads);
+    ctx->cur = &ctx->bb_default;
+    if (rc) { ctx->pool.push_back(b); return rc; }
+    ctx->prepared.push_back(b);
+    return FGPU_OK;
+}
+
+int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "scan_walk_prepared outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    int rc = FGPU_OK;
+    for (size_t i = 0; i < ctx->prepared.size() && !rc; i++) {
+        BatchBufs* b = ctx->prepared[i];
+        if (i > 0 && !ctx->prm.walk_window_span) {   // feedback for the window controller between batches
+            if ((rc = pull_counters(ctx))) break;
+            adapt_window(ctx);
+        }
+        ctx->cur = b;
+        rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
+        ctx->walked_pieces += b->n_pieces;
+    }
+    ctx->cur = &ctx->bb_default;
+    for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
+    ctx->prepared.clear();
+    return rc;
 }
 
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {

@@ -35,6 +35,8 @@ struct BatchBufs {
     uint64_t T = 0;                // stream length = bases + n_reads
     uint64_t n_words = 0;          // ceil(T / 64)
     uint64_t n_reads = 0;
+    uint64_t n_pieces = 0;         // valid pieces found by the pure scan stage
+    uint64_t max_piece_span = 0;   // longest read (+64): how far a piece may reach past its scheduling window
 };
 
 struct KernelStat {
@@ -103,7 +105,6 @@ struct fgpu_ctx {
     uint32_t* cl_members = nullptr;
     void* wdesc = nullptr;           // device WinDesc of the window in flight
     uint64_t window_span = 1ULL << 17;   // adaptive: stream positions per scheduling window
-    uint64_t max_piece_span = 0;     // longest read of the current batch (+k): how far a piece may reach past its window
     uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
     uint64_t scan_imported = 0;      // junction records imported from a previous shard
 
@@ -118,12 +119,19 @@ struct fgpu_ctx {
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
     fgpu_scan_stats carried = {};    // counters handed over by the previous shard (multi-GPU)
 
-    BatchBufs bb;
+    BatchBufs bb_default;                 // the batch of load_batch / scan_batch
+    BatchBufs* cur = &bb_default;         // batch the stages work on
+    std::vector<BatchBufs*> prepared;     // scan_prepare'd batches waiting for the ordered walk, in file order
+    std::vector<BatchBufs*> pool;         // recycled BatchBufs (device buffers kept)
+    std::vector<BatchBufs*> all_batches;  // every heap BatchBufs, for destruction
+    uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;
     std::vector<DevBuf*> owned;
 
     // profiling
     bool profile = false;
+    bool prof_suppress = false;      // inside a grouped region (one event pair around many small launches)
+    bool prof_walk_detail = false;   // FGPU_PROFILE_WALK=1: time the per-window walk kernels individually
     std::vector<KernelStat> kstats;
     std::vector<PendingEvent> pending_events;
 };

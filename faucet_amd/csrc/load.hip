@@ -176,7 +176,7 @@ __global__ void k_probe_contains(const uint32_t* __restrict__ bloom, const uint6
 }  // namespace
 
 int fgpu_stage_load(fgpu_ctx* ctx) {
-    BatchBufs& bb = ctx->bb;
+    BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
     int rc = fgpu_ensure(ctx, &bb.pending, (bb.n_words + FGPU_PADW) * 8);
     if (rc) return rc;
@@ -194,7 +194,7 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
 }
 
 int fgpu_stage_presence(fgpu_ctx* ctx) {
-    BatchBufs& bb = ctx->bb;
+    BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
     const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
     int rc;
@@ -206,7 +206,7 @@ int fgpu_stage_presence(fgpu_ctx* ctx) {
 
 // ---- small utilities used by api.hip and scan_pure.hip --------------------------------------------
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen) {
-    BatchBufs& bb = ctx->bb;
+    BatchBufs& bb = *ctx->cur;
     FGPU_LAUNCH("count_segments", k_count_segments, fgpu_blocks(bb.n_words * 64, 256), 256, (const uint64_t*)bb.bad.p, bb.T, minlen,
                 &ctx->counters->segments);
     return FGPU_OK;

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restric
 }  // namespace
 
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
-    BatchBufs& bb = ctx->bb;
+    BatchBufs& bb = *ctx->cur;
     const uint64_t n = reads->n_reads;
     const unsigned char* d_bases;
     const uint64_t* d_offs;

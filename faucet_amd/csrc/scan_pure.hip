@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
 }  // namespace
 
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
-    BatchBufs& bb = ctx->bb;
+    BatchBufs& bb = *ctx->cur;
     *n_pieces = 0;
     if (bb.T == 0) return FGPU_OK;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
@@ -261,10 +261,11 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     FGPU_LAUNCH("prefix_apply", k_prefix_apply, fgpu_blocks(nw1, 256), 256, prefix, (const uint32_t*)block_sums, nw1);
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->max_piece_span = ctx->counters_host->max_read_len + 64;
+    bb.max_piece_span = ctx->counters_host->max_read_len + 64;
     const uint64_t np = ctx->counters_host->pieces - ctx->scan_pieces_seen;
     ctx->scan_pieces_seen = ctx->counters_host->pieces;
     *n_pieces = np;
+    bb.n_pieces = np;
     if ((rc = fgpu_ensure(ctx, &bb.pieces, (np + 1) * sizeof(uint2)))) return rc;
     if (np) {
         FGPU_LAUNCH("piece_list", k_scan_piece_list, grid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,

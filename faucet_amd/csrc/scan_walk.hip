@@ -682,17 +682,20 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
 // ctx->window_span stream positions).  No host round trip: window extents are derived on the device.
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     if (!n_pieces) return FGPU_OK;
-    BatchBufs& bb = ctx->bb;
+    BatchBufs& bb = *ctx->cur;
     Planes pl{(const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.ps.p, (const uint32_t*)bb.ps_prefix.p,
               (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p, (const uint64_t*)bb.cf0.p, (const uint64_t*)bb.cf1.p,
               (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p};
     JTable jt = make_jt(ctx);
     WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;
-    const uint64_t ext = ctx->max_piece_span;          // a piece that starts inside the window may reach this far beyond it
+    const uint64_t ext = bb.max_piece_span;          // a piece that starts inside the window may reach this far beyond it
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
     const unsigned walk_grid = fgpu_blocks(ctx->wmax, 64);
+    // thousands of tiny launches: by default one event pair around the whole stage
+    const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
+    ctx->prof_suppress = !ctx->prof_walk_detail;
     for (uint64_t lo = 0; lo < T; lo += span) {
         const uint64_t hi = std::min<uint64_t>(T, lo + span);
         const uint64_t pos_end = std::min<uint64_t>(T, hi + ext);
@@ -709,6 +712,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk_zero", k_zero_wt_used, 1, 1, ctx->counters);
         ctx->scan_windows++;
     }
+    ctx->prof_suppress = false;
+    fgpu_prof_end(ctx, stage_tok);
     ctx->scan_piece_base += n_pieces;
     return FGPU_OK;
 }

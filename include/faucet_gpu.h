@@ -143,6 +143,12 @@ int fgpu_bitmap_or(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t n
 int fgpu_scan_begin(fgpu_ctx* ctx);
 /* Pure stage + ordered walk for one batch, in file order. */
 int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
+/* The same in two steps, so that read shards can do the pure part concurrently and only the
+ * ordered walk is serial: scan_prepare runs the pure stage and keeps its bit planes resident
+ * (about 1.6 bytes of HBM per base); scan_walk_prepared walks every prepared batch in the order
+ * they were prepared.  scan_batch(b) == scan_prepare(b); scan_walk_prepared(). */
+int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads);
+int fgpu_scan_walk_prepared(fgpu_ctx* ctx);
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
 /* Junction map after the scan, in CREATION order (inserting the records in this order into a
  * std::unordered_map<kmer_type,Junction> reproduces the reference's dump order,

@@ -194,6 +194,7 @@ struct fo_scanner {
     fo_scan_stats st;
     bool first_end = true;
     std::list<uint64_t> back1, back2;
+    uint64_t bit_tests_valid = 0;   /* bit tests spent inside getValidReads (the rest of bloom->n_tests is junction probing) */
 
     Junction* find(uint64_t key) {
         auto it = map.find(key);
@@ -352,7 +353,9 @@ struct fo_scanner {
         for (const Seg& sg : segs) {
             if (sg.len >= static_cast<uint64_t>(k + 2 * j + 1)) {
                 st.unambiguous_reads++;
+                const uint64_t tests_before = bloom->n_tests;
                 valid_pieces(line + sg.start, static_cast<int>(sg.len), pieces);
+                bit_tests_valid += bloom->n_tests - tests_before;
                 for (const Seg& p : pieces) {
                     std::list<uint64_t> r = scan_forward(line + sg.start + p.start, static_cast<int>(p.len), no_cleaning);
                     result.splice(result.end(), r);
@@ -622,6 +625,7 @@ uint64_t fo_scan_get_junctions(const fo_scanner* s, int order, uint64_t* keys, f
     }
     return s->map.size();
 }
+uint64_t fo_scan_bit_tests_valid(const fo_scanner* s) { return s->bit_tests_valid; }
 int fo_scan_write_junctions(const fo_scanner* s, const char* path) {                 /* JunctionMap.cpp:579-596, Junction.cpp:74-89 */
     FILE* f = fopen(path, "wb");
     if (!f) return -1;

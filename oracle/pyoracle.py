@@ -74,6 +74,7 @@ def lib():
         "fo_scan_get_stats": (None, [vp, C.POINTER(ScanStats)]),
         "fo_scan_get_junctions": (u64, [vp, i32, vp, vp, u64]),
         "fo_scan_write_junctions": (i32, [vp, cp]),
+        "fo_scan_bit_tests_valid": (u64, [vp]),
         "fo_get_valid_reads": (u64, [vp, cp, u64, vp, u64]),
         "fo_test_for_junction": (i32, [vp, cp, u64, i32, C.POINTER(i32)]),
     }
@@ -221,6 +222,9 @@ class Scanner:
         recs = np.zeros(n, dtype=JUNC_DTYPE)
         lib().fo_scan_get_junctions(self.h, 0 if order == "map" else 1, _p(keys), _p(recs), n)
         return keys, recs
+
+    def bit_tests_valid(self) -> int:
+        return int(lib().fo_scan_bit_tests_valid(self.h))
 
     def write_junctions(self, path: str):
         if lib().fo_scan_write_junctions(self.h, path.encode()) != 0:

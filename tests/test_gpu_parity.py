@@ -117,6 +117,26 @@ def test_scan_matches_reference_junctions(name, n_batches, span):
     _scan_and_compare(c, bases, offs, n_batches, span)
 
 
+@pytest.mark.parametrize("name", ["ragged_k31", "twohash_k31_L150"])
+def test_scan_prepare_then_walk_equals_scan_batch(name):
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer)
+    ctx.bloom_upload(L.BLOO2, c.bloom())
+    ctx.scan_begin()
+    for part in chunks(bases, offs, 3):
+        ctx.scan_prepare(part)
+    ctx.scan_walk_prepared()
+    st = ctx.scan_end()
+    cn = c.counters
+    assert st["n_junctions"] == cn["distinct_junctions"] and st["nb_processed"] == cn["nb_processed"]
+    assert st["nb_skipped"] == cn["nb_skipped"] and st["nb_jcheck_kmer"] == cn["nb_jcheck_kmer"]
+    assert st["reads_processed"] == cn["scan_reads_processed"]
+    keys, recs = ctx.junctions()
+    assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
+
+
 def test_load_then_scan_end_to_end_on_device():
     """bloo2 stays resident between the passes (no upload), as in the CLI."""
     c = Case("c1_k21")
