@@ -321,7 +321,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_piece_base = 0;
     ctx->scan_imported = 0;
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), FGPU_MAX_SPAN)
-                                                 : (1ULL << 17);
+                                                 : (1ULL << 19);
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
     ctx->walked_pieces = 0;
@@ -339,7 +339,7 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
         if (f * 8 > p && ctx->window_span > 4096) ctx->window_span /= 2;
-        else if (f * 64 < p && ctx->window_span < FGPU_MAX_SPAN / 2) ctx->window_span *= 2;
+        else if (f * 64 < p && ctx->window_span < FGPU_MAX_SPAN) ctx->window_span *= 2;
     }
     ctx->adapt_followers = ctx->counters_host->followers;
     ctx->adapt_pieces = ctx->walked_pieces;

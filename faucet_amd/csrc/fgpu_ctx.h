@@ -68,6 +68,8 @@ struct DevCounters {
     unsigned long long max_read_len;    // longest read of the batches packed so far (bounds how far a piece reaches)
     unsigned long long wt_used;         // slots claimed in the window table during the current window
     unsigned long long pad;
+    unsigned long long wt_used_b;       // second "slots claimed" counter: consecutive windows alternate
+    unsigned long long pad2;
 };
 
 struct fgpu_ctx {
@@ -162,6 +164,12 @@ int fgpu_prof_collect(fgpu_ctx* ctx);
     } while (0)
 
 static inline unsigned fgpu_blocks(uint64_t n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+// grid of a grid-stride kernel: enough blocks to fill 256 CUs at full occupancy, never more than the work needs
+#define FGPU_GRID_BLOCKS 4096u
+static inline unsigned fgpu_grid(uint64_t n, unsigned per_block) {
+    uint64_t b = (n + per_block - 1) / per_block;
+    return (unsigned)(b < FGPU_GRID_BLOCKS ? (b ? b : 1) : FGPU_GRID_BLOCKS);
+}
 
 // stage entry points implemented in the .hip files
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);

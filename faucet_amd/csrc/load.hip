@@ -18,119 +18,131 @@
 // t is the stream position (pack.hip makes position order == processing order); times are batch-local
 // because a bit that is still 0 in the carry has first[bit] == 0xFFFFFFFF at batch start.
 //
+// Launch shape: a fixed grid of FGPU_GRID_BLOCKS x 256 threads strides over the stream, lanes = consecutive
+// positions (so every per-position plane is written as one 8-byte ballot word per wave) and counters are
+// kept in registers until the wave retires: one atomic per wave per kernel instead of one per 64 positions
+// (same-address atomics serialise at ~10 ns each; 16 M of them per 10^9 positions cost more than the probes).
+//
 // Roofline: HBM/Infinity-Cache random access.  Algorithmic bytes per k-mer:
 //   L/(L-k+1) bytes of bases + 64 B * n_hash (test-and-set on bloo1) + 64 B * rho * n_hash (set on bloo2).
 #include "fgpu_ctx.h"
 
 namespace {
 
-// lanes = consecutive stream positions; one wave covers one 64-position word of every plane
-__global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                   uint64_t T, FdParams fp, const uint32_t* __restrict__ carry,
-                                                   uint32_t* carry_next, uint32_t* bloo2, uint32_t* first,
-                                                   uint64_t* __restrict__ pending, DevCounters* cnt) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = p < T && fd_window_ok(bad, p, fp.k);
-    bool pend = false, hit = false;
-    if (ok) {
-        uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
-        uint64_t hA, hB;
-        fd_hash_pair(canon, fp.tai_mask, hA, hB);
-        // gather the carried-in bits of all n_hash positions first (independent loads in flight)
-        uint32_t missing = 0;
-        uint64_t h = hA;
-        for (int i = 0; i < fp.n_hash; i++) {
-            if (!((carry[h >> 5] >> (h & 31)) & 1u)) missing |= 1u << i;
-            h = (h + hB) & fp.tai_mask;
-        }
-        if (!missing) {
-            hit = true;
-            fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
-        } else {
-            pend = true;
-            h = hA;
-            for (int i = 0; i < fp.n_hash; i++) {
-                if (missing & (1u << i)) {
-                    atomicMin(&first[h], (uint32_t)p);
-                    uint32_t bit = 1u << (h & 31);
-                    if (!(carry_next[h >> 5] & bit)) atomicOr(&carry_next[h >> 5], bit);
-                }
-                h = (h + hB) & fp.tai_mask;
-            }
-        }
-    }
-    uint64_t pm = __ballot(pend);
-    uint64_t okm = __ballot(ok);
-    uint64_t hm = __ballot(hit);
-    if (fd_lane() == 0) {
-        if (p < ((T + 63) & ~63ULL)) pending[p >> 6] = pm;
-        if (okm) atomicAdd(&cnt->kmers, (unsigned long long)__popcll(okm));
-        if (hm) atomicAdd(&cnt->to_bloo2, (unsigned long long)__popcll(hm));
-    }
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (fd_lane() == 0 && v) atomicAdd(dst, v);
 }
 
-__global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, FdParams fp,
+__global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
+                                                   uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ carry,
+                                                   uint32_t* carry_next, uint32_t* bloo2, uint32_t* first,
+                                                   uint64_t* __restrict__ pending, DevCounters* cnt) {
+    unsigned long long n_ok = 0, n_hit = 0;
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool ok = p < T && fd_window_ok(bad, p, fp.k);
+        bool pend = false;
+        if (ok) {
+            n_ok++;
+            uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
+            uint64_t hA, hB;
+            fd_hash_pair(canon, fp.tai_mask, hA, hB);
+            // gather the carried-in bits of all n_hash positions first (independent loads in flight)
+            uint32_t missing = 0;
+            uint64_t h = hA;
+            for (int i = 0; i < fp.n_hash; i++) {
+                if (!((carry[h >> 5] >> (h & 31)) & 1u)) missing |= 1u << i;
+                h = (h + hB) & fp.tai_mask;
+            }
+            if (!missing) {
+                n_hit++;
+                fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+            } else {
+                pend = true;
+                h = hA;
+                for (int i = 0; i < fp.n_hash; i++) {
+                    if (missing & (1u << i)) {
+                        atomicMin(&first[h], (uint32_t)p);
+                        uint32_t bit = 1u << (h & 31);
+                        if (!(carry_next[h >> 5] & bit)) atomicOr(&carry_next[h >> 5], bit);
+                    }
+                    h = (h + hB) & fp.tai_mask;
+                }
+            }
+        }
+        uint64_t pm = __ballot(pend);
+        if (fd_lane() == 0) pending[p >> 6] = pm;
+    }
+    wave_add(&cnt->kmers, n_ok);
+    wave_add(&cnt->to_bloo2, n_hit);
+}
+
+__global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
                                                       const uint32_t* __restrict__ carry, uint32_t* bloo2,
                                                       const uint32_t* __restrict__ first,
                                                       const uint64_t* __restrict__ pending, DevCounters* cnt) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pass = false;
-    if (p < T && ((pending[p >> 6] >> (p & 63)) & 1ULL)) {
+    unsigned long long n_pass = 0;
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        if (!((pending[p >> 6] >> (p & 63)) & 1ULL)) continue;
         uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
         uint64_t hA, hB;
         fd_hash_pair(canon, fp.tai_mask, hA, hB);
-        pass = true;
+        bool pass = true;
         uint64_t h = hA;
         for (int i = 0; i < fp.n_hash; i++) {
             bool before = ((carry[h >> 5] >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
             if (!before) { pass = false; break; }
             h = (h + hB) & fp.tai_mask;
         }
-        if (pass) fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+        if (pass) {
+            n_pass++;
+            fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+        }
     }
-    uint64_t m = __ballot(pass);
-    if (fd_lane() == 0 && m) atomicAdd(&cnt->to_bloo2, (unsigned long long)__popcll(m));
+    wave_add(&cnt->to_bloo2, n_pass);
 }
 
 // multi-GPU helper: OR the bits of every k-mer into a bitmap, no ordering
 __global__ void __launch_bounds__(256) k_presence(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                  uint64_t T, FdParams fp, uint32_t* bitmap, DevCounters* cnt) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = p < T && fd_window_ok(bad, p, fp.k);
-    if (ok) {
+                                                  uint64_t T, uint64_t n_words, FdParams fp, uint32_t* bitmap, DevCounters* cnt) {
+    unsigned long long n_ok = 0;
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        if (!(p < T && fd_window_ok(bad, p, fp.k))) continue;
+        n_ok++;
         uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
         uint64_t hA, hB;
         fd_hash_pair(canon, fp.tai_mask, hA, hB);
         fd_bloom_set(bitmap, hA, hB, fp.tai_mask, fp.n_hash);
     }
-    uint64_t okm = __ballot(ok);
-    if (fd_lane() == 0 && okm) atomicAdd(&cnt->kmers, (unsigned long long)__popcll(okm));
+    wave_add(&cnt->kmers, n_ok);
 }
 
-// unambiguous segments of length >= minlen (utils/Kmer.cpp:77; ReadScanner.cpp:268): one count per
-// segment start whose run of good positions is long enough
-__global__ void __launch_bounds__(256) k_count_segments(const uint64_t* __restrict__ bad, uint64_t T, int minlen,
+// unambiguous segments of length >= minlen (utils/Kmer.cpp:77; ReadScanner.cpp:268).  One thread per 64-position
+// word of the bad mask: run starts are found with bit arithmetic, each start measures its run.
+__global__ void __launch_bounds__(256) k_count_segments(const uint64_t* __restrict__ bad, uint64_t n_words, int minlen,
                                                         unsigned long long* out) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool counted = false;
-    if (p < T) {
-        bool isbad = (bad[p >> 6] >> (p & 63)) & 1ULL;
-        bool prevbad = p == 0 ? true : ((bad[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ULL);
-        if (!isbad && prevbad) {
-            // length of the good run starting at p (bad padding past T terminates the scan)
-            uint64_t q = p;
+    unsigned long long n = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t good = ~bad[w];
+        uint64_t prev_good = w ? (~bad[w - 1]) >> 63 : 0;
+        uint64_t starts = good & ~((good << 1) | prev_good);
+        while (starts) {
+            int s = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            uint64_t p = w * 64 + s;
             int len = 0;
-            while (len < minlen) {
-                uint64_t v = fd_bits_at(bad, q);
+            while (len < minlen) {   // bad padding past the end terminates the scan
+                uint64_t v = fd_bits_at(bad, p + len);
                 if (v) { len += __builtin_ctzll(v); break; }
                 len += 64;
-                q += 64;
             }
-            counted = len >= minlen;
+            if (len >= minlen) n++;
         }
     }
-    uint64_t m = __ballot(counted);
-    if (fd_lane() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+    wave_add(out, n);
 }
 
 __global__ void __launch_bounds__(256) k_popcount(const uint4* __restrict__ words, uint64_t n16, unsigned long long* out) {
@@ -141,8 +153,7 @@ __global__ void __launch_bounds__(256) k_popcount(const uint4* __restrict__ word
         uint4 v = words[i];
         acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (fd_lane() == 0 && acc) atomicAdd(out, acc);
+    wave_add(out, acc);
 }
 
 __global__ void __launch_bounds__(256) k_bitmap_or(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t n16) {
@@ -180,12 +191,12 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     if (bb.T == 0) return FGPU_OK;
     int rc = fgpu_ensure(ctx, &bb.pending, (bb.n_words + FGPU_PADW) * 8);
     if (rc) return rc;
-    const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
+    const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
-    FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd,
+    FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
                 (const uint32_t*)ctx->bloo1, ctx->bloo1_new, ctx->bloo2, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
-    FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, ctx->fd, (const uint32_t*)ctx->bloo1,
-                ctx->bloo2, (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
+    FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd,
+                (const uint32_t*)ctx->bloo1, ctx->bloo2, (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
     int tok = fgpu_prof_begin(ctx, "carry_copy");
     hipError_t e = hipMemcpyAsync(ctx->bloo1, ctx->bloo1_new, ctx->bloom_bytes, hipMemcpyDeviceToDevice, ctx->stream);
     fgpu_prof_end(ctx, tok);
@@ -196,18 +207,17 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
 int fgpu_stage_presence(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
-    const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
     int rc;
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
-    FGPU_LAUNCH("presence", k_presence, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd, ctx->bloo1,
-                ctx->counters);
+    FGPU_LAUNCH("presence", k_presence, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p,
+                bb.T, bb.n_words, ctx->fd, ctx->bloo1, ctx->counters);
     return FGPU_OK;
 }
 
 // ---- small utilities used by api.hip and scan_pure.hip --------------------------------------------
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen) {
     BatchBufs& bb = *ctx->cur;
-    FGPU_LAUNCH("count_segments", k_count_segments, fgpu_blocks(bb.n_words * 64, 256), 256, (const uint64_t*)bb.bad.p, bb.T, minlen,
+    FGPU_LAUNCH("count_segments", k_count_segments, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.bad.p, bb.n_words, minlen,
                 &ctx->counters->segments);
     return FGPU_OK;
 }

@@ -20,33 +20,46 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_scan_valid(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                    uint64_t T, FdParams fp, const uint32_t* __restrict__ bloom,
-                                                    uint64_t* __restrict__ valid, DevCounters* cnt) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = p < T && fd_window_ok(bad, p, fp.k);
-    bool v = false;
-    if (ok) v = fd_bloom_contains_canon(bloom, fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, fp.n_hash);
-    uint64_t vm = __ballot(v);
-    uint64_t okm = __ballot(ok);
-    if (fd_lane() == 0) {
-        valid[p >> 6] = vm;   // grid is sized to whole words; padding words exist
-        if (okm) atomicAdd(&cnt->kmers, (unsigned long long)__popcll(okm));
-    }
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (fd_lane() == 0 && v) atomicAdd(dst, v);
 }
 
-// One thread per position; a thread that sits on the first window of a run of valid windows measures the
-// run, and if it is a piece (>= k windows, inside a long enough segment) publishes ps/pm.
+// fixed grid striding over the stream, lanes = consecutive positions; counters live in registers until the wave retires
+__global__ void __launch_bounds__(256) k_scan_valid(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
+                                                    uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
+                                                    uint64_t* __restrict__ valid, DevCounters* cnt) {
+    unsigned long long n_ok = 0;
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool ok = p < T && fd_window_ok(bad, p, fp.k);
+        bool v = false;
+        if (ok) {
+            n_ok++;
+            v = fd_bloom_contains_canon(bloom, fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, fp.n_hash);
+        }
+        uint64_t vm = __ballot(v);
+        if (fd_lane() == 0) valid[p >> 6] = vm;
+    }
+    wave_add(&cnt->kmers, n_ok);
+}
+
+// One thread per 64-position word of the valid plane: run starts by bit arithmetic; each start measures its run and,
+// if it is a piece (>= k windows, inside a long enough segment), publishes ps/pm.
 __global__ void __launch_bounds__(256) k_scan_pieces(const uint64_t* __restrict__ valid, const uint64_t* __restrict__ bad,
-                                                     uint64_t T, FdParams fp, int check_segment,
+                                                     uint64_t n_words, FdParams fp, int check_segment,
                                                      unsigned long long* pm, uint64_t* __restrict__ ps, DevCounters* cnt) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool start = false;
-    if (p < T) {
-        bool v = (valid[p >> 6] >> (p & 63)) & 1ULL;
-        bool pv = p == 0 ? false : ((valid[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ULL);
-        if (v && !pv) {
-            // run length: first 0 bit at or after p
+    unsigned long long n_pieces = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t vw = valid[w];
+        uint64_t prev = w ? valid[w - 1] >> 63 : 0;
+        uint64_t starts = vw & ~((vw << 1) | prev);
+        uint64_t psw = 0;
+        while (starts) {
+            const int sbit = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const uint64_t p = w * 64 + sbit;
+            // run length: first 0 bit at or after p (zero padding past the end terminates the scan)
             uint64_t q = p, len = 0;
             for (;;) {
                 uint64_t bits = ~fd_bits_at(valid, q);
@@ -68,26 +81,24 @@ __global__ void __launch_bounds__(256) k_scan_pieces(const uint64_t* __restrict_
                 piece = (e - b) >= (uint64_t)(fp.k + 2 * fp.j + 1);
             }
             if (piece) {
-                start = true;
-                // pm bits p .. p+len-1
+                psw |= 1ULL << sbit;
+                n_pieces++;
+                // pm bits p .. p+len-1 (a word can be shared with a neighbouring piece: atomicOr)
                 uint64_t a = p, z = p + len;
                 while (a < z) {
-                    uint64_t w = a >> 6;
-                    uint64_t hi = (w + 1) << 6;
+                    uint64_t wi = a >> 6;
+                    uint64_t hi = (wi + 1) << 6;
                     uint64_t upto = z < hi ? z : hi;
                     int lo_b = (int)(a & 63), n_b = (int)(upto - a);
                     unsigned long long m = (n_b == 64 ? ~0ULL : ((1ULL << n_b) - 1)) << lo_b;
-                    atomicOr(&pm[w], m);
+                    atomicOr(&pm[wi], m);
                     a = upto;
                 }
             }
         }
+        ps[w] = psw;
     }
-    uint64_t sm = __ballot(start);
-    if (fd_lane() == 0) {
-        ps[p >> 6] = sm;
-        if (sm) atomicAdd(&cnt->pieces, (unsigned long long)__popcll(sm));
-    }
+    wave_add(&cnt->pieces, n_pieces);
 }
 
 // exclusive prefix sum of popcount(ps[w]) over the words of the batch: three small kernels
@@ -142,20 +153,24 @@ __global__ void __launch_bounds__(256) k_prefix_apply(uint32_t* __restrict__ pre
 
 // piece list: thread on a piece start writes {start, windows} at its rank
 __global__ void __launch_bounds__(256) k_scan_piece_list(const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pm,
-                                                         const uint32_t* __restrict__ prefix, uint64_t T, uint2* __restrict__ pieces) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= T) return;
-    uint64_t word = ps[p >> 6];
-    if (!((word >> (p & 63)) & 1ULL)) return;
-    uint32_t rank = prefix[p >> 6] + (uint32_t)__popcll(word & ((1ULL << (p & 63)) - 1));
-    uint64_t q = p, len = 0;
-    for (;;) {   // run of pm bits; pieces are separated by at least one 0
-        uint64_t bits = ~fd_bits_at(pm, q);
-        if (bits) { len += __builtin_ctzll(bits); break; }
-        len += 64;
-        q += 64;
+                                                         const uint32_t* __restrict__ prefix, uint64_t n_words, uint2* __restrict__ pieces) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t word = ps[w];
+        uint32_t rank = prefix[w];
+        while (word) {
+            const int sbit = __builtin_ctzll(word);
+            word &= word - 1;
+            const uint64_t p = w * 64 + sbit;
+            uint64_t q = p, len = 0;
+            for (;;) {   // run of pm bits; pieces are separated by at least one 0
+                uint64_t bits = ~fd_bits_at(pm, q);
+                if (bits) { len += __builtin_ctzll(bits); break; }
+                len += 64;
+                q += 64;
+            }
+            pieces[rank++] = make_uint2((uint32_t)p, (uint32_t)len);
+        }
     }
-    pieces[rank] = make_uint2((uint32_t)p, (uint32_t)len);
 }
 
 // JChecker::jcheck: depth-first search for one chain of j present extensions (same truth value as the
@@ -198,32 +213,34 @@ __device__ __forceinline__ void test_for_junction(uint64_t key, int real, const 
 }
 
 __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
-                                                    uint64_t T, FdParams fp, const uint32_t* __restrict__ bloom,
+                                                    uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
                                                     uint64_t* __restrict__ ff, uint64_t* __restrict__ fb, uint64_t* __restrict__ cf0,
                                                     uint64_t* __restrict__ cf1, uint64_t* __restrict__ cb0, uint64_t* __restrict__ cb1) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool f_f = false, f_b = false;
-    int c_f = 0, c_b = 0;
-    if (p < T) {
-        uint64_t wbits = fd_bits_at(pm, p == 0 ? 0 : p - 1);   // bit0 = pm[p-1], bit1 = pm[p], bit2 = pm[p+1]
-        bool here, prev, next;
-        if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
-        else { prev = wbits & 1; here = (wbits >> 1) & 1; next = (wbits >> 2) & 1; }
-        if (here && (prev || next)) {
-            uint64_t km = fd_kmer_at(codes, p, fp.k);
-            if (next) {   // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110)
-                test_for_junction(km, fd_base_at(codes, p + fp.k), fp, bloom, f_f, c_f);
-            }
-            if (prev) {   // facing backward: reverse complement, real extension = complement of the base before (:111-113)
-                test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, p - 1) ^ 2, fp, bloom, f_b, c_b);
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool f_f = false, f_b = false;
+        int c_f = 0, c_b = 0;
+        if (p < T) {
+            uint64_t wbits = fd_bits_at(pm, p == 0 ? 0 : p - 1);   // bit0 = pm[p-1], bit1 = pm[p], bit2 = pm[p+1]
+            bool here, prev, next;
+            if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
+            else { prev = wbits & 1; here = (wbits >> 1) & 1; next = (wbits >> 2) & 1; }
+            if (here && (prev || next)) {
+                uint64_t km = fd_kmer_at(codes, p, fp.k);
+                if (next) {   // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110)
+                    test_for_junction(km, fd_base_at(codes, p + fp.k), fp, bloom, f_f, c_f);
+                }
+                if (prev) {   // facing backward: reverse complement, real extension = complement of the base before (:111-113)
+                    test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, p - 1) ^ 2, fp, bloom, f_b, c_b);
+                }
             }
         }
-    }
-    uint64_t m_ff = __ballot(f_f), m_fb = __ballot(f_b);
-    uint64_t m_cf0 = __ballot(c_f & 1), m_cf1 = __ballot(c_f & 2), m_cb0 = __ballot(c_b & 1), m_cb1 = __ballot(c_b & 2);
-    if (fd_lane() == 0) {
-        uint64_t w = p >> 6;
-        ff[w] = m_ff; fb[w] = m_fb; cf0[w] = m_cf0; cf1[w] = m_cf1; cb0[w] = m_cb0; cb1[w] = m_cb1;
+        uint64_t m_ff = __ballot(f_f), m_fb = __ballot(f_b);
+        uint64_t m_cf0 = __ballot(c_f & 1), m_cf1 = __ballot(c_f & 2), m_cb0 = __ballot(c_b & 1), m_cb1 = __ballot(c_b & 2);
+        if (fd_lane() == 0) {
+            uint64_t w = p >> 6;
+            ff[w] = m_ff; fb[w] = m_fb; cf0[w] = m_cf0; cf1[w] = m_cf1; cb0[w] = m_cb0; cb1[w] = m_cb1;
+        }
     }
 }
 
@@ -244,12 +261,13 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     FGPU_HIP(hipMemsetAsync(bb.pm.p, 0, wb, ctx->stream));
     FGPU_HIP(hipMemsetAsync(bb.ps.p, 0, wb, ctx->stream));
 
-    const unsigned grid = fgpu_blocks(bb.n_words * 64, 256);
+    const unsigned grid = fgpu_grid(bb.n_words * 64, 256);        // kernels with one lane per position
+    const unsigned wgrid = fgpu_grid(bb.n_words, 256);            // kernels with one thread per 64-position word
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k + 2 * ctx->fd.j + 1))) return rc;
-    FGPU_LAUNCH("scan_valid", k_scan_valid, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd,
+    FGPU_LAUNCH("scan_valid", k_scan_valid, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
                 (const uint32_t*)ctx->bloo2, (uint64_t*)bb.valid.p, ctx->counters);
     const int check_segment = ctx->fd.k < 2 * ctx->fd.j + 2;   // otherwise a run of k windows already implies the length gate
-    FGPU_LAUNCH("scan_pieces", k_scan_pieces, grid, 256, (const uint64_t*)bb.valid.p, (const uint64_t*)bb.bad.p, bb.T, ctx->fd,
+    FGPU_LAUNCH("scan_pieces", k_scan_pieces, wgrid, 256, (const uint64_t*)bb.valid.p, (const uint64_t*)bb.bad.p, bb.n_words, ctx->fd,
                 check_segment, (unsigned long long*)bb.pm.p, (uint64_t*)bb.ps.p, ctx->counters);
     uint32_t* prefix = (uint32_t*)bb.ps_prefix.p;
     uint32_t* block_sums = prefix + bb.n_words + FGPU_PADW;
@@ -268,9 +286,9 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     bb.n_pieces = np;
     if ((rc = fgpu_ensure(ctx, &bb.pieces, (np + 1) * sizeof(uint2)))) return rc;
     if (np) {
-        FGPU_LAUNCH("piece_list", k_scan_piece_list, grid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
-                    (const uint32_t*)prefix, bb.T, (uint2*)bb.pieces.p);
-        FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.T, ctx->fd,
+        FGPU_LAUNCH("piece_list", k_scan_piece_list, wgrid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
+                    (const uint32_t*)prefix, bb.n_words, (uint2*)bb.pieces.p);
+        FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.T, bb.n_words, ctx->fd,
                     (const uint32_t*)ctx->bloo2, (uint64_t*)bb.ff.p, (uint64_t*)bb.fb.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p,
                     (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p);
     }

@@ -151,14 +151,16 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 }
 
 // ---- window table -------------------------------------------------------------------------------
-__device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, uint64_t canon, uint32_t piece, DevCounters* cnt) {
+// Returns the slot this call CLAIMED (the caller lists it for the sparse clean-up, one counter atomic per wave),
+// or U_INF when the key was already there.
+__device__ __forceinline__ uint32_t wt_register(const WTable& wt, uint32_t* parent, uint64_t canon, uint32_t piece, DevCounters* cnt) {
     uint64_t h = fd_mix(canon);
     uint64_t s = h & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
         unsigned long long old = atomicCAS((unsigned long long*)&wt.keys[s], (unsigned long long)J_EMPTY, (unsigned long long)canon);
+        uint32_t claimed = U_INF;
         if (old == J_EMPTY) {
-            unsigned long long idx = atomicAdd(&cnt->wt_used, 1ULL);
-            wt.slots[idx] = (uint32_t)s;
+            claimed = (uint32_t)s;
             uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
             atomicOr(&wt.bits[b >> 5], 1u << (b & 31));
             old = canon;
@@ -166,11 +168,12 @@ __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, 
         if (old == canon) {
             uint32_t prev = atomicMin(&wt.owner[s], piece);
             if (prev != U_INF && prev != piece) uf_union(parent, piece, prev);
-            return;
+            return claimed;
         }
         s = (s + 1) & wt.mask;
     }
     atomicOr(&cnt->error_flags, 2ULL);
+    return U_INF;
 }
 
 __device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint64_t canon) {
@@ -203,12 +206,14 @@ __device__ __forceinline__ uint32_t ps_rank(const Planes& pl, uint64_t x) {
     return pl.prefix[x >> 6] + (uint32_t)__popcll(w & ((1ULL << o) - 1));
 }
 
-__global__ void k_walk_setup(Planes pl, uint64_t lo, uint64_t hi, WinDesc* wd) {
-    uint32_t a = ps_rank(pl, lo), b = ps_rank(pl, hi);
-    wd->first_piece = a;
-    wd->n = b - a;
-    wd->lo = lo;
-    wd->hi = hi;
+// every kernel of a window derives the window's piece range itself (two rank queries): no set-up launch
+__device__ __forceinline__ WinDesc make_window(const Planes& pl, uint64_t lo, uint64_t hi) {
+    WinDesc wd;
+    wd.first_piece = ps_rank(pl, lo);
+    wd.n = ps_rank(pl, hi) - wd.first_piece;
+    wd.lo = lo;
+    wd.hi = hi;
+    return wd;
 }
 
 // does window position p (pm[p] == 1) belong to a piece of this window?  returns the window-local piece index
@@ -221,12 +226,13 @@ __device__ __forceinline__ bool piece_in_window(const Planes& pl, const WinDesc&
 }
 
 __global__ void __launch_bounds__(256) k_walk_lookup(Planes pl, FdParams fp, JTable jt, WTable wt, uint32_t* parent,
-                                                     const WinDesc* __restrict__ wdp, uint64_t pos_end, DevCounters* cnt) {
-    const WinDesc wd = *wdp;
+                                                     uint64_t lo, uint64_t hi, uint64_t pos_end, DevCounters* cnt, int parity) {
+    const WinDesc wd = make_window(pl, lo, hi);
     uint64_t p = (wd.lo & ~63ULL) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool inF = false, inB = false;
     uint32_t li;
     uint2 pc;
+    uint32_t claimed = U_INF;
     if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL) && piece_in_window(pl, wd, p, li, pc)) {
         uint64_t km = fd_kmer_at(pl.codes, p, fp.k);
         uint64_t rc = fd_revcomp(km, fp.k);
@@ -242,19 +248,27 @@ __global__ void __launch_bounds__(256) k_walk_lookup(Planes pl, FdParams fp, JTa
         cand |= ((pl.ff[p >> 6] | pl.fb[p >> 6]) >> (p & 63)) & 1ULL;
         cand |= q == len / 2 - (uint32_t)fp.k / 2;                       // add_fake_junction's k-mer (ReadScanner.cpp:94)
         cand |= 2 * q + 1 >= (uint32_t)(2 * fp.max_spacer - 1);           // spacer rule can fire here (ReadScanner.cpp:72)
-        if (cand) wt_register(wt, parent, canon, li, cnt);
+        if (cand) claimed = wt_register(wt, parent, canon, li, cnt);
     }
     uint64_t mF = __ballot(inF), mB = __ballot(inB);
+    // list the slots this wave claimed: one counter atomic per wave
+    uint64_t mC = __ballot(claimed != U_INF);
+    unsigned long long base = 0;
     if (fd_lane() == 0) {
         pl.inF[p >> 6] = mF;
         pl.inB[p >> 6] = mB;
+        if (mC) base = atomicAdd(parity ? &cnt->wt_used_b : &cnt->wt_used, (unsigned long long)__popcll(mC));
+    }
+    if (mC) {
+        base = __shfl(base, 0, 64);
+        if (claimed != U_INF) wt.slots[base + __popcll(mC & ((1ULL << fd_lane()) - 1))] = claimed;
     }
 }
 
 // ---- B: link every piece to the owners of the candidate k-mers that occur on it ---------------------
-__global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTable wt, uint32_t* parent,
-                                                   const WinDesc* __restrict__ wdp, uint64_t pos_end) {
-    const WinDesc wd = *wdp;
+__global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTable wt, uint32_t* parent, uint64_t lo, uint64_t hi,
+                                                   uint64_t pos_end) {
+    const WinDesc wd = make_window(pl, lo, hi);
     uint64_t p = (wd.lo & ~63ULL) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL)) {
         uint64_t canon = fd_canon(fd_kmer_at(pl.codes, p, fp.k), fp.k);
@@ -270,10 +284,10 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
 // ---- C: clusters -> ordered member lists (one block) --------------------------------------------------
 constexpr int CL_BLOCK = 1024;
 __global__ void __launch_bounds__(CL_BLOCK) k_walk_cluster(uint32_t* parent, uint32_t* count, uint32_t* offset, uint32_t* fill,
-                                                           uint32_t* members, const WinDesc* __restrict__ wdp, DevCounters* cnt) {
+                                                           uint32_t* members, Planes pl, uint64_t lo, uint64_t hi, DevCounters* cnt) {
     __shared__ uint32_t sh[CL_BLOCK];
     __shared__ uint32_t carry;
-    const uint32_t n = wdp->n;
+    const uint32_t n = make_window(pl, lo, hi).n;
     // flatten; count followers per root
     for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) { count[i] = 0; fill[i] = 0; }
     __syncthreads();
@@ -330,7 +344,12 @@ struct WalkCtx {
     DevCounters* cnt;
     // per-thread accumulators
     unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created;
-    bool created_now;   // set by junction_get
+    // oriented keys this thread's cluster has created in the current window: the snapshot planes of phase A cannot
+    // know them, every later in-map test of the cluster has to (tandem repeats inside a piece; later pieces of the cluster)
+    static constexpr int NC = 16;
+    uint64_t ckey[NC];
+    int nc;
+    bool c_overflow;    // more than NC creations: fall back to live table lookups
 };
 
 // number of set bits of `plane` at positions [a, b)
@@ -356,11 +375,21 @@ __device__ __forceinline__ uint32_t jcheck_sum(const Planes& pl, uint64_t p0, in
            range_popc(pl.cf0, p0 + fq0, p0 + fq1) + 2 * range_popc(pl.cf1, p0 + fq0, p0 + fq1);
 }
 
-// 64 in-map bits for windows [q, q+64) of the piece: from the snapshot planes, or by live lookups
-__device__ void inmap_chunk(const WalkCtx& wc, uint64_t p0, uint32_t q, uint32_t nwin, bool live, uint64_t& mF, uint64_t& mB) {
-    if (!live) {
+// 64 in-map bits for windows [q, q+64) of the piece: the snapshot planes of phase A, plus whatever this thread's
+// cluster has created since (compared k-mer by k-mer; no memory traffic), or live lookups once that list overflowed
+__device__ void inmap_chunk(const WalkCtx& wc, uint64_t p0, uint32_t q, uint32_t nwin, uint64_t& mF, uint64_t& mB) {
+    if (!wc.c_overflow) {
         mF = fd_bits_at(wc.pl.inF, p0 + q);
         mB = fd_bits_at(wc.pl.inB, p0 + q);
+        if (wc.nc == 0) return;
+        for (uint32_t i = 0; i < 64 && q + i < nwin; i++) {
+            uint64_t km = fd_kmer_at(wc.pl.codes, p0 + q + i, wc.fp.k);
+            uint64_t rc = fd_revcomp(km, wc.fp.k);
+            for (int c = 0; c < wc.nc; c++) {
+                if (wc.ckey[c] == km) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
+                if (wc.ckey[c] == rc) mB |= 1ULL << i;   // backward-facing key = its reverse complement
+            }
+        }
         return;
     }
     mF = mB = 0;
@@ -402,9 +431,9 @@ __device__ uint8_t* junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp) {
         return nullptr;
     }
     uint8_t* rec = wc.jt.recs + (slot * 2 + orient) * 16;
-    wc.created_now = false;
     if (!((present >> orient) & 1u)) {   // JunctionMap::createJunction, JunctionMap.cpp:567-570
-        wc.created_now = true;
+        if (wc.nc < WalkCtx::NC) wc.ckey[wc.nc++] = key;
+        else wc.c_overflow = true;
         uint64_t* r64 = (uint64_t*)rec;
         r64[0] = 0;
         r64[1] = 0;
@@ -415,8 +444,8 @@ __device__ uint8_t* junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp) {
     return rec;
 }
 
-// scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}; `live` = do not trust the snapshot planes
-__device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t piece_seq, bool live) {
+// scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}
+__device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t piece_seq) {
     const int k = wc.fp.k, j = wc.fp.j;
     const int tmax = 2 * (int)nwin - 2 - 2 * j;     // last half-step with distToEnd > 2j
     const int spacer = 2 * wc.fp.max_spacer - 1;
@@ -435,7 +464,7 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
             uint32_t q0 = (uint32_t)(t >> 1);
             for (uint32_t qc = q0; qc < nwin && 2 * (int)qc <= tmax && 2 * (int)qc <= t_sp; qc += 64) {
                 uint64_t mF, mB;
-                inmap_chunk(wc, p0, qc, nwin, live, mF, mB);
+                inmap_chunk(wc, p0, qc, nwin, mF, mB);
                 uint64_t eF = mF | fd_bits_at(wc.pl.ff, p0 + qc);
                 uint64_t eB = mB | fd_bits_at(wc.pl.fb, p0 + qc);
                 if (qc == q0 && (t & 1)) eB &= ~1ULL;   // the backward-facing half-step of q0 is already behind us
@@ -459,7 +488,7 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
         bool in_map;
         {
             uint64_t mF, mB;
-            inmap_chunk(wc, p0, q, nwin, live, mF, mB);
+            inmap_chunk(wc, p0, q, nwin, mF, mB);
             in_map = (fwd ? mF : mB) & 1ULL;
         }
         const bool by_spacer = !in_map && (tn - last_pos >= spacer);
@@ -472,9 +501,6 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
         int real = fwd ? fd_base_at(wc.pl.codes, p0 + q + k) : (fd_base_at(wc.pl.codes, p0 + q - 1) ^ 2);
         uint8_t* rec = junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn);
         if (!rec) return;
-        // a junction created on this piece may recur further along the same piece (tandem repeats): from here on
-        // the snapshot planes are no longer authoritative for this piece
-        if (wc.created_now) live = true;
         last_pos = tn;
         rec_add_cov(rec, real);
         const int ext_fwd = fwd ? real : 4;          // getExtensionIndex(FORWARD)
@@ -518,13 +544,17 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
 
 __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root,
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ offset, uint32_t* members,
-                                             const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, DevCounters* cnt) {
+                                             uint64_t lo, uint64_t hi, uint64_t piece_seq_base, DevCounters* cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    WalkCtx wc{pl, fp, jt, cnt, 0, 0, 0, 0, 0, false};
-    const uint32_t n = wdp->n, first_piece = wdp->first_piece;
+    WalkCtx wc;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt;
+    wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = 0;
+    wc.nc = 0; wc.c_overflow = false;
+    const WinDesc wd = make_window(pl, lo, hi);
+    const uint32_t n = wd.n, first_piece = wd.first_piece;
     if (i < n && root[i] == i) {
         uint2 pc = pl.pieces[first_piece + i];
-        walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + i, false);
+        walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + i);
         uint32_t nm = count[i];
         if (nm) {
             uint32_t* mem = members + offset[i];
@@ -537,7 +567,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
             for (uint32_t a = 0; a < nm; a++) {
                 uint32_t m = mem[a];
                 uint2 pm = pl.pieces[first_piece + m];
-                walk_piece(wc, pm.x, pm.y, piece_seq_base + first_piece + m, true);
+                walk_piece(wc, pm.x, pm.y, piece_seq_base + first_piece + m);
             }
         }
     }
@@ -555,9 +585,13 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
 }
 
 // ---- E: sparse reset of the window table ----------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, DevCounters* cnt, uint32_t* parent, const WinDesc* __restrict__ wdp) {
-    uint64_t used = cnt->wt_used;
-    const uint32_t n = wdp->n;
+// The two "slots used" counters alternate between consecutive windows, so this kernel can also zero the one the
+// next window will count into (it was consumed by the previous window's clean-up).
+__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, DevCounters* cnt, uint32_t* parent, Planes pl, uint64_t lo, uint64_t hi,
+                                                    int parity) {
+    uint64_t used = parity ? cnt->wt_used_b : cnt->wt_used;
+    const uint32_t n = make_window(pl, lo, hi).n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (parity) cnt->wt_used = 0; else cnt->wt_used_b = 0; }
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t a = i; a < used; a += stride) {
@@ -571,7 +605,6 @@ __global__ void __launch_bounds__(256) k_walk_clean(WTable wt, DevCounters* cnt,
     for (uint64_t a = i; a < n; a += stride) parent[a] = (uint32_t)a;
 }
 
-__global__ void k_zero_wt_used(DevCounters* cnt) { cnt->wt_used = 0; }
 
 __global__ void __launch_bounds__(256) k_fill_u64(uint64_t* p, uint64_t n, uint64_t v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -700,16 +733,14 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const uint64_t hi = std::min<uint64_t>(T, lo + span);
         const uint64_t pos_end = std::min<uint64_t>(T, hi + ext);
         const unsigned grid = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) & ~63ULL, 256);
-        FGPU_LAUNCH("walk_setup", k_walk_setup, 1, 1, pl, lo, hi, (WinDesc*)ctx->wdesc);
-        FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, ctx->uf_parent, (const WinDesc*)ctx->wdesc, pos_end,
-                    ctx->counters);
-        FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, (const WinDesc*)ctx->wdesc, pos_end);
+        const int parity = (int)(ctx->scan_windows & 1);
+        FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, ctx->uf_parent, lo, hi, pos_end, ctx->counters, parity);
+        FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, lo, hi, pos_end);
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, 1, CL_BLOCK, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
-                    ctx->cl_members, (const WinDesc*)ctx->wdesc, ctx->counters);
+                    ctx->cl_members, pl, lo, hi, ctx->counters);
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->uf_parent, (const uint32_t*)ctx->cl_count,
-                    (const uint32_t*)ctx->cl_offset, ctx->cl_members, (const WinDesc*)ctx->wdesc, seq_base, ctx->counters);
-        FGPU_LAUNCH("walk_clean", k_walk_clean, 64, 256, wt, ctx->counters, ctx->uf_parent, (const WinDesc*)ctx->wdesc);
-        FGPU_LAUNCH("walk_zero", k_zero_wt_used, 1, 1, ctx->counters);
+                    (const uint32_t*)ctx->cl_offset, ctx->cl_members, lo, hi, seq_base, ctx->counters);
+        FGPU_LAUNCH("walk_clean", k_walk_clean, 64, 256, wt, ctx->counters, ctx->uf_parent, pl, lo, hi, parity);
         ctx->scan_windows++;
     }
     ctx->prof_suppress = false;
