@@ -92,6 +92,7 @@ struct fgpu_ctx {
     uint64_t* jkeys = nullptr;       // canon | present bits in 63,62 ; EMPTY = ~0
     uint8_t* jrecs = nullptr;        // [slot][orient] 16-byte records
     uint64_t* jstamps = nullptr;     // [slot][orient] creation stamp
+    uint32_t* jfilter = nullptr;     // presence filter in front of jkeys (2 bits per slot)
     // window table (candidate keys of the window being walked)
     uint64_t wcap = 0;
     uint64_t* wkeys = nullptr;

@@ -44,8 +44,13 @@ struct JTable {
     uint64_t* keys;
     uint8_t* recs;
     uint64_t* stamps;
-    uint64_t mask;   // capacity - 1
+    uint64_t mask;         // capacity - 1
+    uint32_t* filter;      // presence filter: one bit per hashed canonical k-mer that owns a slot (2 bits per slot of capacity)
+    uint64_t filter_mask;  // filter bits - 1
 };
+
+// filter bit of a canonical k-mer: other hash bits than the slot index uses
+__device__ __forceinline__ uint64_t jt_filter_bit(const JTable& jt, uint64_t canon) { return (fd_mix(canon) >> 24) & jt.filter_mask; }
 
 struct WTable {
     uint64_t* keys;
@@ -237,7 +242,9 @@ __global__ void __launch_bounds__(256) k_walk_lookup(Planes pl, FdParams fp, JTa
         uint64_t km = fd_kmer_at(pl.codes, p, fp.k);
         uint64_t rc = fd_revcomp(km, fp.k);
         uint64_t canon = km < rc ? km : rc;
-        uint32_t present = jt_present_snapshot(jt, canon);
+        // most k-mers own no junction: one bit of a small (cache-resident) filter answers that without touching the table
+        const uint64_t hb = jt_filter_bit(jt, canon);
+        uint32_t present = ((jt.filter[hb >> 5] >> (hb & 31)) & 1u) ? jt_present_snapshot(jt, canon) : 0;
         int oF = km == canon ? 0 : 1;   // orientation of the forward-facing key (the k-mer itself)
         int oB = rc == canon ? 0 : 1;   // orientation of the backward-facing key (its reverse complement)
         inF = (present >> oF) & 1u;
@@ -337,6 +344,17 @@ __global__ void __launch_bounds__(CL_BLOCK) k_walk_cluster(uint32_t* parent, uin
 }
 
 // ---- D: the walk ---------------------------------------------------------------------------------------
+// Everything the walk needs to know about the first 128 windows of a piece sits in registers: the eight bit
+// planes (2 words each) are fetched with one burst of independent loads, after which finding the next event,
+// classifying it and summing NbJCheckKmer increments is bit arithmetic.  Windows beyond 128 (reads longer than
+// ~150 bp) go through the same code with plane words fetched on demand.
+struct PieceView {
+    uint64_t p0;
+    uint32_t nwin;
+    uint64_t inF[2], inB[2], fF[2], fB[2], c0F[2], c1F[2], c0B[2], c1B[2];
+    uint64_t xF[2], xB[2];   // positions whose key this thread's cluster created during the current window
+};
+
 struct WalkCtx {
     Planes pl;
     FdParams fp;
@@ -350,77 +368,126 @@ struct WalkCtx {
     uint64_t ckey[NC];
     int nc;
     bool c_overflow;    // more than NC creations: fall back to live table lookups
+    bool created_now;   // set by junction_get
 };
 
-// number of set bits of `plane` at positions [a, b)
-__device__ __forceinline__ uint32_t range_popc(const uint64_t* plane, uint64_t a, uint64_t b) {
+__device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
+    uint32_t base = c * 64;
+    if (base >= nwin) return 0;
+    uint32_t rem = nwin - base;
+    return rem >= 64 ? ~0ULL : ((1ULL << rem) - 1);
+}
+
+// plane word for windows [64c, 64c+64) of the piece
+__device__ __forceinline__ uint64_t pv_word(const PieceView& v, const uint64_t* regs, const uint64_t* plane, uint32_t c) {
+    if (c < 2) return regs[c];
+    return fd_bits_at(plane, v.p0 + 64ULL * c) & chunk_mask(v.nwin, c);
+}
+
+__device__ void pv_load(PieceView& v, const Planes& pl, uint64_t p0, uint32_t nwin) {
+    v.p0 = p0;
+    v.nwin = nwin;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint64_t m = chunk_mask(nwin, c);
+        const uint64_t p = p0 + 64ULL * c;
+        // words past the piece are never dereferenced beyond the planes' padding: m == 0 skips the loads
+        v.inF[c] = m ? fd_bits_at(pl.inF, p) & m : 0;
+        v.inB[c] = m ? fd_bits_at(pl.inB, p) & m : 0;
+        v.fF[c] = m ? fd_bits_at(pl.ff, p) & m : 0;
+        v.fB[c] = m ? fd_bits_at(pl.fb, p) & m : 0;
+        v.c0F[c] = m ? fd_bits_at(pl.cf0, p) & m : 0;
+        v.c1F[c] = m ? fd_bits_at(pl.cf1, p) & m : 0;
+        v.c0B[c] = m ? fd_bits_at(pl.cb0, p) & m : 0;
+        v.c1B[c] = m ? fd_bits_at(pl.cb1, p) & m : 0;
+        v.xF[c] = v.xB[c] = 0;
+    }
+}
+
+// in-map bits of chunk c that the snapshot cannot know: keys created by this cluster since phase A.
+// Either compared k-mer by k-mer against the short created list (no memory traffic), or, once that list has
+// overflowed, by live table lookups.
+__device__ void created_bits(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+    mF = mB = 0;
+    const uint32_t base = c * 64;
+    for (uint32_t i = 0; i < 64 && base + i < v.nwin; i++) {
+        uint64_t km = fd_kmer_at(wc.pl.codes, v.p0 + base + i, wc.fp.k);
+        uint64_t rc = fd_revcomp(km, wc.fp.k);
+        if (!wc.c_overflow) {
+            for (int n = 0; n < wc.nc; n++) {
+                if (wc.ckey[n] == km) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
+                if (wc.ckey[n] == rc) mB |= 1ULL << i;   // backward-facing key = its reverse complement
+            }
+        } else {
+            uint64_t canon = km < rc ? km : rc;
+            uint64_t slot;
+            uint32_t present;
+            if (jt_find_live(wc.jt, canon, slot, present)) {
+                if ((present >> (km == canon ? 0 : 1)) & 1u) mF |= 1ULL << i;
+                if ((present >> (rc == canon ? 0 : 1)) & 1u) mB |= 1ULL << i;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+    mF = pv_word(v, v.inF, wc.pl.inF, c);
+    mB = pv_word(v, v.inB, wc.pl.inB, c);
+    if (wc.nc == 0 && !wc.c_overflow) return;
+    if (c < 2) { mF |= v.xF[c]; mB |= v.xB[c]; return; }
+    uint64_t a, b;
+    created_bits(wc, v, c, a, b);
+    mF |= a;
+    mB |= b;
+}
+
+// number of set bits of the plane at windows [qa, qb) of the piece
+__device__ __forceinline__ uint32_t pv_popc(const PieceView& v, const uint64_t* regs, const uint64_t* plane, uint32_t qa, uint32_t qb) {
     uint32_t s = 0;
-    while (a < b) {
-        uint64_t v = fd_bits_at(plane, a);
-        uint64_t n = b - a;
-        if (n < 64) v &= (1ULL << n) - 1;
-        s += (uint32_t)__popcll(v);
-        a += 64;
+    if (qb > v.nwin) qb = v.nwin;
+    while (qa < qb) {
+        const uint32_t c = qa >> 6;
+        uint64_t w = pv_word(v, regs, plane, c) >> (qa & 63);
+        const uint32_t n = min(qb - qa, 64u - (qa & 63));
+        if (n < 64) w &= (1ULL << n) - 1;
+        s += (uint32_t)__popcll(w);
+        qa += n;
     }
     return s;
 }
 
-// NbJCheckKmer increments of the half-steps t in [t0, t1) of the piece whose first window is p0
-__device__ __forceinline__ uint32_t jcheck_sum(const Planes& pl, uint64_t p0, int t0, int t1) {
+// NbJCheckKmer increments of the half-steps t in [t0, t1): backward-facing half-steps are 2q, forward-facing 2q+1
+__device__ __forceinline__ uint32_t jcheck_sum(const WalkCtx& wc, const PieceView& v, int t0, int t1) {
     if (t1 <= t0) return 0;
-    // backward-facing half-steps 2q, forward-facing 2q+1
-    uint64_t bq0 = (uint64_t)((t0 + 1) >> 1), bq1 = (uint64_t)((t1 + 1) >> 1);
-    uint64_t fq0 = (uint64_t)(t0 >> 1), fq1 = (uint64_t)(t1 >> 1);
-    return range_popc(pl.cb0, p0 + bq0, p0 + bq1) + 2 * range_popc(pl.cb1, p0 + bq0, p0 + bq1) +
-           range_popc(pl.cf0, p0 + fq0, p0 + fq1) + 2 * range_popc(pl.cf1, p0 + fq0, p0 + fq1);
+    const uint32_t bq0 = (uint32_t)((t0 + 1) >> 1), bq1 = (uint32_t)((t1 + 1) >> 1);
+    const uint32_t fq0 = (uint32_t)(t0 >> 1), fq1 = (uint32_t)(t1 >> 1);
+    return pv_popc(v, v.c0B, wc.pl.cb0, bq0, bq1) + 2 * pv_popc(v, v.c1B, wc.pl.cb1, bq0, bq1) +
+           pv_popc(v, v.c0F, wc.pl.cf0, fq0, fq1) + 2 * pv_popc(v, v.c1F, wc.pl.cf1, fq0, fq1);
 }
 
-// 64 in-map bits for windows [q, q+64) of the piece: the snapshot planes of phase A, plus whatever this thread's
-// cluster has created since (compared k-mer by k-mer; no memory traffic), or live lookups once that list overflowed
-__device__ void inmap_chunk(const WalkCtx& wc, uint64_t p0, uint32_t q, uint32_t nwin, uint64_t& mF, uint64_t& mB) {
-    if (!wc.c_overflow) {
-        mF = fd_bits_at(wc.pl.inF, p0 + q);
-        mB = fd_bits_at(wc.pl.inB, p0 + q);
-        if (wc.nc == 0) return;
-        for (uint32_t i = 0; i < 64 && q + i < nwin; i++) {
-            uint64_t km = fd_kmer_at(wc.pl.codes, p0 + q + i, wc.fp.k);
-            uint64_t rc = fd_revcomp(km, wc.fp.k);
-            for (int c = 0; c < wc.nc; c++) {
-                if (wc.ckey[c] == km) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
-                if (wc.ckey[c] == rc) mB |= 1ULL << i;   // backward-facing key = its reverse complement
-            }
-        }
-        return;
-    }
-    mF = mB = 0;
-    for (uint32_t i = 0; i < 64 && q + i < nwin; i++) {
-        uint64_t km = fd_kmer_at(wc.pl.codes, p0 + q + i, wc.fp.k);
-        uint64_t rc = fd_revcomp(km, wc.fp.k);
-        uint64_t canon = km < rc ? km : rc;
-        uint64_t slot;
-        uint32_t present;
-        if (jt_find_live(wc.jt, canon, slot, present)) {
-            if ((present >> (km == canon ? 0 : 1)) & 1u) mF |= 1ULL << i;
-            if ((present >> (rc == canon ? 0 : 1)) & 1u) mB |= 1ULL << i;
-        }
-    }
-}
-
-struct JRef {   // a junction record in the table
-    uint8_t* rec;
+// A junction record held in two registers: dist[0..4] bytes 0-4, cov[0..3] bytes 5-8, linked mask byte 9.
+struct RecRegs {
+    uint64_t lo, hi;
+    uint64_t* addr;
 };
-
-__device__ __forceinline__ void rec_update(uint8_t* rec, int idx, int length) {   // Junction::update, Junction.cpp:69-71
-    uint8_t l = (uint8_t)length;
-    if (rec[idx] < l) rec[idx] = l;
+__device__ __forceinline__ uint32_t rr_get(const RecRegs& r, int i) { return (uint32_t)((i < 8 ? r.lo >> (8 * i) : r.hi >> (8 * (i - 8))) & 0xFF); }
+__device__ __forceinline__ void rr_set(RecRegs& r, int i, uint32_t val) {
+    if (i < 8) r.lo = (r.lo & ~(0xFFULL << (8 * i))) | ((uint64_t)val << (8 * i));
+    else r.hi = (r.hi & ~(0xFFULL << (8 * (i - 8)))) | ((uint64_t)val << (8 * (i - 8)));
 }
-__device__ __forceinline__ void rec_add_cov(uint8_t* rec, int nuc) {               // Junction::addCoverage, Junction.cpp:59-67
-    uint8_t c = (uint8_t)(rec[5 + nuc] + 1);
-    rec[5 + nuc] = c == 0 ? 255 : c;
+__device__ __forceinline__ void rr_update(RecRegs& r, int idx, int length) {   // Junction::update, Junction.cpp:69-71 (narrowing to uchar)
+    uint32_t l = (uint32_t)length & 0xFF;
+    if (rr_get(r, idx) < l) rr_set(r, idx, l);
 }
+__device__ __forceinline__ void rr_add_cov(RecRegs& r, int nuc) {               // Junction::addCoverage, Junction.cpp:59-67
+    uint32_t c = (rr_get(r, 5 + nuc) + 1) & 0xFF;
+    rr_set(r, 5 + nuc, c == 0 ? 255 : c);
+}
+__device__ __forceinline__ void rr_link(RecRegs& r, int idx) { rr_set(r, 9, rr_get(r, 9) | (1u << idx)); }
+__device__ __forceinline__ void rr_store(const RecRegs& r) { r.addr[0] = r.lo; r.addr[1] = r.hi; }
 
-// find or create the junction keyed by the oriented k-mer `key`
-__device__ uint8_t* junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp) {
+// find or create the junction keyed by the oriented k-mer `key`; the record comes back in registers
+__device__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, RecRegs& out) {
     uint64_t rc = fd_revcomp(key, wc.fp.k);
     uint64_t canon = key < rc ? key : rc;
     int orient = key == canon ? 0 : 1;
@@ -428,20 +495,26 @@ __device__ uint8_t* junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp) {
     uint32_t present;
     if (!jt_find_or_claim(wc.jt, canon, slot, present, wc.cnt)) {
         atomicOr(&wc.cnt->error_flags, 1ULL);
-        return nullptr;
+        return false;
     }
-    uint8_t* rec = wc.jt.recs + (slot * 2 + orient) * 16;
+    out.addr = (uint64_t*)(wc.jt.recs + (slot * 2 + orient) * 16);
+    wc.created_now = false;
     if (!((present >> orient) & 1u)) {   // JunctionMap::createJunction, JunctionMap.cpp:567-570
+        wc.created_now = true;
         if (wc.nc < WalkCtx::NC) wc.ckey[wc.nc++] = key;
         else wc.c_overflow = true;
-        uint64_t* r64 = (uint64_t*)rec;
-        r64[0] = 0;
-        r64[1] = 0;
+        out.lo = out.hi = 0;
         wc.jt.stamps[slot * 2 + orient] = stamp;
         atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
+        // presence filter in front of the table (phase A of later windows tests it before probing)
+        uint64_t hb = jt_filter_bit(wc.jt, canon);
+        atomicOr(&wc.jt.filter[hb >> 5], 1u << (hb & 31));
         wc.n_created++;
+    } else {
+        out.lo = out.addr[0];
+        out.hi = out.addr[1];
     }
-    return rec;
+    return true;
 }
 
 // scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}
@@ -449,10 +522,18 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
     const int k = wc.fp.k, j = wc.fp.j;
     const int tmax = 2 * (int)nwin - 2 - 2 * j;     // last half-step with distToEnd > 2j
     const int spacer = 2 * wc.fp.max_spacer - 1;
+    PieceView v;
+    pv_load(v, wc.pl, p0, nwin);
+    if (wc.nc || wc.c_overflow) {                   // an earlier piece of this cluster created keys
+        created_bits(wc, v, 0, v.xF[0], v.xB[0]);
+        if (nwin > 64) created_bits(wc, v, 1, v.xF[1], v.xB[1]);
+    }
     int t = 2 * j + 1;
     int last_pos = 0;                               // lastJuncPos
     bool have_last = false;
-    uint8_t* last_rec = nullptr;
+    RecRegs last;
+    last.lo = last.hi = 0;
+    last.addr = nullptr;
     int last_t = 0, last_ext_fwd = 0;
 
     while (t <= tmax) {
@@ -460,65 +541,88 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
         int t_sp = last_pos + spacer;
         if (t_sp < t) t_sp = t;
         int t_ev = 0x7fffffff;
+        bool ev_in_map = false;
         {
-            uint32_t q0 = (uint32_t)(t >> 1);
-            for (uint32_t qc = q0; qc < nwin && 2 * (int)qc <= tmax && 2 * (int)qc <= t_sp; qc += 64) {
+            const uint32_t q0 = (uint32_t)(t >> 1);
+            const int t_stop = tmax < t_sp ? tmax : t_sp;
+            for (uint32_t c = q0 >> 6; c * 64 < nwin && 2 * (int)(c * 64) <= t_stop; c++) {
                 uint64_t mF, mB;
-                inmap_chunk(wc, p0, qc, nwin, mF, mB);
-                uint64_t eF = mF | fd_bits_at(wc.pl.ff, p0 + qc);
-                uint64_t eB = mB | fd_bits_at(wc.pl.fb, p0 + qc);
-                if (qc == q0 && (t & 1)) eB &= ~1ULL;   // the backward-facing half-step of q0 is already behind us
-                uint32_t rem = nwin - qc;
-                if (rem < 64) { uint64_t m = (1ULL << rem) - 1; eF &= m; eB &= m; }
-                int tb = eB ? 2 * (int)(qc + __builtin_ctzll(eB)) : 0x7fffffff;
-                int tf = eF ? 2 * (int)(qc + __builtin_ctzll(eF)) + 1 : 0x7fffffff;
+                in_map_words(wc, v, c, mF, mB);
+                uint64_t eF = mF | pv_word(v, v.fF, wc.pl.ff, c);
+                uint64_t eB = mB | pv_word(v, v.fB, wc.pl.fb, c);
+                if (c == (q0 >> 6)) {               // nothing before q0; at q0 the backward half-step is behind us if t is odd
+                    const uint64_t from = ~0ULL << (q0 & 63);
+                    eF &= from;
+                    eB &= from;
+                    if (t & 1) eB &= ~(1ULL << (q0 & 63));
+                }
+                int tb = eB ? 2 * (int)(c * 64 + __builtin_ctzll(eB)) : 0x7fffffff;
+                int tf = eF ? 2 * (int)(c * 64 + __builtin_ctzll(eF)) + 1 : 0x7fffffff;
                 int te = tb < tf ? tb : tf;
-                if (te != 0x7fffffff) { t_ev = te; break; }
+                if (te != 0x7fffffff) {
+                    t_ev = te;
+                    ev_in_map = ((te & 1) ? mF : mB) >> ((te >> 1) & 63) & 1ULL;
+                    break;
+                }
             }
         }
         int tn = t_ev < t_sp ? t_ev : t_sp;
         if (tn > tmax) {   // ran off the end of the piece
             wc.nb_processed += (unsigned long long)(tmax - t + 1);
-            wc.nb_jcheck += jcheck_sum(wc.pl, p0, t, tmax + 1);
+            wc.nb_jcheck += jcheck_sum(wc, v, t, tmax + 1);
             break;
         }
         const uint32_t q = (uint32_t)(tn >> 1);
         const bool fwd = tn & 1;
         // why did we stop here?  (order of the tests in find_next_junction)
         bool in_map;
-        {
+        if (tn == t_ev) {
+            in_map = ev_in_map;
+        } else {           // stopped by the spacer rule before any event: the position itself may still be in the map
             uint64_t mF, mB;
-            inmap_chunk(wc, p0, q, nwin, mF, mB);
-            in_map = (fwd ? mF : mB) & 1ULL;
+            in_map_words(wc, v, q >> 6, mF, mB);
+            in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
         }
         const bool by_spacer = !in_map && (tn - last_pos >= spacer);
         wc.nb_processed += (unsigned long long)(tn - t);
-        wc.nb_jcheck += jcheck_sum(wc.pl, p0, t, (in_map || by_spacer) ? tn : tn + 1);
+        wc.nb_jcheck += jcheck_sum(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
 
         // ---- junction at (q, fwd)  (ReadScanner.cpp:133-192)
         uint64_t km = fd_kmer_at(wc.pl.codes, p0 + q, k);
         uint64_t key = fwd ? km : fd_revcomp(km, k);
         int real = fwd ? fd_base_at(wc.pl.codes, p0 + q + k) : (fd_base_at(wc.pl.codes, p0 + q - 1) ^ 2);
-        uint8_t* rec = junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn);
-        if (!rec) return;
+        RecRegs cur;
+        if (!junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn, cur)) return;
+        if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
+            created_bits(wc, v, 0, v.xF[0], v.xB[0]);
+            if (nwin > 64) created_bits(wc, v, 1, v.xF[1], v.xB[1]);
+        }
+        const bool same = have_last && cur.addr == last.addr;   // the same junction twice in a row: one register copy
+        if (same) cur = last;
         last_pos = tn;
-        rec_add_cov(rec, real);
+        rr_add_cov(cur, real);
         const int ext_fwd = fwd ? real : 4;          // getExtensionIndex(FORWARD)
         const int ext_bwd = fwd ? 4 : real;          // getExtensionIndex(BACKWARD)
         if (have_last) {                             // directLinkJunctions, JunctionMap.cpp:551-561
-            int d = tn - last_t;
-            rec_update(last_rec, last_ext_fwd, d);
-            rec_update(rec, ext_bwd, d);
-            last_rec[9] |= (uint8_t)(1u << last_ext_fwd);
-            rec[9] |= (uint8_t)(1u << ext_bwd);
+            const int d = tn - last_t;
+            if (same) {
+                rr_update(cur, last_ext_fwd, d);
+                rr_link(cur, last_ext_fwd);
+            } else {
+                rr_update(last, last_ext_fwd, d);
+                rr_link(last, last_ext_fwd);
+                rr_store(last);
+            }
+            rr_update(cur, ext_bwd, d);
+            rr_link(cur, ext_bwd);
         } else {
             have_last = true;
-            rec_update(rec, ext_bwd, tn - 2 * j);
+            rr_update(cur, ext_bwd, tn - 2 * j);
         }
-        last_rec = rec;
+        last = cur;
         last_t = tn;
         last_ext_fwd = ext_fwd;
-        int d = rec[ext_fwd];
+        int d = (int)rr_get(cur, ext_fwd);
         if (d < 1) d = 1;
         t = tn + d;
         wc.nb_processed += 1;
@@ -531,14 +635,16 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
         const int m = len / 2 - k / 2;
         uint64_t key = fd_kmer_at(wc.pl.codes, p0 + m, k);
         int real = fd_base_at(wc.pl.codes, p0 + m + k);
-        uint8_t* rec = junction_get(wc, key, (piece_seq << 16) | 0xFFFFULL);
-        if (!rec) return;
-        rec_add_cov(rec, real);
+        RecRegs rec;
+        if (!junction_get(wc, key, (piece_seq << 16) | 0xFFFFULL, rec)) return;
+        rr_add_cov(rec, real);
         const int tm = 2 * m + 1;
-        rec_update(rec, 4, tm - 2 * j);
-        rec_update(rec, real, (2 * (int)nwin - 1 - tm) - 2 * j);
+        rr_update(rec, 4, tm - 2 * j);
+        rr_update(rec, real, (2 * (int)nwin - 1 - tm) - 2 * j);
+        rr_store(rec);
     } else {            // ReadScanner.cpp:202-206
-        rec_update(last_rec, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j);
+        rr_update(last, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j);
+        rr_store(last);
     }
 }
 
@@ -549,7 +655,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = 0;
-    wc.nc = 0; wc.c_overflow = false;
+    wc.nc = 0; wc.c_overflow = false; wc.created_now = false;
     const WinDesc wd = make_window(pl, lo, hi);
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     if (i < n && root[i] == i) {
@@ -671,9 +777,11 @@ __global__ void __launch_bounds__(256) k_import(JTable jt, FdParams fp, const Ex
     r[1] = ((const uint64_t*)e.rec)[1];
     jt.stamps[slot * 2 + orient] = e.stamp;
     atomicOr((unsigned long long*)&jt.keys[slot], 1ULL << (62 + orient));
+    const uint64_t hb = jt_filter_bit(jt, canon);
+    atomicOr(&jt.filter[hb >> 5], 1u << (hb & 31));
 }
 
-JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1}; }
+JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1, ctx->jfilter, ctx->jcap * 2 - 1}; }
 WTable make_wt(fgpu_ctx* ctx) { return WTable{ctx->wkeys, ctx->wowner, ctx->wslots, ctx->wbits, ctx->wcap - 1}; }
 
 }  // namespace
@@ -685,6 +793,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->jkeys, ctx->jcap * 8));
     FGPU_HIP(hipMalloc(&ctx->jrecs, ctx->jcap * 32));
     FGPU_HIP(hipMalloc(&ctx->jstamps, ctx->jcap * 16));
+    FGPU_HIP(hipMalloc(&ctx->jfilter, ctx->jcap * 2 / 8));
     // Scheduling windows span at most FGPU_MAX_SPAN positions (+ one piece length).  Worst case every position is a
     // candidate with a distinct k-mer, so the window table holds 2x that; piece starts are >= k+1 apart.
     ctx->wcap = 4 * FGPU_MAX_SPAN;
@@ -704,6 +813,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
 
 int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wowner, 0xFF, ctx->wcap * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
