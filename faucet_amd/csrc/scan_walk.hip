@@ -118,7 +118,6 @@ __device__ __forceinline__ bool jt_find_or_claim(const JTable& jt, uint64_t cano
         if (w == J_EMPTY) {
             unsigned long long old = atomicCAS((unsigned long long*)&jt.keys[s], (unsigned long long)J_EMPTY, (unsigned long long)canon);
             if (old == J_EMPTY) {
-                atomicAdd(&cnt->table_slots_used, 1ULL);
                 slot = s;
                 present = 0;
                 return true;
@@ -258,18 +257,13 @@ __global__ void __launch_bounds__(256) k_walk_lookup(Planes pl, FdParams fp, JTa
         if (cand) claimed = wt_register(wt, parent, canon, li, cnt);
     }
     uint64_t mF = __ballot(inF), mB = __ballot(inB);
-    // list the slots this wave claimed: one counter atomic per wave
-    uint64_t mC = __ballot(claimed != U_INF);
-    unsigned long long base = 0;
     if (fd_lane() == 0) {
         pl.inF[p >> 6] = mF;
         pl.inB[p >> 6] = mB;
-        if (mC) base = atomicAdd(parity ? &cnt->wt_used_b : &cnt->wt_used, (unsigned long long)__popcll(mC));
     }
-    if (mC) {
-        base = __shfl(base, 0, 64);
-        if (claimed != U_INF) wt.slots[base + __popcll(mC & ((1ULL << fd_lane()) - 1))] = claimed;
-    }
+    // remember which window-table slot this position claimed (for the sparse clean-up).  Indexed by position, NOT
+    // appended through a shared counter: one same-address atomic per wave would serialise the whole kernel.
+    if (claimed != U_INF) wt.slots[p - (wd.lo & ~63ULL)] = claimed;
 }
 
 // ---- B: link every piece to the owners of the candidate k-mers that occur on it ---------------------
@@ -691,17 +685,16 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
 }
 
 // ---- E: sparse reset of the window table ----------------------------------------------------------------
-// The two "slots used" counters alternate between consecutive windows, so this kernel can also zero the one the
-// next window will count into (it was consumed by the previous window's clean-up).
-__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, DevCounters* cnt, uint32_t* parent, Planes pl, uint64_t lo, uint64_t hi,
-                                                    int parity) {
-    uint64_t used = parity ? cnt->wt_used_b : cnt->wt_used;
+// wt.slots is indexed by position relative to the window's (word-aligned) start: U_INF = that position claimed nothing.
+__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent, Planes pl, uint64_t lo, uint64_t hi, uint64_t pos_end) {
     const uint32_t n = make_window(pl, lo, hi).n;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { if (parity) cnt->wt_used = 0; else cnt->wt_used_b = 0; }
+    const uint64_t span = pos_end - (lo & ~63ULL);
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t a = i; a < used; a += stride) {
+    for (uint64_t a = i; a < span; a += stride) {
         uint32_t s = wt.slots[a];
+        if (s == U_INF) continue;
+        wt.slots[a] = U_INF;
         uint64_t key = wt.keys[s];
         uint32_t b = (uint32_t)(fd_mix(key) >> 40) & ((1u << WBITS_LOG2) - 1);
         wt.bits[b >> 5] = 0;   // whole word: every bit of it belongs to a key that is being removed as well
@@ -816,6 +809,7 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wowner, 0xFF, ctx->wcap * 4, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->wslots, 0xFF, ctx->wcap * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
     return FGPU_OK;
@@ -850,7 +844,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     ctx->cl_members, pl, lo, hi, ctx->counters);
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->uf_parent, (const uint32_t*)ctx->cl_count,
                     (const uint32_t*)ctx->cl_offset, ctx->cl_members, lo, hi, seq_base, ctx->counters);
-        FGPU_LAUNCH("walk_clean", k_walk_clean, 64, 256, wt, ctx->counters, ctx->uf_parent, pl, lo, hi, parity);
+        FGPU_LAUNCH("walk_clean", k_walk_clean, 512, 256, wt, ctx->uf_parent, pl, lo, hi, pos_end);
         ctx->scan_windows++;
     }
     ctx->prof_suppress = false;
