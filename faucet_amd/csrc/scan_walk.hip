@@ -345,8 +345,9 @@ __global__ void __launch_bounds__(CL_BLOCK) k_walk_cluster(uint32_t* parent, uin
 struct PieceView {
     uint64_t p0;
     uint32_t nwin;
-    uint64_t inF[2], inB[2], fF[2], fB[2], c0F[2], c1F[2], c0B[2], c1B[2];
-    uint64_t xF[2], xB[2];   // positions whose key this thread's cluster created during the current window
+    // two words per plane, as SCALAR members: runtime-indexed arrays would be demoted to scratch memory
+    uint64_t inF0, inF1, inB0, inB1, fF0, fF1, fB0, fB1, c0F0, c0F1, c1F0, c1F1, c0B0, c0B1, c1B0, c1B1;
+    uint64_t xF0, xF1, xB0, xB1;   // positions whose key this thread's cluster created during the current window
 };
 
 struct WalkCtx {
@@ -359,7 +360,7 @@ struct WalkCtx {
     // oriented keys this thread's cluster has created in the current window: the snapshot planes of phase A cannot
     // know them, every later in-map test of the cluster has to (tandem repeats inside a piece; later pieces of the cluster)
     static constexpr int NC = 16;
-    uint64_t ckey[NC];
+    uint64_t* ckey;     // NC entries, a thread-private array of the kernel (the only part of the state in scratch)
     int nc;
     bool c_overflow;    // more than NC creations: fall back to live table lookups
     bool created_now;   // set by junction_get
@@ -373,75 +374,86 @@ __device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
 }
 
 // plane word for windows [64c, 64c+64) of the piece
-__device__ __forceinline__ uint64_t pv_word(const PieceView& v, const uint64_t* regs, const uint64_t* plane, uint32_t c) {
-    if (c < 2) return regs[c];
+__device__ __forceinline__ uint64_t pv_word(const PieceView& v, uint64_t r0, uint64_t r1, const uint64_t* plane, uint32_t c) {
+    if (c == 0) return r0;
+    if (c == 1) return r1;
     return fd_bits_at(plane, v.p0 + 64ULL * c) & chunk_mask(v.nwin, c);
 }
 
-__device__ void pv_load(PieceView& v, const Planes& pl, uint64_t p0, uint32_t nwin) {
+__device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t p0, uint32_t nwin) {
     v.p0 = p0;
     v.nwin = nwin;
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const uint64_t m = chunk_mask(nwin, c);
-        const uint64_t p = p0 + 64ULL * c;
-        // words past the piece are never dereferenced beyond the planes' padding: m == 0 skips the loads
-        v.inF[c] = m ? fd_bits_at(pl.inF, p) & m : 0;
-        v.inB[c] = m ? fd_bits_at(pl.inB, p) & m : 0;
-        v.fF[c] = m ? fd_bits_at(pl.ff, p) & m : 0;
-        v.fB[c] = m ? fd_bits_at(pl.fb, p) & m : 0;
-        v.c0F[c] = m ? fd_bits_at(pl.cf0, p) & m : 0;
-        v.c1F[c] = m ? fd_bits_at(pl.cf1, p) & m : 0;
-        v.c0B[c] = m ? fd_bits_at(pl.cb0, p) & m : 0;
-        v.c1B[c] = m ? fd_bits_at(pl.cb1, p) & m : 0;
-        v.xF[c] = v.xB[c] = 0;
-    }
+    const uint64_t m0 = chunk_mask(nwin, 0), m1 = chunk_mask(nwin, 1);
+    const uint64_t p1 = p0 + 64;
+    // one burst of independent loads (a piece's second word is skipped when the piece has at most 64 windows)
+    v.inF0 = fd_bits_at(pl.inF, p0) & m0;   v.inF1 = m1 ? fd_bits_at(pl.inF, p1) & m1 : 0;
+    v.inB0 = fd_bits_at(pl.inB, p0) & m0;   v.inB1 = m1 ? fd_bits_at(pl.inB, p1) & m1 : 0;
+    v.fF0 = fd_bits_at(pl.ff, p0) & m0;     v.fF1 = m1 ? fd_bits_at(pl.ff, p1) & m1 : 0;
+    v.fB0 = fd_bits_at(pl.fb, p0) & m0;     v.fB1 = m1 ? fd_bits_at(pl.fb, p1) & m1 : 0;
+    v.c0F0 = fd_bits_at(pl.cf0, p0) & m0;   v.c0F1 = m1 ? fd_bits_at(pl.cf0, p1) & m1 : 0;
+    v.c1F0 = fd_bits_at(pl.cf1, p0) & m0;   v.c1F1 = m1 ? fd_bits_at(pl.cf1, p1) & m1 : 0;
+    v.c0B0 = fd_bits_at(pl.cb0, p0) & m0;   v.c0B1 = m1 ? fd_bits_at(pl.cb0, p1) & m1 : 0;
+    v.c1B0 = fd_bits_at(pl.cb1, p0) & m0;   v.c1B1 = m1 ? fd_bits_at(pl.cb1, p1) & m1 : 0;
+    v.xF0 = v.xF1 = v.xB0 = v.xB1 = 0;
 }
 
 // in-map bits of chunk c that the snapshot cannot know: keys created by this cluster since phase A.
 // Either compared k-mer by k-mer against the short created list (no memory traffic), or, once that list has
 // overflowed, by live table lookups.
-__device__ void created_bits(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
-    mF = mB = 0;
-    const uint32_t base = c * 64;
-    for (uint32_t i = 0; i < 64 && base + i < v.nwin; i++) {
-        uint64_t km = fd_kmer_at(wc.pl.codes, v.p0 + base + i, wc.fp.k);
-        uint64_t rc = fd_revcomp(km, wc.fp.k);
-        if (!wc.c_overflow) {
-            for (int n = 0; n < wc.nc; n++) {
-                if (wc.ckey[n] == km) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
-                if (wc.ckey[n] == rc) mB |= 1ULL << i;   // backward-facing key = its reverse complement
+// Out of line and fed by value on purpose: it is the rare path, and it is the only code that indexes the created-key
+// list at run time — keeping it away from WalkCtx lets the rest of the walk state live in registers.
+__device__ __noinline__ uint4 created_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint32_t n_pos,
+                                                const uint64_t* ckey, int nc, bool overflow, JTable jt) {
+    uint64_t mF = 0, mB = 0;
+    for (uint32_t i = 0; i < n_pos; i++) {
+        uint64_t km = fd_kmer_at(codes, p + i, k);
+        uint64_t rc = fd_revcomp(km, k);
+        if (!overflow) {
+            for (int n = 0; n < nc; n++) {
+                if (ckey[n] == km) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
+                if (ckey[n] == rc) mB |= 1ULL << i;   // backward-facing key = its reverse complement
             }
         } else {
             uint64_t canon = km < rc ? km : rc;
             uint64_t slot;
             uint32_t present;
-            if (jt_find_live(wc.jt, canon, slot, present)) {
+            if (jt_find_live(jt, canon, slot, present)) {
                 if ((present >> (km == canon ? 0 : 1)) & 1u) mF |= 1ULL << i;
                 if ((present >> (rc == canon ? 0 : 1)) & 1u) mB |= 1ULL << i;
             }
         }
     }
+    return make_uint4((uint32_t)mF, (uint32_t)(mF >> 32), (uint32_t)mB, (uint32_t)(mB >> 32));
+}
+
+__device__ __forceinline__ void created_bits(const WalkCtx& wc, const uint64_t* ckey, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+    const uint32_t base = c * 64;
+    const uint32_t n_pos = base >= v.nwin ? 0 : (v.nwin - base < 64 ? v.nwin - base : 64);
+    uint4 r = created_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, n_pos, ckey, wc.nc, wc.c_overflow, wc.jt);
+    mF = (uint64_t)r.x | ((uint64_t)r.y << 32);
+    mB = (uint64_t)r.z | ((uint64_t)r.w << 32);
 }
 
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
-    mF = pv_word(v, v.inF, wc.pl.inF, c);
-    mB = pv_word(v, v.inB, wc.pl.inB, c);
+    const uint64_t* ckey = wc.ckey;
+    mF = pv_word(v, v.inF0, v.inF1, wc.pl.inF, c);
+    mB = pv_word(v, v.inB0, v.inB1, wc.pl.inB, c);
     if (wc.nc == 0 && !wc.c_overflow) return;
-    if (c < 2) { mF |= v.xF[c]; mB |= v.xB[c]; return; }
+    if (c == 0) { mF |= v.xF0; mB |= v.xB0; return; }
+    if (c == 1) { mF |= v.xF1; mB |= v.xB1; return; }
     uint64_t a, b;
-    created_bits(wc, v, c, a, b);
+    created_bits(wc, ckey, v, c, a, b);
     mF |= a;
     mB |= b;
 }
 
 // number of set bits of the plane at windows [qa, qb) of the piece
-__device__ __forceinline__ uint32_t pv_popc(const PieceView& v, const uint64_t* regs, const uint64_t* plane, uint32_t qa, uint32_t qb) {
+__device__ __forceinline__ uint32_t pv_popc(const PieceView& v, uint64_t r0, uint64_t r1, const uint64_t* plane, uint32_t qa, uint32_t qb) {
     uint32_t s = 0;
     if (qb > v.nwin) qb = v.nwin;
     while (qa < qb) {
         const uint32_t c = qa >> 6;
-        uint64_t w = pv_word(v, regs, plane, c) >> (qa & 63);
+        uint64_t w = pv_word(v, r0, r1, plane, c) >> (qa & 63);
         const uint32_t n = min(qb - qa, 64u - (qa & 63));
         if (n < 64) w &= (1ULL << n) - 1;
         s += (uint32_t)__popcll(w);
@@ -455,8 +467,8 @@ __device__ __forceinline__ uint32_t jcheck_sum(const WalkCtx& wc, const PieceVie
     if (t1 <= t0) return 0;
     const uint32_t bq0 = (uint32_t)((t0 + 1) >> 1), bq1 = (uint32_t)((t1 + 1) >> 1);
     const uint32_t fq0 = (uint32_t)(t0 >> 1), fq1 = (uint32_t)(t1 >> 1);
-    return pv_popc(v, v.c0B, wc.pl.cb0, bq0, bq1) + 2 * pv_popc(v, v.c1B, wc.pl.cb1, bq0, bq1) +
-           pv_popc(v, v.c0F, wc.pl.cf0, fq0, fq1) + 2 * pv_popc(v, v.c1F, wc.pl.cf1, fq0, fq1);
+    return pv_popc(v, v.c0B0, v.c0B1, wc.pl.cb0, bq0, bq1) + 2 * pv_popc(v, v.c1B0, v.c1B1, wc.pl.cb1, bq0, bq1) +
+           pv_popc(v, v.c0F0, v.c0F1, wc.pl.cf0, fq0, fq1) + 2 * pv_popc(v, v.c1F0, v.c1F1, wc.pl.cf1, fq0, fq1);
 }
 
 // A junction record held in two registers: dist[0..4] bytes 0-4, cov[0..3] bytes 5-8, linked mask byte 9.
@@ -481,7 +493,7 @@ __device__ __forceinline__ void rr_link(RecRegs& r, int idx) { rr_set(r, 9, rr_g
 __device__ __forceinline__ void rr_store(const RecRegs& r) { r.addr[0] = r.lo; r.addr[1] = r.hi; }
 
 // find or create the junction keyed by the oriented k-mer `key`; the record comes back in registers
-__device__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, RecRegs& out) {
+__device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, RecRegs& out) {
     uint64_t rc = fd_revcomp(key, wc.fp.k);
     uint64_t canon = key < rc ? key : rc;
     int orient = key == canon ? 0 : 1;
@@ -501,8 +513,8 @@ __device__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, RecRegs&
         wc.jt.stamps[slot * 2 + orient] = stamp;
         atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
         // presence filter in front of the table (phase A of later windows tests it before probing)
-        uint64_t hb = jt_filter_bit(wc.jt, canon);
-        atomicOr(&wc.jt.filter[hb >> 5], 1u << (hb & 31));
+        uint64_t hb = fd_mix(canon) >> 24;
+        atomicOr(&wc.jt.filter[(hb & wc.jt.filter_mask) >> 5], 1u << (hb & 31));
         wc.n_created++;
     } else {
         out.lo = out.addr[0];
@@ -512,15 +524,15 @@ __device__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, RecRegs&
 }
 
 // scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}
-__device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t piece_seq) {
+__device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t piece_seq) {
     const int k = wc.fp.k, j = wc.fp.j;
     const int tmax = 2 * (int)nwin - 2 - 2 * j;     // last half-step with distToEnd > 2j
     const int spacer = 2 * wc.fp.max_spacer - 1;
     PieceView v;
     pv_load(v, wc.pl, p0, nwin);
     if (wc.nc || wc.c_overflow) {                   // an earlier piece of this cluster created keys
-        created_bits(wc, v, 0, v.xF[0], v.xB[0]);
-        if (nwin > 64) created_bits(wc, v, 1, v.xF[1], v.xB[1]);
+        created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
+        if (nwin > 64) created_bits(wc, wc.ckey, v, 1, v.xF1, v.xB1);
     }
     int t = 2 * j + 1;
     int last_pos = 0;                               // lastJuncPos
@@ -542,8 +554,8 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
             for (uint32_t c = q0 >> 6; c * 64 < nwin && 2 * (int)(c * 64) <= t_stop; c++) {
                 uint64_t mF, mB;
                 in_map_words(wc, v, c, mF, mB);
-                uint64_t eF = mF | pv_word(v, v.fF, wc.pl.ff, c);
-                uint64_t eB = mB | pv_word(v, v.fB, wc.pl.fb, c);
+                uint64_t eF = mF | pv_word(v, v.fF0, v.fF1, wc.pl.ff, c);
+                uint64_t eB = mB | pv_word(v, v.fB0, v.fB1, wc.pl.fb, c);
                 if (c == (q0 >> 6)) {               // nothing before q0; at q0 the backward half-step is behind us if t is odd
                     const uint64_t from = ~0ULL << (q0 & 63);
                     eF &= from;
@@ -588,8 +600,8 @@ __device__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t pie
         RecRegs cur;
         if (!junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn, cur)) return;
         if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
-            created_bits(wc, v, 0, v.xF[0], v.xB[0]);
-            if (nwin > 64) created_bits(wc, v, 1, v.xF[1], v.xB[1]);
+            created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
+            if (nwin > 64) created_bits(wc, wc.ckey, v, 1, v.xF1, v.xB1);
         }
         const bool same = have_last && cur.addr == last.addr;   // the same junction twice in a row: one register copy
         if (same) cur = last;
@@ -646,29 +658,27 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ offset, uint32_t* members,
                                              uint64_t lo, uint64_t hi, uint64_t piece_seq_base, DevCounters* cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t created_keys[WalkCtx::NC];
     WalkCtx wc;
+    wc.ckey = created_keys;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = 0;
     wc.nc = 0; wc.c_overflow = false; wc.created_now = false;
     const WinDesc wd = make_window(pl, lo, hi);
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     if (i < n && root[i] == i) {
-        uint2 pc = pl.pieces[first_piece + i];
-        walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + i);
-        uint32_t nm = count[i];
-        if (nm) {
-            uint32_t* mem = members + offset[i];
-            for (uint32_t a = 1; a < nm; a++) {   // insertion sort: ascending piece order
-                uint32_t v = mem[a];
-                uint32_t b = a;
-                while (b > 0 && mem[b - 1] > v) { mem[b] = mem[b - 1]; b--; }
-                mem[b] = v;
-            }
-            for (uint32_t a = 0; a < nm; a++) {
-                uint32_t m = mem[a];
-                uint2 pm = pl.pieces[first_piece + m];
-                walk_piece(wc, pm.x, pm.y, piece_seq_base + first_piece + m);
-            }
+        const uint32_t nm = count[i];
+        uint32_t* mem = members + offset[i];
+        for (uint32_t a = 1; a < nm; a++) {   // insertion sort of the followers: ascending piece order
+            uint32_t v = mem[a];
+            uint32_t b = a;
+            while (b > 0 && mem[b - 1] > v) { mem[b] = mem[b - 1]; b--; }
+            mem[b] = v;
+        }
+        for (uint32_t a = 0; a <= nm; a++) {  // the leader first (smallest index of the cluster), then its followers in order
+            const uint32_t m = a == 0 ? i : mem[a - 1];
+            const uint2 pc = pl.pieces[first_piece + m];
+            walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + m);
         }
     }
     // wave-level reduction of the counters
