@@ -321,7 +321,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_piece_base = 0;
     ctx->scan_imported = 0;
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), FGPU_MAX_SPAN)
-                                                 : (1ULL << 19);
+                                                 : (1ULL << 20);
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
     ctx->walked_pieces = 0;

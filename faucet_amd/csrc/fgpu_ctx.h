@@ -14,7 +14,7 @@
 // every per-position plane / code array carries this many padding words past ceil(T/64): kernels run
 // whole 256-thread blocks and funnel-read one word ahead
 #define FGPU_PADW 8
-#define FGPU_MAX_SPAN (1ULL << 20)   // largest scheduling window of the ordered walk, in stream positions
+#define FGPU_MAX_SPAN (1ULL << 22)   // largest scheduling window of the ordered walk, in stream positions
 
 // A growable device buffer (hipMalloc'd; freed with the context).
 struct DevBuf {

@@ -65,7 +65,7 @@ __device__ __forceinline__ uint64_t fd_kmer_at(const uint64_t* __restrict__ code
     uint64_t w = p >> 5;
     int o = (int)(p & 31) * 2;
     uint64_t hi = codes[w], lo = codes[w + 1];
-    uint64_t v = o ? ((hi << o) | (lo >> (64 - o))) : hi;
+    uint64_t v = (hi << o) | ((lo >> 1) >> (63 - o));   // branch-free funnel (o may be 0): both loads issue together
     return v >> (64 - 2 * k);
 }
 
@@ -77,9 +77,8 @@ __device__ __forceinline__ int fd_base_at(const uint64_t* __restrict__ codes, ui
 __device__ __forceinline__ uint64_t fd_bits_at(const uint64_t* __restrict__ plane, uint64_t p) {
     uint64_t w = p >> 6;
     int o = (int)(p & 63);
-    uint64_t lo = plane[w];
-    if (o == 0) return lo;
-    return (lo >> o) | (plane[w + 1] << (64 - o));
+    uint64_t lo = plane[w], hi = plane[w + 1];
+    return (lo >> o) | ((hi << 1) << (63 - o));          // branch-free funnel (o may be 0): both loads issue together
 }
 
 // window [p, p+k) free of bad positions?

@@ -348,6 +348,8 @@ struct PieceView {
     // two words per plane, as SCALAR members: runtime-indexed arrays would be demoted to scratch memory
     uint64_t inF0, inF1, inB0, inB1, fF0, fF1, fB0, fB1, c0F0, c0F1, c1F0, c1F1, c0B0, c0B1, c1B0, c1B1;
     uint64_t xF0, xF1, xB0, xB1;   // positions whose key this thread's cluster created during the current window
+    uint64_t cbase;                // stream position of the first base held in cw0 (multiple of 32)
+    uint64_t cw0, cw1, cw2, cw3, cw4, cw5;   // 192 bases of 2-bit codes: a whole <= 160-base piece, k-mers come out of registers
 };
 
 struct WalkCtx {
@@ -386,15 +388,36 @@ __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t
     const uint64_t m0 = chunk_mask(nwin, 0), m1 = chunk_mask(nwin, 1);
     const uint64_t p1 = p0 + 64;
     // one burst of independent loads (a piece's second word is skipped when the piece has at most 64 windows)
-    v.inF0 = fd_bits_at(pl.inF, p0) & m0;   v.inF1 = m1 ? fd_bits_at(pl.inF, p1) & m1 : 0;
-    v.inB0 = fd_bits_at(pl.inB, p0) & m0;   v.inB1 = m1 ? fd_bits_at(pl.inB, p1) & m1 : 0;
-    v.fF0 = fd_bits_at(pl.ff, p0) & m0;     v.fF1 = m1 ? fd_bits_at(pl.ff, p1) & m1 : 0;
-    v.fB0 = fd_bits_at(pl.fb, p0) & m0;     v.fB1 = m1 ? fd_bits_at(pl.fb, p1) & m1 : 0;
-    v.c0F0 = fd_bits_at(pl.cf0, p0) & m0;   v.c0F1 = m1 ? fd_bits_at(pl.cf0, p1) & m1 : 0;
-    v.c1F0 = fd_bits_at(pl.cf1, p0) & m0;   v.c1F1 = m1 ? fd_bits_at(pl.cf1, p1) & m1 : 0;
-    v.c0B0 = fd_bits_at(pl.cb0, p0) & m0;   v.c0B1 = m1 ? fd_bits_at(pl.cb0, p1) & m1 : 0;
-    v.c1B0 = fd_bits_at(pl.cb1, p0) & m0;   v.c1B1 = m1 ? fd_bits_at(pl.cb1, p1) & m1 : 0;
+    v.inF0 = fd_bits_at(pl.inF, p0) & m0;   v.inF1 = fd_bits_at(pl.inF, p1) & m1;
+    v.inB0 = fd_bits_at(pl.inB, p0) & m0;   v.inB1 = fd_bits_at(pl.inB, p1) & m1;
+    v.fF0 = fd_bits_at(pl.ff, p0) & m0;     v.fF1 = fd_bits_at(pl.ff, p1) & m1;
+    v.fB0 = fd_bits_at(pl.fb, p0) & m0;     v.fB1 = fd_bits_at(pl.fb, p1) & m1;
+    v.c0F0 = fd_bits_at(pl.cf0, p0) & m0;   v.c0F1 = fd_bits_at(pl.cf0, p1) & m1;
+    v.c1F0 = fd_bits_at(pl.cf1, p0) & m0;   v.c1F1 = fd_bits_at(pl.cf1, p1) & m1;
+    v.c0B0 = fd_bits_at(pl.cb0, p0) & m0;   v.c0B1 = fd_bits_at(pl.cb0, p1) & m1;
+    v.c1B0 = fd_bits_at(pl.cb1, p0) & m0;   v.c1B1 = fd_bits_at(pl.cb1, p1) & m1;
     v.xF0 = v.xF1 = v.xB0 = v.xB1 = 0;
+    v.cbase = p0 & ~31ULL;
+    const uint64_t* cw = pl.codes + (v.cbase >> 5);   // padded: reading 6 words from any piece start stays inside the buffer
+    v.cw0 = cw[0]; v.cw1 = cw[1]; v.cw2 = cw[2]; v.cw3 = cw[3]; v.cw4 = cw[4]; v.cw5 = cw[5];
+}
+
+__device__ __forceinline__ uint64_t pv_cw(const PieceView& v, uint32_t w) {
+    return w == 0 ? v.cw0 : w == 1 ? v.cw1 : w == 2 ? v.cw2 : w == 3 ? v.cw3 : w == 4 ? v.cw4 : v.cw5;
+}
+// k-mer / base at stream position p: from the register copy when it covers p, else from memory
+__device__ __forceinline__ uint64_t pv_kmer(const PieceView& v, const uint64_t* codes, uint64_t p, int k) {
+    const uint64_t rel = p - v.cbase;
+    if (rel + (uint64_t)k > 160) return fd_kmer_at(codes, p, k);
+    const uint32_t w = (uint32_t)(rel >> 5);
+    const int o = (int)(rel & 31) * 2;
+    const uint64_t hi = pv_cw(v, w), lo = pv_cw(v, w + 1);
+    return ((hi << o) | ((lo >> 1) >> (63 - o))) >> (64 - 2 * k);
+}
+__device__ __forceinline__ int pv_base(const PieceView& v, const uint64_t* codes, uint64_t p) {
+    const uint64_t rel = p - v.cbase;   // p >= p0 - 1; p0 - 1 can precede cbase only when p0 is a multiple of 32
+    if (p < v.cbase || rel >= 192) return fd_base_at(codes, p);
+    return (int)((pv_cw(v, (uint32_t)(rel >> 5)) >> (62 - 2 * (int)(rel & 31))) & 3);
 }
 
 // in-map bits of chunk c that the snapshot cannot know: keys created by this cluster since phase A.
@@ -594,9 +617,9 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         wc.nb_jcheck += jcheck_sum(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
 
         // ---- junction at (q, fwd)  (ReadScanner.cpp:133-192)
-        uint64_t km = fd_kmer_at(wc.pl.codes, p0 + q, k);
+        uint64_t km = pv_kmer(v, wc.pl.codes, p0 + q, k);
         uint64_t key = fwd ? km : fd_revcomp(km, k);
-        int real = fwd ? fd_base_at(wc.pl.codes, p0 + q + k) : (fd_base_at(wc.pl.codes, p0 + q - 1) ^ 2);
+        int real = fwd ? pv_base(v, wc.pl.codes, p0 + q + k) : (pv_base(v, wc.pl.codes, p0 + q - 1) ^ 2);
         RecRegs cur;
         if (!junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn, cur)) return;
         if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
@@ -639,8 +662,8 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         wc.nb_no_juncs++;
         const int len = (int)nwin + k - 1;
         const int m = len / 2 - k / 2;
-        uint64_t key = fd_kmer_at(wc.pl.codes, p0 + m, k);
-        int real = fd_base_at(wc.pl.codes, p0 + m + k);
+        uint64_t key = pv_kmer(v, wc.pl.codes, p0 + m, k);
+        int real = pv_base(v, wc.pl.codes, p0 + m + k);
         RecRegs rec;
         if (!junction_get(wc, key, (piece_seq << 16) | 0xFFFFULL, rec)) return;
         rr_add_cov(rec, real);
