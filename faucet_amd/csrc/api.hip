@@ -338,8 +338,8 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
-        if (f * 8 > p && ctx->window_span > 4096) ctx->window_span /= 2;
-        else if (f * 64 < p && ctx->window_span < FGPU_MAX_SPAN) ctx->window_span *= 2;
+        if (f * 4 > p && ctx->window_span > 4096) ctx->window_span /= 2;
+        else if (f * 16 < p && ctx->window_span < FGPU_MAX_SPAN) ctx->window_span *= 2;
     }
     ctx->adapt_followers = ctx->counters_host->followers;
     ctx->adapt_pieces = ctx->walked_pieces;

@@ -289,45 +289,36 @@ __global__ void __launch_bounds__(CL_BLOCK) k_walk_cluster(uint32_t* parent, uin
     __shared__ uint32_t sh[CL_BLOCK];
     __shared__ uint32_t carry;
     const uint32_t n = make_window(pl, lo, hi).n;
-    // flatten; count followers per root
+    // flatten (one traversal per piece; the tree is read-only here: all unions happened in the previous kernels);
+    // the flat roots go to scratch behind the member lists and replace the tree after a barrier
     for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) { count[i] = 0; fill[i] = 0; }
     __syncthreads();
     uint32_t nf = 0;
     for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) {
         uint32_t r = i;
         for (;;) { uint32_t pr = parent[r]; if (pr == r) break; r = pr; }
+        members[n + i] = r;
         if (r != i) { atomicAdd(&count[r], 1u); nf++; }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) {   // second sweep writes the flat roots (after all reads of the tree)
-        uint32_t r = i;
-        for (;;) { uint32_t pr = parent[r]; if (pr == r) break; r = pr; }
-        members[n + i] = r;   // scratch: flat root of i, stored behind the member lists
-    }
-    __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) parent[i] = members[n + i];
+    // exclusive scan of count -> offset: every thread owns one contiguous chunk, so ONE block-wide scan suffices
+    const uint32_t per = (n + CL_BLOCK - 1) / CL_BLOCK;
+    const uint32_t c_lo = min(n, threadIdx.x * per), c_hi = min(n, c_lo + per);
+    uint32_t mx = 0, local = 0;
+    for (uint32_t i = c_lo; i < c_hi; i++) { uint32_t c = count[i]; local += c; mx = c > mx ? c : mx; }
+    sh[threadIdx.x] = local;
     __syncthreads();
-    // exclusive scan of count -> offset
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    uint32_t mx = 0;
-    for (uint32_t base = 0; base < n; base += CL_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t c = i < n ? count[i] : 0;
-        mx = c > mx ? c : mx;
-        sh[threadIdx.x] = c;
+    for (int o = 1; o < CL_BLOCK; o <<= 1) {
+        uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
         __syncthreads();
-        for (int o = 1; o < CL_BLOCK; o <<= 1) {
-            uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n) offset[i] = carry + sh[threadIdx.x] - c;
-        __syncthreads();
-        if (threadIdx.x == CL_BLOCK - 1) carry += sh[threadIdx.x];
+        sh[threadIdx.x] += t;
         __syncthreads();
     }
+    uint32_t run = sh[threadIdx.x] - local;
+    for (uint32_t i = c_lo; i < c_hi; i++) { offset[i] = run; run += count[i]; }
+    __syncthreads();
+    (void)carry;
     // scatter followers (unordered inside a cluster; the leader sorts its own short list)
     for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) {
         uint32_t r = parent[i];
