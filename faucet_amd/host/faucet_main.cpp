@@ -1,0 +1,323 @@
+// faucet_main.cpp — the `faucet` command line on top of libfaucet_gpu.so (C ABI, include/faucet_gpu.h).
+//
+// Host side of the hot path in the reference's own language (C++11).  Same flags, same required arguments, same
+// exit codes and the same output files as src/Faucet.cpp:57-182,248-300 for the part of the run this repository
+// covers: the Bloom load pass (-> <prefix>.bloom) and the junction scan (-> <prefix>.junctions).  The contig-graph
+// stage is not part of this build: the program stops where the reference's --no_cleaning run stops producing
+// hot-path files.  No k-mer, hash or junction is computed on the host: everything goes through fgpu_*; if the
+// library finds no gfx950 device the program fails (there is no CPU path).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <fstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "faucet_gpu.h"
+
+namespace {
+
+struct Options {   // globals of src/Faucet.h:14-53
+    float fp_rate = .04f;
+    int j = 1;
+    std::string read_load_file, read_scan_file, bloom_input_file, junctions_prefix, file_prefix;
+    int read_length = 0, k = 0;
+    uint64_t estimated_kmers = 0, singletons = 0;
+    bool load_file_flag = false, scan_file_flag = false, k_val_flag = false, max_len_flag = false, est_kmers_flag = false,
+         est_sing_flag = false, pref_flag = false;
+    bool two_hash = false, from_bloom = false, from_junctions = false, just_load = false, fastq = false, mercy = false,
+         node_graph = false, paired_ends = false, no_cleaning = false, high_cov = false;
+    int max_spacer_dist = 100;
+    uint64_t batch_reads = 2000000;   // not a reference flag: reads handed to the device per call (-batch_reads)
+};
+
+void argument_error() {   // src/Faucet.cpp:50-54
+    fprintf(stderr, "Usage:\n");
+    fprintf(stderr, "./faucet -read_load_file <filename> -read_scan_file <filename> -size_kmer <k> -max_read_length <length> "
+                    "-estimated_kmers <num_kmers> -singletons <num_kmers> -file_prefix <prefix>");
+    fprintf(stderr, "\nOptional arguments: --fastq --mercy --high_cov -max_spacer_dist <dist> -fp rate <rate> -j <int> --two_hash "
+                    "-bloom_file <filename> -junctions_file <filename> --paired_ends --no_cleaning\n");
+}
+
+// src/Faucet.cpp:57-182 (with the missing `return 0` supplied and a bounds check on flag values)
+int handle_arguments(int argc, char** argv, Options& o) {
+    if (argc == 1) { argument_error(); return 1; }
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&](const char*& out) { if (i + 1 >= argc) return false; out = argv[++i]; return true; };
+        const char* v = nullptr;
+        if (a == "-read_load_file") { if (!val(v)) goto bad; o.read_load_file = v; o.load_file_flag = true; }
+        else if (a == "-read_scan_file") { if (!val(v)) goto bad; o.read_scan_file = v; o.scan_file_flag = true; }
+        else if (a == "-size_kmer") { if (!val(v)) goto bad; o.k = atoi(v); o.k_val_flag = true; }
+        else if (a == "-max_read_length") { if (!val(v)) goto bad; o.read_length = atoi(v); o.max_len_flag = true; }
+        else if (a == "-estimated_kmers") { if (!val(v)) goto bad; o.estimated_kmers = (uint64_t)atoll(v); o.est_kmers_flag = true; }
+        else if (a == "-singletons") { if (!val(v)) goto bad; o.singletons = (uint64_t)atoll(v); o.est_sing_flag = true; }
+        else if (a == "-fp") { if (!val(v)) goto bad; o.fp_rate = (float)atof(v); }
+        else if (a == "-j") { if (!val(v)) goto bad; o.j = atoi(v); }
+        else if (a == "-file_prefix") { if (!val(v)) goto bad; o.file_prefix = v; o.pref_flag = true; }
+        else if (a == "--two_hash") o.two_hash = true;
+        else if (a == "--just_load_bloom") o.just_load = true;
+        else if (a == "--no_cleaning") o.no_cleaning = true;
+        else if (a == "--fastq") o.fastq = true;
+        else if (a == "--mercy") o.mercy = true;
+        else if (a == "--high_cov") o.high_cov = true;
+        else if (a == "--node_graph") o.node_graph = true;
+        else if (a == "--paired_ends") o.paired_ends = true;
+        else if (a == "-bloom_file") { if (!val(v)) goto bad; o.bloom_input_file = v; o.from_bloom = true; }
+        else if (a == "-max_spacer_dist") { if (!val(v)) goto bad; o.max_spacer_dist = atoi(v); }
+        else if (a == "-junctions_file") { if (!val(v)) goto bad; o.junctions_prefix = v; o.from_junctions = true; }
+        else if (a == "-batch_reads") { if (!val(v)) goto bad; o.batch_reads = (uint64_t)atoll(v); }
+        else if (a == "--help" || a == "-h") { argument_error(); return 1; }
+        else { fprintf(stderr, "Cannot parse tag %s\n", argv[i]); argument_error(); return 1; }
+        continue;
+    bad:
+        fprintf(stderr, "Missing value after %s\n", a.c_str());
+        argument_error();
+        return 1;
+    }
+    if (!(o.load_file_flag && o.scan_file_flag && o.k_val_flag && o.max_len_flag && o.est_kmers_flag && o.est_sing_flag && o.pref_flag)) {
+        fprintf(stderr, "Some required argument is missing.\n");
+        argument_error();
+        return 1;
+    }
+    if (o.from_junctions && !o.from_bloom) {
+        fprintf(stderr, "Cannot start from junctions without a bloom file.\n");
+        argument_error();
+        return 1;
+    }
+    if (o.from_bloom) printf("Starting from after bloom load based on bloom file.\n");
+    else printf("Starting at the beginning: will load bloom and find junctions from the read set.\n");
+    if (o.just_load) printf("Only loading bloom, dumping and termination.\n");
+    printf("Read load file name: %s\n", o.read_load_file.c_str());
+    printf("Read scan file name: %s\n", o.read_scan_file.c_str());
+    printf("k: %d \n", o.k);
+    printf("Maximal read length: %d\n", o.read_length);
+    printf("Estimated number of distinct kmers, for sizing bloom filter: %llu.\n", (unsigned long long)o.estimated_kmers);
+    printf("False positive rate: %f\n", o.fp_rate);
+    printf("File prefix: %s\n", o.file_prefix.c_str());
+    printf("Max spacer dist: %d\n", o.max_spacer_dist);
+    printf(o.two_hash ? "Using 2 hash functions.\n" : "Using space-optimal hash settings.\n");
+    printf("Paired ends: %d\n", (int)o.paired_ends);
+    return 0;
+}
+
+// Record splitting exactly as the reference's loops do it (utils/Bloom.cpp:280-282,340; src/ReadScanner.cpp:306-308,349):
+//   while (getline(header)) { getline(sequence); ...; if (fastq) getline, getline; }
+// Works on non-seekable input (the reference is fed process substitutions, src/stream_data_from_urls_list.sh:12-15).
+class ReadSource {
+public:
+    ReadSource(const std::string& path, bool fastq) : in_(path.c_str()), fastq_(fastq) {}
+    bool is_open() const { return in_.is_open(); }
+    // next batch of at most max_reads sequence lines; false when the input is exhausted
+    bool next(uint64_t max_reads, std::vector<char>& bases, std::vector<uint64_t>& offsets) {
+        bases.clear();
+        offsets.assign(1, 0);
+        std::string line;
+        while (offsets.size() - 1 < max_reads && std::getline(in_, line)) {
+            line.clear();
+            std::getline(in_, line);
+            bases.insert(bases.end(), line.begin(), line.end());
+            offsets.push_back(bases.size());
+            if (fastq_) { std::getline(in_, line); std::getline(in_, line); }
+        }
+        return offsets.size() > 1;
+    }
+private:
+    std::ifstream in_;
+    bool fastq_;
+};
+
+#define CHECK(call)                                                                   \
+    do {                                                                              \
+        int rc__ = (call);                                                            \
+        if (rc__ != FGPU_OK) {                                                        \
+            fprintf(stderr, "%s failed (%d): %s\n", #call, rc__, fgpu_last_error(ctx)); \
+            return 2;                                                                 \
+        }                                                                             \
+    } while (0)
+
+struct Junction {   // utils/Junction.h:10-18
+    uint8_t cov[4], dist[5], linked[5];
+};
+
+const char kDecode[4] = {'A', 'C', 'T', 'G'};   // utils/Kmer.cpp:21
+
+int write_junctions(const std::string& path, const std::unordered_map<uint64_t, Junction>& map, int k) {
+    // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596), Junction::toString (utils/Junction.cpp:74-89)
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
+    std::string kmer(k, 'A');
+    for (const auto& kv : map) {
+        uint64_t x = kv.first;
+        for (int i = k - 1; i >= 0; i--) { kmer[i] = kDecode[x & 3]; x >>= 2; }
+        const Junction& j = kv.second;
+        fprintf(f, "%s ", kmer.c_str());
+        for (int i = 0; i < 5; i++) fprintf(f, "%d ", j.dist[i]);
+        fprintf(f, " ");
+        for (int i = 0; i < 4; i++) fprintf(f, "%d ", j.cov[i]);
+        fprintf(f, "%d ", j.cov[0] + j.cov[1] + j.cov[2] + j.cov[3]);
+        fprintf(f, " ");
+        for (int i = 0; i < 5; i++) fprintf(f, "%d ", j.linked[i] ? 1 : 0);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    if (handle_arguments(argc, argv, o) == 1) return 1;
+    fgpu_ctx* ctx = nullptr;
+    if (o.k < 1 || o.k > 31) { fprintf(stderr, "k must be in 1..31 on this build\n"); return 1; }
+    if (o.mercy) { fprintf(stderr, "--mercy is not implemented on the device path (SURVEY.md 8f)\n"); return 1; }
+    if (!o.no_cleaning && !o.just_load) {
+        fprintf(stderr, "This build covers the Bloom load pass and the junction scan only: run with --no_cleaning (or --just_load_bloom).\n"
+                        "The contig-graph stage and the pair filters it needs are not part of it.\n");
+        return 1;
+    }
+    if (o.from_junctions) { fprintf(stderr, "-junctions_file restarts after the scan: nothing left for this build to do.\n"); return 1; }
+
+    // ---- filter sizing: getBloomFilterFromReads / getBloomFilterFromFile (src/Faucet.cpp:185-219)
+    uint64_t tai = 0;
+    int32_t n_hash = 0, bits = 0;
+    if (o.from_bloom) {
+        if (o.two_hash) fgpu_size_two_hash(o.estimated_kmers, o.fp_rate, &bits, &tai, &n_hash);
+        else fgpu_size_optimal(o.estimated_kmers, o.fp_rate, &bits, &tai, &n_hash);
+        printf("Bits per kmer: %d \n", bits);
+    } else {
+        int32_t iters = 0;
+        double p1 = fgpu_solve_p1(o.estimated_kmers, o.singletons, o.fp_rate, &iters);
+        if (p1 < 0) {   // the reference prints a message and goes on with nonsense sizes; we refuse
+            fprintf(stderr, "Signs of f(lower_bound) and f(upper_bound) must be opposites: check -singletons (must be > 0)\n");
+            return 1;
+        }
+        printf("After %d iterations the root is: %g\n", iters, p1);
+        printf("p2 is %g p1 estimated as %g\n", (double)o.fp_rate, p1);
+        fgpu_size_optimal(o.estimated_kmers, (float)p1, &bits, &tai, &n_hash);
+        for (int i = 0; i < 2; i++) {   // printed once per filter, utils/Bloom.cpp:234-243
+            printf("Bits per kmer: %d \n", bits);
+            printf("BF memory: %f MB\n", (float)((o.estimated_kmers * (uint64_t)bits) / 8ULL / 1024ULL) / 1024);
+            printf("Number of hash functions: %d \n", n_hash);
+        }
+    }
+
+    fgpu_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.k = o.k;
+    prm.j = o.j;
+    prm.max_spacer_dist = o.max_spacer_dist;
+    prm.n_hash = n_hash;
+    prm.tai = tai;
+    {
+        int rc = fgpu_create(&prm, &ctx);
+        if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(nullptr)); return 2; }
+    }
+    std::vector<char> bases;
+    std::vector<uint64_t> offsets;
+    std::vector<uint8_t> bloom_bytes(tai / 8);
+
+    // ---- pass 1 (load_two_filters, utils/Bloom.cpp:267-350) or -bloom_file (Bloom::load, :580-587)
+    if (o.from_bloom) {
+        FILE* f = fopen(o.bloom_input_file.c_str(), "rb");
+        if (!f) { fprintf(stderr, "cannot open %s\n", o.bloom_input_file.c_str()); return 2; }
+        printf("loading bloom filter from file, nelem %llu \n", (unsigned long long)(tai / 8));
+        size_t got = fread(bloom_bytes.data(), 1, bloom_bytes.size(), f);
+        fclose(f);
+        if (got != bloom_bytes.size()) { fprintf(stderr, "%s is not %llu bytes\n", o.bloom_input_file.c_str(), (unsigned long long)(tai / 8)); return 2; }
+        CHECK(fgpu_bloom_upload(ctx, FGPU_BLOO2, bloom_bytes.data(), bloom_bytes.size()));
+        printf("bloom loaded\n");
+    } else {
+        ReadSource src(o.read_load_file, o.fastq);
+        if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_load_file.c_str()); return 2; }   // the reference silently reads nothing
+        time_t start, stop;
+        time(&start);
+        printf("Weights before load: %f, %f \n", 0.0f, 0.0f);
+        CHECK(fgpu_load_begin(ctx, 0));
+        uint64_t consumed = 0;
+        while (src.next(o.batch_reads, bases, offsets)) {
+            fgpu_reads r = {bases.data(), offsets.data(), offsets.size() - 1, 0};
+            CHECK(fgpu_load_batch(ctx, &r));
+            consumed += r.n_reads;
+            fprintf(stdout, "\rreads consumed: %lld", (long long)consumed);
+            fflush(stdout);
+        }
+        fgpu_load_stats ls;
+        CHECK(fgpu_load_end(ctx, &ls));
+        float w1 = 0, w2 = 0;
+        CHECK(fgpu_bloom_weight(ctx, FGPU_BLOO1, &w1));
+        CHECK(fgpu_bloom_weight(ctx, FGPU_BLOO2, &w2));
+        printf("\n");
+        printf("Weights after load: %f, %f \n", w1, w2);
+        printf("Reads processed: %llu\n", (unsigned long long)ls.reads_processed);
+        printf("Unambiguous reads: %llu\n", (unsigned long long)ls.unambiguous_reads);
+        time(&stop);
+        printf("Time to load: %f \n", difftime(stop, start));
+        CHECK(fgpu_bloom_download(ctx, FGPU_BLOO2, bloom_bytes.data(), bloom_bytes.size()));
+        const std::string path = o.file_prefix + ".bloom";       // Bloom::dump, utils/Bloom.cpp:571-578
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
+        fwrite(bloom_bytes.data(), 1, bloom_bytes.size(), f);
+        fclose(f);
+        printf("bloom dumped \n");
+    }
+    if (o.just_load) { fgpu_destroy(ctx); return 0; }
+
+    // ---- pass 2 (ReadScanner::scanReads, src/ReadScanner.cpp:284-359; printScanSummary :19-27)
+    {
+        ReadSource src(o.read_scan_file, o.fastq);
+        if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_scan_file.c_str()); return 2; }
+        time_t start, stop;
+        time(&start);
+        float w2 = 0;
+        CHECK(fgpu_bloom_weight(ctx, FGPU_BLOO2, &w2));
+        printf("Weight before read scan: %f \n", w2);
+        CHECK(fgpu_scan_begin(ctx));
+        uint64_t scanned = 0;
+        while (src.next(o.batch_reads, bases, offsets)) {
+            fgpu_reads r = {bases.data(), offsets.data(), offsets.size() - 1, 0};
+            CHECK(fgpu_scan_batch(ctx, &r));
+            scanned += r.n_reads;
+            fprintf(stdout, "\rreads scanned: %lld", (long long)scanned);
+            fflush(stdout);
+        }
+        fgpu_scan_stats ss;
+        CHECK(fgpu_scan_end(ctx, &ss));
+        time(&stop);
+        printf("\nReads processed: %llu\n", (unsigned long long)ss.reads_processed);
+        printf("Unambiguous reads: %llu\n", (unsigned long long)ss.unambiguous_reads);
+        printf("Time in seconds for read scan: %f \n", difftime(stop, start));
+        printf("\nDistinct junctions: %llu \n", (unsigned long long)ss.n_junctions);
+        printf("Number of kmers that we j-checked: %llu \n", (unsigned long long)ss.nb_jcheck_kmer);
+        printf("Number of reads with no junctions: %llu \n", (unsigned long long)ss.nb_no_juncs);
+        printf("Number of processed kmers: %llu \n", (unsigned long long)ss.nb_processed);
+        printf("Number of skipped kmers: %llu \n", (unsigned long long)ss.nb_skipped);
+        printf("Reads without errors: %llu\n", (unsigned long long)ss.reads_no_errors);
+
+        // junction records come back in creation order; the reference's container gives the reference's dump order
+        uint64_t n = 0;
+        CHECK(fgpu_scan_junction_count(ctx, &n));
+        std::vector<uint64_t> keys(n ? n : 1);
+        std::vector<fgpu_junction> recs(n ? n : 1);
+        CHECK(fgpu_scan_download_junctions(ctx, keys.data(), recs.data(), keys.size(), &n));
+        std::unordered_map<uint64_t, Junction> junction_map;   // utils/JunctionMap.h:61
+        for (uint64_t i = 0; i < n; i++) {
+            Junction j;
+            memcpy(j.cov, recs[i].cov, 4);
+            memcpy(j.dist, recs[i].dist, 5);
+            memcpy(j.linked, recs[i].linked, 5);
+            junction_map.insert(std::pair<uint64_t, Junction>(keys[i], j));
+        }
+        printf("Writing to junction file\n");
+        if (int rc = write_junctions(o.file_prefix + ".junctions", junction_map, o.k)) return rc;
+        printf("Done writing to junction file\n");
+        printf("Number of junctions: %llu\n", (unsigned long long)junction_map.size());
+    }
+    fgpu_destroy(ctx);
+    return 0;
+}
