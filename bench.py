@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from faucet_amd import _lib as L  # noqa: E402
-from faucet_amd import api  # noqa: E402
+from faucet_amd import api, sharded  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "canonical k-mers/s (load+scan) at k=31, 100bp reads; % HBM roofline"
@@ -84,17 +84,6 @@ def device_batches(reads, batch_reads):
     return out
 
 
-class DevView:
-    """zero-copy torch view of device memory owned by libfaucet_gpu (via __cuda_array_interface__)"""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
-def dev_tensor(ptr, nbytes, device):
-    return torch.as_tensor(DevView(ptr, nbytes), device=device)
-
-
 # ---------------------------------------------------------------------------------------------- one step
 def step_single(ctx, batches):
     ctx.load_begin()
@@ -110,63 +99,14 @@ def step_single(ctx, batches):
     return lst, sst, bloo2, keys, recs
 
 
-def step_multi(ctx, batches, rank, world, device, scratch):
-    nbytes = ctx.tai // 8
-    p1, _ = ctx.bloom_devptr(L.BLOO1)
-    p2, _ = ctx.bloom_devptr(L.BLOO2)
-    b1 = dev_tensor(p1, nbytes, device)
-    b2 = dev_tensor(p2, nbytes, device)
-    gathered = scratch["gathered"]
-    # presence bitmap of this shard -> exclusive prefix-OR over ranks = carried-in bloo1
-    ctx.load_begin()
-    ctx.load_end()                                  # zeroes both filters
-    for b in batches:
-        ctx.presence_batch(b)
-    ctx.synchronize()
-    dist.all_gather_into_tensor(gathered, b1)
-    b1.zero_()
-    torch.cuda.synchronize()
-    for q in range(rank):
-        ctx.bitmap_or(p1, gathered[q * nbytes:(q + 1) * nbytes].data_ptr(), nbytes)
-    ctx.load_begin(keep_carry=True)
-    for b in batches:
-        ctx.load_batch(b)
-    lst = ctx.load_end()
-    # OR-allreduce of bloo2 (RCCL has no OR op: all-gather + local OR kernel)
-    dist.all_gather_into_tensor(gathered, b2)
-    torch.cuda.synchronize()
-    for q in range(world):
-        if q != rank:
-            ctx.bitmap_or(p2, gathered[q * nbytes:(q + 1) * nbytes].data_ptr(), nbytes)
-    bloo2 = ctx.bloom_download(L.BLOO2) if rank == 0 else None
-    # scan: pure stage everywhere at once, ordered walk handed from rank to rank
-    ctx.scan_begin()
-    for b in batches:
-        ctx.scan_prepare(b)
-    hdr = torch.zeros(16, dtype=torch.int64, device=device)
-    names = [n for n, _ in L.ScanStats._fields_]
-    if rank > 0:
-        dist.recv(hdr, src=rank - 1)
-        h = hdr.cpu().tolist()
-        n_in = h[0]
-        buf = torch.empty(max(n_in, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=device)
-        dist.recv(buf, src=rank - 1)
-        torch.cuda.synchronize()
-        ctx.import_table(buf.data_ptr(), n_in, carried=dict(zip(names, h[1:1 + len(names)])))
-    ctx.scan_walk_prepared()
-    sst = ctx.scan_end()
+def step_multi(shard, batches, rank, world):
+    """The read-sharded pipeline of faucet_amd/sharded.py on this rank's GPU."""
+    lst = sharded.load_sharded(shard, batches, rank, world)
+    bloo2 = shard.ctx.bloom_download(L.BLOO2) if rank == 0 else None      # pass-1 output final in host memory
+    sst, last = sharded.scan_sharded(shard, batches, rank, world)
     keys = recs = None
-    if rank < world - 1:
-        n_out = ctx.table_entries()
-        buf = torch.empty(max(n_out, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=device)
-        ctx.export_table(buf.data_ptr(), buf.numel())
-        ctx.synchronize()
-        hdr[0] = n_out
-        hdr[1:1 + len(names)] = torch.tensor([sst[n] for n in names], dtype=torch.int64)
-        dist.send(hdr, dst=rank + 1)
-        dist.send(buf, dst=rank + 1)
-    else:
-        keys, recs = ctx.junctions()
+    if last:
+        keys, recs = shard.junctions()                                     # pass-2 output final in host memory
     return lst, sst, bloo2, keys, recs
 
 
@@ -253,14 +193,12 @@ def main():
     torch.cuda.synchronize()
 
     ctx = api.Context(k, tai, nh, device=local_rank, profile=True)
-    scratch = {}
-    if world > 1:
-        scratch["gathered"] = torch.empty(world * (tai // 8), dtype=torch.uint8, device=device)
+    shard = sharded.GpuShard(ctx, device) if world > 1 else None
 
     def one_step():
         if world == 1:
             return step_single(ctx, batches)
-        return step_multi(ctx, batches, rank, world, device, scratch)
+        return step_multi(shard, batches, rank, world)
 
     def fence():
         ctx.synchronize()
@@ -319,7 +257,7 @@ def main():
     T = None
     if not args.no_cpu:
         T = reference_bit_counts(k, L_, args.err, args.reads * L_ / args.genome, tai / E)
-    heavy = {n: v for n, v in ktimes.items() if n in ("pack", "load_mark", "load_resolve", "scan_valid", "scan_flags", "walk_stage")}
+    heavy = {n: v for n, v in ktimes.items() if n in ("pack", "load_mark", "load_resolve", "scan_valid", "scan_flags")}
     if heavy:
         name = max(heavy, key=lambda n: heavy[n][1])
         launches, total_ms = heavy[name]
@@ -332,12 +270,17 @@ def main():
             "load_resolve": 64.0 * nh * rho,                     # sets on bloo2 (rho = occurrences routed to bloo2 / N)
             "scan_valid": 64.0 * (T["T_valid"] if T else nh),    # validity bit tests the reference performs (early exit)
             "scan_flags": 64.0 * (T["T_junc"] if T else 0.0),    # alternate-extension + jcheck bit tests WITH the reference's skipping
-            "walk_stage": 0.0,
         }[name]
         avg_ms = total_ms / launches
         achieved = per_kmer * kmers_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes, when a summary for this kernel is committed
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f).get("bytes_per_launch", {}).get("k_" + name)
+        res["device_time_share"] = {n: round(ms / (1e3 * elapsed), 4) for n, (c, ms) in ktimes.items() if ms / (1e3 * elapsed) > 0.01}
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                            "algorithmic_bytes_per_kmer": per_kmer, "kmers_per_launch": kmers_per_launch}
     if T:
         ab64 = 2 * L_ / (L_ - k + 1) + 64.0 * (T["T_load"] + T["T_valid"] + T["T_junc"])

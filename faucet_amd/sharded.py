@@ -1,0 +1,151 @@
+"""Read-sharded two-pass pipeline over N processes (one per GPU): the exchange steps of DESIGN.md §5.
+
+The reference is single-process; this is the multi-GPU host logic that SURVEY.md §8(e) asks for, kept apart from
+`bench.py` so that the protocol itself (which collective, in which order, on which bitmap) is testable with the `gloo`
+backend on CPU.  It talks to a *backend* object; the product backend is `GpuShard` below (libfaucet_gpu.so through
+`api.Context`); the CPU tests plug in an oracle-backed stand-in with the same methods.
+
+Pass 1 (exact):
+    presence bitmap of the shard  ->  all-gather  ->  carried-in bloo1 of rank r = OR of the bitmaps of ranks < r
+    ->  ordered load of the shard ->  bloo2 := OR over ranks (all-gather + local OR; RCCL has no bitwise-OR reduction)
+Pass 2:
+    pure stage on every rank at once (no collective)  ->  the ordered junction walk is handed from rank to rank:
+    recv table from r-1, import, walk own shard, export, send to r+1.  The last rank holds the final map.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+_STAT_NAMES = [n for n, _ in L.ScanStats._fields_]
+
+
+def load_sharded(backend, batches, rank: int, world: int):
+    """Returns this shard's load stats; afterwards every rank holds the global bloo2."""
+    backend.clear_filters()
+    for b in batches:
+        backend.presence(b)
+    b1 = backend.bloom_tensor(L.BLOO1)
+    nbytes = b1.numel()
+    gathered = backend.scratch(world * nbytes)
+    backend.fence()
+    dist.all_gather_into_tensor(gathered, b1)
+    backend.fence()
+    b1.zero_()
+    backend.fence()
+    for q in range(rank):                                  # exclusive prefix-OR
+        backend.or_into(L.BLOO1, gathered[q * nbytes:(q + 1) * nbytes])
+    stats = backend.load(batches, keep_carry=True)
+    b2 = backend.bloom_tensor(L.BLOO2)
+    backend.fence()
+    dist.all_gather_into_tensor(gathered, b2)
+    backend.fence()
+    for q in range(world):                                 # OR-allreduce
+        if q != rank:
+            backend.or_into(L.BLOO2, gathered[q * nbytes:(q + 1) * nbytes])
+    backend.fence()
+    return stats
+
+
+def scan_sharded(backend, batches, rank: int, world: int):
+    """Returns (stats, is_last): on the last rank the stats are the whole run's and backend.junctions() is the final map."""
+    backend.scan_begin()
+    for b in batches:
+        backend.scan_prepare(b)                            # pure stage: all ranks concurrently
+    hdr = backend.header_tensor()
+    if rank > 0:
+        dist.recv(hdr, src=rank - 1)
+        h = hdr.cpu().tolist()
+        n_in = int(h[0])
+        buf = backend.scratch(max(n_in, 1) * L.TABLE_ENTRY_BYTES, tag="table_in")
+        dist.recv(buf, src=rank - 1)
+        backend.fence()
+        backend.import_table(buf, n_in, dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]])))
+    backend.scan_walk_prepared()                           # ordered walk of this shard
+    stats = backend.scan_end()
+    if rank < world - 1:
+        n_out, buf = backend.export_table()
+        backend.fence()
+        hdr.zero_()
+        hdr[0] = n_out
+        hdr[1:1 + len(_STAT_NAMES)] = torch.tensor([stats[n] for n in _STAT_NAMES], dtype=torch.int64)
+        dist.send(hdr, dst=rank + 1)
+        dist.send(buf, dst=rank + 1)
+    return stats, rank == world - 1
+
+
+class _DevView:
+    """zero-copy torch view of device memory owned by libfaucet_gpu (through __cuda_array_interface__)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class GpuShard:
+    """The product backend: one api.Context on one MI355X."""
+
+    def __init__(self, ctx, device):
+        self.ctx, self.device = ctx, device
+        self._scratch = {}
+
+    def fence(self):
+        self.ctx.synchronize()
+        torch.cuda.synchronize(self.device)
+
+    def scratch(self, nbytes, tag="gather"):
+        t = self._scratch.get(tag)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._scratch[tag] = t
+        return t[:nbytes]
+
+    def header_tensor(self):
+        return torch.zeros(16, dtype=torch.int64, device=self.device)
+
+    def clear_filters(self):
+        self.ctx.load_begin()
+        self.ctx.load_end()
+
+    def presence(self, batch):
+        self.ctx.presence_batch(batch)
+
+    def bloom_tensor(self, which):
+        ptr, nbytes = self.ctx.bloom_devptr(which)
+        return torch.as_tensor(_DevView(ptr, nbytes), device=self.device)
+
+    def or_into(self, which, src):
+        ptr, nbytes = self.ctx.bloom_devptr(which)
+        self.ctx.bitmap_or(ptr, src.data_ptr(), nbytes)
+
+    def load(self, batches, keep_carry):
+        self.ctx.load_begin(keep_carry=keep_carry)
+        for b in batches:
+            self.ctx.load_batch(b)
+        return self.ctx.load_end()
+
+    def scan_begin(self):
+        self.ctx.scan_begin()
+
+    def scan_prepare(self, batch):
+        self.ctx.scan_prepare(batch)
+
+    def scan_walk_prepared(self):
+        self.ctx.scan_walk_prepared()
+
+    def scan_end(self):
+        return self.ctx.scan_end()
+
+    def import_table(self, buf, n, carried):
+        self.ctx.import_table(buf.data_ptr(), n, carried=carried)
+
+    def export_table(self):
+        n = self.ctx.table_entries()
+        buf = self.scratch(max(n, 1) * L.TABLE_ENTRY_BYTES, tag="table_out")
+        got = self.ctx.export_table(buf.data_ptr(), buf.numel())
+        assert got == n
+        return n, buf
+
+    def junctions(self):
+        return self.ctx.junctions()

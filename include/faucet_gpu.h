@@ -156,7 +156,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
 int fgpu_scan_junction_count(fgpu_ctx* ctx, uint64_t* n);
 int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* recs, uint64_t cap, uint64_t* n_out);
 /* Multi-GPU hand-over of the ordered state between consecutive read shards: export on rank r
- * (device buffer of fgpu_scan_table_bytes()), import on rank r+1 before its first scan_batch. */
+ * (device buffer of n_entries * FGPU_TABLE_ENTRY_BYTES), import on rank r+1 before its first scan_batch. */
 int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries);
 int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries);
 int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries, const fgpu_scan_stats* carried);

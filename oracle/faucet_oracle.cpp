@@ -626,6 +626,15 @@ uint64_t fo_scan_get_junctions(const fo_scanner* s, int order, uint64_t* keys, f
     return s->map.size();
 }
 uint64_t fo_scan_bit_tests_valid(const fo_scanner* s) { return s->bit_tests_valid; }
+/* test-only: start a scanner from a junction map handed over by another process (records in creation order) */
+void fo_scan_import(fo_scanner* s, const uint64_t* keys, const fo_junction* recs, uint64_t n, const fo_scan_stats* carried) {
+    for (uint64_t i = 0; i < n; i++) {
+        Junction* j = s->create(keys[i]);
+        for (int c = 0; c < 4; c++) j->cov[c] = recs[i].cov[c];
+        for (int c = 0; c < 5; c++) { j->dist[c] = recs[i].dist[c]; j->linked[c] = recs[i].linked[c] != 0; }
+    }
+    if (carried) s->st = *carried;
+}
 int fo_scan_write_junctions(const fo_scanner* s, const char* path) {                 /* JunctionMap.cpp:579-596, Junction.cpp:74-89 */
     FILE* f = fopen(path, "wb");
     if (!f) return -1;

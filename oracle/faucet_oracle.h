@@ -123,6 +123,8 @@ void     fo_scan_get_stats(const fo_scanner*, fo_scan_stats*);
 /* Junction map contents.  order = 0: iteration order of the std::unordered_map (= dump order of
  * JunctionMap::writeToFile, JunctionMap.cpp:588-593); order = 1: creation order. */
 uint64_t fo_scan_get_junctions(const fo_scanner*, int order, uint64_t* keys, fo_junction* recs, uint64_t cap);
+/* test-only (no reference counterpart): continue from a junction map and counters produced elsewhere */
+void fo_scan_import(fo_scanner*, const uint64_t* keys, const fo_junction* recs, uint64_t n, const fo_scan_stats* carried);
 /* of the filter's bit tests (fo_bloom_bit_tests), how many were made by getValidReads (:233-257) */
 uint64_t fo_scan_bit_tests_valid(const fo_scanner*);
 /* writeToFile (JunctionMap.cpp:579-596) — the .junctions text format of Junction.cpp:74-89 */

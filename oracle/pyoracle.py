@@ -75,6 +75,7 @@ def lib():
         "fo_scan_get_junctions": (u64, [vp, i32, vp, vp, u64]),
         "fo_scan_write_junctions": (i32, [vp, cp]),
         "fo_scan_bit_tests_valid": (u64, [vp]),
+        "fo_scan_import": (None, [vp, vp, vp, u64, C.POINTER(ScanStats)]),
         "fo_get_valid_reads": (u64, [vp, cp, u64, vp, u64]),
         "fo_test_for_junction": (i32, [vp, cp, u64, i32, C.POINTER(i32)]),
     }
@@ -222,6 +223,12 @@ class Scanner:
         recs = np.zeros(n, dtype=JUNC_DTYPE)
         lib().fo_scan_get_junctions(self.h, 0 if order == "map" else 1, _p(keys), _p(recs), n)
         return keys, recs
+
+    def import_junctions(self, keys, recs, carried: dict = None):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        recs = np.ascontiguousarray(recs, dtype=JUNC_DTYPE)
+        st = ScanStats(**{k: int(v) for k, v in carried.items()}) if carried else None
+        lib().fo_scan_import(self.h, _p(keys), _p(recs), len(keys), C.byref(st) if st is not None else None)
 
     def bit_tests_valid(self) -> int:
         return int(lib().fo_scan_bit_tests_valid(self.h))

@@ -1,0 +1,80 @@
+"""CPU-only checks of the product side: the C ABI library loads and exports every symbol include/faucet_gpu.h
+declares, host-only entry points (sizing) match the reference's known answers, compute entry points fail loudly
+without a GPU, and the `faucet` CLI handles arguments like the reference (exit code 1)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from faucet_amd import _lib as L
+from faucet_amd import api
+from tests.golden_util import kat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "faucet_gpu.h")).read()
+    declared = set(re.findall(r"\b(fgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fgpu_ctx", "fgpu_params", "fgpu_reads"}
+    lib = C.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in faucet_gpu.h but not exported"
+    # and the ctypes table binds every one of them
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    L.load()
+
+
+def test_struct_layouts_match_header_sizes():
+    assert C.sizeof(L.Params) == 64 and C.sizeof(L.Reads) == 32
+    assert C.sizeof(L.LoadStats) == 32 and C.sizeof(L.ScanStats) == 96
+    assert api.JUNC_DTYPE.itemsize == 14 and C.sizeof(L.KernelTime) == 64
+
+
+@pytest.mark.parametrize("d", kat("sizing"), ids=lambda d: f"E{d['E']}_S{d['S']}_fp{d['fp']:.2f}")
+def test_product_sizing_matches_reference(d):
+    p1 = api.solve_p1(d["E"], d["S"], d["fp"])
+    assert p1 == d["p1"]
+    _, tai, nh = api.size_optimal(d["E"], np.float32(p1))
+    assert tai == d["tai"] and nh == d["n_hash"]
+
+
+def test_tai_rounding_matches_reference():
+    (d,) = kat("tai")
+    for req, tai in d["cases"]:
+        assert L.load().fgpu_bloom_tai(req) == tai
+    assert api.size_two_hash(1000, 0.04)[2] == 2 and api.size_two_hash(1000, 0.04)[0] == 10
+
+
+def test_solver_rejects_unbracketed_root():
+    with pytest.raises(ValueError):
+        api.solve_p1(100000, 0)
+
+
+@pytest.mark.skipif(L.load().fgpu_device_count() > 0, reason="this check is for boxes without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(api.FaucetGpuError, match="no HIP device|HIP"):
+        api.Context(21, 1 << 19, 3)
+
+
+def _cli(*args):
+    return subprocess.run([os.path.join(ROOT, "faucet_amd", "faucet"), *args], capture_output=True, text=True)
+
+
+def test_cli_argument_errors_exit_1():
+    assert _cli().returncode == 1
+    r = _cli("-read_load_file", "x.fa", "-size_kmer", "21")
+    assert r.returncode == 1 and "Some required argument is missing." in r.stderr
+    r = _cli("-bogus")
+    assert r.returncode == 1 and "Cannot parse tag -bogus" in r.stderr
+    base = ["-read_load_file", "x", "-read_scan_file", "x", "-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "100000",
+            "-singletons", "20000", "-file_prefix", "/tmp/p"]
+    r = _cli(*base, "-junctions_file", "j")
+    assert r.returncode == 1 and "Cannot start from junctions without a bloom file." in r.stderr
+    r = _cli(*base)          # cleaning needs Stage 3, which this build does not have: refuse instead of differing
+    assert r.returncode == 1 and "--no_cleaning" in r.stderr
+    r = _cli(*base[:-6], "-estimated_kmers", "100000", "-singletons", "0", "-file_prefix", "/tmp/p", "--no_cleaning")
+    assert r.returncode == 1 and "singletons" in r.stderr

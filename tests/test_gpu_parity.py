@@ -270,3 +270,25 @@ def test_two_shard_scan_table_handover_is_exact():
     assert st["reads_no_errors"] == cn["reads_no_errors"] and st["nb_jcheck_kmer"] == cn["nb_jcheck_kmer"]
     keys, recs = b.junctions()
     assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
+
+
+@pytest.mark.parametrize("name", ["c1_k21", "ragged_k31", "j2_spacer20_k15"])
+def test_cli_writes_the_reference_files(name, tmp_path):
+    """The stand-alone host: same flags as the reference, byte-identical .bloom and .junctions (dump order included)."""
+    import os
+    import subprocess
+    c = Case(name)
+    reads = tmp_path / "reads.fa"
+    reads.write_bytes(c.reads_text())
+    args = [a if not a.endswith(".fa") else str(reads) for a in c.meta["args"]]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
+                        "-batch_reads", "400"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "out.bloom", dtype=np.uint8), c.bloom())
+    assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
+    cn = c.counters
+    assert f"Distinct junctions: {cn['distinct_junctions']} " in r.stdout
+    assert f"Number of processed kmers: {cn['nb_processed']} " in r.stdout
+    assert f"Reads processed: {cn['load_reads_processed']}" in r.stdout
+    assert "Weights after load: %s, %s" % tuple(cn["weights_after_load"]) in r.stdout

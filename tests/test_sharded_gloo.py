@@ -1,0 +1,145 @@
+"""The multi-GPU host protocol (faucet_amd/sharded.py) on CPU: 2 processes, gloo, with an oracle-backed stand-in for the
+device backend.  Checks that the exchange steps (presence bitmaps -> exclusive prefix-OR -> ordered load -> OR-allreduce;
+pure scan everywhere -> walk handed rank to rank) reproduce the single-process result byte for byte."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from faucet_amd import _lib as L
+from faucet_amd import sharded
+from oracle import pyoracle as po
+from tests.golden_util import Case
+
+ENTRY = np.dtype([("key", np.uint64), ("stamp", np.uint64), ("dist", np.uint8, 5), ("cov", np.uint8, 4), ("linked", np.uint8),
+                  ("pad", np.uint8, 6)])
+assert ENTRY.itemsize == L.TABLE_ENTRY_BYTES
+
+
+class OracleShard:
+    """CPU stand-in with the method set of sharded.GpuShard (TEST ONLY: the product backend is GpuShard)."""
+
+    def __init__(self, k, tai, nh, j, spacer):
+        self.k, self.tai, self.nh, self.j, self.spacer = k, tai, nh, j, spacer
+        self.b1, self.b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+        self.sc = None
+        self.prepared = []
+
+    def fence(self):
+        pass
+
+    def scratch(self, nbytes, tag="gather"):
+        return torch.empty(nbytes, dtype=torch.uint8)
+
+    def header_tensor(self):
+        return torch.zeros(16, dtype=torch.int64)
+
+    def clear_filters(self):
+        self.b1.bits()[:] = 0
+        self.b2.bits()[:] = 0
+
+    def presence(self, batch):
+        po.load_single_filter(self.b1, batch[0], batch[1], self.k)
+
+    def bloom_tensor(self, which):
+        return torch.from_numpy((self.b1 if which == L.BLOO1 else self.b2).bits())
+
+    def or_into(self, which, src):
+        (self.b1 if which == L.BLOO1 else self.b2).bits()[:] |= src.numpy()
+
+    def load(self, batches, keep_carry):
+        assert keep_carry
+        st = None
+        for b in batches:
+            st = po.load_two_filters(self.b1, self.b2, b[0], b[1], self.k)
+        return {"kmers": int(st.kmers)}
+
+    def scan_begin(self):
+        self.sc = po.Scanner(self.k, self.j, self.spacer, self.b2)
+        self.prepared = []
+
+    def scan_prepare(self, batch):
+        self.prepared.append(batch)
+
+    def scan_walk_prepared(self):
+        for b in self.prepared:
+            self.sc.scan_reads(b[0], b[1])
+
+    def scan_end(self):
+        st = self.sc.stats()
+        return {n: st.get(n, 0) for n in sharded._STAT_NAMES}
+
+    def import_table(self, buf, n, carried):
+        e = buf.numpy()[: n * L.TABLE_ENTRY_BYTES].view(ENTRY)
+        recs = np.zeros(n, dtype=po.JUNC_DTYPE)
+        recs["dist"], recs["cov"] = e["dist"], e["cov"]
+        recs["linked"] = (e["linked"][:, None] >> np.arange(5)) & 1
+        order = np.argsort(e["stamp"], kind="stable")
+        oc = {k: carried[k] for k in ("reads_processed", "unambiguous_reads", "reads_no_errors", "nb_jcheck_kmer", "nb_no_juncs",
+                                      "nb_processed", "nb_skipped")}
+        oc.update(empty_count=0, not_empty_count=0, n_junctions=0)
+        self.sc.import_junctions(e["key"][order], recs[order], oc)
+
+    def export_table(self):
+        keys, recs = self.sc.junctions("creation")
+        e = np.zeros(max(len(keys), 1), dtype=ENTRY)
+        e["key"][: len(keys)] = keys
+        e["stamp"][: len(keys)] = np.arange(len(keys))
+        e["dist"][: len(keys)], e["cov"][: len(keys)] = recs["dist"], recs["cov"]
+        e["linked"][: len(keys)] = (recs["linked"].astype(np.uint8) << np.arange(5, dtype=np.uint8)).sum(axis=1)
+        return len(keys), torch.from_numpy(e.view(np.uint8).reshape(-1).copy())
+
+    def junctions(self):
+        return self.sc.junctions("creation")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    n = len(offs) - 1
+    cuts = np.linspace(0, n, world + 1).astype(int)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    mine = [(bases, offs[lo:(lo + hi) // 2 + 1].copy()), (bases, offs[(lo + hi) // 2:hi + 1].copy())]   # two batches per shard
+    tai, nh, _, _ = po.sizing_from_cli(c.E, c.S)
+    be = OracleShard(c.k, tai, nh, c.j, c.spacer)
+    sharded.load_sharded(be, mine, rank, world)
+    np.save(os.path.join(out_dir, f"bloo2_{rank}.npy"), be.b2.bits().copy())
+    st, last = sharded.scan_sharded(be, mine, rank, world)
+    if last:
+        keys, recs = be.junctions()
+        lines = po.junction_lines(keys, recs, c.k)
+        with open(os.path.join(out_dir, "junctions.txt"), "w") as f:
+            f.write("\n".join(lines))
+        np.save(os.path.join(out_dir, "stats.npy"), np.array([st["nb_processed"], st["nb_skipped"], st["nb_jcheck_kmer"], st["nb_no_juncs"],
+                                                               st["reads_no_errors"], st["reads_processed"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("c1_k21", 2), ("ragged_k31", 2), ("j2_spacer20_k15", 3)])
+def test_sharded_protocol_matches_single_process(name, world, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    c = Case(name)
+    for r in range(world):      # every rank ends up with the reference's bloo2
+        assert np.array_equal(np.load(tmp_path / f"bloo2_{r}.npy"), c.bloom())
+    got = (tmp_path / "junctions.txt").read_text().split("\n")
+    assert sorted(got) == sorted(c.junction_lines())
+    cn = c.counters
+    st = np.load(tmp_path / "stats.npy")
+    assert list(st) == [cn["nb_processed"], cn["nb_skipped"], cn["nb_jcheck_kmer"], cn["nb_no_juncs"], cn["reads_no_errors"],
+                        cn["scan_reads_processed"]]
