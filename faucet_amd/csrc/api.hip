@@ -184,7 +184,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
-    void* ptrs[] = {ctx->bloo1, ctx->bloo1_new, ctx->bloo2, ctx->first, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys, ctx->wowner,
+    void* ptrs[] = {ctx->bloo1, ctx->bloo1_new, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys, ctx->wowner,
                     ctx->wslots, ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_members, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -213,10 +213,20 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
             return FGPU_ERR_NOMEM;
         }
     }
+    if (!ctx->pair) {   // working copy of both filters, interleaved word by word, for the duration of a load pass
+        hipError_t e = hipMalloc(&ctx->pair, ctx->bloom_bytes * 2);
+        if (e != hipSuccess) {
+            ctx->err = std::string("hipMalloc of the interleaved filter pair failed: ") + hipGetErrorString(e);
+            ctx->pair = nullptr;
+            return FGPU_ERR_NOMEM;
+        }
+    }
     FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(ctx->bloo1_new, ctx->bloo1, ctx->bloom_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream));
+    int rc = fgpu_load_pair_begin(ctx);
+    if (rc) return rc;
     FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
     memset(&ctx->load_stats, 0, sizeof(ctx->load_stats));
     ctx->phase = 1;
@@ -256,7 +266,8 @@ int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
 int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 1) { ctx->err = "load_end without load_begin"; return FGPU_ERR_STATE; }
-    int rc = pull_counters(ctx);
+    int rc = fgpu_load_pair_end(ctx);   // bloo1 / bloo2 back as the two raw bit arrays of the .bloom format
+    if (!rc) rc = pull_counters(ctx);
     ctx->phase = 0;
     if (rc) return rc;
     ctx->load_stats.kmers = ctx->counters_host->kmers;

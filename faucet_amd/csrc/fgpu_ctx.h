@@ -84,6 +84,7 @@ struct fgpu_ctx {
     uint32_t* bloo1_new = nullptr;   // carry_old | bits set during the current batch
     uint32_t* bloo2 = nullptr;
     uint32_t* first = nullptr;       // first-set time per Bloom bit, 4*tai bytes (allocated at load_begin)
+    uint2* pair = nullptr;           // {bloo1 word, bloo2 word} interleaved: the working copy of both filters during a load pass
     uint64_t bloom_bytes = 0;
     int phase = 0;                   // 0 idle, 1 loading, 2 scanning
 
@@ -176,6 +177,8 @@ static inline unsigned fgpu_grid(uint64_t n, unsigned per_block) {
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_stage_load(fgpu_ctx* ctx);
 int fgpu_stage_presence(fgpu_ctx* ctx);
+int fgpu_load_pair_begin(fgpu_ctx* ctx);
+int fgpu_load_pair_end(fgpu_ctx* ctx);
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);

@@ -34,9 +34,12 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
     if (fd_lane() == 0 && v) atomicAdd(dst, v);
 }
 
+// During a load pass the two filters live INTERLEAVED: pair[w] = {word w of the carried-in bloo1, word w of bloo2}.
+// Both filters use the same bit positions (same hashes, same size), so one 8-byte load serves the carry test and
+// the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                   uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ carry,
-                                                   uint32_t* carry_next, uint32_t* bloo2, uint32_t* first,
+                                                   uint64_t T, uint64_t n_words, FdParams fp, uint2* pair,
+                                                   uint32_t* carry_next, uint32_t* first,
                                                    uint64_t* __restrict__ pending, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
@@ -48,16 +51,24 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
             uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
             uint64_t hA, hB;
             fd_hash_pair(canon, fp.tai_mask, hA, hB);
-            // gather the carried-in bits of all n_hash positions first (independent loads in flight)
-            uint32_t missing = 0;
+            // gather both filters' bits of all n_hash positions first (independent loads in flight)
+            uint32_t missing = 0, b2_missing = 0;
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
-                if (!((carry[h >> 5] >> (h & 31)) & 1u)) missing |= 1u << i;
+                const uint2 v = pair[h >> 5];
+                if (!((v.x >> (h & 31)) & 1u)) missing |= 1u << i;
+                if (!((v.y >> (h & 31)) & 1u)) b2_missing |= 1u << i;
                 h = (h + hB) & fp.tai_mask;
             }
             if (!missing) {
                 n_hit++;
-                fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+                if (b2_missing) {   // a stale 0 only costs a redundant atomic; bits are never cleared
+                    h = hA;
+                    for (int i = 0; i < fp.n_hash; i++) {
+                        if (b2_missing & (1u << i)) atomicOr(&pair[h >> 5].y, 1u << (h & 31));
+                        h = (h + hB) & fp.tai_mask;
+                    }
+                }
             } else {
                 pend = true;
                 h = hA;
@@ -79,8 +90,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
-                                                      const uint32_t* __restrict__ carry, uint32_t* bloo2,
-                                                      const uint32_t* __restrict__ first,
+                                                      uint2* pair, const uint32_t* __restrict__ first,
                                                       const uint64_t* __restrict__ pending, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
@@ -90,18 +100,44 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
         uint64_t hA, hB;
         fd_hash_pair(canon, fp.tai_mask, hA, hB);
         bool pass = true;
+        uint32_t b2_missing = 0;
         uint64_t h = hA;
         for (int i = 0; i < fp.n_hash; i++) {
-            bool before = ((carry[h >> 5] >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
+            const uint2 v = pair[h >> 5];
+            bool before = ((v.x >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
             if (!before) { pass = false; break; }
+            if (!((v.y >> (h & 31)) & 1u)) b2_missing |= 1u << i;
             h = (h + hB) & fp.tai_mask;
         }
         if (pass) {
             n_pass++;
-            fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+            h = hA;
+            for (int i = 0; i < fp.n_hash; i++) {
+                if (b2_missing & (1u << i)) atomicOr(&pair[h >> 5].y, 1u << (h & 31));
+                h = (h + hB) & fp.tai_mask;
+            }
         }
     }
     wave_add(&cnt->to_bloo2, n_pass);
+}
+
+// pair[w] = {a[w], b[w]} (b == nullptr: zero) / the reverse / refresh of the carry half after a batch
+__global__ void __launch_bounds__(256) k_pair_join(uint2* __restrict__ pair, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                   uint64_t n32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x)
+        pair[i] = make_uint2(a[i], b ? b[i] : 0u);
+}
+__global__ void __launch_bounds__(256) k_pair_split(const uint2* __restrict__ pair, uint32_t* __restrict__ a, uint32_t* __restrict__ b,
+                                                    uint64_t n32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint2 v = pair[i];
+        a[i] = v.x;
+        b[i] = v.y;
+    }
+}
+__global__ void __launch_bounds__(256) k_pair_set_carry(uint2* __restrict__ pair, const uint32_t* __restrict__ a, uint64_t n32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x)
+        pair[i].x = a[i];
 }
 
 // multi-GPU helper: OR the bits of every k-mer into a bitmap, no ordering
@@ -194,13 +230,21 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                (const uint32_t*)ctx->bloo1, ctx->bloo1_new, ctx->bloo2, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
-    FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd,
-                (const uint32_t*)ctx->bloo1, ctx->bloo2, (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
-    int tok = fgpu_prof_begin(ctx, "carry_copy");
-    hipError_t e = hipMemcpyAsync(ctx->bloo1, ctx->bloo1_new, ctx->bloom_bytes, hipMemcpyDeviceToDevice, ctx->stream);
-    fgpu_prof_end(ctx, tok);
-    FGPU_HIP(e);
+                ctx->pair, ctx->bloo1_new, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
+    FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
+                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
+    // carry := carry | bits set during this batch
+    FGPU_LAUNCH("carry_update", k_pair_set_carry, 2048, 256, ctx->pair, (const uint32_t*)ctx->bloo1_new, ctx->bloom_bytes / 4);
+    return FGPU_OK;
+}
+
+// interleave the carried-in bloo1 with an empty bloo2 at the start of a load pass, split them again at its end
+int fgpu_load_pair_begin(fgpu_ctx* ctx) {
+    FGPU_LAUNCH("pair_join", k_pair_join, 2048, 256, ctx->pair, (const uint32_t*)ctx->bloo1, (const uint32_t*)nullptr, ctx->bloom_bytes / 4);
+    return FGPU_OK;
+}
+int fgpu_load_pair_end(fgpu_ctx* ctx) {
+    FGPU_LAUNCH("pair_split", k_pair_split, 2048, 256, (const uint2*)ctx->pair, ctx->bloo1, ctx->bloo2, ctx->bloom_bytes / 4);
     return FGPU_OK;
 }
 
