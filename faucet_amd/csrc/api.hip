@@ -50,18 +50,19 @@ int fgpu_prof_begin(fgpu_ctx* ctx, const char* name) {
     PendingEvent pe;
     pe.stat = idx;
     if (hipEventCreate(&pe.a) != hipSuccess || hipEventCreate(&pe.b) != hipSuccess) return -1;
-    hipEventRecord(pe.a, ctx->stream);
+    hipEventRecord(pe.a, ctx->launch_stream);
     ctx->pending_events.push_back(pe);
     return (int)ctx->pending_events.size() - 1;
 }
 
 void fgpu_prof_end(fgpu_ctx* ctx, int token) {
     if (token < 0) return;
-    hipEventRecord(ctx->pending_events[token].b, ctx->stream);
+    hipEventRecord(ctx->pending_events[token].b, ctx->launch_stream);
 }
 
 int fgpu_prof_collect(fgpu_ctx* ctx) {
     if (ctx->pending_events.empty()) return FGPU_OK;
+    FGPU_HIP(hipStreamSynchronize(ctx->wstream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     for (PendingEvent& pe : ctx->pending_events) {
         float ms = 0;
@@ -83,7 +84,15 @@ static int check_errors(fgpu_ctx* ctx) {
     return FGPU_OK;
 }
 
+// everything issued so far, on both streams, has completed
+static int sync_all(fgpu_ctx* ctx) {
+    FGPU_HIP(hipStreamSynchronize(ctx->wstream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
 static int pull_counters(fgpu_ctx* ctx) {
+    FGPU_HIP(hipStreamSynchronize(ctx->wstream));
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     return check_errors(ctx);
@@ -158,6 +167,12 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
         ctx->own_stream = true;
     }
+    ctx->launch_stream = ctx->stream;
+    if (!rc) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        if ((e = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (walk)", e);
+    }
     if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
     if (!rc && (e = hipMalloc(&ctx->bloo1_new, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1_new", e);
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
@@ -181,6 +196,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
 
 void fgpu_destroy(fgpu_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->wstream) hipStreamSynchronize(ctx->wstream);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
@@ -189,15 +205,19 @@ void fgpu_destroy(fgpu_ctx* ctx) {
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
+    if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
-    for (BatchBufs* b : ctx->all_batches) delete b;
+    for (BatchBufs* b : ctx->all_batches) {
+        if (b->pure_done) hipEventDestroy(b->pure_done);
+        if (b->walk_done) hipEventDestroy(b->walk_done);
+        delete b;
+    }
     delete ctx;
 }
 
 int fgpu_synchronize(fgpu_ctx* ctx) {
     if (!ctx) return FGPU_ERR_ARG;
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    return FGPU_OK;
+    return sync_all(ctx);
 }
 
 // ---- pass 1 --------------------------------------------------------------------------------------------------
@@ -356,13 +376,31 @@ static void adapt_window(fgpu_ctx* ctx) {
     ctx->adapt_pieces = ctx->walked_pieces;
 }
 
+static BatchBufs* acquire_batch(fgpu_ctx* ctx) {
+    // FIFO over (at least) two BatchBufs, so that the one handed out was last walked two batches ago
+    BatchBufs* b;
+    if (ctx->pool.size() >= 2) { b = ctx->pool.front(); ctx->pool.erase(ctx->pool.begin()); }
+    else {
+        b = new BatchBufs();
+        ctx->all_batches.push_back(b);
+        hipEventCreateWithFlags(&b->pure_done, hipEventDisableTiming);
+        hipEventCreateWithFlags(&b->walk_done, hipEventDisableTiming);
+    }
+    return b;
+}
+
 static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
     ctx->cur = b;
+    if (b->walk_pending) {   // the walk stream may still be reading this batch's planes
+        FGPU_HIP(hipEventSynchronize(b->walk_done));
+        b->walk_pending = false;
+    }
     int rc = fgpu_stage_pack(ctx, reads);
     uint64_t n_pieces = 0;
     if (!rc) rc = fgpu_stage_scan_pure(ctx, &n_pieces);   // ends with the batch's only synchronisation (piece count)
     if (!rc) rc = check_errors(ctx);
     if (!rc) ctx->scan_stats.reads_processed += reads->n_reads;
+    if (!rc && b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
     return rc;
 }
 
@@ -373,11 +411,16 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     int rc = check_reads(ctx, reads);
     if (rc) return rc;
     FGPU_HIP(hipSetDevice(ctx->prm.device));
-    if ((rc = scan_pure_into(ctx, &ctx->bb_default, reads))) return rc;
-    adapt_window(ctx);   // the pure stage's synchronisation just refreshed the counters
-    if ((rc = fgpu_stage_scan_walk(ctx, ctx->cur->n_pieces))) return rc;
-    ctx->walked_pieces += ctx->cur->n_pieces;
-    return FGPU_OK;
+    BatchBufs* b = acquire_batch(ctx);
+    rc = scan_pure_into(ctx, b, reads);          // main stream; overlaps the previous batch's walk on the walk stream
+    if (!rc) {
+        adapt_window(ctx);                       // counters as of the pure stage's synchronisation (the walk may lag one batch)
+        rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
+        ctx->walked_pieces += b->n_pieces;
+    }
+    ctx->cur = &ctx->bb_default;
+    ctx->pool.push_back(b);
+    return rc;
 }
 
 int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
@@ -387,8 +430,13 @@ int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if (rc) return rc;
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     BatchBufs* b;
-    if (!ctx->pool.empty()) { b = ctx->pool.back(); ctx->pool.pop_back(); }
-    else { b = new BatchBufs(); ctx->all_batches.push_back(b); }
+    if (!ctx->pool.empty()) { b = ctx->pool.front(); ctx->pool.erase(ctx->pool.begin()); }
+    else {
+        b = new BatchBufs();
+        ctx->all_batches.push_back(b);
+        hipEventCreateWithFlags(&b->pure_done, hipEventDisableTiming);
+        hipEventCreateWithFlags(&b->walk_done, hipEventDisableTiming);
+    }
     rc = scan_pure_into(ctx, b, reads);
     ctx->cur = &ctx->bb_default;
     if (rc) { ctx->pool.push_back(b); return rc; }
@@ -444,12 +492,14 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
 
 int fgpu_scan_junction_count(fgpu_ctx* ctx, uint64_t* n) {
     if (!ctx || !n) return FGPU_ERR_ARG;
+    if (int rc = sync_all(ctx)) return rc;
     return fgpu_scan_download_impl(ctx, nullptr, nullptr, 0, n);
 }
 
 int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* recs, uint64_t cap, uint64_t* n_out) {
     if (!ctx || !keys || !recs || !n_out) return FGPU_ERR_ARG;
     if (!ctx->jkeys) { *n_out = 0; return FGPU_OK; }
+    if (int rc = sync_all(ctx)) return rc;
     return fgpu_scan_download_impl(ctx, keys, recs, cap, n_out);
 }
 
@@ -468,7 +518,9 @@ int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uin
 int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries, const fgpu_scan_stats* carried) {
     if (!ctx || (n_entries && !dev_buf)) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "import_table outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
-    int rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
+    int rc = sync_all(ctx);
+    if (rc) return rc;
+    rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
     if (rc) return rc;
     ctx->scan_imported += n_entries;
     if (carried) ctx->carried = *carried;

@@ -37,6 +37,9 @@ struct BatchBufs {
     uint64_t n_reads = 0;
     uint64_t n_pieces = 0;         // valid pieces found by the pure scan stage
     uint64_t max_piece_span = 0;   // longest read (+64): how far a piece may reach past its scheduling window
+    hipEvent_t pure_done = nullptr;   // main stream: planes of this batch are complete
+    hipEvent_t walk_done = nullptr;   // walk stream: the walk has finished with this batch's buffers
+    bool walk_pending = false;
 };
 
 struct KernelStat {
@@ -75,7 +78,9 @@ struct DevCounters {
 struct fgpu_ctx {
     fgpu_params prm;
     FdParams fd;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // main stream: pack, load, pure scan stage, transfers
+    hipStream_t wstream = nullptr;         // walk stream: the ordered walk of batch b overlaps the pure stage of batch b+1
+    hipStream_t launch_stream = nullptr;   // where FGPU_LAUNCH puts kernels (and profiling events) right now
     bool own_stream = false;
     std::string err;
 
@@ -160,7 +165,7 @@ int fgpu_prof_collect(fgpu_ctx* ctx);
 #define FGPU_LAUNCH(name, kernel, grid, block, ...)                                        \
     do {                                                                                   \
         int tok__ = fgpu_prof_begin(ctx, name);                                            \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, ctx->stream, __VA_ARGS__);  \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, ctx->launch_stream, __VA_ARGS__);  \
         fgpu_prof_end(ctx, tok__);                                                         \
         FGPU_HIP(hipGetLastError());                                                       \
     } while (0)

@@ -854,6 +854,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
     const unsigned walk_grid = fgpu_blocks(ctx->wmax, 64);
+    // the whole stage goes to the walk stream, behind the completion of this batch's pure stage
+    ctx->launch_stream = ctx->wstream;
+    if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(ctx->wstream, bb.pure_done, 0));
     // thousands of tiny launches: by default one event pair around the whole stage
     const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
     ctx->prof_suppress = !ctx->prof_walk_detail;
@@ -873,6 +876,11 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     }
     ctx->prof_suppress = false;
     fgpu_prof_end(ctx, stage_tok);
+    if (bb.walk_done) {
+        FGPU_HIP(hipEventRecord(bb.walk_done, ctx->wstream));
+        bb.walk_pending = true;
+    }
+    ctx->launch_stream = ctx->stream;
     ctx->scan_piece_base += n_pieces;
     return FGPU_OK;
 }
