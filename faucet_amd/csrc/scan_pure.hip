@@ -16,6 +16,8 @@
 //
 // Roofline: random bit probes into bloo2 (Infinity-Cache / HBM); algorithmic bytes per k-mer:
 //   L/(L-k+1) B of bases + 64 B per bit test the reference semantics perform (validity, alternate extensions, jcheck).
+#include <algorithm>
+
 #include "fgpu_ctx.h"
 
 namespace {
@@ -261,7 +263,9 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     FGPU_HIP(hipMemsetAsync(bb.pm.p, 0, wb, ctx->stream));
     FGPU_HIP(hipMemsetAsync(bb.ps.p, 0, wb, ctx->stream));
 
-    const unsigned grid = fgpu_grid(bb.n_words * 64, 256);        // kernels with one lane per position
+    // kernels with one lane per position (capping the grid to leave wave slots for the concurrently running walk of
+    // the previous batch was measured and does not pay: the walk is slowed by memory contention, not by slots)
+    const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     const unsigned wgrid = fgpu_grid(bb.n_words, 256);            // kernels with one thread per 64-position word
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k + 2 * ctx->fd.j + 1))) return rc;
     FGPU_LAUNCH("scan_valid", k_scan_valid, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
