@@ -180,8 +180,16 @@ def main():
         os.environ["FGPU_PROFILE_WALK"] = "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    # FAUCET_FORCE_SHARDED=1 runs the multi-GPU code path (RCCL collectives, table hand-over) even with one rank, so that
+    # it can be exercised on a single-GPU box; it is never the default
+    force_sharded = os.environ.get("FAUCET_FORCE_SHARDED", "0") == "1"
+    if world > 1 or force_sharded:
+        if "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     k, L_ = args.k, args.read_len
     E, S = args.estimated_kmers * world, args.singletons * world
@@ -193,10 +201,10 @@ def main():
     torch.cuda.synchronize()
 
     ctx = api.Context(k, tai, nh, device=local_rank, profile=True)
-    shard = sharded.GpuShard(ctx, device) if world > 1 else None
+    shard = sharded.GpuShard(ctx, device) if (world > 1 or force_sharded) else None
 
     def one_step():
-        if world == 1:
+        if world == 1 and not force_sharded:
             return step_single(ctx, batches)
         return step_multi(shard, batches, rank, world)
 
@@ -231,9 +239,8 @@ def main():
     ktimes = ctx.kernel_times()
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     value = kmers_total * args.steps / elapsed
@@ -297,7 +304,7 @@ def main():
                                "sample": f"first {n_s} of the {args.reads} reads ({nk} k-mers), same 2 x {tai // 8 >> 20} MiB filters; "
                                          f"load+scan took {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
     print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
