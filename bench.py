@@ -169,6 +169,13 @@ def main():
     ap.add_argument("--profile-walk", action="store_true", help="time the per-window walk kernels individually")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL prints its version banner there) go to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (line + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -303,7 +310,7 @@ def main():
         res["cpu_baseline"] = {"value": v, "unit": "k-mers/s", "cores": 1, "kind": "port",
                                "sample": f"first {n_s} of the {args.reads} reads ({nk} k-mers), same 2 x {tai // 8 >> 20} MiB filters; "
                                          f"load+scan took {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
-    print(json.dumps(res))
+    emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
