@@ -143,7 +143,14 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
 
     fgpu_ctx* ctx = new fgpu_ctx();
     ctx->prm = *p;
-    if (!ctx->prm.junction_capacity) ctx->prm.junction_capacity = 1ULL << 24;
+    if (!ctx->prm.junction_capacity) {
+        // default: one slot per 32 filter bits (2^24 slots for config 2's 2^29-bit filters, 2^27 for 2^32 bits), within 2^22..2^28;
+        // at the reference's ~0.1 junctions per read that leaves the table below 10 % load
+        uint64_t c = p->tai / 32;
+        if (c < (1ULL << 22)) c = 1ULL << 22;
+        if (c > (1ULL << 28)) c = 1ULL << 28;
+        ctx->prm.junction_capacity = c;
+    }
     if (!ctx->prm.max_batch_bases) ctx->prm.max_batch_bases = 1ULL << 30;
     ctx->fd.k = p->k;
     ctx->fd.j = p->j;
