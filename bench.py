@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (cpu_baseline and reference bit counts)")
     ap.add_argument("--profile-walk", action="store_true", help="time the per-window walk kernels individually")
+    ap.add_argument("--host-input", action="store_true",
+                    help="hand the reads over as HOST buffers (PCIe copy inside the timed region); diagnostic only, never the headline value")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL prints its version banner there) go to stderr
@@ -204,7 +206,11 @@ def main():
     genome = make_genome(args.genome * world, 2, device)
     reads = make_reads(genome, args.reads, L_, args.err, 1000 + rank, device)
     del genome
-    batches = device_batches(reads, args.batch_reads)
+    if args.host_input:
+        host = reads.cpu().numpy()
+        batches = [api.ReadBatch.from_matrix(host[lo:lo + args.batch_reads]) for lo in range(0, args.reads, args.batch_reads)]
+    else:
+        batches = device_batches(reads, args.batch_reads)
     torch.cuda.synchronize()
 
     ctx = api.Context(k, tai, nh, device=local_rank, profile=True)
@@ -254,7 +260,7 @@ def main():
     res = {
         "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic" + (" (host buffers: PCIe copies inside the timed region)" if args.host_input else ""),
         "config": {"workload": f"{args.reads * world} synthetic {L_} bp reads ({args.reads} per GPU), k={k}, "
                                f"estimated_kmers={E}, singletons={S}, genome {args.genome * world} bp, {args.err:.0%} substitutions; "
                                f"filters 2 x {tai // 8 >> 20} MiB, {nh} hash functions",
