@@ -282,50 +282,23 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
     }
 }
 
-// ---- C: clusters -> ordered member lists (one block) --------------------------------------------------
-constexpr int CL_BLOCK = 1024;
-__global__ void __launch_bounds__(CL_BLOCK) k_walk_cluster(uint32_t* parent, uint32_t* count, uint32_t* offset, uint32_t* fill,
-                                                           uint32_t* members, Planes pl, uint64_t lo, uint64_t hi, DevCounters* cnt) {
-    __shared__ uint32_t sh[CL_BLOCK];
-    __shared__ uint32_t carry;
+// ---- C: clusters -> member lists ---------------------------------------------------------------------
+// One pass over the pieces of the window (the union-find is final: every union happened in the kernels before):
+// flat root of every piece, and every follower pushes itself onto its root's singly linked list.  No scan, no
+// second launch; the leader of a cluster sorts its (short) list when it walks.
+__global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict__ parent, uint32_t* count, uint32_t* head,
+                                                      uint32_t* __restrict__ flat, uint32_t* __restrict__ next, Planes pl, uint64_t lo,
+                                                      uint64_t hi) {
     const uint32_t n = make_window(pl, lo, hi).n;
-    // flatten (one traversal per piece; the tree is read-only here: all unions happened in the previous kernels);
-    // the flat roots go to scratch behind the member lists and replace the tree after a barrier
-    for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) { count[i] = 0; fill[i] = 0; }
-    __syncthreads();
-    uint32_t nf = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t r = i;
         for (;;) { uint32_t pr = parent[r]; if (pr == r) break; r = pr; }
-        members[n + i] = r;
-        if (r != i) { atomicAdd(&count[r], 1u); nf++; }
+        flat[i] = r;
+        if (r != i) {
+            next[i] = atomicExch(&head[r], i);
+            atomicAdd(&count[r], 1u);
+        }
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) parent[i] = members[n + i];
-    // exclusive scan of count -> offset: every thread owns one contiguous chunk, so ONE block-wide scan suffices
-    const uint32_t per = (n + CL_BLOCK - 1) / CL_BLOCK;
-    const uint32_t c_lo = min(n, threadIdx.x * per), c_hi = min(n, c_lo + per);
-    uint32_t mx = 0, local = 0;
-    for (uint32_t i = c_lo; i < c_hi; i++) { uint32_t c = count[i]; local += c; mx = c > mx ? c : mx; }
-    sh[threadIdx.x] = local;
-    __syncthreads();
-    for (int o = 1; o < CL_BLOCK; o <<= 1) {
-        uint32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t run = sh[threadIdx.x] - local;
-    for (uint32_t i = c_lo; i < c_hi; i++) { offset[i] = run; run += count[i]; }
-    __syncthreads();
-    (void)carry;
-    // scatter followers (unordered inside a cluster; the leader sorts its own short list)
-    for (uint32_t i = threadIdx.x; i < n; i += CL_BLOCK) {
-        uint32_t r = parent[i];
-        if (r != i) members[offset[r] + atomicAdd(&fill[r], 1u)] = i;
-    }
-    if (nf) atomicAdd(&cnt->followers, (unsigned long long)nf);
-    if (mx) atomicMax(&cnt->max_cluster, (unsigned long long)(mx + 1));
 }
 
 // ---- D: the walk ---------------------------------------------------------------------------------------
@@ -668,9 +641,11 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
     }
 }
 
+constexpr uint32_t LOCAL_MEMBERS = 16;
 __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root,
-                                             const uint32_t* __restrict__ count, const uint32_t* __restrict__ offset, uint32_t* members,
-                                             uint64_t lo, uint64_t hi, uint64_t piece_seq_base, DevCounters* cnt) {
+                                             const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
+                                             const uint32_t* __restrict__ next, uint32_t* pool, uint64_t lo, uint64_t hi,
+                                             uint64_t piece_seq_base, DevCounters* cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t created_keys[WalkCtx::NC];
     WalkCtx wc;
@@ -680,26 +655,39 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     wc.nc = 0; wc.c_overflow = false; wc.created_now = false;
     const WinDesc wd = make_window(pl, lo, hi);
     const uint32_t n = wd.n, first_piece = wd.first_piece;
+    unsigned long long n_follow = 0, biggest = 0;
     if (i < n && root[i] == i) {
         const uint32_t nm = count[i];
-        uint32_t* mem = members + offset[i];
-        for (uint32_t a = 1; a < nm; a++) {   // insertion sort of the followers: ascending piece order
-            uint32_t v = mem[a];
-            uint32_t b = a;
-            while (b > 0 && mem[b - 1] > v) { mem[b] = mem[b - 1]; b--; }
-            mem[b] = v;
+        uint32_t local_mem[LOCAL_MEMBERS];
+        uint32_t* mem = local_mem;
+        if (nm) {   // followers: off the linked list, into ascending piece order (the leader is the smallest index of the cluster)
+            n_follow = nm;
+            biggest = nm + 1;
+            if (nm > LOCAL_MEMBERS) mem = pool + atomicAdd(&cnt->pad2, (unsigned long long)nm);   // rare: giant cluster, list in global memory
+            uint32_t j = 0;
+            for (uint32_t m = head[i]; m != U_INF && j < nm; m = next[m]) mem[j++] = m;
+            for (uint32_t gap = nm / 2; gap > 0; gap /= 2)          // shell sort: fine for 2 members and for 10^5
+                for (uint32_t a = gap; a < nm; a++) {
+                    uint32_t v = mem[a];
+                    uint32_t b = a;
+                    while (b >= gap && mem[b - gap] > v) { mem[b] = mem[b - gap]; b -= gap; }
+                    mem[b] = v;
+                }
         }
-        for (uint32_t a = 0; a <= nm; a++) {  // the leader first (smallest index of the cluster), then its followers in order
+        for (uint32_t a = 0; a <= nm; a++) {
             const uint32_t m = a == 0 ? i : mem[a - 1];
             const uint2 pc = pl.pieces[first_piece + m];
             walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + m);
         }
     }
     // wave-level reduction of the counters
-    unsigned long long v[5] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, wc.n_created};
-    for (int c = 0; c < 5; c++)
+    unsigned long long v[6] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, wc.n_created, n_follow};
+    for (int c = 0; c < 6; c++)
         for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_down(v[c], o, 64);
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(biggest, o, 64); biggest = t > biggest ? t : biggest; }
     if (fd_lane() == 0) {
+        if (v[5]) atomicAdd(&cnt->followers, v[5]);
+        if (biggest) atomicMax(&cnt->max_cluster, biggest);
         if (v[0]) atomicAdd(&cnt->nb_processed, v[0]);
         if (v[1]) atomicAdd(&cnt->nb_skipped, v[1]);
         if (v[2]) atomicAdd(&cnt->nb_jcheck, v[2]);
@@ -710,8 +698,10 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
 
 // ---- E: sparse reset of the window table ----------------------------------------------------------------
 // wt.slots is indexed by position relative to the window's (word-aligned) start: U_INF = that position claimed nothing.
-__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent, Planes pl, uint64_t lo, uint64_t hi, uint64_t pos_end) {
+__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent, uint32_t* count, uint32_t* head, DevCounters* cnt, Planes pl,
+                                                    uint64_t lo, uint64_t hi, uint64_t pos_end) {
     const uint32_t n = make_window(pl, lo, hi).n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->pad2 = 0;   // pool cursor of the giant-cluster lists
     const uint64_t span = pos_end - (lo & ~63ULL);
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -725,7 +715,11 @@ __global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent,
         wt.keys[s] = J_EMPTY;
         wt.owner[s] = U_INF;
     }
-    for (uint64_t a = i; a < n; a += stride) parent[a] = (uint32_t)a;
+    for (uint64_t a = i; a < n; a += stride) {
+        parent[a] = (uint32_t)a;
+        count[a] = 0;
+        head[a] = U_INF;
+    }
 }
 
 
@@ -836,6 +830,8 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->wslots, 0xFF, ctx->wcap * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
+    FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, ctx->wmax * 4, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->cl_offset, 0xFF, ctx->wmax * 4, ctx->stream));
     return FGPU_OK;
 }
 
@@ -867,11 +863,13 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const int parity = (int)(ctx->scan_windows & 1);
         FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, ctx->uf_parent, lo, hi, pos_end, ctx->counters, parity);
         FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, lo, hi, pos_end);
-        FGPU_LAUNCH("walk_cluster", k_walk_cluster, 1, CL_BLOCK, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
-                    ctx->cl_members, pl, lo, hi, ctx->counters);
-        FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->uf_parent, (const uint32_t*)ctx->cl_count,
-                    (const uint32_t*)ctx->cl_offset, ctx->cl_members, lo, hi, seq_base, ctx->counters);
-        FGPU_LAUNCH("walk_clean", k_walk_clean, 512, 256, wt, ctx->uf_parent, pl, lo, hi, pos_end);
+        // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
+        FGPU_LAUNCH("walk_cluster", k_walk_cluster, 256, 256, (const uint32_t*)ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
+                    ctx->cl_members, pl, lo, hi);
+        FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
+                    (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, lo, hi, seq_base,
+                    ctx->counters);
+        FGPU_LAUNCH("walk_clean", k_walk_clean, 512, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
     }
     ctx->prof_suppress = false;
