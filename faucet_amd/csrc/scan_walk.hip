@@ -110,11 +110,13 @@ __device__ __forceinline__ bool jt_find_live(const JTable& jt, uint64_t canon, u
     return false;
 }
 
-// find or claim the slot of canon; returns false when the table is full
-__device__ __forceinline__ bool jt_find_or_claim(const JTable& jt, uint64_t canon, uint64_t& slot, uint32_t& present, DevCounters* cnt) {
-    uint64_t s = fd_mix(canon) & jt.mask;
+// find or claim the slot of canon; returns false when the table is full.  `w_first` is the (already loaded) key word of the
+// home slot, so that the caller can have the record of the home slot in flight at the same time.
+__device__ __forceinline__ bool jt_find_or_claim(const JTable& jt, uint64_t canon, uint64_t home, uint64_t w_first, uint64_t& slot,
+                                                 uint32_t& present, DevCounters* cnt) {
+    uint64_t s = home;
     for (uint64_t n = 0; n <= jt.mask; n++) {
-        uint64_t w = ld_agent(&jt.keys[s]);
+        uint64_t w = n == 0 ? w_first : ld_agent(&jt.keys[s]);
         if (w == J_EMPTY) {
             unsigned long long old = atomicCAS((unsigned long long*)&jt.keys[s], (unsigned long long)J_EMPTY, (unsigned long long)canon);
             if (old == J_EMPTY) {
@@ -288,8 +290,10 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
 // second launch; the leader of a cluster sorts its (short) list when it walks.
 __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict__ parent, uint32_t* count, uint32_t* head,
                                                       uint32_t* __restrict__ flat, uint32_t* __restrict__ next, Planes pl, uint64_t lo,
-                                                      uint64_t hi) {
-    const uint32_t n = make_window(pl, lo, hi).n;
+                                                      uint64_t hi, WinDesc* wd_out) {
+    const WinDesc wd = make_window(pl, lo, hi);
+    const uint32_t n = wd.n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *wd_out = wd;   // the walk kernel reads it with one uniform load
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t r = i;
         for (;;) { uint32_t pr = parent[r]; if (pr == r) break; r = pr; }
@@ -486,7 +490,13 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     int orient = key == canon ? 0 : 1;
     uint64_t slot;
     uint32_t present;
-    if (!jt_find_or_claim(wc.jt, canon, slot, present, wc.cnt)) {
+    // the key word and the record of the home slot are requested together: at the table's low load factor the key is
+    // almost always in its home slot, so an event costs one memory round trip instead of two
+    const uint64_t home = fd_mix(canon) & wc.jt.mask;
+    const uint64_t* spec = (const uint64_t*)(wc.jt.recs + (home * 2 + orient) * 16);
+    const uint64_t w_first = ld_agent(&wc.jt.keys[home]);
+    const uint64_t spec_lo = spec[0], spec_hi = spec[1];
+    if (!jt_find_or_claim(wc.jt, canon, home, w_first, slot, present, wc.cnt)) {
         atomicOr(&wc.cnt->error_flags, 1ULL);
         return false;
     }
@@ -503,6 +513,9 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
         uint64_t hb = fd_mix(canon) >> 24;
         atomicOr(&wc.jt.filter[(hb & wc.jt.filter_mask) >> 5], 1u << (hb & 31));
         wc.n_created++;
+    } else if (slot == home) {
+        out.lo = spec_lo;
+        out.hi = spec_hi;
     } else {
         out.lo = out.addr[0];
         out.hi = out.addr[1];
@@ -644,7 +657,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
 constexpr uint32_t LOCAL_MEMBERS = 16;
 __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root,
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
-                                             const uint32_t* __restrict__ next, uint32_t* pool, uint64_t lo, uint64_t hi,
+                                             const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
                                              uint64_t piece_seq_base, DevCounters* cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t created_keys[WalkCtx::NC];
@@ -653,11 +666,15 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = 0;
     wc.nc = 0; wc.c_overflow = false; wc.created_now = false;
-    const WinDesc wd = make_window(pl, lo, hi);
+    const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;
-    if (i < n && root[i] == i) {
-        const uint32_t nm = count[i];
+    // everything the thread needs to start is requested at once (no dependent loads before the plane burst)
+    const uint32_t ii = i < n ? i : 0;
+    const uint32_t my_root = root[ii], my_count = count[ii], my_head = head[ii];
+    const uint2 my_piece = pl.pieces[first_piece + ii];
+    if (i < n && my_root == i) {
+        const uint32_t nm = my_count;
         uint32_t local_mem[LOCAL_MEMBERS];
         uint32_t* mem = local_mem;
         if (nm) {   // followers: off the linked list, into ascending piece order (the leader is the smallest index of the cluster)
@@ -665,7 +682,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
             biggest = nm + 1;
             if (nm > LOCAL_MEMBERS) mem = pool + atomicAdd(&cnt->pad2, (unsigned long long)nm);   // rare: giant cluster, list in global memory
             uint32_t j = 0;
-            for (uint32_t m = head[i]; m != U_INF && j < nm; m = next[m]) mem[j++] = m;
+            for (uint32_t m = my_head; m != U_INF && j < nm; m = next[m]) mem[j++] = m;
             for (uint32_t gap = nm / 2; gap > 0; gap /= 2)          // shell sort: fine for 2 members and for 10^5
                 for (uint32_t a = gap; a < nm; a++) {
                     uint32_t v = mem[a];
@@ -676,7 +693,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         }
         for (uint32_t a = 0; a <= nm; a++) {
             const uint32_t m = a == 0 ? i : mem[a - 1];
-            const uint2 pc = pl.pieces[first_piece + m];
+            const uint2 pc = a == 0 ? my_piece : pl.pieces[first_piece + m];
             walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + m);
         }
     }
@@ -782,7 +799,8 @@ __global__ void __launch_bounds__(256) k_import(JTable jt, FdParams fp, const Ex
     int orient = e.key == canon ? 0 : 1;
     uint64_t slot;
     uint32_t present;
-    if (!jt_find_or_claim(jt, canon, slot, present, cnt)) { atomicOr(&cnt->error_flags, 1ULL); return; }
+    const uint64_t home = fd_mix(canon) & jt.mask;
+    if (!jt_find_or_claim(jt, canon, home, ld_agent(&jt.keys[home]), slot, present, cnt)) { atomicOr(&cnt->error_flags, 1ULL); return; }
     uint64_t* r = (uint64_t*)(jt.recs + (slot * 2 + orient) * 16);
     r[0] = ((const uint64_t*)e.rec)[0];
     r[1] = ((const uint64_t*)e.rec)[1];
@@ -865,10 +883,10 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, lo, hi, pos_end);
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, 256, 256, (const uint32_t*)ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
-                    ctx->cl_members, pl, lo, hi);
+                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc);
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
-                    (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, lo, hi, seq_base,
-                    ctx->counters);
+                    (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
+                    seq_base, ctx->counters);
         FGPU_LAUNCH("walk_clean", k_walk_clean, 512, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
     }
