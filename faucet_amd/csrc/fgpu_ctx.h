@@ -30,6 +30,7 @@ struct BatchBufs {
     DevBuf pending;                // pass 1: occurrences that need the first-set-time test
     // pass 2 planes (1 bit per stream position, LSB first)
     DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
+    DevBuf lk;                     // walk: positions whose k-mer is a registered candidate of the current window
     DevBuf ps_prefix;              // exclusive prefix of popcount(ps) per 64-bit word (uint32)
     DevBuf pieces;                 // uint2 {start position, windows} per valid piece, in stream order
     uint64_t T = 0;                // stream length = bases + n_reads

@@ -254,7 +254,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     if (bb.T == 0) return FGPU_OK;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
     int rc;
-    DevBuf* planes[] = {&bb.valid, &bb.pm, &bb.ps, &bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1, &bb.inF, &bb.inB};
+    DevBuf* planes[] = {&bb.valid, &bb.pm, &bb.ps, &bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1, &bb.inF, &bb.inB, &bb.lk};
     for (DevBuf* b : planes)
         if ((rc = fgpu_ensure(ctx, b, wb))) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.ps_prefix, (bb.n_words + FGPU_PADW + bb.n_words / SCAN_BLOCK + 2) * 4))) return rc;

@@ -76,6 +76,7 @@ struct Planes {
     const uint64_t *ff, *fb, *cf0, *cf1, *cb0, *cb1;
     uint64_t *inF, *inB;
     const uint2* pieces;
+    uint64_t* lk;
 };
 
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
@@ -273,15 +274,23 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
                                                    uint64_t pos_end) {
     const WinDesc wd = make_window(pl, lo, hi);
     uint64_t p = (wd.lo & ~63ULL) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
     if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL)) {
         uint64_t canon = fd_canon(fd_kmer_at(pl.codes, p, fp.k), fp.k);
         uint32_t owner = wt_owner(wt, canon);
         if (owner != U_INF) {
             uint32_t li;
             uint2 pc;
-            if (piece_in_window(pl, wd, p, li, pc) && owner != li) uf_union(parent, li, owner);
+            if (piece_in_window(pl, wd, p, li, pc)) {
+                hit = true;
+                if (owner != li) uf_union(parent, li, owner);
+            }
         }
     }
+    // lk plane: the only positions where a key created DURING this window can sit (a key is only ever created at a
+    // registered candidate), so the walk compares its created-key list at these few positions instead of all of them
+    uint64_t m = __ballot(hit);
+    if (fd_lane() == 0) pl.lk[p >> 6] = m;
 }
 
 // ---- C: clusters -> member lists ---------------------------------------------------------------------
@@ -316,6 +325,7 @@ struct PieceView {
     // two words per plane, as SCALAR members: runtime-indexed arrays would be demoted to scratch memory
     uint64_t inF0, inF1, inB0, inB1, fF0, fF1, fB0, fB1, c0F0, c0F1, c1F0, c1F1, c0B0, c0B1, c1B0, c1B1;
     uint64_t xF0, xF1, xB0, xB1;   // positions whose key this thread's cluster created during the current window
+    uint64_t lk0, lk1;             // positions holding a registered candidate k-mer (where created keys can sit)
     uint64_t cbase;                // stream position of the first base held in cw0 (multiple of 32)
     uint64_t cw0, cw1, cw2, cw3, cw4, cw5;   // 192 bases of 2-bit codes: a whole <= 160-base piece, k-mers come out of registers
 };
@@ -334,6 +344,7 @@ struct WalkCtx {
     int nc;
     bool c_overflow;    // more than NC creations: fall back to live table lookups
     bool created_now;   // set by junction_get
+    int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
 };
 
 __device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
@@ -365,6 +376,7 @@ __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t
     v.c0B0 = fd_bits_at(pl.cb0, p0) & m0;   v.c0B1 = fd_bits_at(pl.cb0, p1) & m1;
     v.c1B0 = fd_bits_at(pl.cb1, p0) & m0;   v.c1B1 = fd_bits_at(pl.cb1, p1) & m1;
     v.xF0 = v.xF1 = v.xB0 = v.xB1 = 0;
+    v.lk0 = fd_bits_at(pl.lk, p0) & m0;     v.lk1 = fd_bits_at(pl.lk, p1) & m1;
     v.cbase = p0 & ~31ULL;
     const uint64_t* cw = pl.codes + (v.cbase >> 5);   // padded: reading 6 words from any piece start stays inside the buffer
     v.cw0 = cw[0]; v.cw1 = cw[1]; v.cw2 = cw[2]; v.cw3 = cw[3]; v.cw4 = cw[4]; v.cw5 = cw[5];
@@ -393,10 +405,12 @@ __device__ __forceinline__ int pv_base(const PieceView& v, const uint64_t* codes
 // overflowed, by live table lookups.
 // Out of line and fed by value on purpose: it is the rare path, and it is the only code that indexes the created-key
 // list at run time — keeping it away from WalkCtx lets the rest of the walk state live in registers.
-__device__ __noinline__ uint4 created_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint32_t n_pos,
+__device__ __noinline__ uint4 created_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint64_t where,
                                                 const uint64_t* ckey, int nc, bool overflow, JTable jt) {
     uint64_t mF = 0, mB = 0;
-    for (uint32_t i = 0; i < n_pos; i++) {
+    while (where) {   // only the candidate positions of the chunk
+        const uint32_t i = (uint32_t)__builtin_ctzll(where);
+        where &= where - 1;
         uint64_t km = fd_kmer_at(codes, p + i, k);
         uint64_t rc = fd_revcomp(km, k);
         if (!overflow) {
@@ -418,9 +432,11 @@ __device__ __noinline__ uint4 created_bits_impl(const uint64_t* __restrict__ cod
 }
 
 __device__ __forceinline__ void created_bits(const WalkCtx& wc, const uint64_t* ckey, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+    if (wc.dbg & 1) { mF = mB = 0; return; }
     const uint32_t base = c * 64;
-    const uint32_t n_pos = base >= v.nwin ? 0 : (v.nwin - base < 64 ? v.nwin - base : 64);
-    uint4 r = created_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, n_pos, ckey, wc.nc, wc.c_overflow, wc.jt);
+    const uint64_t where = pv_word(v, v.lk0, v.lk1, wc.pl.lk, c);
+    if (!where) { mF = mB = 0; return; }
+    uint4 r = created_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, where, ckey, wc.nc, wc.c_overflow, wc.jt);
     mF = (uint64_t)r.x | ((uint64_t)r.y << 32);
     mB = (uint64_t)r.z | ((uint64_t)r.w << 32);
 }
@@ -455,7 +471,7 @@ __device__ __forceinline__ uint32_t pv_popc(const PieceView& v, uint64_t r0, uin
 
 // NbJCheckKmer increments of the half-steps t in [t0, t1): backward-facing half-steps are 2q, forward-facing 2q+1
 __device__ __forceinline__ uint32_t jcheck_sum(const WalkCtx& wc, const PieceView& v, int t0, int t1) {
-    if (t1 <= t0) return 0;
+    if (t1 <= t0 || (wc.dbg & 4)) return 0;
     const uint32_t bq0 = (uint32_t)((t0 + 1) >> 1), bq1 = (uint32_t)((t1 + 1) >> 1);
     const uint32_t fq0 = (uint32_t)(t0 >> 1), fq1 = (uint32_t)(t1 >> 1);
     return pv_popc(v, v.c0B0, v.c0B1, wc.pl.cb0, bq0, bq1) + 2 * pv_popc(v, v.c1B0, v.c1B1, wc.pl.cb1, bq0, bq1) +
@@ -658,14 +674,14 @@ constexpr uint32_t LOCAL_MEMBERS = 16;
 __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root,
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
-                                             uint64_t piece_seq_base, DevCounters* cnt) {
+                                             uint64_t piece_seq_base, DevCounters* cnt, int dbg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t created_keys[WalkCtx::NC];
     WalkCtx wc;
     wc.ckey = created_keys;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = 0;
-    wc.nc = 0; wc.c_overflow = false; wc.created_now = false;
+    wc.nc = 0; wc.c_overflow = false; wc.created_now = false; wc.dbg = dbg;
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;
@@ -674,7 +690,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     const uint32_t my_root = root[ii], my_count = count[ii], my_head = head[ii];
     const uint2 my_piece = pl.pieces[first_piece + ii];
     if (i < n && my_root == i) {
-        const uint32_t nm = my_count;
+        const uint32_t nm = (dbg & 2) ? 0 : my_count;
         uint32_t local_mem[LOCAL_MEMBERS];
         uint32_t* mem = local_mem;
         if (nm) {   // followers: off the linked list, into ascending piece order (the leader is the smallest index of the cluster)
@@ -860,7 +876,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     BatchBufs& bb = *ctx->cur;
     Planes pl{(const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.ps.p, (const uint32_t*)bb.ps_prefix.p,
               (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p, (const uint64_t*)bb.cf0.p, (const uint64_t*)bb.cf1.p,
-              (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p};
+              (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p,
+              (uint64_t*)bb.lk.p};
     JTable jt = make_jt(ctx);
     WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;
@@ -868,9 +885,12 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
     const unsigned walk_grid = fgpu_blocks(ctx->wmax, 64);
+    static const int dbg_walk = getenv("FGPU_DEBUG_WALK") ? atoi(getenv("FGPU_DEBUG_WALK")) : 0;
     // the whole stage goes to the walk stream, behind the completion of this batch's pure stage
-    ctx->launch_stream = ctx->wstream;
-    if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(ctx->wstream, bb.pure_done, 0));
+    static const bool no_overlap = getenv("FGPU_NO_OVERLAP") && getenv("FGPU_NO_OVERLAP")[0] == '1';   // measurement aid
+    hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
+    ctx->launch_stream = walk_stream;
+    if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(walk_stream, bb.pure_done, 0));
     // thousands of tiny launches: by default one event pair around the whole stage
     const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
     ctx->prof_suppress = !ctx->prof_walk_detail;
@@ -886,14 +906,14 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc);
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
                     (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
-                    seq_base, ctx->counters);
+                    seq_base, ctx->counters, dbg_walk);
         FGPU_LAUNCH("walk_clean", k_walk_clean, 512, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
     }
     ctx->prof_suppress = false;
     fgpu_prof_end(ctx, stage_tok);
     if (bb.walk_done) {
-        FGPU_HIP(hipEventRecord(bb.walk_done, ctx->wstream));
+        FGPU_HIP(hipEventRecord(bb.walk_done, walk_stream));
         bb.walk_pending = true;
     }
     ctx->launch_stream = ctx->stream;
