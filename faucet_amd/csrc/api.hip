@@ -181,14 +181,12 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         if ((e = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (walk)", e);
     }
     if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
-    if (!rc && (e = hipMalloc(&ctx->bloo1_new, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1_new", e);
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
     if (!rc && (e = hipMalloc(&ctx->counters, sizeof(DevCounters))) != hipSuccess) fail("hipMalloc counters", e);
     if (!rc && (e = hipHostMalloc(&ctx->counters_host, sizeof(DevCounters))) != hipSuccess) fail("hipHostMalloc", e);
     if (!rc) {
         memset(ctx->counters_host, 0, sizeof(DevCounters));
         hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream);
-        hipMemsetAsync(ctx->bloo1_new, 0, ctx->bloom_bytes, ctx->stream);
         hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream);
         hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream);
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) fail("initial memset", e);
@@ -250,7 +248,6 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     }
     FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));
-    FGPU_HIP(hipMemcpyAsync(ctx->bloo1_new, ctx->bloo1, ctx->bloom_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream));
     int rc = fgpu_load_pair_begin(ctx);
     if (rc) return rc;

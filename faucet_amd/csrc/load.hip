@@ -38,8 +38,7 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
 // Both filters use the same bit positions (same hashes, same size), so one 8-byte load serves the carry test and
 // the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                   uint64_t T, uint64_t n_words, FdParams fp, uint2* pair,
-                                                   uint32_t* carry_next, uint32_t* first,
+                                                   uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first,
                                                    uint64_t* __restrict__ pending, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
@@ -73,11 +72,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 pend = true;
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
-                    if (missing & (1u << i)) {
-                        atomicMin(&first[h], (uint32_t)p);
-                        uint32_t bit = 1u << (h & 31);
-                        if (!(carry_next[h >> 5] & bit)) atomicOr(&carry_next[h >> 5], bit);
-                    }
+                    if (missing & (1u << i)) atomicMin(&first[h], (uint32_t)p);   // the next carry is derived from first[] (k_carry_from_first)
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -135,9 +130,19 @@ __global__ void __launch_bounds__(256) k_pair_split(const uint2* __restrict__ pa
         b[i] = v.y;
     }
 }
-__global__ void __launch_bounds__(256) k_pair_set_carry(uint2* __restrict__ pair, const uint32_t* __restrict__ a, uint64_t n32) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x)
-        pair[i].x = a[i];
+// carry := carry | bits set during the batch.  A bit is set iff its first-set time is no longer "never": one streaming
+// pass over first[] (4 bytes per Bloom bit, lanes = consecutive bits, one ballot per 64 bits) replaces one atomicOr per
+// newly set bit in the mark kernel.
+__global__ void __launch_bounds__(256) k_carry_from_first(uint2* __restrict__ pair, const uint32_t* __restrict__ first, uint64_t tai) {
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < tai; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t m = __ballot(first[b] != 0xFFFFFFFFu);
+        if (fd_lane() == 0 && m) {
+            uint64_t w = b >> 5;   // b is a multiple of 64 here: two consecutive 32-bit words of the carry half
+            uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+            if (lo) pair[w].x |= lo;
+            if (hi) pair[w + 1].x |= hi;
+        }
+    }
 }
 
 // multi-GPU helper: OR the bits of every k-mer into a bitmap, no ordering
@@ -230,11 +235,11 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->bloo1_new, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
+                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
                 (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
     // carry := carry | bits set during this batch
-    FGPU_LAUNCH("carry_update", k_pair_set_carry, 2048, 256, ctx->pair, (const uint32_t*)ctx->bloo1_new, ctx->bloom_bytes / 4);
+    FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint32_t*)ctx->first, ctx->prm.tai);
     return FGPU_OK;
 }
 
