@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "libfaucet_gpu.so")
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_CAPACITY, ERR_NOMEM = range(6)
 BLOO1, BLOO2 = 0, 1
 FLAG_PROFILE = 1
+FLAG_EAGER_FLAGS = 2
 TABLE_ENTRY_BYTES = 32
 
 

@@ -81,6 +81,11 @@ static int check_errors(fgpu_ctx* ctx) {
     // device-side error flags (table overflow) are surfaced at the synchronising calls
     if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
+    if (ctx->counters_host->error_flags & 4ULL) {
+        ctx->err = "lazy-flag check failed: the walk scanned a position whose junction test was not evaluated; "
+                   "repeat the scan with FGPU_FLAG_EAGER_FLAGS";
+        return FGPU_ERR_STATE;
+    }
     return FGPU_OK;
 }
 

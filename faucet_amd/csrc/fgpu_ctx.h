@@ -31,6 +31,7 @@ struct BatchBufs {
     // pass 2 planes (1 bit per stream position, LSB first)
     DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
     DevBuf lk;                     // walk: positions whose k-mer is a registered candidate of the current window
+    DevBuf nF, nB, need;           // lazy flags: in-map snapshot planes of the pure stage, positions whose flags get evaluated
     DevBuf ps_prefix;              // exclusive prefix of popcount(ps) per 64-bit word (uint32)
     DevBuf pieces;                 // uint2 {start position, windows} per valid piece, in stream order
     uint64_t T = 0;                // stream length = bases + n_reads
@@ -187,6 +188,7 @@ int fgpu_load_pair_begin(fgpu_ctx* ctx);
 int fgpu_load_pair_end(fgpu_ctx* ctx);
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
+int fgpu_stage_scan_need(fgpu_ctx* ctx);
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);
 int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out);
 int fgpu_util_or(fgpu_ctx* ctx, void* dst, const void* src, uint64_t nbytes);

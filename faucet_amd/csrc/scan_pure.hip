@@ -215,14 +215,14 @@ __device__ __forceinline__ void test_for_junction(uint64_t key, int real, const 
 }
 
 __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
-                                                    uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
+                                                    const uint64_t* __restrict__ need, uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
                                                     uint64_t* __restrict__ ff, uint64_t* __restrict__ fb, uint64_t* __restrict__ cf0,
                                                     uint64_t* __restrict__ cf1, uint64_t* __restrict__ cb0, uint64_t* __restrict__ cb1) {
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool f_f = false, f_b = false;
         int c_f = 0, c_b = 0;
-        if (p < T) {
+        if (p < T && ((need[p >> 6] >> (p & 63)) & 1ULL)) {   // only where the walk can stop skipping (scan_walk.hip, "lazy flags")
             uint64_t wbits = fd_bits_at(pm, p == 0 ? 0 : p - 1);   // bit0 = pm[p-1], bit1 = pm[p], bit2 = pm[p+1]
             bool here, prev, next;
             if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
@@ -254,7 +254,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     if (bb.T == 0) return FGPU_OK;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
     int rc;
-    DevBuf* planes[] = {&bb.valid, &bb.pm, &bb.ps, &bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1, &bb.inF, &bb.inB, &bb.lk};
+    DevBuf* planes[] = {&bb.valid, &bb.pm, &bb.ps, &bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1, &bb.inF, &bb.inB, &bb.lk, &bb.nF, &bb.nB, &bb.need};
     for (DevBuf* b : planes)
         if ((rc = fgpu_ensure(ctx, b, wb))) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.ps_prefix, (bb.n_words + FGPU_PADW + bb.n_words / SCAN_BLOCK + 2) * 4))) return rc;
@@ -292,7 +292,9 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     if (np) {
         FGPU_LAUNCH("piece_list", k_scan_piece_list, wgrid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
                     (const uint32_t*)prefix, bb.n_words, (uint2*)bb.pieces.p);
-        FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.T, bb.n_words, ctx->fd,
+        if ((rc = fgpu_stage_scan_need(ctx))) return rc;
+        FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.need.p,
+                    bb.T, bb.n_words, ctx->fd,
                     (const uint32_t*)ctx->bloo2, (uint64_t*)bb.ff.p, (uint64_t*)bb.fb.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p,
                     (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p);
     }

@@ -77,6 +77,7 @@ struct Planes {
     uint64_t *inF, *inB;
     const uint2* pieces;
     uint64_t* lk;
+    const uint64_t* need;
 };
 
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
@@ -326,6 +327,7 @@ struct PieceView {
     uint64_t inF0, inF1, inB0, inB1, fF0, fF1, fB0, fB1, c0F0, c0F1, c1F0, c1F1, c0B0, c0B1, c1B0, c1B1;
     uint64_t xF0, xF1, xB0, xB1;   // positions whose key this thread's cluster created during the current window
     uint64_t lk0, lk1;             // positions holding a registered candidate k-mer (where created keys can sit)
+    uint64_t nd0, nd1;             // positions whose flags the pure stage evaluated (need plane)
     uint64_t cbase;                // stream position of the first base held in cw0 (multiple of 32)
     uint64_t cw0, cw1, cw2, cw3, cw4, cw5;   // 192 bases of 2-bit codes: a whole <= 160-base piece, k-mers come out of registers
 };
@@ -377,6 +379,7 @@ __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t
     v.c1B0 = fd_bits_at(pl.cb1, p0) & m0;   v.c1B1 = fd_bits_at(pl.cb1, p1) & m1;
     v.xF0 = v.xF1 = v.xB0 = v.xB1 = 0;
     v.lk0 = fd_bits_at(pl.lk, p0) & m0;     v.lk1 = fd_bits_at(pl.lk, p1) & m1;
+    v.nd0 = fd_bits_at(pl.need, p0) & m0;   v.nd1 = fd_bits_at(pl.need, p1) & m1;
     v.cbase = p0 & ~31ULL;
     const uint64_t* cw = pl.codes + (v.cbase >> 5);   // padded: reading 6 words from any piece start stays inside the buffer
     v.cw0 = cw[0]; v.cw1 = cw[1]; v.cw2 = cw[2]; v.cw3 = cw[3]; v.cw4 = cw[4]; v.cw5 = cw[5];
@@ -476,6 +479,13 @@ __device__ __forceinline__ uint32_t jcheck_sum(const WalkCtx& wc, const PieceVie
     const uint32_t fq0 = (uint32_t)(t0 >> 1), fq1 = (uint32_t)(t1 >> 1);
     return pv_popc(v, v.c0B0, v.c0B1, wc.pl.cb0, bq0, bq1) + 2 * pv_popc(v, v.c1B0, v.c1B1, wc.pl.cb1, bq0, bq1) +
            pv_popc(v, v.c0F0, v.c0F1, wc.pl.cf0, fq0, fq1) + 2 * pv_popc(v, v.c1F0, v.c1F1, wc.pl.cf1, fq0, fq1);
+}
+
+// every half-step in [t0, t1) is being scanned: its flags must have been evaluated (need plane); otherwise raise error bit 4
+__device__ __forceinline__ void check_scanned(WalkCtx& wc, const PieceView& v, int t0, int t1) {
+    if (t1 <= t0) return;
+    const uint32_t qa = (uint32_t)(t0 >> 1), qb = (uint32_t)((t1 - 1) >> 1) + 1;
+    if (pv_popc(v, v.nd0, v.nd1, wc.pl.need, qa, qb) != (qb < v.nwin ? qb : v.nwin) - qa) atomicOr(&wc.cnt->error_flags, 4ULL);
 }
 
 // A junction record held in two registers: dist[0..4] bytes 0-4, cov[0..3] bytes 5-8, linked mask byte 9.
@@ -592,6 +602,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         if (tn > tmax) {   // ran off the end of the piece
             wc.nb_processed += (unsigned long long)(tmax - t + 1);
             wc.nb_jcheck += jcheck_sum(wc, v, t, tmax + 1);
+            check_scanned(wc, v, t, tmax + 1);
             break;
         }
         const uint32_t q = (uint32_t)(tn >> 1);
@@ -608,6 +619,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         const bool by_spacer = !in_map && (tn - last_pos >= spacer);
         wc.nb_processed += (unsigned long long)(tn - t);
         wc.nb_jcheck += jcheck_sum(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
+        check_scanned(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
 
         // ---- junction at (q, fwd)  (ReadScanner.cpp:133-192)
         uint64_t km = pv_kmer(v, wc.pl.codes, p0 + q, k);
@@ -767,6 +779,115 @@ __global__ void __launch_bounds__(256) k_iota_u32(uint32_t* p, uint64_t n) {
     for (; i < n; i += stride) p[i] = (uint32_t)i;
 }
 
+// ---- lazy flags: which positions can the walk ever stop skipping at? -------------------------------------------
+// testForJunction is only ever evaluated at half-steps the walk SCANS (it skips `dist` half-steps after every junction).
+// The pure stage therefore evaluates it only on a superset of the scanned positions, computed here per batch from whatever
+// state the junction table is in at that moment (the previous batch's walk may still be running: every value read is a
+// value the table had at some earlier time, and the argument below only needs the table to grow monotonically):
+//   * a position in the map stays in the map; a scanned stretch ends at the first in-map position, now or later, so
+//     junctions that appear later only shorten stretches that are already marked;
+//   * a skip that lands exactly ON an in-map junction is final: every later piece reads the same distance, lands on the
+//     same junction and re-links the same distance, so that distance is never raised;
+//   * after any other skip (distance not yet converged) everything up to the end of the piece is marked.
+// New junctions created inside a scanned stretch (flagged, spacer, fake) start with distance 0, i.e. the walk goes on
+// scanning: they do not change which positions are visited.  The walk double-checks: scanning a position whose need bit
+// is clear raises error bit 4 (surfaced as FGPU_ERR_STATE), it never silently uses a flag that was not computed.
+__global__ void __launch_bounds__(256) k_need_lookup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm, uint64_t n_words,
+                                                     FdParams fp, JTable jt, uint64_t* __restrict__ nF, uint64_t* __restrict__ nB) {
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool inF = false, inB = false;
+        if ((pm[p >> 6] >> (p & 63)) & 1ULL) {
+            uint64_t km = fd_kmer_at(codes, p, fp.k);
+            uint64_t rc = fd_revcomp(km, fp.k);
+            uint64_t canon = km < rc ? km : rc;
+            const uint64_t hb = jt_filter_bit(jt, canon);
+            if ((jt.filter[hb >> 5] >> (hb & 31)) & 1u) {
+                uint32_t present = jt_present_snapshot(jt, canon);
+                inF = (present >> (km == canon ? 0 : 1)) & 1u;
+                inB = (present >> (rc == canon ? 0 : 1)) & 1u;
+            }
+        }
+        uint64_t mF = __ballot(inF), mB = __ballot(inB);
+        if (fd_lane() == 0) { nF[p >> 6] = mF; nB[p >> 6] = mB; }
+    }
+}
+
+__device__ __forceinline__ void need_mark(unsigned long long* need, uint64_t a, uint64_t z) {   // positions [a, z)
+    while (a < z) {
+        uint64_t wi = a >> 6;
+        uint64_t hi = (wi + 1) << 6;
+        uint64_t upto = z < hi ? z : hi;
+        int lo_b = (int)(a & 63), n_b = (int)(upto - a);
+        unsigned long long m = (n_b == 64 ? ~0ULL : ((1ULL << n_b) - 1)) << lo_b;
+        atomicOr(&need[wi], m);
+        a = upto;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_need_prewalk(const uint64_t* __restrict__ codes, const uint2* __restrict__ pieces, uint64_t n_pieces,
+                                                      FdParams fp, JTable jt, const uint64_t* __restrict__ nF, const uint64_t* __restrict__ nB,
+                                                      unsigned long long* need) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pieces; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 pc = pieces[i];
+        const uint64_t p0 = pc.x;
+        const uint32_t nwin = pc.y;
+        const int k = fp.k, j = fp.j;
+        const int tmax = 2 * (int)nwin - 2 - 2 * j;
+        int t = 2 * j + 1;
+        while (t <= tmax) {
+            // first in-map half-step >= t
+            int t_ev = 0x7fffffff;
+            const uint32_t q0 = (uint32_t)(t >> 1);
+            for (uint32_t qc = q0; qc < nwin && 2 * (int)qc <= tmax; qc += 64) {
+                uint64_t eF = fd_bits_at(nF, p0 + qc), eB = fd_bits_at(nB, p0 + qc);
+                if (qc == q0 && (t & 1)) eB &= ~1ULL;
+                const uint32_t rem = nwin - qc;
+                if (rem < 64) { const uint64_t m = (1ULL << rem) - 1; eF &= m; eB &= m; }
+                const int tb = eB ? 2 * (int)(qc + __builtin_ctzll(eB)) : 0x7fffffff;
+                const int tf = eF ? 2 * (int)(qc + __builtin_ctzll(eF)) + 1 : 0x7fffffff;
+                const int te = tb < tf ? tb : tf;
+                if (te != 0x7fffffff) { t_ev = te; break; }
+            }
+            if (t_ev > tmax) {   // scans to the end of the piece
+                need_mark(need, p0 + (uint64_t)(t >> 1), p0 + (uint64_t)(tmax >> 1) + 1);
+                break;
+            }
+            need_mark(need, p0 + (uint64_t)(t >> 1), p0 + (uint64_t)(t_ev >> 1) + 1);
+            // the junction's current skip distance
+            const uint32_t q = (uint32_t)(t_ev >> 1);
+            const bool fwd = t_ev & 1;
+            const uint64_t km = fd_kmer_at(codes, p0 + q, k);
+            const uint64_t rc = fd_revcomp(km, k);
+            const uint64_t key = fwd ? km : rc;
+            const uint64_t canon = km < rc ? km : rc;
+            const int orient = key == canon ? 0 : 1;
+            const int ext_fwd = fwd ? fd_base_at(codes, p0 + q + k) : 4;
+            uint64_t s = fd_mix(canon) & jt.mask;
+            int d = 1;
+            for (uint64_t n = 0; n <= jt.mask; n++) {
+                const uint64_t w = jt.keys[s];
+                if (w == J_EMPTY) break;
+                if ((w & J_KEYMASK) == canon) {
+                    const uint8_t dv = jt.recs[(s * 2 + orient) * 16 + ext_fwd];
+                    d = dv < 1 ? 1 : dv;
+                    break;
+                }
+                s = (s + 1) & jt.mask;
+            }
+            const int land = t_ev + d;
+            if (land > tmax) break;                       // jumps off the piece: nothing more is scanned
+            const uint32_t lq = (uint32_t)(land >> 1);
+            const uint64_t lbits = (land & 1) ? fd_bits_at(nF, p0 + lq) : fd_bits_at(nB, p0 + lq);
+            if (!(lbits & 1ULL)) {                        // distance not converged yet: anything up to the end may be scanned
+                need_mark(need, p0 + lq, p0 + (uint64_t)(tmax >> 1) + 1);
+                break;
+            }
+            t = land;                                     // lands on a junction: a final skip
+        }
+    }
+}
+
 // ---- export: compact the present records ------------------------------------------------------------------
 struct ExportEntry {   // FGPU_TABLE_ENTRY_BYTES = 32
     uint64_t key;      // oriented k-mer
@@ -858,6 +979,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
 
 int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wowner, 0xFF, ctx->wcap * 4, ctx->stream));
@@ -869,6 +991,24 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     return FGPU_OK;
 }
 
+// Pure-stage helper (main stream): need plane of the current batch = superset of the positions the walk will scan.
+int fgpu_stage_scan_need(fgpu_ctx* ctx) {
+    BatchBufs& bb = *ctx->cur;
+    const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
+    if (ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) {   // evaluate testForJunction everywhere
+        FGPU_HIP(hipMemsetAsync(bb.need.p, 0xFF, wb, ctx->stream));
+        return FGPU_OK;
+    }
+    FGPU_HIP(hipMemsetAsync(bb.need.p, 0, wb, ctx->stream));
+    if (!bb.n_pieces) return FGPU_OK;
+    JTable jt = make_jt(ctx);
+    FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
+                bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p);
+    FGPU_LAUNCH("need_prewalk", k_need_prewalk, fgpu_grid(bb.n_pieces, 256), 256, (const uint64_t*)bb.codes.p, (const uint2*)bb.pieces.p,
+                bb.n_pieces, ctx->fd, jt, (const uint64_t*)bb.nF.p, (const uint64_t*)bb.nB.p, (unsigned long long*)bb.need.p);
+    return FGPU_OK;
+}
+
 // Walk the pieces of the current batch, scheduling window after scheduling window (position ranges of
 // ctx->window_span stream positions).  No host round trip: window extents are derived on the device.
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
@@ -877,7 +1017,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     Planes pl{(const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.ps.p, (const uint32_t*)bb.ps_prefix.p,
               (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p, (const uint64_t*)bb.cf0.p, (const uint64_t*)bb.cf1.p,
               (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p,
-              (uint64_t*)bb.lk.p};
+              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p};
     JTable jt = make_jt(ctx);
     WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;

@@ -58,6 +58,8 @@ typedef struct {
 } fgpu_params;
 
 #define FGPU_FLAG_PROFILE 1     /* bracket every kernel with HIP events (fgpu_kernel_times) */
+#define FGPU_FLAG_EAGER_FLAGS 2 /* evaluate testForJunction at every position instead of only where the walk can stop
+                                 * skipping (same results; the lazy default self-checks and fails with FGPU_ERR_STATE) */
 
 /* A batch of sequence lines in file order: read i = bases[offsets[i] .. offsets[i+1]).  Any byte
  * may occur; everything except upper-case A C G T splits a read exactly as isValidNuc /

@@ -80,9 +80,9 @@ def test_load_matches_reference_bloom(name, n_batches):
     assert f"{ctx.bloom_weight(L.BLOO1):f}" == w[0] and f"{ctx.bloom_weight(L.BLOO2):f}" == w[1]
 
 
-def _scan_and_compare(c, bases, offs, n_batches, span):
+def _scan_and_compare(c, bases, offs, n_batches, span, eager=False):
     tai, nh = api.load_filter_shape(c.E, c.S)
-    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer, walk_window_span=span)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer, walk_window_span=span, eager_flags=eager)
     ctx.bloom_upload(L.BLOO2, c.bloom())
     sc = api.ReadScanner(ctx)
     st = sc.scanReads(chunks(bases, offs, n_batches))
@@ -115,6 +115,13 @@ def test_scan_matches_reference_junctions(name, n_batches, span):
     c = Case(name)
     bases, offs = po.reads_from_lines(c.lines())
     _scan_and_compare(c, bases, offs, n_batches, span)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_scan_eager_flags_mode_gives_the_same_result(name):
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    _scan_and_compare(c, bases, offs, 5, 0, eager=True)
 
 
 @pytest.mark.parametrize("name", ["ragged_k31", "twohash_k31_L150"])
