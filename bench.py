@@ -269,7 +269,8 @@ def main():
         "kmers_per_step": kmers_total,
         "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
-                    "walk_max_cluster_rank0": int(sst["walk_max_cluster"])},
+                    "walk_max_cluster_rank0": int(sst["walk_max_cluster"]),
+                    "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"])},
         "kernel_ms_per_step_rank0": {n: round(ms / args.steps, 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
     }
 

@@ -494,6 +494,8 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     s.walk_windows = ctx->scan_windows;
     s.walk_followers = c.followers;
     s.walk_max_cluster = c.max_cluster;
+    s.flag_positions = c.flag_positions;
+    s.piece_positions = c.piece_positions;
     memset(&ctx->carried, 0, sizeof(ctx->carried));
     if (stats) *stats = s;
     return FGPU_OK;

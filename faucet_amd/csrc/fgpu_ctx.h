@@ -75,6 +75,8 @@ struct DevCounters {
     unsigned long long pad;
     unsigned long long wt_used_b;       // second "slots claimed" counter: consecutive windows alternate
     unsigned long long pad2;
+    unsigned long long flag_positions;  // positions where the flags kernel evaluated testForJunction
+    unsigned long long piece_positions; // positions inside valid pieces
 };
 
 struct fgpu_ctx {

@@ -217,12 +217,16 @@ __device__ __forceinline__ void test_for_junction(uint64_t key, int real, const 
 __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
                                                     const uint64_t* __restrict__ need, uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
                                                     uint64_t* __restrict__ ff, uint64_t* __restrict__ fb, uint64_t* __restrict__ cf0,
-                                                    uint64_t* __restrict__ cf1, uint64_t* __restrict__ cb0, uint64_t* __restrict__ cb1) {
+                                                    uint64_t* __restrict__ cf1, uint64_t* __restrict__ cb0, uint64_t* __restrict__ cb1,
+                                                    DevCounters* cnt) {
     const uint64_t total = n_words * 64;
+    unsigned long long n_eval = 0, n_piece = 0;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool f_f = false, f_b = false;
         int c_f = 0, c_b = 0;
+        if (p < T) n_piece += (pm[p >> 6] >> (p & 63)) & 1ULL;
         if (p < T && ((need[p >> 6] >> (p & 63)) & 1ULL)) {   // only where the walk can stop skipping (scan_walk.hip, "lazy flags")
+            n_eval++;
             uint64_t wbits = fd_bits_at(pm, p == 0 ? 0 : p - 1);   // bit0 = pm[p-1], bit1 = pm[p], bit2 = pm[p+1]
             bool here, prev, next;
             if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
@@ -244,6 +248,8 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
             ff[w] = m_ff; fb[w] = m_fb; cf0[w] = m_cf0; cf1[w] = m_cf1; cb0[w] = m_cb0; cb1[w] = m_cb1;
         }
     }
+    wave_add(&cnt->flag_positions, n_eval);
+    wave_add(&cnt->piece_positions, n_piece);
 }
 
 }  // namespace
@@ -296,7 +302,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
         FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.need.p,
                     bb.T, bb.n_words, ctx->fd,
                     (const uint32_t*)ctx->bloo2, (uint64_t*)bb.ff.p, (uint64_t*)bb.fb.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p,
-                    (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p);
+                    (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p, ctx->counters);
     }
     return FGPU_OK;
 }

@@ -93,6 +93,8 @@ typedef struct {
     uint64_t walk_windows;       /* scheduling windows executed */
     uint64_t walk_followers;     /* pieces that had to wait for an earlier piece of their cluster */
     uint64_t walk_max_cluster;   /* largest dependency cluster seen */
+    uint64_t flag_positions;     /* window positions at which testForJunction was evaluated (lazy flags: a subset of all) */
+    uint64_t piece_positions;    /* window positions inside valid pieces */
 } fgpu_scan_stats;
 
 /* Junction record, field for field utils/Junction.h:10-18 (cov is private there). */
