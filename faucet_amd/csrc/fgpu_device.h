@@ -99,20 +99,6 @@ __device__ __forceinline__ bool fd_bloom_contains(const uint32_t* __restrict__ b
     return true;
 }
 
-// Same truth value, different schedule: for up to 4 hash functions all words are requested before any is tested
-// (k-mers of valid reads are mostly present, so all n_hash bits are needed anyway and the loads overlap).
-__device__ __forceinline__ bool fd_bloom_contains_mlp(const uint32_t* __restrict__ bloom, uint64_t hA, uint64_t hB,
-                                                      uint64_t tai_mask, int n_hash) {
-    if (n_hash > 4) return fd_bloom_contains(bloom, hA, hB, tai_mask, n_hash);
-    const uint64_t h0 = hA, h1 = (h0 + hB) & tai_mask, h2 = (h1 + hB) & tai_mask, h3 = (h2 + hB) & tai_mask;
-    const uint32_t w0 = bloom[h0 >> 5];
-    const uint32_t w1 = n_hash > 1 ? bloom[h1 >> 5] : ~0u;
-    const uint32_t w2 = n_hash > 2 ? bloom[h2 >> 5] : ~0u;
-    const uint32_t w3 = n_hash > 3 ? bloom[h3 >> 5] : ~0u;
-    return ((w0 >> (h0 & 31)) & (w1 >> (n_hash > 1 ? (h1 & 31) : 0)) & (w2 >> (n_hash > 2 ? (h2 & 31) : 0)) &
-            (w3 >> (n_hash > 3 ? (h3 & 31) : 0)) & 1u) != 0;
-}
-
 __device__ __forceinline__ bool fd_bloom_contains_canon(const uint32_t* __restrict__ bloom, uint64_t canon,
                                                         uint64_t tai_mask, int n_hash) {
     uint64_t hA, hB;

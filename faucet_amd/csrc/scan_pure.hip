@@ -38,9 +38,7 @@ __global__ void __launch_bounds__(256) k_scan_valid(const uint64_t* __restrict__
         bool v = false;
         if (ok) {
             n_ok++;
-            uint64_t hA, hB;
-            fd_hash_pair(fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, hA, hB);
-            v = fd_bloom_contains_mlp(bloom, hA, hB, fp.tai_mask, fp.n_hash);
+            v = fd_bloom_contains_canon(bloom, fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, fp.n_hash);
         }
         uint64_t vm = __ballot(v);
         if (fd_lane() == 0) valid[p >> 6] = vm;
@@ -201,39 +199,19 @@ __device__ bool jcheck_dfs(uint64_t kmer, const FdParams& fp, const uint32_t* __
     return false;
 }
 
-// One alternate extension of testForJunction: the candidate k-mer, its hashes and the filter word of its first bit.
-// The first-bit loads of all alternates (3 per facing, both facings) are issued before any of them is looked at:
-// ~90 % of them decide "absent" on that first bit, and six independent loads in flight hide the latency that a
-// one-probe-at-a-time loop exposes.
-struct AltProbe {
-    uint64_t e, hA, hB;
-    uint32_t w;
-};
-__device__ __forceinline__ AltProbe alt_issue(uint64_t key, int nt, const FdParams& fp, const uint32_t* __restrict__ bloom) {
-    AltProbe a;
-    a.e = ((key << 2) | (uint64_t)nt) & fp.kmask;
-    fd_hash_pair(fd_canon(a.e, fp.k), fp.tai_mask, a.hA, a.hB);
-    a.w = bloom[a.hA >> 5];
-    return a;
-}
-__device__ __forceinline__ bool alt_present(const AltProbe& a, const FdParams& fp, const uint32_t* __restrict__ bloom) {
-    if (!((a.w >> (a.hA & 31)) & 1u)) return false;
-    uint64_t h = (a.hA + a.hB) & fp.tai_mask;
-    for (int i = 1; i < fp.n_hash; i++) {   // rare: the remaining bits, one after the other (Bloom::contains' early exit)
-        if (!((bloom[h >> 5] >> (h & 31)) & 1u)) return false;
-        h = (h + a.hB) & fp.tai_mask;
-    }
-    return true;
-}
-// testForJunction given the three alternates in nt order (the real extension left out): same flag and the same
-// NbJCheckKmer increment as the reference's sequential loop (src/ReadScanner.cpp:44-53)
-__device__ __forceinline__ void test_for_junction(const AltProbe& a0, const AltProbe& a1, const AltProbe& a2, const FdParams& fp,
-                                                  const uint32_t* __restrict__ bloom, bool& flag, int& njc) {
+// testForJunction for the k-mer `key` (already oriented towards the extension) with real next base `real`
+__device__ __forceinline__ void test_for_junction(uint64_t key, int real, const FdParams& fp, const uint32_t* __restrict__ bloom,
+                                                  bool& flag, int& njc) {
     flag = false;
     njc = 0;
-    if (alt_present(a0, fp, bloom)) { njc++; if (jcheck_dfs(a0.e, fp, bloom)) { flag = true; return; } }
-    if (alt_present(a1, fp, bloom)) { njc++; if (jcheck_dfs(a1.e, fp, bloom)) { flag = true; return; } }
-    if (alt_present(a2, fp, bloom)) { njc++; if (jcheck_dfs(a2.e, fp, bloom)) { flag = true; return; } }
+    for (int nt = 0; nt < 4; nt++) {
+        if (nt == real) continue;
+        uint64_t e = ((key << 2) | (uint64_t)nt) & fp.kmask;
+        if (fd_bloom_contains_canon(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
+            njc++;
+            if (jcheck_dfs(e, fp, bloom)) { flag = true; return; }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
@@ -254,26 +232,13 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
             if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
             else { prev = wbits & 1; here = (wbits >> 1) & 1; next = (wbits >> 2) & 1; }
             if (here && (prev || next)) {
-                const uint64_t km = fd_kmer_at(codes, p, fp.k);
-                const uint64_t rc = fd_revcomp(km, fp.k);
-                // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110);
-                // facing backward: reverse complement, real extension = complement of the base before (:111-113)
-                const int real_f = next ? fd_base_at(codes, p + fp.k) : 0;
-                const int real_b = prev ? (fd_base_at(codes, p - 1) ^ 2) : 0;
-                // alternate a of a facing is nucleotide a + (a >= real): the three nt != real, in ascending order
-                AltProbe f0, f1, f2, b0, b1, b2;
-                if (next) {
-                    f0 = alt_issue(km, 0 + (0 >= real_f), fp, bloom);
-                    f1 = alt_issue(km, 1 + (1 >= real_f), fp, bloom);
-                    f2 = alt_issue(km, 2 + (2 >= real_f), fp, bloom);
+                uint64_t km = fd_kmer_at(codes, p, fp.k);
+                if (next) {   // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110)
+                    test_for_junction(km, fd_base_at(codes, p + fp.k), fp, bloom, f_f, c_f);
                 }
-                if (prev) {
-                    b0 = alt_issue(rc, 0 + (0 >= real_b), fp, bloom);
-                    b1 = alt_issue(rc, 1 + (1 >= real_b), fp, bloom);
-                    b2 = alt_issue(rc, 2 + (2 >= real_b), fp, bloom);
+                if (prev) {   // facing backward: reverse complement, real extension = complement of the base before (:111-113)
+                    test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, p - 1) ^ 2, fp, bloom, f_b, c_b);
                 }
-                if (next) test_for_junction(f0, f1, f2, fp, bloom, f_f, c_f);
-                if (prev) test_for_junction(b0, b1, b2, fp, bloom, f_b, c_b);
             }
         }
         uint64_t m_ff = __ballot(f_f), m_fb = __ballot(f_b);
