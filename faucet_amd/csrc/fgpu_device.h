@@ -106,6 +106,22 @@ __device__ __forceinline__ bool fd_bloom_contains_canon(const uint32_t* __restri
     return fd_bloom_contains(bloom, hA, hB, tai_mask, n_hash);
 }
 
+// The same answer for k-mers that are mostly ABSENT (alternate extensions): the second hash is only computed when the
+// first bit is set, which is the exception there; oldHash costs more instructions than the probe it feeds.
+__device__ __forceinline__ bool fd_bloom_contains_canon_lazy(const uint32_t* __restrict__ bloom, uint64_t canon,
+                                                             uint64_t tai_mask, int n_hash) {
+    const uint64_t hA = fd_old_hash(canon, FD_SEED0) & tai_mask;
+    if (!((bloom[hA >> 5] >> (hA & 31)) & 1u)) return false;
+    if (n_hash == 1) return true;
+    const uint64_t hB = fd_old_hash(canon, FD_SEED1) & tai_mask;
+    uint64_t h = (hA + hB) & tai_mask;
+    for (int i = 1; i < n_hash; i++) {
+        if (!((bloom[h >> 5] >> (h & 31)) & 1u)) return false;
+        h = (h + hB) & tai_mask;
+    }
+    return true;
+}
+
 // Bloom::add (utils/Bloom.h:217-226) on a monotone bitmap shared by the whole grid: test first
 // (a stale 0 only costs a redundant atomic; a 1 is never stale because bits are never cleared).
 __device__ __forceinline__ void fd_bloom_set(uint32_t* bloom, uint64_t hA, uint64_t hB, uint64_t tai_mask, int n_hash) {

@@ -189,7 +189,7 @@ __device__ bool jcheck_dfs(uint64_t kmer, const FdParams& fp, const uint32_t* __
         if (stack_nt[depth] == 4) { depth--; continue; }
         int nt = stack_nt[depth]++;
         uint64_t e = ((stack_k[depth] << 2) | (uint64_t)nt) & fp.kmask;
-        if (fd_bloom_contains_canon(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
+        if (fd_bloom_contains_canon_lazy(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
             if (depth + 1 == J) return true;
             depth++;
             stack_k[depth] = e;
@@ -207,7 +207,7 @@ __device__ __forceinline__ void test_for_junction(uint64_t key, int real, const 
     for (int nt = 0; nt < 4; nt++) {
         if (nt == real) continue;
         uint64_t e = ((key << 2) | (uint64_t)nt) & fp.kmask;
-        if (fd_bloom_contains_canon(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
+        if (fd_bloom_contains_canon_lazy(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
             njc++;
             if (jcheck_dfs(e, fp, bloom)) { flag = true; return; }
         }
