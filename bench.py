@@ -163,9 +163,10 @@ def main():
     ap.add_argument("--estimated-kmers", type=int, default=100_000_000, help="per GPU")
     ap.add_argument("--singletons", type=int, default=20_000_000, help="per GPU")
     ap.add_argument("--err", type=float, default=0.01)
-    ap.add_argument("--batch-reads", type=int, default=2_000_000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
+    ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (cpu_baseline and reference bit counts)")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the streaming-copy / random-access ceiling measurements")
     ap.add_argument("--profile-walk", action="store_true", help="time the per-window walk kernels individually")
     ap.add_argument("--host-input", action="store_true",
                     help="hand the reads over as HOST buffers (PCIe copy inside the timed region); diagnostic only, never the headline value")
@@ -304,11 +305,31 @@ def main():
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                            "algorithmic_bytes_per_kmer": per_kmer, "kmers_per_launch": kmers_per_launch}
     if T:
-        ab64 = 2 * L_ / (L_ - k + 1) + 64.0 * (T["T_load"] + T["T_valid"] + T["T_junc"])
-        res["pipeline_ab64"] = {"bytes_per_kmer": ab64, "achieved_GBps": ab64 * value / 1e9, "frac_of_hbm_peak": ab64 * value / 1e9 / HBM_PEAK_GBPS,
+        tsum = T["T_load"] + T["T_valid"] + T["T_junc"]
+        ab64 = 2 * L_ / (L_ - k + 1) + 64.0 * tsum
+        res["pipeline_ab64"] = {"bytes_per_kmer": ab64, "ab32_bytes_per_kmer": ab64 - 32.0 * tsum, "ab128_bytes_per_kmer": ab64 + 64.0 * tsum, "achieved_GBps": ab64 * value / 1e9, "frac_of_hbm_peak": ab64 * value / 1e9 / HBM_PEAK_GBPS,
                                 "T_load": T["T_load"], "T_valid": T["T_valid"], "T_junc": T["T_junc"], "rho_sample": T["rho"],
                                 "rho_gpu_run": lst["to_bloo2"] / max(kmers_local, 1),
                                 "counted_on": f"oracle, {T['sample_reads']} reads of a {T['sample_genome']} bp genome (same coverage, error rate, bits per estimated k-mer)"}
+
+    # ---- measured ceilings of this device for the two access patterns of the path, ~1 s in total
+    if not args.no_ceilings:
+        n_acc = 1 << 28
+        cl = {"stream_copy_GBps": ctx.diag_stream_copy(1 << 30, 5),
+              "random_load32_per_s_filter": ctx.diag_random_access(tai // 8, n_acc, 0, 3),          # one load filter (probes)
+              "random_test_or32_per_s_pair": ctx.diag_random_access(tai // 4, n_acc, 2, 3),         # both filters (Bloom::add)
+              "random_atomic_min32_per_s_first": ctx.diag_random_access(tai * 4, n_acc, 1, 3),      # first-set times, 4 B per filter bit
+              "filter_bytes": tai // 8, "first_bytes": tai * 4, "accesses_per_measurement": n_acc}
+        cl["random_load_64B_sector_GBps"] = cl["random_load32_per_s_filter"] * 64 / 1e9
+        props = torch.cuda.get_device_properties(device)
+        cl["device"] = {"name": props.name, "hbm_bytes": props.total_memory, **ctx.diag_device_attr()}
+        da = cl["device"]       # DDR-style estimate from what the runtime reports: 2 transfers per clock over the bus width
+        cl["device"]["reported_peak_GBps"] = 2.0 * da["memory_clock_khz"] * 1e3 * da["memory_bus_bits"] / 8 / 1e9
+        res["ceilings"] = cl
+        if T:
+            # random accesses the pipeline performs per second against what the device sustains for bare ones
+            res["pipeline_ab64"]["bit_accesses_per_s"] = tsum * value
+            res["pipeline_ab64"]["frac_of_random_access_ceiling"] = tsum * value / cl["random_load32_per_s_filter"]
 
     # ---- CPU baseline beside it (N = 1 only): the oracle on this host's cores, 1 thread like the reference
     if world == 1 and not args.no_cpu:

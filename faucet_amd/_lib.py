@@ -84,6 +84,9 @@ SIGNATURES = {
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
     "fgpu_kernel_times": (C.c_int, [_vp, _P(KernelTime), C.c_int]),
     "fgpu_kernel_times_reset": (C.c_int, [_vp]),
+    "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),
+    "fgpu_diag_random_access": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_int, _P(_f64)]),
+    "fgpu_diag_device_attr": (C.c_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
 }
 
 _lib = None

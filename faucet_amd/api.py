@@ -230,6 +230,23 @@ class Context:
     def kernel_times_reset(self):
         self._c(self.lib.fgpu_kernel_times_reset(self.h))
 
+    def diag_stream_copy(self, nbytes: int, iters: int = 5) -> float:
+        """measured streaming-copy rate of this device, GB/s (read + write)"""
+        out = C.c_double(0)
+        self._c(self.lib.fgpu_diag_stream_copy(self.h, nbytes, iters, C.byref(out)))
+        return out.value
+
+    def diag_device_attr(self) -> dict:
+        v = [C.c_int32(0) for _ in range(4)]
+        self._c(self.lib.fgpu_diag_device_attr(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("memory_clock_khz", "memory_bus_bits", "l2_bytes", "compute_units"), [int(x.value) for x in v]))
+
+    def diag_random_access(self, table_bytes: int, n_access: int, mode: int = 0, iters: int = 3) -> float:
+        """measured independent random 32-bit accesses/s into a table of table_bytes (0 load, 1 atomicMin, 2 test+atomicOr)"""
+        out = C.c_double(0)
+        self._c(self.lib.fgpu_diag_random_access(self.h, table_bytes, n_access, mode, iters, C.byref(out)))
+        return out.value
+
 
 # ---- reference-shaped front end -------------------------------------------------------------------------------------
 class Bloom:

@@ -183,6 +183,15 @@ typedef struct {
 int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap);
 int fgpu_kernel_times_reset(fgpu_ctx* ctx);
 
+/* ---- measured ceilings (no reference counterpart) ---------------------------------
+ * Streaming device-to-device copy of `bytes` (read + write counted), GB/s. */
+int fgpu_diag_stream_copy(fgpu_ctx* ctx, uint64_t bytes, int iters, double* gb_per_s);
+/* n_access independent random 32-bit accesses into a table of table_bytes (power of two) per iteration.
+ * mode 0 = load, 1 = atomicMin (the load pass' first-set times), 2 = test-then-atomicOr (Bloom::add). */
+int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_access, int mode, int iters, double* access_per_s);
+/* Memory clock (kHz), bus width (bits), L2 bytes and CU count as the HIP runtime reports them. */
+int fgpu_diag_device_attr(fgpu_ctx* ctx, int32_t* mem_clock_khz, int32_t* mem_bus_bits, int32_t* l2_bytes, int32_t* compute_units);
+
 #ifdef __cplusplus
 }
 #endif

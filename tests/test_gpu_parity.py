@@ -223,6 +223,17 @@ def test_state_machine_errors():
         api.Context(21, 1000, 3)
 
 
+def test_ceiling_diagnostics_run_and_reject_bad_arguments():
+    ctx = api.Context(21, 1 << 19, 3)
+    assert ctx.diag_stream_copy(1 << 24, 2) > 1.0                     # GB/s
+    for mode in (0, 1, 2):
+        assert ctx.diag_random_access(1 << 22, 1 << 20, mode, 2) > 1e6   # accesses/s
+    with pytest.raises(api.FaucetGpuError):
+        ctx.diag_random_access(3 << 20, 1 << 20, 0, 1)                # not a power of two
+    with pytest.raises(api.FaucetGpuError):
+        ctx.diag_random_access(1 << 22, 1 << 20, 7, 1)
+
+
 def test_two_shard_load_prefix_or_is_exact():
     """Multi-GPU pass 1 emulated with two contexts on one device: presence bitmaps, exclusive
     prefix-OR as the carried-in state of the later shard, OR of the shards' bloo2."""
