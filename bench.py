@@ -271,7 +271,8 @@ def main():
         "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
                     "walk_max_cluster_rank0": int(sst["walk_max_cluster"]),
-                    "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"])},
+                    "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"]),
+                    "valid_reused_rank0": int(sst["valid_reused"])},
         "kernel_ms_per_step_rank0": {n: round(ms / args.steps, 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
     }
 
@@ -323,8 +324,6 @@ def main():
         cl["random_load_64B_sector_GBps"] = cl["random_load32_per_s_filter"] * 64 / 1e9
         props = torch.cuda.get_device_properties(device)
         cl["device"] = {"name": props.name, "hbm_bytes": props.total_memory, **ctx.diag_device_attr()}
-        da = cl["device"]       # DDR-style estimate from what the runtime reports: 2 transfers per clock over the bus width
-        cl["device"]["reported_peak_GBps"] = 2.0 * da["memory_clock_khz"] * 1e3 * da["memory_bus_bits"] / 8 / 1e9
         res["ceilings"] = cl
         if T:
             # random accesses the pipeline performs per second against what the device sustains for bare ones

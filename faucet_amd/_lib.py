@@ -14,6 +14,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_CAPACITY, ERR_NOMEM = range(6)
 BLOO1, BLOO2 = 0, 1
 FLAG_PROFILE = 1
 FLAG_EAGER_FLAGS = 2
+FLAG_NO_RESIDENT = 4
 TABLE_ENTRY_BYTES = 32
 
 
@@ -37,7 +38,7 @@ class LoadStats(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("reads_processed", "unambiguous_reads", "reads_no_errors", "nb_jcheck_kmer", "nb_no_juncs",
                                           "nb_processed", "nb_skipped", "n_junctions", "kmers", "walk_windows", "walk_followers",
-                                          "walk_max_cluster", "flag_positions", "piece_positions")]
+                                          "walk_max_cluster", "flag_positions", "piece_positions", "valid_reused")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

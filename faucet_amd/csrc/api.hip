@@ -157,6 +157,8 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         ctx->prm.junction_capacity = c;
     }
     if (!ctx->prm.max_batch_bases) ctx->prm.max_batch_bases = 1ULL << 30;
+    // load batches kept in HBM for the scan of the same reads: 4 bits per base, at most an eighth of the device memory
+    ctx->resident_budget = (p->flags & FGPU_FLAG_NO_RESIDENT) ? 0 : prop.totalGlobalMem / 8;
     ctx->fd.k = p->k;
     ctx->fd.j = p->j;
     ctx->fd.n_hash = p->n_hash;
@@ -217,6 +219,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
     if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    for (ResidentBatch* r : ctx->resident) delete r;
     for (BatchBufs* b : ctx->all_batches) {
         if (b->pure_done) hipEventDestroy(b->pure_done);
         if (b->walk_done) hipEventDestroy(b->walk_done);
@@ -252,6 +255,7 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
         }
     }
     FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
+    fgpu_resident_reset(ctx, true);
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream));
     int rc = fgpu_load_pair_begin(ctx);
@@ -317,6 +321,7 @@ int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nb
 
 int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t nbytes) {
     if (!ctx || !host_in || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    if (which == FGPU_BLOO2) fgpu_resident_reset(ctx, false);   // the kept "routed to bloo2" planes speak about the filter this replaces
     FGPU_HIP(hipMemcpyAsync(bloom_ptr(ctx, which), host_in, nbytes, hipMemcpyHostToDevice, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     return FGPU_OK;
@@ -365,6 +370,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
     ctx->walked_pieces = 0;
+    ctx->scan_batch_index = 0;
     for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
     ctx->prepared.clear();
     ctx->cur = &ctx->bb_default;
@@ -496,6 +502,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     s.walk_max_cluster = c.max_cluster;
     s.flag_positions = c.flag_positions;
     s.piece_positions = c.piece_positions;
+    s.valid_reused = c.valid_reused;
     memset(&ctx->carried, 0, sizeof(ctx->carried));
     if (stats) *stats = s;
     return FGPU_OK;

@@ -28,6 +28,8 @@ struct BatchBufs {
     DevBuf codes, bad;             // normalized stream: 2-bit codes, bad-position mask
     DevBuf readflag;               // 1 byte per read: has interior non-ACGT characters
     DevBuf pending;                // pass 1: occurrences that need the first-set-time test
+    DevBuf sure;                   // pass 1: occurrences routed to bloo2 (kept for the scan as ResidentBatch::sure)
+    DevBuf same;                   // pass 2: one word, non-zero iff this batch equals the load batch of the same index
     // pass 2 planes (1 bit per stream position, LSB first)
     DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
     DevBuf lk;                     // walk: positions whose k-mer is a registered candidate of the current window
@@ -42,6 +44,14 @@ struct BatchBufs {
     hipEvent_t pure_done = nullptr;   // main stream: planes of this batch are complete
     hipEvent_t walk_done = nullptr;   // walk stream: the walk has finished with this batch's buffers
     bool walk_pending = false;
+};
+
+// Planes of a load batch kept in HBM for the scan pass over the same reads: codes/bad identify the batch (the scan compares
+// them word for word), `sure` marks the occurrences the load pass routed to bloo2 -- their bits are in the final filter
+// by construction, so getValidReads' probe of them is known to answer "present" without touching the filter.
+struct ResidentBatch {
+    DevBuf codes, bad, sure;
+    uint64_t T = 0, n_words = 0;
 };
 
 struct KernelStat {
@@ -77,6 +87,7 @@ struct DevCounters {
     unsigned long long pad2;
     unsigned long long flag_positions;  // positions where the flags kernel evaluated testForJunction
     unsigned long long piece_positions; // positions inside valid pieces
+    unsigned long long valid_reused;    // validity answers taken from the load pass' resident planes instead of probing
 };
 
 struct fgpu_ctx {
@@ -96,6 +107,11 @@ struct fgpu_ctx {
     uint2* pair = nullptr;           // {bloo1 word, bloo2 word} interleaved: the working copy of both filters during a load pass
     uint64_t bloom_bytes = 0;
     int phase = 0;                   // 0 idle, 1 loading, 2 scanning
+    std::vector<ResidentBatch*> resident;  // load batches kept for the scan, in load order (buffers recycled across passes)
+    uint64_t resident_count = 0;     // entries of `resident` that hold the current load pass
+    uint64_t resident_bytes = 0, resident_budget = 0;
+    bool resident_open = false;      // the current load pass is still keeping its batches
+    uint64_t scan_batch_index = 0;   // scan batch i pairs with resident[i]
 
     // pass 2 state: junction table (open addressing on the canonical k-mer)
     uint64_t jcap = 0;               // slots (power of two)
@@ -188,6 +204,7 @@ int fgpu_stage_load(fgpu_ctx* ctx);
 int fgpu_stage_presence(fgpu_ctx* ctx);
 int fgpu_load_pair_begin(fgpu_ctx* ctx);
 int fgpu_load_pair_end(fgpu_ctx* ctx);
+void fgpu_resident_reset(fgpu_ctx* ctx, bool keep_going);
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_stage_scan_need(fgpu_ctx* ctx);

@@ -39,12 +39,12 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
 // the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                    uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first,
-                                                   uint64_t* __restrict__ pending, DevCounters* cnt) {
+                                                   uint64_t* __restrict__ pending, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool ok = p < T && fd_window_ok(bad, p, fp.k);
-        bool pend = false;
+        bool pend = false, hit = false;
         if (ok) {
             n_ok++;
             uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
             }
             if (!missing) {
                 n_hit++;
+                hit = true;
                 if (b2_missing) {   // a stale 0 only costs a redundant atomic; bits are never cleared
                     h = hA;
                     for (int i = 0; i < fp.n_hash; i++) {
@@ -77,8 +78,11 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 }
             }
         }
-        uint64_t pm = __ballot(pend);
-        if (fd_lane() == 0) pending[p >> 6] = pm;
+        uint64_t pm = __ballot(pend), hm = __ballot(hit);
+        if (fd_lane() == 0) {
+            pending[p >> 6] = pm;
+            sure[p >> 6] = hm;
+        }
     }
     wave_add(&cnt->kmers, n_ok);
     wave_add(&cnt->to_bloo2, n_hit);
@@ -86,32 +90,38 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
                                                       uint2* pair, const uint32_t* __restrict__ first,
-                                                      const uint64_t* __restrict__ pending, DevCounters* cnt) {
+                                                      const uint64_t* __restrict__ pending, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
-        if (!((pending[p >> 6] >> (p & 63)) & 1ULL)) continue;
-        uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
-        uint64_t hA, hB;
-        fd_hash_pair(canon, fp.tai_mask, hA, hB);
-        bool pass = true;
-        uint32_t b2_missing = 0;
-        uint64_t h = hA;
-        for (int i = 0; i < fp.n_hash; i++) {
-            const uint2 v = pair[h >> 5];
-            bool before = ((v.x >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
-            if (!before) { pass = false; break; }
-            if (!((v.y >> (h & 31)) & 1u)) b2_missing |= 1u << i;
-            h = (h + hB) & fp.tai_mask;
-        }
-        if (pass) {
-            n_pass++;
-            h = hA;
+        const uint64_t pw = pending[p >> 6];   // wave-uniform: the 64 lanes of a wave cover one word
+        if (!pw) continue;
+        bool pass = false;
+        if ((pw >> (p & 63)) & 1ULL) {
+            uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
+            uint64_t hA, hB;
+            fd_hash_pair(canon, fp.tai_mask, hA, hB);
+            pass = true;
+            uint32_t b2_missing = 0;
+            uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
-                if (b2_missing & (1u << i)) atomicOr(&pair[h >> 5].y, 1u << (h & 31));
+                const uint2 v = pair[h >> 5];
+                bool before = ((v.x >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
+                if (!before) { pass = false; break; }
+                if (!((v.y >> (h & 31)) & 1u)) b2_missing |= 1u << i;
                 h = (h + hB) & fp.tai_mask;
             }
+            if (pass) {
+                n_pass++;
+                h = hA;
+                for (int i = 0; i < fp.n_hash; i++) {
+                    if (b2_missing & (1u << i)) atomicOr(&pair[h >> 5].y, 1u << (h & 31));
+                    h = (h + hB) & fp.tai_mask;
+                }
+            }
         }
+        const uint64_t sm = __ballot(pass);
+        if (fd_lane() == 0 && sm) sure[p >> 6] |= sm;
     }
     wave_add(&cnt->to_bloo2, n_pass);
 }
@@ -227,20 +237,55 @@ __global__ void k_probe_contains(const uint32_t* __restrict__ bloom, const uint6
 
 }  // namespace
 
+// Forget the kept batches (their buffers are recycled by the next load pass).  keep_going: a new load pass starts.
+void fgpu_resident_reset(fgpu_ctx* ctx, bool keep_going) {
+    ctx->resident_count = 0;
+    ctx->resident_bytes = 0;
+    ctx->resident_open = keep_going && ctx->resident_budget > 0;
+}
+
+// Keep the batch's stream and its routed-to-bloo2 plane for the scan pass (data stays in HBM between the passes
+// instead of being recomputed by probing); stops silently once the budget is used: the scan then probes as usual.
+static int fgpu_resident_keep(fgpu_ctx* ctx) {
+    if (!ctx->resident_open) return FGPU_OK;
+    BatchBufs& bb = *ctx->cur;
+    const uint64_t cb = 2 * (bb.n_words + FGPU_PADW) * 8, pb = (bb.n_words + FGPU_PADW) * 8;
+    if (ctx->resident_bytes + cb + 2 * pb > ctx->resident_budget) {
+        ctx->resident_open = false;   // batches pair by index: once one is missing, later ones would not line up
+        return FGPU_OK;
+    }
+    if (ctx->resident_count == ctx->resident.size()) ctx->resident.push_back(new ResidentBatch());
+    ResidentBatch& r = *ctx->resident[ctx->resident_count];
+    if (fgpu_ensure(ctx, &r.codes, cb) || fgpu_ensure(ctx, &r.bad, pb) || fgpu_ensure(ctx, &r.sure, pb)) {
+        (void)hipGetLastError();
+        ctx->resident_open = false;   // out of memory: do without
+        return FGPU_OK;
+    }
+    r.T = bb.T;
+    r.n_words = bb.n_words;
+    FGPU_HIP(hipMemcpyAsync(r.codes.p, bb.codes.p, cb, hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(r.bad.p, bb.bad.p, pb, hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(r.sure.p, bb.sure.p, pb, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->resident_count++;
+    ctx->resident_bytes += cb + 2 * pb;
+    return FGPU_OK;
+}
+
 int fgpu_stage_load(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
     int rc = fgpu_ensure(ctx, &bb.pending, (bb.n_words + FGPU_PADW) * 8);
     if (rc) return rc;
+    if ((rc = fgpu_ensure(ctx, &bb.sure, (bb.n_words + FGPU_PADW) * 8))) return rc;
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, ctx->counters);
+                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
-                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, ctx->counters);
+                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     // carry := carry | bits set during this batch
     FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint32_t*)ctx->first, ctx->prm.tai);
-    return FGPU_OK;
+    return fgpu_resident_keep(ctx);
 }
 
 // interleave the carried-in bloo1 with an empty bloo2 at the start of a load pass, split them again at its end

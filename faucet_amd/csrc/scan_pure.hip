@@ -27,23 +27,45 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
     if (fd_lane() == 0 && v) atomicAdd(dst, v);
 }
 
-// fixed grid striding over the stream, lanes = consecutive positions; counters live in registers until the wave retires
+// Is this batch, word for word, the load batch kept under the same index?  *same starts non-zero; any differing word clears it.
+__global__ void __launch_bounds__(256) k_scan_same(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ kept_codes, uint64_t n_code_words,
+                                                   const uint64_t* __restrict__ bad, const uint64_t* __restrict__ kept_bad, uint64_t n_words,
+                                                   uint32_t* same) {
+    bool differ = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_code_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        differ |= codes[i] != kept_codes[i];
+        if (i < n_words) differ |= bad[i] != kept_bad[i];
+    }
+    if (__ballot(differ) && fd_lane() == 0) *same = 0;
+}
+
+// fixed grid striding over the stream, lanes = consecutive positions; counters live in registers until the wave retires.
+// sure/same (optional): occurrences the load pass routed to bloo2 are in the filter by construction -- when the batch is the
+// load batch (same != 0) their answer is "present" without a probe.
 __global__ void __launch_bounds__(256) k_scan_valid(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                     uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
+                                                    const uint64_t* __restrict__ sure, const uint32_t* __restrict__ same,
                                                     uint64_t* __restrict__ valid, DevCounters* cnt) {
-    unsigned long long n_ok = 0;
+    unsigned long long n_ok = 0, n_reused = 0;
     const uint64_t total = n_words * 64;
+    const bool reuse = sure && *same != 0;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool ok = p < T && fd_window_ok(bad, p, fp.k);
         bool v = false;
         if (ok) {
             n_ok++;
-            v = fd_bloom_contains_canon(bloom, fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, fp.n_hash);
+            if (reuse && ((sure[p >> 6] >> (p & 63)) & 1ULL)) {
+                v = true;
+                n_reused++;
+            } else {
+                v = fd_bloom_contains_canon(bloom, fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, fp.n_hash);
+            }
         }
         uint64_t vm = __ballot(v);
         if (fd_lane() == 0) valid[p >> 6] = vm;
     }
     wave_add(&cnt->kmers, n_ok);
+    wave_add(&cnt->valid_reused, n_reused);
 }
 
 // One thread per 64-position word of the valid plane: run starts by bit arithmetic; each start measures its run and,
@@ -274,8 +296,20 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     const unsigned wgrid = fgpu_grid(bb.n_words, 256);            // kernels with one thread per 64-position word
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k + 2 * ctx->fd.j + 1))) return rc;
+    // the load pass' batch of the same index, if it was kept and has the same shape: compare the streams on the device
+    const ResidentBatch* kept = ctx->scan_batch_index < ctx->resident_count ? ctx->resident[ctx->scan_batch_index] : nullptr;
+    ctx->scan_batch_index++;
+    if (kept && (kept->T != bb.T || kept->n_words != bb.n_words)) kept = nullptr;
+    if (kept) {
+        if ((rc = fgpu_ensure(ctx, &bb.same, 64))) return rc;
+        FGPU_HIP(hipMemsetAsync(bb.same.p, 0x01, 4, ctx->stream));
+        const uint64_t ncw = 2 * bb.n_words;   // 32 bases per code word
+        FGPU_LAUNCH("scan_same", k_scan_same, fgpu_grid(ncw, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)kept->codes.p, ncw,
+                    (const uint64_t*)bb.bad.p, (const uint64_t*)kept->bad.p, bb.n_words, (uint32_t*)bb.same.p);
+    }
     FGPU_LAUNCH("scan_valid", k_scan_valid, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                (const uint32_t*)ctx->bloo2, (uint64_t*)bb.valid.p, ctx->counters);
+                (const uint32_t*)ctx->bloo2, kept ? (const uint64_t*)kept->sure.p : (const uint64_t*)nullptr,
+                kept ? (const uint32_t*)bb.same.p : (const uint32_t*)nullptr, (uint64_t*)bb.valid.p, ctx->counters);
     const int check_segment = ctx->fd.k < 2 * ctx->fd.j + 2;   // otherwise a run of k windows already implies the length gate
     FGPU_LAUNCH("scan_pieces", k_scan_pieces, wgrid, 256, (const uint64_t*)bb.valid.p, (const uint64_t*)bb.bad.p, bb.n_words, ctx->fd,
                 check_segment, (unsigned long long*)bb.pm.p, (uint64_t*)bb.ps.p, ctx->counters);

@@ -102,7 +102,7 @@ class GpuShard:
         return t[:nbytes]
 
     def header_tensor(self):
-        return torch.zeros(16, dtype=torch.int64, device=self.device)
+        return torch.zeros(32, dtype=torch.int64, device=self.device)
 
     def clear_filters(self):
         self.ctx.load_begin()

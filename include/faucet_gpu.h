@@ -58,6 +58,7 @@ typedef struct {
 } fgpu_params;
 
 #define FGPU_FLAG_PROFILE 1     /* bracket every kernel with HIP events (fgpu_kernel_times) */
+#define FGPU_FLAG_NO_RESIDENT 4 /* do not keep the load batches in HBM for the scan pass (see fgpu_load_batch) */
 #define FGPU_FLAG_EAGER_FLAGS 2 /* evaluate testForJunction at every position instead of only where the walk can stop
                                  * skipping (same results; the lazy default self-checks and fails with FGPU_ERR_STATE) */
 
@@ -95,6 +96,7 @@ typedef struct {
     uint64_t walk_max_cluster;   /* largest dependency cluster seen */
     uint64_t flag_positions;     /* window positions at which testForJunction was evaluated (lazy flags: a subset of all) */
     uint64_t piece_positions;    /* window positions inside valid pieces */
+    uint64_t valid_reused;       /* getValidReads answers taken from the load pass' resident planes (no filter probe) */
 } fgpu_scan_stats;
 
 /* Junction record, field for field utils/Junction.h:10-18 (cov is private there). */

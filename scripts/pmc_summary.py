@@ -18,9 +18,8 @@ def our(name):
 
 
 def short(name):
-    n = name.split("(")[0]
-    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    return n.strip()
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].strip()
 
 
 def counters(d, counter):

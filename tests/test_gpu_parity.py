@@ -193,6 +193,61 @@ def test_random_inputs_vs_oracle(n_reads, L_, k, G, err, E, S, j, n_rate, repeat
     assert np.array_equal(recs["linked"], orecs["linked"])
 
 
+def _scan_equals_oracle(sc, sst, osc):
+    ost = osc.stats()
+    for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors",
+                "unambiguous_reads", "reads_processed"):
+        assert sst[key] == ost[key], key
+    keys, recs = sc.junctions()
+    okeys, orecs = osc.junctions("creation")
+    assert np.array_equal(keys, okeys)
+    assert np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
+    assert np.array_equal(recs["linked"], orecs["linked"])
+
+
+@pytest.mark.parametrize("n_rate", [0.0, 0.004])
+def test_scan_reuses_the_resident_load_planes_only_for_the_same_reads(n_rate):
+    """Scanning the batches that were loaded takes getValidReads' answer for every occurrence the load routed to bloo2
+    from the kept plane (no probe); other reads, another batching, a replaced filter or FGPU_FLAG_NO_RESIDENT probe as
+    usual.  The results are the oracle's in every case."""
+    k, E, S = 31, 2_000_000, 400_000
+    bases, offs = _random_case(20000, 100, k, 40000, 0.01, 77, n_rate, 3)
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+
+    ctx = api.Context(k, tai, nh)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, 3))
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits()) and st["to_bloo2"] == lst.to_bloo2
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, 3))
+    assert sst["valid_reused"] == lst.to_bloo2 > 0          # same reads, same batches: every routed occurrence is reused
+    _scan_equals_oracle(sc, sst, osc)
+    sst = sc.scanReads(chunks(bases, offs, 2))              # other batch boundaries: nothing lines up, nothing is reused
+    assert sst["valid_reused"] == 0
+    _scan_equals_oracle(sc, sst, osc)
+
+    # other reads of the same shape against the same filter: the stream comparison must refuse them
+    bases2, offs2 = _random_case(20000, 100, k, 40000, 0.01, 78, n_rate, 3)
+    if len(bases2) == len(bases):
+        osc2 = po.Scanner(k, 1, 100, b2)
+        osc2.scan_reads(bases2, offs2)
+        sst = sc.scanReads(chunks(bases2, offs2, 3))
+        assert sst["valid_reused"] == 0
+        _scan_equals_oracle(sc, sst, osc2)
+
+    ctx.bloom_upload(L.BLOO2, b2.bits())                    # a filter from outside: the kept planes are dropped
+    sst = sc.scanReads(chunks(bases, offs, 3))
+    assert sst["valid_reused"] == 0
+    _scan_equals_oracle(sc, sst, osc)
+
+    ctx2 = api.Context(k, tai, nh, keep_resident=False)
+    api.load_two_filters(api.Bloom(ctx2, L.BLOO1), api.Bloom(ctx2, L.BLOO2), chunks(bases, offs, 3))
+    sc2 = api.ReadScanner(ctx2)
+    sst = sc2.scanReads(chunks(bases, offs, 3))
+    assert sst["valid_reused"] == 0
+    _scan_equals_oracle(sc2, sst, osc)
+
+
 def test_empty_and_degenerate_batches():
     ctx = api.Context(21, 1 << 19, 3)
     ctx.load_begin()
