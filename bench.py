@@ -214,7 +214,7 @@ def main():
         batches = device_batches(reads, args.batch_reads)
     torch.cuda.synchronize()
 
-    ctx = api.Context(k, tai, nh, device=local_rank, profile=True)
+    ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
     shard = sharded.GpuShard(ctx, device) if (world > 1 or force_sharded) else None
 
     def one_step():

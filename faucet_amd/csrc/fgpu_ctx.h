@@ -14,7 +14,7 @@
 // every per-position plane / code array carries this many padding words past ceil(T/64): kernels run
 // whole 256-thread blocks and funnel-read one word ahead
 #define FGPU_PADW 8
-#define FGPU_MAX_SPAN (1ULL << 22)   // largest scheduling window of the ordered walk, in stream positions
+#define FGPU_MAX_SPAN (1ULL << 24)   // largest scheduling window of the ordered walk, in stream positions
 
 // A growable device buffer (hipMalloc'd; freed with the context).
 struct DevBuf {
@@ -134,6 +134,7 @@ struct fgpu_ctx {
     uint32_t* cl_members = nullptr;
     void* wdesc = nullptr;           // device WinDesc of the window in flight
     uint64_t window_span = 1ULL << 17;   // adaptive: stream positions per scheduling window
+    uint64_t max_span = FGPU_MAX_SPAN;   // upper bound of window_span (sizes the window table)
     uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
     uint64_t scan_imported = 0;      // junction records imported from a previous shard
 

@@ -962,8 +962,8 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->jfilter, ctx->jcap * 2 / 8));
     // Scheduling windows span at most FGPU_MAX_SPAN positions (+ one piece length).  Worst case every position is a
     // candidate with a distinct k-mer, so the window table holds 2x that; piece starts are >= k+1 apart.
-    ctx->wcap = 4 * FGPU_MAX_SPAN;
-    ctx->wmax = (uint32_t)(FGPU_MAX_SPAN / (uint64_t)(ctx->fd.k + 1) + 2);
+    ctx->wcap = 4 * ctx->max_span;
+    ctx->wmax = (uint32_t)(ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2);
     FGPU_HIP(hipMalloc(&ctx->wdesc, 64));
     FGPU_HIP(hipMalloc(&ctx->wkeys, ctx->wcap * 8));
     FGPU_HIP(hipMalloc(&ctx->wowner, ctx->wcap * 4));
