@@ -272,7 +272,8 @@ def main():
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
                     "walk_max_cluster_rank0": int(sst["walk_max_cluster"]),
                     "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"]),
-                    "valid_reused_rank0": int(sst["valid_reused"])},
+                    "valid_reused_rank0": int(sst["valid_reused"]), "nb_processed_rank0": int(sst["nb_processed"]),
+                    "nb_skipped_rank0": int(sst["nb_skipped"]), "nb_jcheck_kmer_rank0": int(sst["nb_jcheck_kmer"])},
         "kernel_ms_per_step_rank0": {n: round(ms / args.steps, 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
     }
 

@@ -25,6 +25,8 @@
 //
 // Roofline: HBM/Infinity-Cache random access.  Algorithmic bytes per k-mer:
 //   L/(L-k+1) bytes of bases + 64 B * n_hash (test-and-set on bloo1) + 64 B * rho * n_hash (set on bloo2).
+#include <algorithm>
+
 #include "fgpu_ctx.h"
 
 namespace {
@@ -32,6 +34,18 @@ namespace {
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (fd_lane() == 0 && v) atomicAdd(dst, v);
+}
+
+// one atomic per BLOCK (for short kernels whose tail would otherwise be a queue of same-address atomics)
+__device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long long v) {
+    __shared__ unsigned long long part[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (fd_lane() == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(dst, t);
+    }
 }
 
 // During a load pass the two filters live INTERLEAVED: pair[w] = {word w of the carried-in bloo1, word w of bloo2}.
@@ -143,12 +157,23 @@ __global__ void __launch_bounds__(256) k_pair_split(const uint2* __restrict__ pa
 // carry := carry | bits set during the batch.  A bit is set iff its first-set time is no longer "never": one streaming
 // pass over first[] (4 bytes per Bloom bit, lanes = consecutive bits, one ballot per 64 bits) replaces one atomicOr per
 // newly set bit in the mark kernel.
-__global__ void __launch_bounds__(256) k_carry_from_first(uint2* __restrict__ pair, const uint32_t* __restrict__ first, uint64_t tai) {
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < tai; b += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t m = __ballot(first[b] != 0xFFFFFFFFu);
-        if (fd_lane() == 0 && m) {
-            uint64_t w = b >> 5;   // b is a multiple of 64 here: two consecutive 32-bit words of the carry half
-            uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+__global__ void __launch_bounds__(256) k_carry_from_first(uint2* __restrict__ pair, const uint4* __restrict__ first4, uint64_t tai) {
+    // 16 bytes per lane (a wave covers 256 consecutive Bloom bits = 1 KiB of first[]); the lane's four "was set" bits are
+    // OR-reduced over groups of 16 lanes into one 64-bit word of the carry, which the group's first lane merges in
+    const uint64_t n4 = tai / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = first4[i];
+        const uint32_t nib = (v.x != 0xFFFFFFFFu ? 1u : 0u) | (v.y != 0xFFFFFFFFu ? 2u : 0u) | (v.z != 0xFFFFFFFFu ? 4u : 0u) |
+                             (v.w != 0xFFFFFFFFu ? 8u : 0u);
+        const int g = fd_lane() & 15;
+        uint32_t lo = g < 8 ? nib << (4 * g) : 0u, hi = g >= 8 ? nib << (4 * (g - 8)) : 0u;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            lo |= __shfl_xor(lo, o, 64);
+            hi |= __shfl_xor(hi, o, 64);
+        }
+        if (g == 0) {
+            const uint64_t w = i >> 3;   // 4 bits per lane: lane i's bits start at Bloom bit 4i = carry word 4i/32
             if (lo) pair[w].x |= lo;
             if (hi) pair[w + 1].x |= hi;
         }
@@ -193,7 +218,7 @@ __global__ void __launch_bounds__(256) k_count_segments(const uint64_t* __restri
             if (len >= minlen) n++;
         }
     }
-    wave_add(out, n);
+    block_add(out, n);
 }
 
 __global__ void __launch_bounds__(256) k_popcount(const uint4* __restrict__ words, uint64_t n16, unsigned long long* out) {
@@ -284,7 +309,7 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
                 (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     // carry := carry | bits set during this batch
-    FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint32_t*)ctx->first, ctx->prm.tai);
+    FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
     return fgpu_resident_keep(ctx);
 }
 
@@ -311,7 +336,7 @@ int fgpu_stage_presence(fgpu_ctx* ctx) {
 // ---- small utilities used by api.hip and scan_pure.hip --------------------------------------------
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen) {
     BatchBufs& bb = *ctx->cur;
-    FGPU_LAUNCH("count_segments", k_count_segments, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.bad.p, bb.n_words, minlen,
+    FGPU_LAUNCH("count_segments", k_count_segments, std::min(fgpu_grid(bb.n_words, 256), 1024u), 256, (const uint64_t*)bb.bad.p, bb.n_words, minlen,
                 &ctx->counters->segments);
     return FGPU_OK;
 }

@@ -18,56 +18,107 @@ namespace {
 
 __device__ __forceinline__ bool is_acgt(unsigned char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
-// one thread per 64 stream positions: 1 bad word + 2 code words, plain stores
+// 32 mask bits -> the even bits of a 64-bit word (bit j -> bit 2j)
+__device__ __forceinline__ uint64_t spread32(uint32_t v) {
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+
+// One LANE per stream position, one wave per 64-position word: the bases are read as coalesced 64-byte rows, the bad
+// word and the two code-bit planes come out of three ballots.  Every wave takes a contiguous run of words; the read
+// that contains a position is found once per run (binary search) and then followed with a cursor over a window of 64
+// read start positions held one per lane, so that the only memory access per word is the row of bases itself.
 __global__ void __launch_bounds__(256) k_pack(const unsigned char* __restrict__ bases, const uint64_t* __restrict__ offs,
                                               uint64_t n_reads, uint64_t T, uint64_t n_words, uint64_t* __restrict__ codes,
                                               uint64_t* __restrict__ bad, unsigned char* __restrict__ readflag) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_words + FGPU_PADW) return;
-    if (g >= n_words) {   // padding words so that funnel reads past the end see "bad"
-        bad[g] = ~0ULL;
-        codes[2 * g] = 0;
-        codes[2 * g + 1] = 0;
-        return;
-    }
+    const uint64_t total_words = n_words + FGPU_PADW;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t per = (total_words + n_waves - 1) / n_waves;
+    const uint64_t w0 = wave * per, w1 = w0 + per < total_words ? w0 + per : total_words;
+    if (w0 >= w1) return;
+    const int lane = fd_lane();
     const uint64_t off0 = offs[0];
-    uint64_t s0 = g * 64;
-    // largest i with S_i <= s0
-    uint64_t lo = 0, hi = n_reads - 1;
-    while (lo < hi) {
-        uint64_t mid = (lo + hi + 1) >> 1;
-        uint64_t S = (offs[mid] - off0) + mid;
-        if (S <= s0) lo = mid; else hi = mid - 1;
+    const uint64_t NEVER = ~0ULL;
+    // largest i with S_i <= first position of the run (S_i = offs[i] - off0 + i; S_n = T); the same in every lane
+    uint64_t cur = 0;
+    {
+        const uint64_t s0 = w0 * 64;
+        uint64_t lo = 0, hi = n_reads - 1;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi + 1) >> 1;
+            if ((offs[mid] - off0) + mid <= s0) lo = mid; else hi = mid - 1;
+        }
+        cur = lo;
     }
-    uint64_t i = lo;
-    uint64_t rbeg = offs[i], rend = offs[i + 1];
-    uint64_t S = (rbeg - off0) + i;
-    uint64_t c = s0 - S;              // character index inside read i (== len: the separator)
-    uint64_t len = rend - rbeg;
-    uint64_t badw = 0, cw0 = 0, cw1 = 0;
-    for (int q = 0; q < 64; q++) {
-        uint64_t s = s0 + q;
-        int code = 0;
-        bool isbad = true;
-        if (s < T) {
-            if (c < len) {
-                unsigned char ch = bases[rbeg + c];
-                if (is_acgt(ch)) { isbad = false; code = (ch >> 1) & 3; }
-                else readflag[i] = 1;   // benign same-value race between the threads sharing read i
-                c++;
-            } else {   // separator after read i; move on to read i+1
-                i++;
-                if (i < n_reads) { rbeg = rend; rend = offs[i + 1]; len = rend - rbeg; }
-                c = 0;
+    uint64_t base = NEVER, Sreg = 0;   // lane l holds S_{base+l}
+    constexpr int U = 4;               // words per trip: the U rows of bases are loaded together (independent loads in flight)
+    for (uint64_t wb = w0; wb < w1; wb += U) {
+        uint64_t addr[U], rd[U];
+        bool chr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t w = wb + u;
+            chr[u] = false;
+            addr[u] = 0;
+            rd[u] = 0;
+            if (w >= w1 || w >= n_words) continue;
+            if (base == NEVER || cur + 2 > base + 63) {
+                base = cur;
+                const uint64_t j = base + lane;
+                Sreg = j <= n_reads ? (offs[j] - off0) + j : NEVER;
+            }
+            const int r = (int)(cur - base);
+            const uint64_t S0 = __shfl(Sreg, r, 64), S1 = __shfl(Sreg, r + 1, 64), S2 = __shfl(Sreg, r + 2, 64);
+            const uint64_t s = w * 64 + lane;
+            uint64_t i, Si, Sn;   // read containing position s (its characters or its separator), its start, the next start
+            if (s < S1) { i = cur; Si = S0; Sn = S1; }
+            else if (s < S2) { i = cur + 1; Si = S1; Sn = S2; }
+            else {   // reads shorter than a word: follow the offsets in memory
+                i = cur + 2; Si = S2;
+                for (;;) {
+                    Sn = i + 1 <= n_reads ? (offs[i + 1] - off0) + (i + 1) : NEVER;
+                    if (s < Sn) break;
+                    i++;
+                    Si = Sn;
+                }
+            }
+            chr[u] = s < T && s + 1 < Sn;   // a character of read i (s + 1 == Sn: its separator)
+            addr[u] = (Si + off0 - i) + (s - Si);
+            rd[u] = i;
+            cur = __shfl(i, 63, 64);
+            if (cur > n_reads - 1) cur = n_reads - 1;
+        }
+        unsigned char ch[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) ch[u] = chr[u] ? bases[addr[u]] : (unsigned char)0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t w = wb + u;
+            if (w >= w1) continue;
+            if (w >= n_words) {   // padding words so that funnel reads past the end see "bad"
+                if (lane == 0) { bad[w] = ~0ULL; codes[2 * w] = 0; codes[2 * w + 1] = 0; }
+                continue;
+            }
+            int code = 0;
+            bool isbad = true;
+            if (chr[u]) {
+                if (is_acgt(ch[u])) { isbad = false; code = (ch[u] >> 1) & 3; }
+                else readflag[rd[u]] = 1;   // benign same-value race between the lanes sharing a read
+            }
+            const uint64_t badw = __ballot(isbad), hi = __ballot(code & 2), lo = __ballot(code & 1);
+            if (lane < 2) {   // lane t assembles code word t: position q of its half -> bits 63-2q (high code bit), 62-2q (low)
+                const uint32_t h32 = (uint32_t)(hi >> (32 * lane)), l32 = (uint32_t)(lo >> (32 * lane));
+                codes[2 * w + lane] = (spread32(__brev(h32)) << 1) | spread32(__brev(l32));
+                if (lane == 0) bad[w] = badw;
             }
         }
-        if (isbad) badw |= 1ULL << q;
-        if (q < 32) cw0 |= (uint64_t)code << (62 - 2 * q);
-        else cw1 |= (uint64_t)code << (62 - 2 * (q - 32));
     }
-    bad[g] = badw;
-    codes[2 * g] = cw0;
-    codes[2 * g + 1] = cw1;
 }
 
 // one thread per read that has interior bad characters: rewrite its positions in reverse token order
@@ -75,10 +126,10 @@ __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restric
                                                   uint64_t n_reads, unsigned long long* codes, unsigned long long* bad,
                                                   const unsigned char* __restrict__ readflag, unsigned long long* max_len) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    {   // longest read of the batch (one atomic per wave)
+    {   // longest read of the batch: an atomic only when the wave raises the maximum (same-address atomics serialise)
         unsigned long long l = i < n_reads ? (unsigned long long)(offs[i + 1] - offs[i]) : 0;
         for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(l, o, 64); l = t > l ? t : l; }
-        if ((threadIdx.x & 63) == 0 && l) atomicMax(max_len, l);
+        if ((threadIdx.x & 63) == 0 && l > *(volatile unsigned long long*)max_len) atomicMax(max_len, l);
     }
     if (i >= n_reads || !readflag[i]) return;
     const uint64_t off0 = offs[0];
@@ -159,7 +210,7 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if ((rc = fgpu_ensure(ctx, &bb.bad, (bb.n_words + FGPU_PADW) * 8))) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.readflag, n + 16))) return rc;
     FGPU_HIP(hipMemsetAsync(bb.readflag.p, 0, n, ctx->stream));
-    FGPU_LAUNCH("pack", k_pack, fgpu_blocks(bb.n_words + FGPU_PADW, 256), 256, d_bases, d_offs, n, T, bb.n_words, (uint64_t*)bb.codes.p,
+    FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) * 8, 256), 256, d_bases, d_offs, n, T, bb.n_words, (uint64_t*)bb.codes.p,
                 (uint64_t*)bb.bad.p, (unsigned char*)bb.readflag.p);
     FGPU_LAUNCH("pack_fix", k_pack_fix, fgpu_blocks(n, 256), 256, d_bases, d_offs, n, (unsigned long long*)bb.codes.p,
                 (unsigned long long*)bb.bad.p, (const unsigned char*)bb.readflag.p, &ctx->counters->max_read_len);

@@ -236,38 +236,83 @@ __device__ __forceinline__ void test_for_junction(uint64_t key, int real, const 
     }
 }
 
+// position of the n-th set bit of x (n < popcount(x))
+__device__ __forceinline__ int select_bit(uint64_t x, int n) {
+    int pos = 0;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const int c = __popcll(x & ((1ULL << sh) - 1));
+        if (n >= c) { x >>= sh; pos += sh; n -= c; }
+    }
+    return pos;
+}
+
+// testForJunction where the walk may need it.  Work item = (position, direction) with the need bit set and a neighbour
+// window on that side.  Only a third to a half of the positions qualify, so a lane-per-position layout would leave most
+// lanes of a wave idle while the others wait for their probes: instead a wave takes 256 positions at a time, gathers the
+// two work masks of each of the four words, and hands the set bits out densely, 64 items per round (rank -> word by
+// prefix counts, rank within the word -> bit by popcount bisection).  Results are rare non-zero bits: atomicOr into
+// zero-initialised planes.
 __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
                                                     const uint64_t* __restrict__ need, uint64_t T, uint64_t n_words, FdParams fp, const uint32_t* __restrict__ bloom,
-                                                    uint64_t* __restrict__ ff, uint64_t* __restrict__ fb, uint64_t* __restrict__ cf0,
-                                                    uint64_t* __restrict__ cf1, uint64_t* __restrict__ cb0, uint64_t* __restrict__ cb1,
+                                                    unsigned long long* ff, unsigned long long* fb, unsigned long long* cf0,
+                                                    unsigned long long* cf1, unsigned long long* cb0, unsigned long long* cb1,
                                                     DevCounters* cnt) {
-    const uint64_t total = n_words * 64;
+    const int lane = fd_lane();
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_chunks = (n_words + 3) / 4;
     unsigned long long n_eval = 0, n_piece = 0;
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
-        bool f_f = false, f_b = false;
-        int c_f = 0, c_b = 0;
-        if (p < T) n_piece += (pm[p >> 6] >> (p & 63)) & 1ULL;
-        if (p < T && ((need[p >> 6] >> (p & 63)) & 1ULL)) {   // only where the walk can stop skipping (scan_walk.hip, "lazy flags")
-            n_eval++;
-            uint64_t wbits = fd_bits_at(pm, p == 0 ? 0 : p - 1);   // bit0 = pm[p-1], bit1 = pm[p], bit2 = pm[p+1]
-            bool here, prev, next;
-            if (p == 0) { prev = false; here = wbits & 1; next = (wbits >> 1) & 1; }
-            else { prev = wbits & 1; here = (wbits >> 1) & 1; next = (wbits >> 2) & 1; }
-            if (here && (prev || next)) {
-                uint64_t km = fd_kmer_at(codes, p, fp.k);
-                if (next) {   // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110)
-                    test_for_junction(km, fd_base_at(codes, p + fp.k), fp, bloom, f_f, c_f);
-                }
-                if (prev) {   // facing backward: reverse complement, real extension = complement of the base before (:111-113)
-                    test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, p - 1) ^ 2, fp, bloom, f_b, c_b);
+    for (uint64_t chunk = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; chunk < n_chunks; chunk += n_waves) {
+        // lanes 0..3: forward work mask of word 4*chunk + lane; lanes 4..7: backward work mask of word 4*chunk + lane - 4
+        uint64_t mine = 0;
+        if (lane < 8) {
+            const uint64_t w = chunk * 4 + (lane & 3);
+            if (w < n_words) {
+                const uint64_t tmask = (w + 1) * 64 <= T ? ~0ULL : (T > w * 64 ? (1ULL << (T - w * 64)) - 1 : 0ULL);
+                const uint64_t pmw = pm[w] & tmask, nd = need[w] & tmask;
+                if (lane < 4) {
+                    mine = nd & pmw & ((pmw >> 1) | (pm[w + 1] << 63));          // a window follows: facing forward
+                    n_eval += __popcll(nd);
+                    n_piece += __popcll(pmw);
+                } else {
+                    mine = nd & pmw & ((pmw << 1) | (w ? pm[w - 1] >> 63 : 0ULL));   // a window precedes: facing backward
                 }
             }
         }
-        uint64_t m_ff = __ballot(f_f), m_fb = __ballot(f_b);
-        uint64_t m_cf0 = __ballot(c_f & 1), m_cf1 = __ballot(c_f & 2), m_cb0 = __ballot(c_b & 1), m_cb1 = __ballot(c_b & 2);
-        if (fd_lane() == 0) {
-            uint64_t w = p >> 6;
-            ff[w] = m_ff; fb[w] = m_fb; cf0[w] = m_cf0; cf1[w] = m_cf1; cb0[w] = m_cb0; cb1[w] = m_cb1;
+        uint64_t m[8];
+        int cum[9];
+        cum[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            m[q] = __shfl(mine, q, 64);
+            cum[q + 1] = cum[q] + __popcll(m[q]);
+        }
+        for (int t = lane; t < cum[8]; t += 64) {
+            // which mask holds item t (uniform bounds, per-lane t), which bit of it
+            int q = 0;
+            uint64_t mq = m[0];
+            int before = 0;
+#pragma unroll
+            for (int c = 1; c < 8; c++)
+                if (t >= cum[c]) { q = c; mq = m[c]; before = cum[c]; }
+            const int bit = select_bit(mq, t - before);
+            const uint64_t w = chunk * 4 + (q & 3);
+            const uint64_t pos = w * 64 + bit;
+            const uint64_t km = fd_kmer_at(codes, pos, fp.k);
+            bool flag;
+            int njc;
+            const unsigned long long bm = 1ULL << bit;
+            if (q < 4) {   // facing forward: real extension = base after the window (utils/ReadKmer.cpp:107-110)
+                test_for_junction(km, fd_base_at(codes, pos + fp.k), fp, bloom, flag, njc);
+                if (flag) atomicOr(&ff[w], bm);
+                if (njc & 1) atomicOr(&cf0[w], bm);
+                if (njc & 2) atomicOr(&cf1[w], bm);
+            } else {       // facing backward: reverse complement, real extension = complement of the base before (:111-113)
+                test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, pos - 1) ^ 2, fp, bloom, flag, njc);
+                if (flag) atomicOr(&fb[w], bm);
+                if (njc & 1) atomicOr(&cb0[w], bm);
+                if (njc & 2) atomicOr(&cb1[w], bm);
+            }
         }
     }
     wave_add(&cnt->flag_positions, n_eval);
@@ -333,10 +378,12 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
         FGPU_LAUNCH("piece_list", k_scan_piece_list, wgrid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
                     (const uint32_t*)prefix, bb.n_words, (uint2*)bb.pieces.p);
         if ((rc = fgpu_stage_scan_need(ctx))) return rc;
-        FGPU_LAUNCH("scan_flags", k_scan_flags, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.need.p,
-                    bb.T, bb.n_words, ctx->fd,
-                    (const uint32_t*)ctx->bloo2, (uint64_t*)bb.ff.p, (uint64_t*)bb.fb.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p,
-                    (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p, ctx->counters);
+        DevBuf* outs[] = {&bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1};
+        for (DevBuf* o : outs) FGPU_HIP(hipMemsetAsync(o->p, 0, wb, ctx->stream));
+        FGPU_LAUNCH("scan_flags", k_scan_flags, fgpu_grid(bb.n_words * 16, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
+                    (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
+                    (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,
+                    (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters);
     }
     return FGPU_OK;
 }

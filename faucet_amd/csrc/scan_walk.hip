@@ -896,14 +896,28 @@ struct ExportEntry {   // FGPU_TABLE_ENTRY_BYTES = 32
 };
 
 __global__ void __launch_bounds__(256) k_export(JTable jt, FdParams fp, ExportEntry* out, uint64_t* stamps_out, unsigned long long* n_out) {
-    uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > jt.mask) return;
-    uint64_t w = jt.keys[s];
-    if (w == J_EMPTY) return;
-    uint64_t canon = w & J_KEYMASK;
+    // one same-address atomic per BLOCK (they serialise at ~10 ns each): ranks inside the block come from ballots
+    __shared__ unsigned wave_total[4];
+    __shared__ unsigned long long block_base;
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t w = s <= jt.mask ? jt.keys[s] : J_EMPTY;
+    const bool has0 = w != J_EMPTY && ((w >> 62) & 1ULL), has1 = w != J_EMPTY && ((w >> 63) & 1ULL);
+    const uint64_t m0 = __ballot(has0), m1 = __ballot(has1);
+    const uint64_t below = (1ULL << fd_lane()) - 1;
+    unsigned rank = (unsigned)(__popcll(m0 & below) + __popcll(m1 & below));
+    const int wave = (int)(threadIdx.x >> 6);
+    if (fd_lane() == 0) wave_total[wave] = (unsigned)(__popcll(m0) + __popcll(m1));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        block_base = total ? atomicAdd(n_out, (unsigned long long)total) : 0ULL;
+    }
+    __syncthreads();
+    for (int q = 0; q < wave; q++) rank += wave_total[q];
+    unsigned long long idx = block_base + rank;
+    const uint64_t canon = w & J_KEYMASK;
     for (int o = 0; o < 2; o++) {
-        if (!((w >> (62 + o)) & 1ULL)) continue;
-        unsigned long long idx = atomicAdd(n_out, 1ULL);
+        if (!(o == 0 ? has0 : has1)) continue;
         ExportEntry e;
         e.key = o == 0 ? canon : fd_revcomp(canon, fp.k);
         e.stamp = jt.stamps[s * 2 + o];
@@ -912,6 +926,7 @@ __global__ void __launch_bounds__(256) k_export(JTable jt, FdParams fp, ExportEn
         ((uint64_t*)e.rec)[1] = r[1];
         out[idx] = e;
         stamps_out[idx] = e.stamp;
+        idx++;
     }
 }
 
