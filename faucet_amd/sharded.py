@@ -20,6 +20,7 @@ import torch.distributed as dist
 from . import _lib as L
 
 _STAT_NAMES = [n for n, _ in L.ScanStats._fields_]
+HEADER_WORDS = 1 + len(_STAT_NAMES)          # [entries in the table, carried scan counters...]
 
 
 def load_sharded(backend, batches, rank: int, world: int):
@@ -102,7 +103,7 @@ class GpuShard:
         return t[:nbytes]
 
     def header_tensor(self):
-        return torch.zeros(32, dtype=torch.int64, device=self.device)
+        return torch.zeros(HEADER_WORDS, dtype=torch.int64, device=self.device)
 
     def clear_filters(self):
         self.ctx.load_begin()

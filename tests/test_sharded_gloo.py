@@ -36,7 +36,7 @@ class OracleShard:
         return torch.empty(nbytes, dtype=torch.uint8)
 
     def header_tensor(self):
-        return torch.zeros(16, dtype=torch.int64)
+        return torch.zeros(sharded.HEADER_WORDS, dtype=torch.int64)
 
     def clear_filters(self):
         self.b1.bits()[:] = 0
