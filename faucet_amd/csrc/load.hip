@@ -11,10 +11,11 @@
 //   k_load_mark   (all windows)     test the carried-in bitmap (bloo1 as it stood before this batch).
 //                                   All bits set  -> the occurrence certainly goes to bloo2: set its bits there.
 //                                   Otherwise     -> atomicMin(first[bit], t) for the bits not yet in the carry,
-//                                                    OR them into the next carry, flag the occurrence as pending.
+//                                                    flag the occurrence as pending.
 //   k_load_resolve (pending only)   bit is "set before t" iff it is in the carry or first[bit] < t;
 //                                   all bits set before t -> bloo2.
-//   then carry := next carry (D2D copy).
+//   k_carry_from_first              carry |= bits whose first-set time is no longer "never" (one sweep of first[]).
+// Both kernels also write the `sure` plane (occurrence routed to bloo2), which the scan of the same reads reuses.
 // t is the stream position (pack.hip makes position order == processing order); times are batch-local
 // because a bit that is still 0 in the carry has first[bit] == 0xFFFFFFFF at batch start.
 //
