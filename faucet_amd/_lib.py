@@ -15,6 +15,8 @@ BLOO1, BLOO2 = 0, 1
 FLAG_PROFILE = 1
 FLAG_EAGER_FLAGS = 2
 FLAG_NO_RESIDENT = 4
+FLAG_RECORD_STOPS = 8
+STOP_POS_MASK, STOP_FORWARD, STOP_FIRST, STOP_FAKE = 0x0FFFFFFF, 1 << 28, 1 << 29, 1 << 30
 TABLE_ENTRY_BYTES = 32
 
 
@@ -76,6 +78,7 @@ SIGNATURES = {
     "fgpu_scan_prepare": (C.c_int, [_vp, _P(Reads)]),
     "fgpu_scan_walk_prepared": (C.c_int, [_vp]),
     "fgpu_scan_end": (C.c_int, [_vp, _P(ScanStats)]),
+    "fgpu_scan_take_stops": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(C.c_int64)]),
     "fgpu_scan_junction_count": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_scan_download_junctions": (C.c_int, [_vp, _vp, _vp, _u64, _P(_u64)]),
     "fgpu_scan_table_entries": (C.c_int, [_vp, _P(_u64)]),

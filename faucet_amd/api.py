@@ -92,6 +92,7 @@ class ReadBatch:
         return L.Reads(self.bases_ptr, self.offsets_ptr, self.n_reads, int(self.on_device))
 
 
+STOP_DTYPE = np.dtype([("ext", "<u8"), ("read", "<u4"), ("info", "<u4")])
 JUNC_DTYPE = np.dtype([("cov", np.uint8, 4), ("dist", np.uint8, 5), ("linked", np.uint8, 5)])
 
 
@@ -99,10 +100,10 @@ class Context:
     """One fgpu_ctx: one MI355X, one pair of load filters, one junction map."""
 
     def __init__(self, k, tai, n_hash, j=1, max_spacer_dist=100, device=0, profile=False, junction_capacity=0,
-                 max_batch_bases=0, stream=None, walk_window_span=0, eager_flags=False, keep_resident=True):
+                 max_batch_bases=0, stream=None, walk_window_span=0, eager_flags=False, keep_resident=True, record_stops=False):
         self.lib = L.load()
         flags = ((L.FLAG_PROFILE if profile else 0) | (L.FLAG_EAGER_FLAGS if eager_flags else 0)
-                 | (0 if keep_resident else L.FLAG_NO_RESIDENT))
+                 | (0 if keep_resident else L.FLAG_NO_RESIDENT) | (L.FLAG_RECORD_STOPS if record_stops else 0))
         p = L.Params(k, j, max_spacer_dist, n_hash, tai, device, flags, junction_capacity,
                      max_batch_bases, stream, walk_window_span)
         h = C.c_void_p()
@@ -222,6 +223,20 @@ class Context:
 
     def synchronize(self):
         self._c(self.lib.fgpu_synchronize(self.h))
+
+    def take_stops(self):
+        """scanInputRead's lists of the next scanned batch: (batch number, structured array) or None when none is left"""
+        n, seq = C.c_uint64(0), C.c_int64(0)
+        rc = self.lib.fgpu_scan_take_stops(self.h, None, 0, C.byref(n), C.byref(seq))
+        if rc not in (L.OK, L.ERR_CAPACITY):
+            self._c(rc)
+        if seq.value < 0:
+            return None
+        if rc == L.OK:                      # an empty batch fits any buffer and has been consumed
+            return int(seq.value), np.zeros(0, dtype=STOP_DTYPE)
+        out = np.zeros(max(int(n.value), 1), dtype=STOP_DTYPE)
+        self._c(self.lib.fgpu_scan_take_stops(self.h, out.ctypes.data, len(out), C.byref(n), C.byref(seq)))
+        return int(seq.value), out[:int(n.value)]
 
     def kernel_times(self) -> dict:
         arr = (L.KernelTime * 64)()

@@ -166,6 +166,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     ctx->fd.kmask = (1ULL << (2 * p->k)) - 1;
     ctx->fd.tai_mask = p->tai - 1;
     ctx->profile = (p->flags & FGPU_FLAG_PROFILE) != 0;
+    ctx->record_stops = (p->flags & FGPU_FLAG_RECORD_STOPS) != 0;
     { const char* e = getenv("FGPU_PROFILE_WALK"); ctx->prof_walk_detail = e && e[0] == '1'; }
     ctx->bloom_bytes = p->tai / 8;
     if (const char* e = getenv("FGPU_MAX_SPAN_LOG2")) {   // experiment knob
@@ -375,6 +376,10 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->adapt_pieces = 0;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
+    ctx->scan_batch_seq = 0;
+    for (BatchBufs* b : ctx->to_harvest) b->stops_pending = false;   // lists of an earlier scan nobody asked for
+    ctx->to_harvest.clear();
+    ctx->stop_queue.clear();
     for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
     ctx->prepared.clear();
     ctx->cur = &ctx->bb_default;
@@ -410,7 +415,19 @@ static BatchBufs* acquire_batch(fgpu_ctx* ctx) {
     return b;
 }
 
+// after the walk of batch b has been issued: its lists become available (FGPU_FLAG_RECORD_STOPS)
+static void note_walked(fgpu_ctx* ctx, BatchBufs* b) {
+    if (!ctx->record_stops) return;
+    b->stops_pending = true;
+    ctx->to_harvest.push_back(b);
+}
+
 static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
+    if (b->stops_pending) {   // the buffers still hold the visit planes of an earlier batch: bring its lists to the host first
+        int hrc = fgpu_scan_harvest(ctx, b);
+        if (hrc) return hrc;
+    }
+    b->seq = ctx->scan_batch_seq++;
     ctx->cur = b;
     if (b->walk_pending) {   // the walk stream may still be reading this batch's planes
         FGPU_HIP(hipEventSynchronize(b->walk_done));
@@ -438,6 +455,7 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
         adapt_window(ctx);                       // counters as of the pure stage's synchronisation (the walk may lag one batch)
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
         ctx->walked_pieces += b->n_pieces;
+        if (!rc) note_walked(ctx, b);
     }
     ctx->cur = &ctx->bb_default;
     ctx->pool.push_back(b);
@@ -479,6 +497,7 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
         ctx->cur = b;
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
         ctx->walked_pieces += b->n_pieces;
+        if (!rc) note_walked(ctx, b);
     }
     ctx->cur = &ctx->bb_default;
     for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
@@ -486,10 +505,31 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
     return rc;
 }
 
+int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* n_out, int64_t* batch_seq) {
+    if (!ctx || !n_out || !batch_seq) return FGPU_ERR_ARG;
+    if (!ctx->record_stops) { ctx->err = "fgpu_scan_take_stops needs FGPU_FLAG_RECORD_STOPS"; return FGPU_ERR_STATE; }
+    *n_out = 0;
+    *batch_seq = -1;
+    if (ctx->stop_queue.empty() && !ctx->to_harvest.empty()) {
+        FGPU_HIP(hipSetDevice(ctx->prm.device));
+        int rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());
+        if (rc) return rc;
+    }
+    if (ctx->stop_queue.empty()) return FGPU_OK;
+    StopBatch& sb = ctx->stop_queue.front();
+    *n_out = sb.stops.size();
+    *batch_seq = (int64_t)sb.seq;
+    if (sb.stops.size() > cap || (sb.stops.size() && !out)) return FGPU_ERR_CAPACITY;
+    if (!sb.stops.empty()) memcpy(out, sb.stops.data(), sb.stops.size() * sizeof(fgpu_stop));
+    ctx->stop_queue.pop_front();
+    return FGPU_OK;
+}
+
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_end without scan_begin"; return FGPU_ERR_STATE; }
     int rc = pull_counters(ctx);
+    while (!rc && !ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());   // every walk has finished
     ctx->phase = 0;
     if (rc) return rc;
     const DevCounters& c = *ctx->counters_host;

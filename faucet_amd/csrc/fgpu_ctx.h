@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "../../include/faucet_gpu.h"
+#include <deque>
+
 #include "fgpu_device.h"
 
 // every per-position plane / code array carries this many padding words past ceil(T/64): kernels run
@@ -36,6 +38,13 @@ struct BatchBufs {
     DevBuf nF, nB, need;           // lazy flags: in-map snapshot planes of the pure stage, positions whose flags get evaluated
     DevBuf ps_prefix;              // exclusive prefix of popcount(ps) per 64-bit word (uint32)
     DevBuf pieces;                 // uint2 {start position, windows} per valid piece, in stream order
+    // FGPU_FLAG_RECORD_STOPS: where the walk stopped (junction visits), for scanInputRead's return value
+    DevBuf sF, sB;                 // 1 bit per stream position: a junction was visited here facing FORWARD / BACKWARD
+    DevBuf piece_read;             // uint32 per piece: index of the read (in the batch) the piece lies on
+    DevBuf stop_off, stop_out;     // harvest scratch: stops per piece / exclusive offsets, the records
+    const uint64_t* d_offs = nullptr;   // device offsets of the batch being packed (valid during that API call only)
+    uint64_t seq = 0;              // number of the batch within its scan
+    bool stops_pending = false;    // walked with recording on, not harvested yet
     uint64_t T = 0;                // stream length = bases + n_reads
     uint64_t n_words = 0;          // ceil(T / 64)
     uint64_t n_reads = 0;
@@ -52,6 +61,11 @@ struct BatchBufs {
 struct ResidentBatch {
     DevBuf codes, bad, sure;
     uint64_t T = 0, n_words = 0;
+};
+
+struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_scan_take_stops
+    uint64_t seq;
+    std::vector<fgpu_stop> stops;
 };
 
 struct KernelStat {
@@ -154,6 +168,10 @@ struct fgpu_ctx {
     std::vector<BatchBufs*> prepared;     // scan_prepare'd batches waiting for the ordered walk, in file order
     std::vector<BatchBufs*> pool;         // recycled BatchBufs (device buffers kept)
     std::vector<BatchBufs*> all_batches;  // every heap BatchBufs, for destruction
+    bool record_stops = false;            // FGPU_FLAG_RECORD_STOPS
+    std::vector<BatchBufs*> to_harvest;   // walked batches whose stops are still on the device, in scan order
+    std::deque<StopBatch> stop_queue;     // harvested, not yet taken
+    uint64_t scan_batch_seq = 0;
     uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;
     std::vector<DevBuf*> owned;
@@ -215,4 +233,5 @@ int fgpu_util_or(fgpu_ctx* ctx, void* dst, const void* src, uint64_t nbytes);
 int fgpu_util_probe_hash(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t* d_canon, uint64_t* d_hA, uint64_t* d_hB);
 int fgpu_util_probe_contains(fgpu_ctx* ctx, const uint32_t* bloom, const uint64_t* d_canon, uint64_t n, unsigned char* d_out);
 int fgpu_scan_alloc(fgpu_ctx* ctx);
+int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_scan_reset(fgpu_ctx* ctx);

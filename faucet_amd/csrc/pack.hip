@@ -198,6 +198,7 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     bb.T = T;
     bb.n_words = (T + 63) / 64;
     bb.n_reads = n;
+    bb.d_offs = d_offs;
     int rc;
     if (n == 0) {   // nothing to pack; later stages see an empty stream
         if ((rc = fgpu_ensure(ctx, &bb.codes, 64))) return rc;

@@ -197,6 +197,20 @@ __global__ void __launch_bounds__(256) k_scan_piece_list(const uint64_t* __restr
     }
 }
 
+// read (index in the batch) every piece lies on: largest i with S_i <= piece start, S_i = offs[i] - offs[0] + i
+__global__ void __launch_bounds__(256) k_scan_piece_read(const uint2* __restrict__ pieces, uint64_t n_pieces, const uint64_t* __restrict__ offs,
+                                                         uint64_t n_reads, uint32_t* __restrict__ piece_read) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const uint64_t off0 = offs[0], s0 = pieces[i].x;
+    uint64_t lo = 0, hi = n_reads - 1;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi + 1) >> 1;
+        if ((offs[mid] - off0) + mid <= s0) lo = mid; else hi = mid - 1;
+    }
+    piece_read[i] = (uint32_t)lo;
+}
+
 // JChecker::jcheck: depth-first search for one chain of j present extensions (same truth value as the
 // reference's level-by-level search; nothing else about it is observable).
 __device__ bool jcheck_dfs(uint64_t kmer, const FdParams& fp, const uint32_t* __restrict__ bloom) {
@@ -324,6 +338,7 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     BatchBufs& bb = *ctx->cur;
     *n_pieces = 0;
+    bb.n_pieces = 0;   // the buffers are recycled: an empty batch must not inherit the previous batch's pieces
     if (bb.T == 0) return FGPU_OK;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
     int rc;
@@ -377,6 +392,11 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     if (np) {
         FGPU_LAUNCH("piece_list", k_scan_piece_list, wgrid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
                     (const uint32_t*)prefix, bb.n_words, (uint2*)bb.pieces.p);
+        if (ctx->record_stops) {   // the offsets are the caller's and only valid during this call
+            if ((rc = fgpu_ensure(ctx, &bb.piece_read, np * 4))) return rc;
+            FGPU_LAUNCH("piece_read", k_scan_piece_read, fgpu_blocks(np, 256), 256, (const uint2*)bb.pieces.p, np, bb.d_offs, bb.n_reads,
+                        (uint32_t*)bb.piece_read.p);
+        }
         if ((rc = fgpu_stage_scan_need(ctx))) return rc;
         DevBuf* outs[] = {&bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1};
         for (DevBuf* o : outs) FGPU_HIP(hipMemsetAsync(o->p, 0, wb, ctx->stream));

@@ -78,6 +78,7 @@ struct Planes {
     const uint2* pieces;
     uint64_t* lk;
     const uint64_t* need;
+    unsigned long long *sF, *sB;   // junction visits (FGPU_FLAG_RECORD_STOPS), else nullptr
 };
 
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
@@ -627,6 +628,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         int real = fwd ? pv_base(v, wc.pl.codes, p0 + q + k) : (pv_base(v, wc.pl.codes, p0 + q - 1) ^ 2);
         RecRegs cur;
         if (!junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn, cur)) return;
+        if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
         if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
             created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
             if (nwin > 64) created_bits(wc, wc.ckey, v, 1, v.xF1, v.xB1);
@@ -1032,7 +1034,14 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     Planes pl{(const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.ps.p, (const uint32_t*)bb.ps_prefix.p,
               (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p, (const uint64_t*)bb.cf0.p, (const uint64_t*)bb.cf1.p,
               (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p,
-              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p};
+              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p, nullptr, nullptr};
+    if (ctx->record_stops) {
+        const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
+        int rc;
+        if ((rc = fgpu_ensure(ctx, &bb.sF, wb)) || (rc = fgpu_ensure(ctx, &bb.sB, wb))) return rc;
+        pl.sF = (unsigned long long*)bb.sF.p;
+        pl.sB = (unsigned long long*)bb.sB.p;
+    }
     JTable jt = make_jt(ctx);
     WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;
@@ -1046,6 +1055,11 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
     ctx->launch_stream = walk_stream;
     if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(walk_stream, bb.pure_done, 0));
+    if (ctx->record_stops) {
+        const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
+        FGPU_HIP(hipMemsetAsync(bb.sF.p, 0, wb, walk_stream));
+        FGPU_HIP(hipMemsetAsync(bb.sB.p, 0, wb, walk_stream));
+    }
     // thousands of tiny launches: by default one event pair around the whole stage
     const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
     ctx->prof_suppress = !ctx->prof_walk_detail;
@@ -1073,6 +1087,109 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     }
     ctx->launch_stream = ctx->stream;
     ctx->scan_piece_base += n_pieces;
+    return FGPU_OK;
+}
+
+// ---- scanInputRead's lists (FGPU_FLAG_RECORD_STOPS) ---------------------------------------------------------------
+namespace {
+__device__ __forceinline__ uint64_t piece_chunk(const unsigned long long* plane, uint64_t p0, uint32_t nwin, uint32_t c) {
+    return fd_bits_at((const uint64_t*)plane, p0 + 64ULL * c) & chunk_mask(nwin, c);
+}
+
+// elements of the list of every piece: one per junction visit, or the single fake junction (ReadScanner.cpp:195-200)
+__global__ void __launch_bounds__(256) k_stop_count(const uint2* __restrict__ pieces, uint64_t n_pieces, const unsigned long long* sF,
+                                                    const unsigned long long* sB, uint32_t* __restrict__ count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const uint2 pc = pieces[i];
+    uint32_t n = 0;
+    for (uint32_t c = 0; c * 64 < pc.y; c++) n += __popcll(piece_chunk(sF, pc.x, pc.y, c)) + __popcll(piece_chunk(sB, pc.x, pc.y, c));
+    count[i] = n ? n : 1u;
+}
+
+__global__ void __launch_bounds__(256) k_stop_fill(const uint2* __restrict__ pieces, uint64_t n_pieces, const unsigned long long* sF,
+                                                   const unsigned long long* sB, const uint32_t* __restrict__ offset,
+                                                   const uint32_t* __restrict__ piece_read, const uint64_t* __restrict__ codes, FdParams fp,
+                                                   fgpu_stop* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const uint2 pc = pieces[i];
+    const uint64_t p0 = pc.x;
+    const uint32_t nwin = pc.y, rd = piece_read[i];
+    fgpu_stop* o = out + offset[i];
+    uint32_t n = 0;
+    for (uint32_t c = 0; c * 64 < nwin; c++) {
+        const uint64_t wF = piece_chunk(sF, p0, nwin, c), wB = piece_chunk(sB, p0, nwin, c);
+        uint64_t any = wF | wB;
+        while (any) {
+            const int b = __builtin_ctzll(any);
+            any &= any - 1;
+            const uint32_t q = c * 64 + b;
+            if ((wB >> b) & 1ULL) {   // half-step 2q: facing BACKWARD, the extension is the reverse complement of the window before
+                fgpu_stop e;
+                e.ext = fd_revcomp(fd_kmer_at(codes, p0 + q - 1, fp.k), fp.k);
+                e.read = rd;
+                e.info = q | (n == 0 ? FGPU_STOP_FIRST : 0u);
+                o[n++] = e;
+            }
+            if ((wF >> b) & 1ULL) {   // half-step 2q+1: facing FORWARD, the extension is the next window
+                fgpu_stop e;
+                e.ext = fd_kmer_at(codes, p0 + q + 1, fp.k);
+                e.read = rd;
+                e.info = q | FGPU_STOP_FORWARD | (n == 0 ? FGPU_STOP_FIRST : 0u);
+                o[n++] = e;
+            }
+        }
+    }
+    if (n == 0) {   // add_fake_junction: middle k-mer facing FORWARD (ReadScanner.cpp:92-104)
+        const uint32_t m = (nwin + (uint32_t)fp.k - 1) / 2 - (uint32_t)fp.k / 2;
+        fgpu_stop e;
+        e.ext = fd_kmer_at(codes, p0 + m + 1, fp.k);
+        e.read = rd;
+        e.info = m | FGPU_STOP_FORWARD | FGPU_STOP_FIRST | FGPU_STOP_FAKE;
+        o[0] = e;
+    }
+}
+}  // namespace
+
+// Bring the stops of a walked batch to the host queue (waits for that batch's walk only).
+int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
+    for (size_t i = 0; i < ctx->to_harvest.size(); i++)
+        if (ctx->to_harvest[i] == b) { ctx->to_harvest.erase(ctx->to_harvest.begin() + i); break; }
+    if (!b->stops_pending) return FGPU_OK;
+    if (b->walk_pending) {
+        FGPU_HIP(hipEventSynchronize(b->walk_done));
+        b->walk_pending = false;
+    }
+    ctx->stop_queue.emplace_back();
+    StopBatch& sb = ctx->stop_queue.back();
+    sb.seq = b->seq;
+    b->stops_pending = false;
+    const uint64_t np = b->n_pieces;
+    if (!np) return FGPU_OK;
+    int rc;
+    if ((rc = fgpu_ensure(ctx, &b->stop_off, (2 * np + 2) * 4))) return rc;
+    uint32_t* count = (uint32_t*)b->stop_off.p;
+    uint32_t* offset = count + np + 1;
+    hipLaunchKernelGGL(k_stop_count, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const uint2*)b->pieces.p, np,
+                       (const unsigned long long*)b->sF.p, (const unsigned long long*)b->sB.p, count);
+    size_t tmp_bytes = 0;
+    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, offset, 0u, np, rocprim::plus<uint32_t>(), ctx->stream));
+    DevBuf& tmp = ctx->probe_buf;
+    if ((rc = fgpu_ensure(ctx, &tmp, tmp_bytes + 16))) return rc;
+    FGPU_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, count, offset, 0u, np, rocprim::plus<uint32_t>(), ctx->stream));
+    uint32_t last[2];
+    FGPU_HIP(hipMemcpyAsync(&last[0], count + np - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&last[1], offset + np - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t total = (uint64_t)last[0] + last[1];
+    if ((rc = fgpu_ensure(ctx, &b->stop_out, total * sizeof(fgpu_stop)))) return rc;
+    hipLaunchKernelGGL(k_stop_fill, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const uint2*)b->pieces.p, np,
+                       (const unsigned long long*)b->sF.p, (const unsigned long long*)b->sB.p, (const uint32_t*)offset,
+                       (const uint32_t*)b->piece_read.p, (const uint64_t*)b->codes.p, ctx->fd, (fgpu_stop*)b->stop_out.p);
+    sb.stops.resize(total);
+    FGPU_HIP(hipMemcpyAsync(sb.stops.data(), b->stop_out.p, total * sizeof(fgpu_stop), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
     return FGPU_OK;
 }
 

@@ -58,6 +58,7 @@ typedef struct {
 } fgpu_params;
 
 #define FGPU_FLAG_PROFILE 1     /* bracket every kernel with HIP events (fgpu_kernel_times) */
+#define FGPU_FLAG_RECORD_STOPS 8 /* keep scanInputRead's return value for every read (fgpu_scan_take_stops) */
 #define FGPU_FLAG_NO_RESIDENT 4 /* do not keep the load batches in HBM for the scan pass (see fgpu_load_batch) */
 #define FGPU_FLAG_EAGER_FLAGS 2 /* evaluate testForJunction at every position instead of only where the walk can stop
                                  * skipping (same results; the lazy default self-checks and fails with FGPU_ERR_STATE) */
@@ -98,6 +99,19 @@ typedef struct {
     uint64_t piece_positions;    /* window positions inside valid pieces */
     uint64_t valid_reused;       /* getValidReads answers taken from the load pass' resident planes (no filter probe) */
 } fgpu_scan_stats;
+
+/* One element of the list ReadScanner::scanInputRead returns for a read (src/ReadScanner.cpp:260-282): the real-extension
+ * k-mer pushed at a junction visit of scan_forward (:140) or add_fake_junction's extension (:197,:103), with what the
+ * callers of that list need to know about the visit (:147-169, :208-225).  Needs FGPU_FLAG_RECORD_STOPS. */
+typedef struct {
+    uint64_t ext;    /* ReadKmer::getRealExtension() at the visit */
+    uint32_t read;   /* index of the read within its batch */
+    uint32_t info;   /* bits 0-27 ReadKmer::pos inside the valid piece; FGPU_STOP_* bits */
+} fgpu_stop;
+#define FGPU_STOP_POS_MASK 0x0FFFFFFFu
+#define FGPU_STOP_FORWARD  (1u << 28)   /* facing FORWARD (else BACKWARD) */
+#define FGPU_STOP_FIRST    (1u << 29)   /* first element of its valid piece (= of one scan_forward call) */
+#define FGPU_STOP_FAKE     (1u << 30)   /* the piece had no junction: this is add_fake_junction's element */
 
 /* Junction record, field for field utils/Junction.h:10-18 (cov is private there). */
 typedef struct {
@@ -156,6 +170,13 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_scan_walk_prepared(fgpu_ctx* ctx);
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
+/* scanInputRead's lists of one scanned batch, flattened in processing order (reads in file order; inside a read the
+ * valid pieces in the order scanInputRead walks them; inside a piece by half-step).  Batches come out in scan order,
+ * one per call: *batch_seq = number of the batch within the scan, or -1 (and *n_out = 0) when none is left.  The
+ * call waits for the ordered walk of that batch only, so calling it once after every fgpu_scan_batch (it then returns
+ * the previous batch) keeps the walk of the newest batch overlapped; after fgpu_scan_end call it until -1.
+ * FGPU_ERR_CAPACITY: *n_out = elements needed, nothing consumed. */
+int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* n_out, int64_t* batch_seq);
 /* Junction map after the scan, in CREATION order (inserting the records in this order into a
  * std::unordered_map<kmer_type,Junction> reproduces the reference's dump order,
  * utils/JunctionMap.cpp:588-593).  keys are the oriented k-mers (ReadKmer::getKmer). */

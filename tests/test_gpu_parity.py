@@ -365,3 +365,72 @@ def test_cli_writes_the_reference_files(name, tmp_path):
     assert f"Number of processed kmers: {cn['nb_processed']} " in r.stdout
     assert f"Reads processed: {cn['load_reads_processed']}" in r.stdout
     assert "Weights after load: %s, %s" % tuple(cn["weights_after_load"]) in r.stdout
+
+
+def _oracle_lists(bases, offs, k, j, spacer, bloom_bits, tai, nh):
+    """scanInputRead's return value for every read, from the oracle driven read by read"""
+    b2 = po.Bloom(tai, nh)
+    b2.set_bits(bloom_bits)
+    osc = po.Scanner(k, j, spacer, b2)
+    lists = []
+    for i in range(len(offs) - 1):
+        lists.append([int(x) for x in osc.scan_input_read(bytes(bases[int(offs[i]):int(offs[i + 1])]))])
+    return osc, lists
+
+
+@pytest.mark.parametrize("n_batches", [1, 4])
+@pytest.mark.parametrize("n_rate", [0.0, 0.004])
+def test_scan_input_read_lists_match_the_oracle(n_batches, n_rate):
+    """fgpu_scan_take_stops = the list scanInputRead returns per read (src/ReadScanner.cpp:260-282), batch by batch."""
+    k, E, S = 25, 1_000_000, 200_000
+    bases, offs = _random_case(12000, 110, k, 30000, 0.012, 99, n_rate, 3)
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    _, want = _oracle_lists(bases, offs, k, 1, 100, b2.bits(), tai, nh)
+    ctx = api.Context(k, tai, nh, record_stops=True)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    parts = chunks(bases, offs, n_batches)
+    got = []
+    ctx.scan_begin()
+    first_read = 0
+    bounds = []
+    for part in parts:
+        ctx.scan_batch(part)
+        bounds.append(first_read)
+        first_read += part.n_reads
+    sst = ctx.scan_end()
+    seqs = []
+    while True:
+        t = ctx.take_stops()
+        if t is None:
+            break
+        seq, st = t
+        seqs.append(seq)
+        lists = [[] for _ in range(parts[seq].n_reads)]
+        assert np.all(np.diff(st["read"].astype(np.int64)) >= 0)          # reads in file order
+        for e in st:
+            lists[int(e["read"])].append(int(e["ext"]))
+        got.extend(lists)
+        # every piece contributes at least one element and starts with FIRST; a fake element is alone in its piece
+        first = (st["info"] & L.STOP_FIRST) != 0
+        fake = (st["info"] & L.STOP_FAKE) != 0
+        assert first.sum() > 0 and np.all(first[fake])
+    assert seqs == list(range(len(parts)))
+    assert got == want
+    _scan_equals_oracle(ctx, sst, osc)
+
+
+def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
+    k, E, S = 25, 1_000_000, 200_000
+    bases, offs = _random_case(9000, 100, k, 30000, 0.01, 5, 0.0, 2)
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    ctx = api.Context(k, tai, nh)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    parts = chunks(bases, offs, 3)
+    empty = api.ReadBatch.from_lines([])
+    ctx.scan_begin()
+    for part in (parts[0], parts[1], empty, empty, parts[2], empty):
+        ctx.scan_batch(part)
+    sst = ctx.scan_end()
+    _scan_equals_oracle(ctx, sst, osc)
