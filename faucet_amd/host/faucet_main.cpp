@@ -2,17 +2,23 @@
 //
 // Host side of the hot path in the reference's own language (C++11).  Same flags, same required arguments, same
 // exit codes and the same output files as src/Faucet.cpp:57-182,248-300 for the part of the run this repository
-// covers: the Bloom load pass (-> <prefix>.bloom) and the junction scan (-> <prefix>.junctions).  The contig-graph
-// stage is not part of this build: the program stops where the reference's --no_cleaning run stops producing
-// hot-path files.  No k-mer, hash or junction is computed on the host: everything goes through fgpu_*; if the
-// library finds no gfx950 device the program fails (there is no CPU path).
+// covers: the Bloom load pass (-> <prefix>.bloom) and the junction scan (-> <prefix>.junctions, and without
+// --no_cleaning <prefix>.short_pair_filter / .long_pair_filter).  The contig-graph stage is not part of this build:
+// the program stops after the last file the scan produces (exit code 3 when the reference would have gone on to the
+// contig graph; the reference itself can be restarted from these files with -bloom_file / -junctions_file).
+// No k-mer window, filter probe or junction is computed on the host: everything goes through fgpu_*; if the library
+// finds no gfx950 device the program fails (there is no CPU path).  What stays on the host is what SURVEY.md 8(b)
+// leaves there: the JunctionMap container that fixes the dump order, and the two pair filters, which are fed from
+// scanInputRead's per-read lists (fgpu_scan_take_stops) exactly as ReadScanner does it.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <fstream>
+#include <list>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -146,6 +152,143 @@ struct Junction {   // utils/Junction.h:10-18
 
 const char kDecode[4] = {'A', 'C', 'T', 'G'};   // utils/Kmer.cpp:21
 
+// ---- the pair filters (host side, as in the reference) ---------------------------------------------------------
+uint64_t revcomp(uint64_t x, int k) {   // utils/Kmer.cpp:238-252: complement every 2-bit code (x ^ 2), reverse their order
+    uint64_t r = 0;
+    for (int i = 0; i < k; i++) { r = (r << 2) | ((x & 3) ^ 2); x >>= 2; }
+    return r;
+}
+uint64_t canonical(uint64_t x, int k) { const uint64_t r = revcomp(x, k); return x < r ? x : r; }   // utils/Kmer.cpp:531-533
+
+uint64_t old_hash(uint64_t key, uint64_t seed) {   // Bloom::oldHash, utils/Bloom.h:134-145
+    uint64_t h = seed;
+    h ^= (h << 7) ^ key * (h >> 3) ^ (~((h << 11) + (key ^ (h >> 5))));
+    h = (~h) + (h << 21);
+    h = h ^ (h >> 24);
+    h = (h + (h << 3)) + (h << 8);
+    h = h ^ (h >> 14);
+    h = (h + (h << 2)) + (h << 4);
+    h = h ^ (h >> 28);
+    h = h + (h << 31);
+    return h;
+}
+const uint64_t kSeed0 = 0xffaa54ffe6e6e6e7ULL, kSeed1 = 0x1140aada557088a4ULL;   // seed_tab[0..1], utils/Bloom.h:56-68 with user_seed 0
+
+struct PairFilter {   // a Bloom used through addPair / containsPair only (utils/Bloom.cpp:127-154, Bloom.h:217-258)
+    uint64_t tai = 0;
+    int n_hash = 0;
+    std::vector<uint8_t> bits;
+    void create(uint64_t elements, float fp) {   // create_bloom_filter_optimal, utils/Bloom.cpp:229-247
+        int32_t bpk = 0, nh = 0;
+        fgpu_size_optimal(elements, fp, &bpk, &tai, &nh);
+        n_hash = nh;
+        printf("Bits per kmer: %d \n", bpk);
+        printf("BF memory: %f MB\n", (float)((elements * (uint64_t)bpk) / 8ULL / 1024ULL) / 1024);
+        printf("Number of hash functions: %d \n", n_hash);
+        bits.assign(tai / 8, 0);
+    }
+    void hashes(uint64_t k1, uint64_t k2, int k, uint64_t& h0, uint64_t& h1) const {
+        const uint64_t e1 = canonical(k1, k), e2 = canonical(k2, k);
+        h0 = old_hash(std::min(e1, e2), kSeed0) & (tai - 1);
+        h1 = old_hash(std::max(e1, e2), kSeed1) & (tai - 1);
+    }
+    void add_pair(uint64_t k1, uint64_t k2, int k) {
+        uint64_t h0, h1;
+        hashes(k1, k2, k, h0, h1);
+        for (int i = 0; i < n_hash; i++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & (tai - 1); }
+    }
+    bool contains_pair(uint64_t k1, uint64_t k2, int k) const {
+        uint64_t h0, h1;
+        hashes(k1, k2, k, h0, h1);
+        for (int i = 0; i < n_hash; i++) { if (!(bits[h0 >> 3] & (1u << (h0 & 7)))) return false; h0 = (h0 + h1) & (tai - 1); }
+        return true;
+    }
+    float weight() const {   // Bloom::weight, utils/Bloom.cpp:191-203
+        long w = 0;
+        for (uint8_t b : bits) w += __builtin_popcount(b);
+        return (float)w / (float)tai;
+    }
+    int dump(const std::string& path) const {   // Bloom::dump, utils/Bloom.cpp:571-578
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
+        fwrite(bits.data(), 1, bits.size(), f);
+        fclose(f);
+        return 0;
+    }
+};
+
+// What ReadScanner does with scanInputRead's lists: the short-pair rules at the end of scan_forward
+// (src/ReadScanner.cpp:208-225) per valid piece, and the paired-end loop of scanReads (:317-343) per read pair.
+struct PairLogic {
+    int k = 0;
+    bool paired_ends = false, no_cleaning = false;
+    PairFilter* short_pf = nullptr;
+    PairFilter* long_pf = nullptr;
+    bool first_end = true;
+    std::list<uint64_t> back1, back2;
+    int empty_count = 0, not_empty_count = 0;
+
+    void piece(const fgpu_stop* s, size_t n) {   // one scan_forward call
+        if (no_cleaning || !short_pf) return;
+        if (n == 2) {
+            bool have_first_back = false, have_last_fwd = false;
+            uint32_t rev_pos = 0, for_pos = 0;
+            uint64_t first_back = 0, last_fwd = 0;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t pos = s[i].info & FGPU_STOP_POS_MASK;
+                if (s[i].info & FGPU_STOP_FAKE) continue;
+                if (!(s[i].info & FGPU_STOP_FORWARD)) {
+                    if (!have_first_back) { have_first_back = true; first_back = s[i].ext; rev_pos = pos; }
+                } else {
+                    if (!have_last_fwd) { have_last_fwd = true; for_pos = pos; }
+                    last_fwd = s[i].ext;
+                }
+            }
+            if (have_first_back && have_last_fwd && !(rev_pos > for_pos)) short_pf->add_pair(first_back, last_fwd, k);
+            if ((have_first_back && !have_last_fwd) || (!have_first_back && have_last_fwd)) short_pf->add_pair(s[0].ext, s[1].ext, k);
+        } else if (n > 2) {
+            for (size_t i = 0; i + 2 < n; i++) short_pf->add_pair(s[i].ext, s[i + 2].ext, k);
+        }
+    }
+    void read(const fgpu_stop* s, size_t n) {   // one iteration of the loop in scanReads
+        std::list<uint64_t>& back = first_end ? back1 : back2;
+        back.clear();
+        size_t a = 0;
+        while (a < n) {
+            size_t b = a + 1;
+            while (b < n && !(s[b].info & FGPU_STOP_FIRST)) b++;
+            piece(s + a, b - a);
+            for (size_t i = a; i < b; i++) back.push_back(s[i].ext);
+            a = b;
+        }
+        if (paired_ends && !first_end) {
+            if (!back1.empty() && !back2.empty()) {
+                not_empty_count++;
+                for (uint64_t pair1 : back1) {
+                    bool paired = false;
+                    if (!no_cleaning) {
+                        for (uint64_t pair2 : back2)
+                            if (long_pf->contains_pair(pair1, pair2, k)) { paired = true; break; }
+                        if (!paired) long_pf->add_pair(pair1, back2.front(), k);
+                    }
+                }
+            } else {
+                empty_count++;
+            }
+        }
+        first_end = !first_end;
+    }
+    void batch(const std::vector<fgpu_stop>& stops, uint64_t n_reads) {   // reads of a batch, in file order
+        size_t a = 0;
+        for (uint64_t r = 0; r < n_reads; r++) {
+            size_t b = a;
+            while (b < stops.size() && stops[b].read == r) b++;
+            read(stops.data() + a, b - a);
+            a = b;
+        }
+    }
+};
+
 int write_junctions(const std::string& path, const std::unordered_map<uint64_t, Junction>& map, int k) {
     // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596), Junction::toString (utils/Junction.cpp:74-89)
     FILE* f = fopen(path.c_str(), "wb");
@@ -176,11 +319,6 @@ int main(int argc, char** argv) {
     fgpu_ctx* ctx = nullptr;
     if (o.k < 1 || o.k > 31) { fprintf(stderr, "k must be in 1..31 on this build\n"); return 1; }
     if (o.mercy) { fprintf(stderr, "--mercy is not implemented on the device path (SURVEY.md 8f)\n"); return 1; }
-    if (!o.no_cleaning && !o.just_load) {
-        fprintf(stderr, "This build covers the Bloom load pass and the junction scan only: run with --no_cleaning (or --just_load_bloom).\n"
-                        "The contig-graph stage and the pair filters it needs are not part of it.\n");
-        return 1;
-    }
     if (o.from_junctions) { fprintf(stderr, "-junctions_file restarts after the scan: nothing left for this build to do.\n"); return 1; }
 
     // ---- filter sizing: getBloomFilterFromReads / getBloomFilterFromFile (src/Faucet.cpp:185-219)
@@ -214,6 +352,8 @@ int main(int argc, char** argv) {
     prm.max_spacer_dist = o.max_spacer_dist;
     prm.n_hash = n_hash;
     prm.tai = tai;
+    const bool want_lists = !o.no_cleaning || o.paired_ends;   // scanInputRead's lists feed the pair filters and the pair counts
+    if (want_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
     {
         int rc = fgpu_create(&prm, &ctx);
         if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(nullptr)); return 2; }
@@ -266,6 +406,13 @@ int main(int argc, char** argv) {
         fclose(f);
         printf("bloom dumped \n");
     }
+    // ---- pair filters (src/Faucet.cpp:266-283): created, and their sizes printed, before --just_load_bloom returns
+    PairFilter short_pf, long_pf;
+    {
+        const uint64_t E = o.estimated_kmers;
+        short_pf.create(o.high_cov ? E / 2 : E / 20, 0.01f);
+        if (o.paired_ends) long_pf.create(o.high_cov ? E / 2 : E / 10, 0.01f);
+    }
     if (o.just_load) { fgpu_destroy(ctx); return 0; }
 
     // ---- pass 2 (ReadScanner::scanReads, src/ReadScanner.cpp:284-359; printScanSummary :19-27)
@@ -279,17 +426,53 @@ int main(int argc, char** argv) {
         printf("Weight before read scan: %f \n", w2);
         CHECK(fgpu_scan_begin(ctx));
         uint64_t scanned = 0;
+        PairLogic pairs;
+        pairs.k = o.k;
+        pairs.paired_ends = o.paired_ends;
+        pairs.no_cleaning = o.no_cleaning;
+        pairs.short_pf = &short_pf;
+        pairs.long_pf = o.paired_ends ? &long_pf : nullptr;
+        std::vector<uint64_t> batch_n_reads;
+        std::vector<fgpu_stop> stops;
+        // lists of the oldest batch whose walk is done (the newest one keeps walking while the next batch is prepared)
+        auto take = [&](bool& got) -> int {
+            got = false;
+            uint64_t n = 0;
+            int64_t seq = -1;
+            int rc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
+            if (rc == FGPU_ERR_CAPACITY) {
+                stops.resize(n);
+                rc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
+            }
+            if (rc != FGPU_OK) { fprintf(stderr, "fgpu_scan_take_stops failed (%d): %s\n", rc, fgpu_last_error(ctx)); return 2; }
+            if (seq < 0) return 0;
+            got = true;
+            std::vector<fgpu_stop> view(stops.begin(), stops.begin() + n);
+            pairs.batch(view, batch_n_reads[(size_t)seq]);
+            return 0;
+        };
         while (src.next(o.batch_reads, bases, offsets)) {
             fgpu_reads r = {bases.data(), offsets.data(), offsets.size() - 1, 0};
             CHECK(fgpu_scan_batch(ctx, &r));
+            batch_n_reads.push_back(r.n_reads);
+            if (want_lists && batch_n_reads.size() > 1) {
+                bool got;
+                if (int rc = take(got)) return rc;
+            }
             scanned += r.n_reads;
             fprintf(stdout, "\rreads scanned: %lld", (long long)scanned);
             fflush(stdout);
         }
         fgpu_scan_stats ss;
         CHECK(fgpu_scan_end(ctx, &ss));
+        if (want_lists) {
+            bool got = true;
+            while (got)
+                if (int rc = take(got)) return rc;
+        }
         time(&stop);
-        printf("\nReads processed: %llu\n", (unsigned long long)ss.reads_processed);
+        printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);
+        printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);
         printf("Unambiguous reads: %llu\n", (unsigned long long)ss.unambiguous_reads);
         printf("Time in seconds for read scan: %f \n", difftime(stop, start));
         printf("\nDistinct junctions: %llu \n", (unsigned long long)ss.n_junctions);
@@ -316,8 +499,20 @@ int main(int argc, char** argv) {
         printf("Writing to junction file\n");
         if (int rc = write_junctions(o.file_prefix + ".junctions", junction_map, o.k)) return rc;
         printf("Done writing to junction file\n");
+        if (!o.no_cleaning) {   // src/Faucet.cpp:297-300
+            if (int rc = short_pf.dump(o.file_prefix + ".short_pair_filter")) return rc;
+            if (o.paired_ends)
+                if (int rc = long_pf.dump(o.file_prefix + ".long_pair_filter")) return rc;
+        }
+        printf("Weight of short pair filter: %f\n", short_pf.weight());
+        if (o.paired_ends) printf("Weight of long pair filter: %f\n", long_pf.weight());
         printf("Number of junctions: %llu\n", (unsigned long long)junction_map.size());
     }
     fgpu_destroy(ctx);
+    if (!o.no_cleaning) {
+        fprintf(stderr, "The contig-graph stage is not part of this build: the load and scan outputs have been written; the reference\n"
+                        "can continue from them (-bloom_file / -junctions_file).\n");
+        return 3;
+    }
     return 0;
 }

@@ -434,3 +434,33 @@ def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
         ctx.scan_batch(part)
     sst = ctx.scan_end()
     _scan_equals_oracle(ctx, sst, osc)
+
+
+@pytest.mark.parametrize("batch_reads", [400, 333, 100000])
+def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_path):
+    """BASELINE config 3's shape: --fastq --paired_ends WITHOUT --no_cleaning.  All four files the reference writes before
+    its contig-graph stage are byte-identical (the long pair filter is check-then-insert, i.e. order-dependent); the
+    program then stops with exit code 3 because that stage is not part of this build."""
+    import os
+    import subprocess
+    c = Case("pe_fastq_k21")
+    reads = tmp_path / "reads.fq"
+    reads.write_bytes(c.reads_text())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
+                        "-batch_reads", str(batch_reads)] + c.meta["args"], capture_output=True, text=True)
+    assert r.returncode == 3, r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "out.bloom", dtype=np.uint8), c.bloom())
+    assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
+    assert np.array_equal(np.fromfile(tmp_path / "out.short_pair_filter", dtype=np.uint8), c.pair_filter("short"))
+    assert np.array_equal(np.fromfile(tmp_path / "out.long_pair_filter", dtype=np.uint8), c.pair_filter("long"))
+    cn = c.counters
+    assert f"Empty count: {cn['empty_count']}, not empty count: {cn['not_empty_count']}" in r.stdout
+    assert f"Distinct junctions: {cn['distinct_junctions']} " in r.stdout
+    # with --no_cleaning the pair filters stay empty and are not written, the pair counts are still reported
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "nc"),
+                        "-batch_reads", str(batch_reads), "--no_cleaning"] + c.meta["args"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not (tmp_path / "nc.short_pair_filter").exists()
+    assert f"Empty count: {cn['empty_count']}, not empty count: {cn['not_empty_count']}" in r.stdout
+    assert "Weight of short pair filter: 0.000000" in r.stdout
