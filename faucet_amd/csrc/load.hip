@@ -54,7 +54,8 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
 // the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                    uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first,
-                                                   uint64_t* __restrict__ pending, uint64_t* __restrict__ sure, DevCounters* cnt) {
+                                                   uint32_t* carry_next, uint64_t* __restrict__ pending, uint64_t* __restrict__ sure,
+                                                   DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
@@ -88,7 +89,13 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 pend = true;
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
-                    if (missing & (1u << i)) atomicMin(&first[h], (uint32_t)p);   // the next carry is derived from first[] (k_carry_from_first)
+                    if (missing & (1u << i)) {
+                        // the next carry is derived from first[] by a sweep (k_carry_from_first) or, for filters too large to
+                        // sweep per batch, collected here by whoever touches the bit first
+                        // (an atomic whose result is used is markedly slower than a fire-and-forget one: test-then-set instead)
+                        atomicMin(&first[h], (uint32_t)p);
+                        if (carry_next && !((carry_next[h >> 5] >> (h & 31)) & 1u)) atomicOr(&carry_next[h >> 5], 1u << (h & 31));
+                    }
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -178,6 +185,14 @@ __global__ void __launch_bounds__(256) k_carry_from_first(uint2* __restrict__ pa
             if (lo) pair[w].x |= lo;
             if (hi) pair[w + 1].x |= hi;
         }
+    }
+}
+
+// carry |= bits collected in carry_next (streaming, tai/8 bytes; carry_next keeps accumulating: OR is idempotent)
+__global__ void __launch_bounds__(256) k_carry_merge(uint2* __restrict__ pair, const uint32_t* __restrict__ carry_next, uint64_t n32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = carry_next[i];
+        if (v) pair[i].x |= v;
     }
 }
 
@@ -306,11 +321,12 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
+                ctx->pair, ctx->first, ctx->bloo1_new, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
                 (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     // carry := carry | bits set during this batch
-    FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
+    if (ctx->bloo1_new) FGPU_LAUNCH("carry_update", k_carry_merge, 4096, 256, ctx->pair, (const uint32_t*)ctx->bloo1_new, ctx->bloom_bytes / 4);
+    else FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
     return fgpu_resident_keep(ctx);
 }
 

@@ -464,3 +464,26 @@ def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_p
     assert not (tmp_path / "nc.short_pair_filter").exists()
     assert f"Empty count: {cn['empty_count']}, not empty count: {cn['not_empty_count']}" in r.stdout
     assert "Weight of short pair filter: 0.000000" in r.stdout
+
+
+@pytest.mark.parametrize("log_tai,nh", [(33, 3), (32, 2)])
+def test_config4_sized_filters_index_past_32_bits(log_tai, nh):
+    """BASELINE config 4's filter shape (2^33 bits = 1 GiB per filter, 32 GiB of first-set times): bit positions, the
+    interleaved pair, the carry sweep and the junction scan must all be 64-bit clean.  Small read set, full-size filters."""
+    k, tai = 31, 1 << log_tai
+    bases, offs = _random_case(60000, 100, k, 120000, 0.01, 2024, 0.001, 3)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    ctx = api.Context(k, tai, nh)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, 3))
+    assert st["kmers"] == lst.kmers and st["to_bloo2"] == lst.to_bloo2
+    got2 = ctx.bloom_download(L.BLOO2)
+    want2 = b2.bits()
+    assert np.array_equal(got2, want2)
+    set_bits = np.flatnonzero(want2)
+    assert set_bits.size and set_bits.max() >= (tai // 8) * 3 // 4           # the data does reach the top quarter of the array
+    assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, 3))
+    assert sst["valid_reused"] == lst.to_bloo2
+    _scan_equals_oracle(sc, sst, osc)
+    ctx.close()
