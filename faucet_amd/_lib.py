@@ -27,7 +27,8 @@ class Params(C.Structure):
 
 
 class Reads(C.Structure):
-    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("on_device", C.c_int32)]
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("on_device", C.c_int32),
+                ("reserved", C.c_int32), ("starts", C.c_void_p)]
 
 
 class LoadStats(C.Structure):
@@ -73,6 +74,7 @@ SIGNATURES = {
     "fgpu_bloom_weight": (C.c_int, [_vp, C.c_int, _P(_f32)]),
     "fgpu_bloom_devptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(_u64)]),
     "fgpu_bitmap_or": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "fgpu_text_split": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, C.c_int, _P(Reads), _P(_u64)]),
     "fgpu_scan_begin": (C.c_int, [_vp]),
     "fgpu_scan_batch": (C.c_int, [_vp, _P(Reads)]),
     "fgpu_scan_prepare": (C.c_int, [_vp, _P(Reads)]),

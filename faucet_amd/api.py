@@ -61,9 +61,10 @@ def load_filter_shape(estimated_kmers: int, singletons: int, fp: float = 0.04):
 class ReadBatch:
     """Sequence lines in file order.  Host numpy arrays or device pointers (e.g. torch tensors' data_ptr())."""
 
-    def __init__(self, bases, offsets, n_reads=None, on_device=False, keepalive=None):
+    def __init__(self, bases, offsets, n_reads=None, on_device=False, keepalive=None, starts=None):
         self.on_device = bool(on_device)
         self._keep = (bases, offsets, keepalive)
+        self.starts_ptr = int(starts) if starts else None      # device batches whose reads lie inside raw text
         if on_device:
             self.bases_ptr, self.offsets_ptr = int(bases), int(offsets)
             self.n_reads = int(n_reads)
@@ -89,7 +90,7 @@ class ReadBatch:
         return cls(np.ascontiguousarray(mat).reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(ln))
 
     def c_struct(self):
-        return L.Reads(self.bases_ptr, self.offsets_ptr, self.n_reads, int(self.on_device))
+        return L.Reads(self.bases_ptr, self.offsets_ptr, self.n_reads, int(self.on_device), 0, self.starts_ptr)
 
 
 STOP_DTYPE = np.dtype([("ext", "<u8"), ("read", "<u4"), ("info", "<u4")])
@@ -223,6 +224,15 @@ class Context:
 
     def synchronize(self):
         self._c(self.lib.fgpu_synchronize(self.h))
+
+    def text_split(self, text: bytes, fastq: bool, final_chunk: bool):
+        """Record splitting of raw FASTA/FASTQ text on the device (the reference's getline loops).  Returns (ReadBatch that
+        points into the device copy of the text and is valid until the next text_split, bytes consumed)."""
+        buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, np.uint8)
+        out, used = L.Reads(), C.c_uint64(0)
+        self._c(self.lib.fgpu_text_split(self.h, buf.ctypes.data, len(text), 0, int(fastq), int(final_chunk), C.byref(out), C.byref(used)))
+        rb = ReadBatch(out.bases or 0, out.offsets or 0, n_reads=int(out.n_reads), on_device=True, starts=out.starts)
+        return rb, int(used.value)
 
     def take_stops(self):
         """scanInputRead's lists of the next scanned batch: (batch number, structured array) or None when none is left"""

@@ -174,6 +174,7 @@ struct fgpu_ctx {
     uint64_t scan_batch_seq = 0;
     uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;
+    DevBuf text_buf, text_nl, text_rank, text_tmp, text_rec;   // fgpu_text_split: the text and the batch that points into it
     std::vector<DevBuf*> owned;
 
     // profiling

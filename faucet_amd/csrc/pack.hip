@@ -34,7 +34,7 @@ __device__ __forceinline__ uint64_t spread32(uint32_t v) {
 // that contains a position is found once per run (binary search) and then followed with a cursor over a window of 64
 // read start positions held one per lane, so that the only memory access per word is the row of bases itself.
 __global__ void __launch_bounds__(256) k_pack(const unsigned char* __restrict__ bases, const uint64_t* __restrict__ offs,
-                                              uint64_t n_reads, uint64_t T, uint64_t n_words, uint64_t* __restrict__ codes,
+                                              const uint64_t* __restrict__ starts, uint64_t n_reads, uint64_t T, uint64_t n_words, uint64_t* __restrict__ codes,
                                               uint64_t* __restrict__ bad, unsigned char* __restrict__ readflag) {
     const uint64_t total_words = n_words + FGPU_PADW;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned char* __restrict__ 
                 }
             }
             chr[u] = s < T && s + 1 < Sn;   // a character of read i (s + 1 == Sn: its separator)
-            addr[u] = (Si + off0 - i) + (s - Si);
+            // first byte of read i: offs[i] for contiguous batches, starts[i] when the reads lie inside raw text
+            addr[u] = (starts ? (chr[u] ? starts[i] : 0) : Si + off0 - i) + (s - Si);
             rd[u] = i;
             cur = __shfl(i, 63, 64);
             if (cur > n_reads - 1) cur = n_reads - 1;
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned char* __restrict__ 
 
 // one thread per read that has interior bad characters: rewrite its positions in reverse token order
 __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restrict__ bases, const uint64_t* __restrict__ offs,
-                                                  uint64_t n_reads, unsigned long long* codes, unsigned long long* bad,
+                                                  const uint64_t* __restrict__ starts, uint64_t n_reads, unsigned long long* codes, unsigned long long* bad,
                                                   const unsigned char* __restrict__ readflag, unsigned long long* max_len) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {   // longest read of the batch: an atomic only when the wave raises the maximum (same-address atomics serialise)
@@ -133,8 +134,9 @@ __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restric
     }
     if (i >= n_reads || !readflag[i]) return;
     const uint64_t off0 = offs[0];
-    uint64_t rbeg = offs[i], L = offs[i + 1] - rbeg;
-    uint64_t S = (rbeg - off0) + i;
+    const uint64_t L = offs[i + 1] - offs[i];
+    const uint64_t S = (offs[i] - off0) + i;
+    const uint64_t rbeg = starts ? starts[i] : offs[i];
     uint64_t s = 0;
     while (s < L) {
         bool good = is_acgt(bases[rbeg + s]);
@@ -167,8 +169,11 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     const uint64_t n = reads->n_reads;
     const unsigned char* d_bases;
     const uint64_t* d_offs;
+    const uint64_t* d_starts = nullptr;
     uint64_t total;
+    if (reads->starts && !reads->on_device) { ctx->err = "fgpu_reads.starts needs a device batch"; return FGPU_ERR_ARG; }
     if (reads->on_device) {
+        d_starts = reads->starts;
         uint64_t ends[2];
         FGPU_HIP(hipMemcpyAsync(&ends[0], reads->offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
         FGPU_HIP(hipMemcpyAsync(&ends[1], reads->offsets + n, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -211,9 +216,9 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if ((rc = fgpu_ensure(ctx, &bb.bad, (bb.n_words + FGPU_PADW) * 8))) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.readflag, n + 16))) return rc;
     FGPU_HIP(hipMemsetAsync(bb.readflag.p, 0, n, ctx->stream));
-    FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) * 8, 256), 256, d_bases, d_offs, n, T, bb.n_words, (uint64_t*)bb.codes.p,
+    FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) * 8, 256), 256, d_bases, d_offs, d_starts, n, T, bb.n_words, (uint64_t*)bb.codes.p,
                 (uint64_t*)bb.bad.p, (unsigned char*)bb.readflag.p);
-    FGPU_LAUNCH("pack_fix", k_pack_fix, fgpu_blocks(n, 256), 256, d_bases, d_offs, n, (unsigned long long*)bb.codes.p,
+    FGPU_LAUNCH("pack_fix", k_pack_fix, fgpu_blocks(n, 256), 256, d_bases, d_offs, d_starts, n, (unsigned long long*)bb.codes.p,
                 (unsigned long long*)bb.bad.p, (const unsigned char*)bb.readflag.p, &ctx->counters->max_read_len);
     return FGPU_OK;
 }

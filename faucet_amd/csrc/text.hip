@@ -1,0 +1,139 @@
+// text.hip — input side: FASTA / FASTQ record splitting on the device.
+//
+// Replaces the reading loops of the reference (utils/Bloom.cpp:280-282,340; src/ReadScanner.cpp:306-308,349):
+//     while (getline(header)) { getline(sequence); ...; if (fastq) { getline; getline; } }
+// A record is P = 2 (FASTA) or 4 (FASTQ) lines; its read is line 1 of the record, whatever the lines contain (the
+// reference never looks at '>' / '@' / '+').  On a chunk of raw file text:
+//   k_text_newlines   one lane per byte, ballot -> newline bit plane + per-word counts
+//   rocPRIM scan      rank of every newline
+//   k_text_records    every newline of rank m: m % P == 0 ends a header (the read starts behind it), m % P == 1 ends a read,
+//                     m % P == P-1 ends a record
+//   rocPRIM scan      lengths -> offsets
+// The batch handed out points INTO the text (fgpu_reads.starts): no compaction copy; pack.hip reads the bases from there.
+// Streaming (1 byte read per byte of text), negligible next to the passes; it exists so that a host does not spend
+// seconds in getline per pass while the device needs a tenth of that for the pass itself.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "fgpu_ctx.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_text_newlines(const unsigned char* __restrict__ text, uint64_t n, uint64_t n_words,
+                                                       uint64_t* __restrict__ nl, uint32_t* __restrict__ count) {
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t m = __ballot(p < n && text[p] == '\n');
+        if (fd_lane() == 0) {
+            nl[p >> 6] = m;
+            count[p >> 6] = (uint32_t)__popcll(m);
+        }
+    }
+}
+
+// defaults for records whose header / read line is not terminated inside the text (only possible in the final chunk):
+// an absent read is empty, an unterminated one runs to the end of the text
+__global__ void __launch_bounds__(256) k_text_defaults(uint64_t* __restrict__ starts, uint64_t* __restrict__ ends, uint64_t n_rec, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t)gridDim.x * blockDim.x) {
+        starts[i] = n;
+        ends[i] = n;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_text_records(const uint64_t* __restrict__ nl, const uint32_t* __restrict__ rank, uint64_t n_words,
+                                                      uint32_t P, uint64_t n_rec, uint64_t* __restrict__ starts, uint64_t* __restrict__ ends,
+                                                      uint64_t* __restrict__ rec_end) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t bits = nl[w];
+        uint64_t m = rank[w];
+        while (bits) {
+            const uint64_t pos = w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const uint64_t r = m / P, c = m % P;
+            if (r < n_rec) {
+                if (c == 0) starts[r] = pos + 1;
+                else if (c == 1) ends[r] = pos;
+                if (c == P - 1) rec_end[r] = pos + 1;
+            }
+            m++;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_text_lengths(const uint64_t* __restrict__ starts, const uint64_t* __restrict__ ends, uint64_t n_rec,
+                                                      uint64_t* __restrict__ len) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_rec; i += (uint64_t)gridDim.x * blockDim.x)
+        len[i] = i < n_rec ? ends[i] - starts[i] : 0;   // one extra 0 so that the exclusive scan also yields the total
+}
+
+}  // namespace
+
+extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
+                               fgpu_reads* out, uint64_t* consumed) {
+    if (!ctx || !out || !consumed || (nbytes && !text)) return FGPU_ERR_ARG;
+    if (ctx->phase == 2 && !ctx->prepared.empty()) { ctx->err = "fgpu_text_split while prepared batches still point into the previous text"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    memset(out, 0, sizeof(*out));
+    out->on_device = 1;
+    *consumed = 0;
+    if (nbytes == 0) return FGPU_OK;
+    int rc;
+    const unsigned char* d_text;
+    if (text_on_device) {
+        d_text = (const unsigned char*)text;
+    } else {
+        if ((rc = fgpu_ensure(ctx, &ctx->text_buf, nbytes + 64))) return rc;
+        FGPU_HIP(hipMemcpyAsync(ctx->text_buf.p, text, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        d_text = (const unsigned char*)ctx->text_buf.p;
+    }
+    const uint64_t n_words = (nbytes + 63) / 64;
+    const uint32_t P = fastq ? 4u : 2u;
+    if ((rc = fgpu_ensure(ctx, &ctx->text_nl, n_words * 8))) return rc;
+    if ((rc = fgpu_ensure(ctx, &ctx->text_rank, (2 * n_words + 2) * 4))) return rc;
+    uint64_t* nl = (uint64_t*)ctx->text_nl.p;
+    uint32_t* count = (uint32_t*)ctx->text_rank.p;
+    uint32_t* rank = count + n_words + 1;
+    FGPU_LAUNCH("text_newlines", k_text_newlines, fgpu_grid(n_words * 64, 256), 256, d_text, nbytes, n_words, nl, count);
+    size_t tmp_bytes = 0, tmp2 = 0;
+    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), ctx->stream));
+    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, n_words * 64 / 2 + 2, rocprim::plus<uint64_t>(), ctx->stream));
+    if (tmp2 > tmp_bytes) tmp_bytes = tmp2;   // the second scan (at most one record per 2 bytes) reuses the scratch
+    if ((rc = fgpu_ensure(ctx, &ctx->text_tmp, tmp_bytes + 16))) return rc;
+    FGPU_HIP(rocprim::exclusive_scan(ctx->text_tmp.p, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), ctx->stream));
+    uint32_t last[2];
+    unsigned char last_byte = 0;
+    FGPU_HIP(hipMemcpyAsync(&last[0], count + n_words - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&last[1], rank + n_words - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&last_byte, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t n_newlines = (uint64_t)last[0] + last[1];
+    // lines as getline counts them: every '\n' ends one; at the end of the file a non-empty unterminated tail is one more
+    const uint64_t n_lines = n_newlines + ((final_chunk && last_byte != '\n') ? 1 : 0);
+    const uint64_t n_rec = final_chunk ? (n_lines + P - 1) / P : n_newlines / P;
+    if (n_rec == 0) return FGPU_OK;   // not even one complete record: the caller reads more
+    if (n_rec >= 0xFFFFFFFFULL) { ctx->err = "more than 2^32 records in one chunk of text"; return FGPU_ERR_CAPACITY; }
+    if ((rc = fgpu_ensure(ctx, &ctx->text_rec, (4 * n_rec + 4) * 8))) return rc;
+    uint64_t* starts = (uint64_t*)ctx->text_rec.p;
+    uint64_t* ends = starts + n_rec;         // becomes the lengths
+    uint64_t* offsets = ends + n_rec + 1;    // n_rec + 1 entries
+    uint64_t* rec_end = offsets + n_rec + 1;
+    FGPU_LAUNCH("text_defaults", k_text_defaults, fgpu_grid(n_rec, 256), 256, starts, ends, n_rec, nbytes);
+    FGPU_HIP(hipMemsetAsync(rec_end, 0, n_rec * 8, ctx->stream));
+    FGPU_LAUNCH("text_records", k_text_records, fgpu_grid(n_words, 256), 256, (const uint64_t*)nl, (const uint32_t*)rank, n_words, P, n_rec,
+                starts, ends, rec_end);
+    FGPU_LAUNCH("text_lengths", k_text_lengths, fgpu_grid(n_rec + 1, 256), 256, (const uint64_t*)starts, (const uint64_t*)ends, n_rec, ends);
+    size_t need = tmp_bytes;
+    FGPU_HIP(rocprim::exclusive_scan(ctx->text_tmp.p, need, ends, offsets, (uint64_t)0, n_rec + 1, rocprim::plus<uint64_t>(), ctx->stream));
+    uint64_t used = nbytes;
+    if (!final_chunk) {
+        FGPU_HIP(hipMemcpyAsync(&used, rec_end + n_rec - 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *consumed = used;
+    out->bases = (const char*)d_text;
+    out->offsets = offsets;
+    out->starts = starts;
+    out->n_reads = n_rec;
+    return FGPU_OK;
+}

@@ -66,12 +66,17 @@ typedef struct {
 /* A batch of sequence lines in file order: read i = bases[offsets[i] .. offsets[i+1]).  Any byte
  * may occur; everything except upper-case A C G T splits a read exactly as isValidNuc /
  * getUnambiguousReads do (utils/Kmer.cpp:50-80).  offsets[0] need not be 0.
- * on_device != 0: both pointers are device (HBM) pointers on params.device. */
+ * on_device != 0: all pointers are device (HBM) pointers on params.device.
+ * starts != NULL (device batches only): the reads are not contiguous in `bases` -- read i is
+ * bases[starts[i] .. starts[i] + offsets[i+1] - offsets[i]) (sequence lines inside raw FASTA/FASTQ text,
+ * see fgpu_text_split); offsets still carries the lengths as differences. */
 typedef struct {
     const char*     bases;
     const uint64_t* offsets;    /* n_reads + 1 entries */
     uint64_t        n_reads;
     int32_t         on_device;
+    int32_t         reserved;
+    const uint64_t* starts;     /* n_reads entries, or NULL */
 } fgpu_reads;
 
 typedef struct {
@@ -157,6 +162,19 @@ int fgpu_bloom_devptr(fgpu_ctx* ctx, int which, void** dptr, uint64_t* nbytes);
 /* dst |= src over nbytes (device pointers, nbytes multiple of 16): the local step of the
  * prefix-OR / OR-allreduce that RCCL cannot express as a reduction op. */
 int fgpu_bitmap_or(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t nbytes);
+
+/* ---- input side: record splitting on the device ------------------------------------------------
+ * The reference's reading loop (utils/Bloom.cpp:280-282,340; src/ReadScanner.cpp:306-308,349):
+ *     while (getline(header)) { getline(sequence); ...; if (fastq) { getline; getline; } }
+ * applied to `nbytes` of file text (host or device memory).  Fills *out with a DEVICE batch (bases = the text on the
+ * device, starts/offsets = the sequence line of every record) that stays valid until the next fgpu_text_split on this
+ * context, ready for fgpu_load_batch / fgpu_scan_batch / fgpu_presence_batch.
+ * final_chunk == 0: only records whose 2 (FASTA) or 4 (FASTQ) lines all end inside the text are taken; *consumed = bytes
+ * they occupy -- the caller prepends the rest to the next chunk.  final_chunk != 0: the text ends the file; a last line
+ * without a newline, a missing sequence line (empty read) and missing FASTQ tail lines are handled as getline handles
+ * them; *consumed = nbytes.  A carriage return before the newline stays part of the line, as it does in the reference. */
+int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
+                    fgpu_reads* out, uint64_t* consumed);
 
 /* ---- pass 2: junction scan (replaces ReadScanner::scanReads, src/ReadScanner.cpp:284-359) ------- */
 /* Uses bloo2 as resident on the device (after fgpu_load_end or fgpu_bloom_upload). */

@@ -487,3 +487,86 @@ def test_config4_sized_filters_index_past_32_bits(log_tai, nh):
     assert sst["valid_reused"] == lst.to_bloo2
     _scan_equals_oracle(sc, sst, osc)
     ctx.close()
+
+
+def _getline_records(text: bytes, fastq: bool):
+    """the reference's reading loop (utils/Bloom.cpp:280-282,340) in Python: the sequence line of every record"""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()                     # a final newline does not start another line
+    reads, i = [], 0
+    while i < len(lines):
+        i += 1                          # header (whatever it contains)
+        reads.append(lines[i] if i < len(lines) else b"")
+        i += 1
+        if fastq:
+            i += 2
+    return reads
+
+
+def _load_split(ctx, text, fastq, chunk):
+    """stream `text` through fgpu_text_split in chunks of `chunk` bytes, carrying the unconsumed tail, into a load pass"""
+    ctx.load_begin()
+    carry, pos, n_reads = b"", 0, 0
+    while True:
+        nxt = text[pos:pos + chunk]
+        pos += len(nxt)
+        final = pos >= len(text)
+        buf = carry + nxt
+        rb, used = ctx.text_split(buf, fastq, final)
+        if rb.n_reads:
+            ctx.load_batch(rb)
+            n_reads += rb.n_reads
+        carry = buf[used:]
+        if final:
+            assert used == len(buf)
+            break
+    return ctx.load_end(), n_reads
+
+
+@pytest.mark.parametrize("name", ["c1_k21", "pe_fastq_k21", "ragged_k31"])
+@pytest.mark.parametrize("chunk", [1 << 30, 4099, 997])
+def test_device_record_splitting_reproduces_the_reference_bloom(name, chunk):
+    c = Case(name)
+    text = c.reads_text()
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer)
+    st, n_reads = _load_split(ctx, text, c.fastq, chunk)
+    assert n_reads == len(c.lines()) == st["reads_processed"]
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), c.bloom())
+    # and the scan of a split batch (whole text) gives the reference's junctions
+    rb, used = ctx.text_split(text, c.fastq, True)
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads([rb])
+    keys, recs = sc.junctions()
+    assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
+    assert sst["valid_reused"] == 0 or chunk == 1 << 30        # same batch as the load only when the load was one chunk
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_device_record_splitting_edge_cases_follow_getline(fastq):
+    k = 5
+    seqs = [b"ACGTTGCATGCA", b"", b"ACGTNNACGTACGTAC", b"TTTTTTTTTT\r", b"acgtACGTACGTAA", b"GATTACAGATTACA"]
+    def record(i, s):
+        return (b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n") if fastq else (b">r%d\n" % i + s + b"\n")
+    full = b"".join(record(i, s) for i, s in enumerate(seqs))
+    texts = [full, full[:-1],                       # no final newline
+             full + (b"@last\n" if fastq else b">last\n"),        # header without a sequence line: an empty read
+             full + (b"@last" if fastq else b">last"),            # ... unterminated
+             full + (b"@x\nACGTACGTAC" if fastq else b">x\nACGTACGTAC"),   # unterminated sequence line / missing FASTQ tail
+             full + (b"@x\nACGTACGTAC\n+" if fastq else b">x\nACGTACGTAC\n>y"),
+             b"\n\n" + full, b"", b"\n", b"ACGT"]
+    for text in texts:
+        want = _getline_records(text, fastq)
+        for chunk in (1 << 20, 7, 23):
+            ctx = api.Context(k, 1 << 12, 2)
+            st, n_reads = _load_split(ctx, text, fastq, chunk)
+            assert n_reads == len(want), (text, chunk)
+            ref = api.Context(k, 1 << 12, 2)
+            ref.load_begin()
+            if want:
+                ref.load_batch(api.ReadBatch.from_lines(want))
+            rst = ref.load_end()
+            assert st["kmers"] == rst["kmers"] and st["unambiguous_reads"] == rst["unambiguous_reads"], (text, chunk)
+            assert np.array_equal(ctx.bloom_download(L.BLOO1), ref.bloom_download(L.BLOO1)), (text, chunk)
+            assert np.array_equal(ctx.bloom_download(L.BLOO2), ref.bloom_download(L.BLOO2)), (text, chunk)
