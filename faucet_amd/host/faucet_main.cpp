@@ -38,7 +38,8 @@ struct Options {   // globals of src/Faucet.h:14-53
     bool two_hash = false, from_bloom = false, from_junctions = false, just_load = false, fastq = false, mercy = false,
          node_graph = false, paired_ends = false, no_cleaning = false, high_cov = false;
     int max_spacer_dist = 100;
-    uint64_t batch_reads = 2000000;   // not a reference flag: reads handed to the device per call (-batch_reads)
+    uint64_t batch_reads = 0;         // not a reference flag: > 0 = split records on the host, this many reads per device call
+    uint64_t chunk_mb = 256;          // not a reference flag: file text handed to the device per call, records split there
 };
 
 void argument_error() {   // src/Faucet.cpp:50-54
@@ -77,6 +78,7 @@ int handle_arguments(int argc, char** argv, Options& o) {
         else if (a == "-max_spacer_dist") { if (!val(v)) goto bad; o.max_spacer_dist = atoi(v); }
         else if (a == "-junctions_file") { if (!val(v)) goto bad; o.junctions_prefix = v; o.from_junctions = true; }
         else if (a == "-batch_reads") { if (!val(v)) goto bad; o.batch_reads = (uint64_t)atoll(v); }
+        else if (a == "-chunk_mb") { if (!val(v)) goto bad; o.chunk_mb = (uint64_t)atoll(v); if (!o.chunk_mb) o.chunk_mb = 1; }
         else if (a == "--help" || a == "-h") { argument_error(); return 1; }
         else { fprintf(stderr, "Cannot parse tag %s\n", argv[i]); argument_error(); return 1; }
         continue;
@@ -135,6 +137,64 @@ public:
 private:
     std::ifstream in_;
     bool fastq_;
+};
+
+// The same loop with the records split on the device (fgpu_text_split): the host only moves file text, `chunk` bytes at a
+// time, and carries the unconsumed tail (an incomplete record) over to the next call.  Works on non-seekable input.
+class TextSource {
+public:
+    TextSource(const std::string& path, bool fastq, uint64_t chunk) : f_(fopen(path.c_str(), "rb")), fastq_(fastq), chunk_(chunk) {}
+    ~TextSource() { if (f_) fclose(f_); }
+    bool is_open() const { return f_ != nullptr; }
+    // 1 = a batch (device pointers, valid until the next call), 0 = input exhausted, < 0 = -status of a failed call
+    int next(fgpu_ctx* ctx, fgpu_reads* out) {
+        for (;;) {
+            if (eof_ && fill_ == 0) return 0;
+            if (!eof_) {
+                if (buf_.size() < fill_ + chunk_) buf_.resize(fill_ + chunk_);
+                const size_t got = fread(buf_.data() + fill_, 1, chunk_, f_);
+                fill_ += got;
+                if (got < chunk_) eof_ = true;
+            }
+            uint64_t used = 0;
+            const int rc = fgpu_text_split(ctx, buf_.data(), fill_, 0, fastq_ ? 1 : 0, eof_ ? 1 : 0, out, &used);
+            if (rc != FGPU_OK) return -rc;
+            memmove(buf_.data(), buf_.data() + used, fill_ - used);
+            fill_ -= used;
+            if (out->n_reads) return 1;
+            if (eof_) return 0;          // nothing but an empty tail
+            // no complete record inside a whole chunk (a very long line): keep the text and read on
+        }
+    }
+private:
+    FILE* f_;
+    bool fastq_, eof_ = false;
+    uint64_t chunk_;
+    std::vector<char> buf_;
+    size_t fill_ = 0;
+};
+
+// one interface over both ways of cutting the input into batches
+class BatchSource {
+public:
+    BatchSource(const Options& o, const std::string& path)
+        : host_(o.batch_reads ? new ReadSource(path, o.fastq) : nullptr),
+          text_(o.batch_reads ? nullptr : new TextSource(path, o.fastq, o.chunk_mb << 20)), batch_reads_(o.batch_reads) {}
+    ~BatchSource() { delete host_; delete text_; }
+    bool is_open() const { return host_ ? host_->is_open() : text_->is_open(); }
+    int next(fgpu_ctx* ctx, fgpu_reads* out) {
+        if (text_) return text_->next(ctx, out);
+        if (!host_->next(batch_reads_, bases_, offsets_)) return 0;
+        fgpu_reads r = {bases_.data(), offsets_.data(), offsets_.size() - 1, 0, 0, nullptr};
+        *out = r;
+        return 1;
+    }
+private:
+    ReadSource* host_;
+    TextSource* text_;
+    uint64_t batch_reads_;
+    std::vector<char> bases_;
+    std::vector<uint64_t> offsets_;
 };
 
 #define CHECK(call)                                                                   \
@@ -358,8 +418,6 @@ int main(int argc, char** argv) {
         int rc = fgpu_create(&prm, &ctx);
         if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(nullptr)); return 2; }
     }
-    std::vector<char> bases;
-    std::vector<uint64_t> offsets;
     std::vector<uint8_t> bloom_bytes(tai / 8);
 
     // ---- pass 1 (load_two_filters, utils/Bloom.cpp:267-350) or -bloom_file (Bloom::load, :580-587)
@@ -373,15 +431,16 @@ int main(int argc, char** argv) {
         CHECK(fgpu_bloom_upload(ctx, FGPU_BLOO2, bloom_bytes.data(), bloom_bytes.size()));
         printf("bloom loaded\n");
     } else {
-        ReadSource src(o.read_load_file, o.fastq);
+        BatchSource src(o, o.read_load_file);
         if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_load_file.c_str()); return 2; }   // the reference silently reads nothing
         time_t start, stop;
         time(&start);
         printf("Weights before load: %f, %f \n", 0.0f, 0.0f);
         CHECK(fgpu_load_begin(ctx, 0));
         uint64_t consumed = 0;
-        while (src.next(o.batch_reads, bases, offsets)) {
-            fgpu_reads r = {bases.data(), offsets.data(), offsets.size() - 1, 0};
+        fgpu_reads r;
+        for (int more; (more = src.next(ctx, &r)) != 0;) {
+            if (more < 0) { fprintf(stderr, "fgpu_text_split failed (%d): %s\n", -more, fgpu_last_error(ctx)); return 2; }
             CHECK(fgpu_load_batch(ctx, &r));
             consumed += r.n_reads;
             fprintf(stdout, "\rreads consumed: %lld", (long long)consumed);
@@ -417,7 +476,7 @@ int main(int argc, char** argv) {
 
     // ---- pass 2 (ReadScanner::scanReads, src/ReadScanner.cpp:284-359; printScanSummary :19-27)
     {
-        ReadSource src(o.read_scan_file, o.fastq);
+        BatchSource src(o, o.read_scan_file);
         if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_scan_file.c_str()); return 2; }
         time_t start, stop;
         time(&start);
@@ -451,8 +510,9 @@ int main(int argc, char** argv) {
             pairs.batch(view, batch_n_reads[(size_t)seq]);
             return 0;
         };
-        while (src.next(o.batch_reads, bases, offsets)) {
-            fgpu_reads r = {bases.data(), offsets.data(), offsets.size() - 1, 0};
+        fgpu_reads r;
+        for (int more; (more = src.next(ctx, &r)) != 0;) {
+            if (more < 0) { fprintf(stderr, "fgpu_text_split failed (%d): %s\n", -more, fgpu_last_error(ctx)); return 2; }
             CHECK(fgpu_scan_batch(ctx, &r));
             batch_n_reads.push_back(r.n_reads);
             if (want_lists && batch_n_reads.size() > 1) {

@@ -345,8 +345,9 @@ def test_two_shard_scan_table_handover_is_exact():
     assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
 
 
+@pytest.mark.parametrize("how", [["-batch_reads", "400"], [], ["-chunk_mb", "1"]])
 @pytest.mark.parametrize("name", ["c1_k21", "ragged_k31", "j2_spacer20_k15"])
-def test_cli_writes_the_reference_files(name, tmp_path):
+def test_cli_writes_the_reference_files(name, how, tmp_path):
     """The stand-alone host: same flags as the reference, byte-identical .bloom and .junctions (dump order included)."""
     import os
     import subprocess
@@ -355,8 +356,8 @@ def test_cli_writes_the_reference_files(name, tmp_path):
     reads.write_bytes(c.reads_text())
     args = [a if not a.endswith(".fa") else str(reads) for a in c.meta["args"]]
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
-    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
-                        "-batch_reads", "400"] + args, capture_output=True, text=True)
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out")]
+                       + how + args, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "out.bloom", dtype=np.uint8), c.bloom())
     assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
@@ -436,7 +437,7 @@ def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
     _scan_equals_oracle(ctx, sst, osc)
 
 
-@pytest.mark.parametrize("batch_reads", [400, 333, 100000])
+@pytest.mark.parametrize("batch_reads", [400, 333, 100000, 0])
 def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_path):
     """BASELINE config 3's shape: --fastq --paired_ends WITHOUT --no_cleaning.  All four files the reference writes before
     its contig-graph stage are byte-identical (the long pair filter is check-then-insert, i.e. order-dependent); the
@@ -447,8 +448,9 @@ def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_p
     reads = tmp_path / "reads.fq"
     reads.write_bytes(c.reads_text())
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
-    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
-                        "-batch_reads", str(batch_reads)] + c.meta["args"], capture_output=True, text=True)
+    how = ["-batch_reads", str(batch_reads)] if batch_reads else []      # 0: the default, records split on the device
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out")]
+                       + how + c.meta["args"], capture_output=True, text=True)
     assert r.returncode == 3, r.stderr
     assert np.array_equal(np.fromfile(tmp_path / "out.bloom", dtype=np.uint8), c.bloom())
     assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
@@ -459,7 +461,7 @@ def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_p
     assert f"Distinct junctions: {cn['distinct_junctions']} " in r.stdout
     # with --no_cleaning the pair filters stay empty and are not written, the pair counts are still reported
     r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "nc"),
-                        "-batch_reads", str(batch_reads), "--no_cleaning"] + c.meta["args"], capture_output=True, text=True)
+                        "--no_cleaning"] + how + c.meta["args"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert not (tmp_path / "nc.short_pair_filter").exists()
     assert f"Empty count: {cn['empty_count']}, not empty count: {cn['not_empty_count']}" in r.stdout
