@@ -81,6 +81,8 @@ def device_batches(reads, batch_reads):
         hi = min(n, lo + batch_reads)
         o = offs[lo:hi + 1]
         out.append(api.ReadBatch(reads.data_ptr(), o.data_ptr(), n_reads=hi - lo, on_device=True, keepalive=(reads, offs, o)))
+    # the library runs on its own non-blocking stream: what torch's stream is still writing (reads, offsets) must be finished
+    torch.cuda.synchronize(reads.device)
     return out
 
 

@@ -583,7 +583,8 @@ int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries) { return fgpu_sc
 int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries) {
     if (!ctx || !dev_buf || !n_entries) return FGPU_ERR_ARG;
     uint64_t n = 0;
-    int rc = fgpu_scan_junction_count(ctx, &n);
+    int rc = sync_all(ctx);   // walks still running on the walk stream are part of the table
+    if (!rc) rc = fgpu_scan_junction_count(ctx, &n);
     if (rc) return rc;
     if (buf_bytes < n * FGPU_TABLE_ENTRY_BYTES) { ctx->err = "export buffer too small"; return FGPU_ERR_CAPACITY; }
     if ((rc = fgpu_ensure(ctx, &ctx->export_stamps, n * 8 + 8))) return rc;
@@ -597,6 +598,9 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     if (rc) return rc;
     rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
     if (rc) return rc;
+    // the import runs on the main stream, the ordered walk on the walk stream behind events recorded BEFORE this call
+    // (end of each prepared batch's pure stage): without this wait the walk would start on a half-imported table
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
     ctx->scan_imported += n_entries;
     if (carried) ctx->carried = *carried;
     // creation stamps of this shard must sort after everything imported

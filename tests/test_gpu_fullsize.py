@@ -1,0 +1,170 @@
+"""BASELINE.json's configurations at their FULL sizes on one MI355X, through size-independent properties (the oracle needs
+minutes per configuration at these sizes, so it checks a sample; everything else is checked by invariants):
+
+* determinism under re-batching: other batch boundaries, another walk-window span, eager flags, no resident planes and
+  device-side record splitting must give the same bloo2 bytes and the same junction records in the same creation order;
+* sharding: the two-shard protocol (presence bitmaps -> prefix-OR -> ordered load with kept carry -> OR of bloo2; table
+  hand-over for the walk) gives the single-shard result;
+* filter algebra: bloo2 is a subset of bloo1's bits (an occurrence only goes to bloo2 when all its bits are in bloo1), weight =
+  popcount / tai, kmers = reads x (L - k + 1) for clean reads, to_bloo2 <= kmers;
+* a prefix sample against the oracle: the load of the first reads alone (exactly what the oracle computes).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+from faucet_amd import _lib as L
+from faucet_amd import api
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _run(reads, k, tai, nh, batch_reads, **ctx_kw):
+    ctx = api.Context(k, tai, nh, **ctx_kw)
+    batches = bench.device_batches(reads, batch_reads)
+    lst, sst, bloo2, keys, recs = bench.step_single(ctx, batches)
+    bloo1 = ctx.bloom_download(L.BLOO1)
+    w2 = ctx.bloom_weight(L.BLOO2)
+    ctx.close()
+    return lst, sst, bloo1, bloo2, keys, recs, w2
+
+
+@pytest.fixture(scope="module")
+def config2():
+    """10 M x 100 bp, k = 31, estimated_kmers 1e8 / singletons 2e7 (BASELINE config 2), in HBM"""
+    dev = torch.device("cuda", 0)
+    reads = bench.make_reads(bench.make_genome(20_000_000, 2, dev), 10_000_000, 100, 0.01, 1000, dev)
+    tai, nh = api.load_filter_shape(100_000_000, 20_000_000)
+    base = _run(reads, 31, tai, nh, 1_000_000)
+    return reads, tai, nh, base
+
+
+def test_config2_filter_algebra_and_counters(config2):
+    reads, tai, nh, (lst, sst, bloo1, bloo2, keys, recs, w2) = config2
+    assert (tai, nh) == (1 << 29, 3)
+    assert lst["kmers"] == 10_000_000 * 70 == sst["kmers"]
+    assert 0 < lst["to_bloo2"] < lst["kmers"]
+    assert not np.any(bloo2 & ~bloo1)                                   # bloo2's bits are a subset of bloo1's
+    pop2 = int(np.unpackbits(bloo2).sum())
+    assert f"{w2:f}" == f"{np.float32(pop2) / np.float32(tai):f}"
+    assert sst["reads_processed"] == 10_000_000 and sst["n_junctions"] == len(keys) > 100_000
+    assert len(np.unique(keys)) == len(keys)                            # one record per oriented junction k-mer
+    assert sst["nb_processed"] + sst["nb_skipped"] > 0 and sst["valid_reused"] == lst["to_bloo2"]
+    cov = recs["cov"].astype(np.int64).sum(axis=1)
+    assert cov.min() >= 1                                               # every junction was visited by the read that created it
+
+
+@pytest.mark.parametrize("variant", ["batches_2.5M", "span_2^18", "eager_flags", "no_resident", "batches_333333"])
+def test_config2_is_invariant_under_scheduling_choices(config2, variant):
+    reads, tai, nh, base = config2
+    kw, batch = {}, 1_000_000
+    if variant == "batches_2.5M":
+        batch = 2_500_000
+    elif variant == "batches_333333":
+        batch = 333_333
+    elif variant == "span_2^18":
+        kw["walk_window_span"] = 1 << 18
+    elif variant == "eager_flags":
+        kw["eager_flags"] = True
+    elif variant == "no_resident":
+        kw["keep_resident"] = False
+    lst, sst, bloo1, bloo2, keys, recs, _ = _run(reads, 31, tai, nh, batch, **kw)
+    b = base
+    assert lst["to_bloo2"] == b[0]["to_bloo2"]
+    assert _digest(bloo2) == _digest(b[3]) and _digest(bloo1) == _digest(b[2])
+    for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors", "unambiguous_reads"):
+        assert sst[key] == b[1][key], key
+    assert np.array_equal(keys, b[4])                                    # same records, same creation order
+    assert _digest(recs) == _digest(b[5])
+
+
+def test_config2_prefix_sample_against_the_oracle(config2):
+    """the first 150 k reads alone: the device result must be the oracle's, bit for bit (same 64 MiB filters)"""
+    reads, tai, nh, _ = config2
+    n = 150_000
+    sample = reads[:n].contiguous()
+    lst, sst, bloo1, bloo2, keys, recs, _ = _run(sample, 31, tai, nh, 60_000)
+    bases, offs = po.reads_from_matrix(sample.cpu().numpy())
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    olst = po.load_two_filters(b1, b2, bases, offs, 31)
+    assert np.array_equal(bloo2, b2.bits()) and np.array_equal(bloo1, b1.bits())
+    assert lst["to_bloo2"] == olst.to_bloo2
+    osc = po.Scanner(31, 1, 100, b2)
+    osc.scan_reads(bases, offs)
+    okeys, orecs = osc.junctions("creation")
+    assert np.array_equal(keys, okeys) and np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
+
+
+def test_config2_two_shards_equal_one(config2):
+    """reads 0..5M on shard A, 5M..10M on shard B (one process, two contexts): the exchange steps of DESIGN.md section 5"""
+    reads, tai, nh, base = config2
+    half = reads.shape[0] // 2
+    parts = [bench.device_batches(reads[:half], 1_000_000), bench.device_batches(reads[half:], 1_000_000)]
+    ctxs = [api.Context(31, tai, nh), api.Context(31, tai, nh)]
+    pres = []
+    for ctx, bs in zip(ctxs, parts):                   # presence bitmaps (would be all-gathered)
+        ctx.load_begin(); ctx.load_end()
+        for b in bs:
+            ctx.presence_batch(b)
+        pres.append(ctx.bloom_download(L.BLOO1))
+    st = []
+    for r, (ctx, bs) in enumerate(zip(ctxs, parts)):   # carried-in bloo1 = OR of the earlier shards' presence
+        ctx.bloom_upload(L.BLOO1, np.zeros_like(pres[0]) if r == 0 else pres[0])
+        ctx.load_begin(keep_carry=True)
+        for b in bs:
+            ctx.load_batch(b)
+        st.append(ctx.load_end())
+    bloo2 = ctxs[0].bloom_download(L.BLOO2) | ctxs[1].bloom_download(L.BLOO2)
+    assert _digest(bloo2) == _digest(base[3])
+    assert st[0]["to_bloo2"] + st[1]["to_bloo2"] == base[0]["to_bloo2"]
+    for ctx in ctxs:
+        ctx.bloom_upload(L.BLOO2, bloo2)
+    # scan: both shards prepare, the walk goes A then B with the table handed over
+    for ctx, bs in zip(ctxs, parts):
+        ctx.scan_begin()
+        for b in bs:
+            ctx.scan_prepare(b)
+    ctxs[0].scan_walk_prepared()
+    sa = ctxs[0].scan_end()
+    n_entries = ctxs[0].table_entries()
+    table = torch.empty(max(n_entries, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=reads.device)
+    assert ctxs[0].export_table(table.data_ptr(), table.numel()) == n_entries
+    ctxs[1].import_table(table.data_ptr(), n_entries, carried=sa)
+    ctxs[1].scan_walk_prepared()
+    sb = ctxs[1].scan_end()
+    keys, recs = ctxs[1].junctions()
+    assert np.array_equal(keys, base[4]) and _digest(recs) == _digest(base[5])
+    for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors", "reads_processed"):
+        assert sb[key] == base[1][key], key
+
+
+def test_config5_two_hash_high_error_150bp():
+    """BASELINE config 5's shape (--two_hash, 150 bp reads, 5 % errors: dense junctions) at 2 M reads: invariance under
+    re-batching on the device, and a 60 k-read prefix against the oracle."""
+    dev = torch.device("cuda", 0)
+    k, Lr, n = 31, 150, 2_000_000
+    reads = bench.make_reads(bench.make_genome(6_000_000, 5, dev), n, Lr, 0.05, 77, dev)
+    bits, tai, nh = api.size_two_hash(400_000_000, 0.04)
+    assert nh == 2
+    a = _run(reads, k, tai, nh, 500_000)
+    b = _run(reads, k, tai, nh, 777_777, walk_window_span=1 << 19)
+    assert _digest(a[3]) == _digest(b[3]) and np.array_equal(a[4], b[4]) and _digest(a[5]) == _digest(b[5])
+    assert a[0]["kmers"] == n * (Lr - k + 1)
+    sample = reads[:60_000].contiguous()
+    lst, sst, bloo1, bloo2, keys, recs, _ = _run(sample, k, tai, nh, 25_000)
+    bases, offs = po.reads_from_matrix(sample.cpu().numpy())
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    po.load_two_filters(b1, b2, bases, offs, k)
+    assert np.array_equal(bloo2, b2.bits())
+    osc = po.Scanner(k, 1, 100, b2)
+    osc.scan_reads(bases, offs)
+    okeys, orecs = osc.junctions("creation")
+    assert np.array_equal(keys, okeys) and np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["linked"], orecs["linked"])
