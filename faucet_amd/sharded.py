@@ -23,6 +23,34 @@ _STAT_NAMES = [n for n, _ in L.ScanStats._fields_]
 HEADER_WORDS = 1 + len(_STAT_NAMES)          # [entries in the table, carried scan counters...]
 
 
+# RCCL moves device tensors directly.  With the gloo backend (CPU tests; two ranks sharing one GPU when no multi-GPU box is
+# at hand) device tensors are staged through host memory: same protocol, same library calls, another transport.
+def _staged(t):
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather(out, t):
+    if _staged(t):
+        h = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(h, t.cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, t)
+
+
+def _send(t, dst):
+    dist.send(t.cpu() if _staged(t) else t, dst=dst)
+
+
+def _recv(t, src):
+    if _staged(t):
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src=src)
+        t.copy_(h)
+    else:
+        dist.recv(t, src=src)
+
+
 def load_sharded(backend, batches, rank: int, world: int):
     """Returns this shard's load stats; afterwards every rank holds the global bloo2."""
     backend.clear_filters()
@@ -32,7 +60,7 @@ def load_sharded(backend, batches, rank: int, world: int):
     nbytes = b1.numel()
     gathered = backend.scratch(world * nbytes)
     backend.fence()
-    dist.all_gather_into_tensor(gathered, b1)
+    _all_gather(gathered, b1)
     backend.fence()
     b1.zero_()
     backend.fence()
@@ -41,7 +69,7 @@ def load_sharded(backend, batches, rank: int, world: int):
     stats = backend.load(batches, keep_carry=True)
     b2 = backend.bloom_tensor(L.BLOO2)
     backend.fence()
-    dist.all_gather_into_tensor(gathered, b2)
+    _all_gather(gathered, b2)
     backend.fence()
     for q in range(world):                                 # OR-allreduce
         if q != rank:
@@ -57,11 +85,11 @@ def scan_sharded(backend, batches, rank: int, world: int):
         backend.scan_prepare(b)                            # pure stage: all ranks concurrently
     hdr = backend.header_tensor()
     if rank > 0:
-        dist.recv(hdr, src=rank - 1)
+        _recv(hdr, rank - 1)
         h = hdr.cpu().tolist()
         n_in = int(h[0])
         buf = backend.scratch(max(n_in, 1) * L.TABLE_ENTRY_BYTES, tag="table_in")
-        dist.recv(buf, src=rank - 1)
+        _recv(buf, rank - 1)
         backend.fence()
         backend.import_table(buf, n_in, dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]])))
     backend.scan_walk_prepared()                           # ordered walk of this shard
@@ -72,8 +100,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
         hdr.zero_()
         hdr[0] = n_out
         hdr[1:1 + len(_STAT_NAMES)] = torch.tensor([stats[n] for n in _STAT_NAMES], dtype=torch.int64)
-        dist.send(hdr, dst=rank + 1)
-        dist.send(buf, dst=rank + 1)
+        _send(hdr, rank + 1)
+        _send(buf, rank + 1)
     return stats, rank == world - 1
 
 

@@ -168,3 +168,22 @@ def test_config5_two_hash_high_error_150bp():
     osc.scan_reads(bases, offs)
     okeys, orecs = osc.junctions("creation")
     assert np.array_equal(keys, okeys) and np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["linked"], orecs["linked"])
+
+
+@pytest.mark.parametrize("ranks,per_rank", [(2, 2_000_000), (3, 700_000)])
+def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank):
+    """bench.py's multi-GPU path (sharded.py over GpuShard) in real separate processes, one per rank, all on this GPU with gloo as
+    the transport (scripts/two_rank_check.py): result identical to one context fed all shards in file order."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "scripts", "two_rank_check.py"), str(per_rank)],
+                       capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "RESULT PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
