@@ -190,6 +190,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch sees no GPU (there is no CPU fallback)")
     if args.profile_walk:
         os.environ["FGPU_PROFILE_WALK"] = "1"
+    # FAUCET_SHARE_GPU=1 + FAUCET_DIST_BACKEND=gloo: all ranks on cuda:0 with gloo as the transport -- a way to run the N > 1 code
+    # path on a single-GPU box (functional check only; never a scaling number)
+    if os.environ.get("FAUCET_SHARE_GPU", "0") == "1":
+        local_rank = 0
+    backend = os.environ.get("FAUCET_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # FAUCET_FORCE_SHARDED=1 runs the multi-GPU code path (RCCL collectives, table hand-over) even with one rank, so that
@@ -199,9 +204,9 @@ def main():
         if "RANK" not in os.environ:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": device} if backend == "nccl" else {}))
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
     k, L_ = args.k, args.read_len
     E, S = args.estimated_kmers * world, args.singletons * world
