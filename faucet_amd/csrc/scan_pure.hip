@@ -400,7 +400,10 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
         if ((rc = fgpu_stage_scan_need(ctx))) return rc;
         DevBuf* outs[] = {&bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1};
         for (DevBuf* o : outs) FGPU_HIP(hipMemsetAsync(o->p, 0, wb, ctx->stream));
-        FGPU_LAUNCH("scan_flags", k_scan_flags, fgpu_grid(bb.n_words * 16, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
+        // twice the usual grid: shorter-lived blocks free wave slots more often, which lets the high-priority walk kernels of the
+        // previous batch in sooner (walk stage 86 -> 80 ms per step; beyond 16 K blocks the flags kernel itself slows down)
+        const unsigned flags_grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(bb.n_words / 16, 1), 2 * FGPU_GRID_BLOCKS);
+        FGPU_LAUNCH("scan_flags", k_scan_flags, flags_grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
                     (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
                     (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,
                     (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters);
