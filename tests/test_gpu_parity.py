@@ -572,3 +572,91 @@ def test_device_record_splitting_edge_cases_follow_getline(fastq):
             assert st["kmers"] == rst["kmers"] and st["unambiguous_reads"] == rst["unambiguous_reads"], (text, chunk)
             assert np.array_equal(ctx.bloom_download(L.BLOO1), ref.bloom_download(L.BLOO1)), (text, chunk)
             assert np.array_equal(ctx.bloom_download(L.BLOO2), ref.bloom_download(L.BLOO2)), (text, chunk)
+
+
+def _check_against_oracle(bases, offs, k, E, S, j, spacer=100, load_chunks=3, scan_chunks=2, **ctx_kw):
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, j, spacer)
+    ctx = api.Context(k, tai, nh, j=j, max_spacer_dist=spacer, **ctx_kw)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, load_chunks))
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits()) and np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    assert st["kmers"] == lst.kmers and st["to_bloo2"] == lst.to_bloo2
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, scan_chunks))
+    _scan_equals_oracle(sc, sst, osc)
+    return sst
+
+
+def test_reads_of_two_thousand_bases():
+    """pieces far beyond the 128 windows the walk keeps in registers"""
+    bases, offs = _random_case(1500, 2000, 31, 60000, 0.01, 11, 0.0005, 4)
+    _check_against_oracle(bases, offs, 31, 2_000_000, 400_000, 1)
+
+
+@pytest.mark.parametrize("j", [3, 4])
+def test_deeper_jcheck(j):
+    bases, offs = _random_case(10000, 120, 23, 15000, 0.02, 70 + j, 0.0, 6)
+    _check_against_oracle(bases, offs, 23, 800_000, 200_000, j)
+
+
+@pytest.mark.parametrize("period,k", [(7, 15), (53, 21), (200, 31)])
+def test_periodic_genome_tandem_repeats(period, k):
+    """the same k-mer many times inside one piece and in every piece: created-key tracking inside clusters, giant clusters"""
+    rng = np.random.default_rng(period)
+    unit = synth._ACGT[rng.integers(0, 4, size=period)]
+    genome = np.tile(unit, 40000 // period + 2)[:40000].copy()
+    mut = rng.random(genome.shape) < 0.002                      # a few point differences between the copies
+    genome[mut] = synth._ACGT[rng.integers(0, 4, size=int(mut.sum()))]
+    r = synth.make_reads(genome, 6000, 150, 0.004, period + 1)
+    bases, offs = po.reads_from_matrix(r)
+    sst = _check_against_oracle(bases, offs, k, 500_000, 100_000, 1, scan_chunks=3)
+    assert sst["walk_max_cluster"] >= 2
+
+
+def test_many_tiny_reads_and_small_spacer():
+    """reads shorter than a 64-position word (the pack kernel's slow path), shorter than k, empty; spacer rule firing often"""
+    rng = np.random.default_rng(5)
+    g = synth.make_genome(5000, 9)
+    lines = []
+    for _ in range(30000):
+        ln = int(rng.integers(0, 70))
+        s = int(rng.integers(0, 5000 - 70))
+        lines.append(bytes(g[s:s + ln]))
+    bases, offs = po.reads_from_lines(lines)
+    _check_against_oracle(bases, offs, 11, 200_000, 50_000, 1, spacer=6, load_chunks=4, scan_chunks=5)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_small_inputs_against_the_oracle(seed):
+    """random k, j, spacer, read lengths, alphabets and batchings on small inputs (where corner cases live)"""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(3, 32))
+    j = int(rng.integers(0, 4))
+    spacer = int(rng.choice([2, 5, 20, 100]))
+    G = int(rng.integers(200, 4000))
+    g = synth.make_genome(G, seed, repeats=int(rng.integers(0, 4)), repeat_len=min(G // 4, 3 * k))
+    alphabet = np.frombuffer(rng.choice([b"ACGT", b"ACGTN", b"ACGTNacgt-"]), dtype=np.uint8)
+    lines = []
+    for _ in range(int(rng.integers(1, 1500))):
+        ln = int(rng.integers(0, min(G, int(rng.choice([40, 130, 400])))))
+        s = int(rng.integers(0, G - ln + 1))
+        r = g[s:s + ln].copy()
+        m = rng.random(ln) < rng.choice([0.0, 0.01, 0.05])
+        r[m] = alphabet[rng.integers(0, len(alphabet), size=int(m.sum()))]
+        if rng.random() < 0.5:
+            r = synth._COMP[r[::-1]]
+            r[r == 0] = ord("N")
+        lines.append(bytes(r))
+    bases, offs = po.reads_from_lines(lines)
+    tai = 1 << int(rng.integers(10, 20))
+    nh = int(rng.integers(1, 5))
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, j, spacer)
+    ctx = api.Context(k, tai, nh, j=j, max_spacer_dist=spacer, walk_window_span=int(rng.choice([0, 64, 1000, 1 << 16])),
+                      record_stops=bool(rng.integers(0, 2)))
+    nlb, nsb = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, nlb))
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits()) and np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    assert st["kmers"] == lst.kmers and st["to_bloo2"] == lst.to_bloo2 and st["unambiguous_reads"] == lst.unambiguous_reads
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, nsb))
+    _scan_equals_oracle(sc, sst, osc)
