@@ -1076,7 +1076,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
                     (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, ctx->counters, dbg_walk);
-        FGPU_LAUNCH("walk_clean", k_walk_clean, 512, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
+        FGPU_LAUNCH("walk_clean", k_walk_clean, 2048, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
     }
     ctx->prof_suppress = false;
