@@ -80,6 +80,7 @@ SIGNATURES = {
     "fgpu_scan_prepare": (C.c_int, [_vp, _P(Reads)]),
     "fgpu_scan_walk_prepared": (C.c_int, [_vp]),
     "fgpu_scan_end": (C.c_int, [_vp, _P(ScanStats)]),
+    "fgpu_scan_set_eager": (C.c_int, [_vp, C.c_int]),
     "fgpu_scan_take_stops": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(C.c_int64)]),
     "fgpu_scan_junction_count": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_scan_download_junctions": (C.c_int, [_vp, _vp, _vp, _u64, _P(_u64)]),

@@ -234,6 +234,9 @@ class Context:
         rb = ReadBatch(out.bases or 0, out.offsets or 0, n_reads=int(out.n_reads), on_device=True, starts=out.starts)
         return rb, int(used.value)
 
+    def scan_set_eager(self, on: bool):
+        self._c(self.lib.fgpu_scan_set_eager(self.h, int(on)))
+
     def take_stops(self):
         """scanInputRead's lists of the next scanned batch: (batch number, structured array) or None when none is left"""
         n, seq = C.c_uint64(0), C.c_int64(0)
@@ -314,8 +317,23 @@ class ReadScanner:
     def __init__(self, ctx: Context):
         self.ctx = ctx
         self.stats = None
+        self.fell_back_to_eager = False
 
     def scanReads(self, batches):                    # src/ReadScanner.cpp:284-359
+        try:
+            return self._scan(batches)
+        except FaucetGpuError as e:                  # the lazy-flag self-check fired: same scan with the flags evaluated everywhere
+            if "lazy-flag" not in str(e):
+                raise
+            try:
+                self.ctx.scan_end()
+            except FaucetGpuError:
+                pass
+            self.ctx.scan_set_eager(True)
+            self.fell_back_to_eager = True
+            return self._scan(batches)
+
+    def _scan(self, batches):
         self.ctx.scan_begin()
         for b in batches:
             self.ctx.scan_batch(b)

@@ -81,9 +81,12 @@ static int check_errors(fgpu_ctx* ctx) {
     // device-side error flags (table overflow) are surfaced at the synchronising calls
     if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
-    if (ctx->counters_host->error_flags & 4ULL) {
+    // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
+    static const bool force_lazy_fail = getenv("FGPU_DEBUG_LAZY_FAIL") && getenv("FGPU_DEBUG_LAZY_FAIL")[0] == '1';
+    const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
+    if ((ctx->counters_host->error_flags & 4ULL) || (force_lazy_fail && lazy && ctx->phase == 2)) {
         ctx->err = "lazy-flag check failed: the walk scanned a position whose junction test was not evaluated; "
-                   "repeat the scan with FGPU_FLAG_EAGER_FLAGS";
+                   "repeat the scan after fgpu_scan_set_eager(ctx, 1) (or with FGPU_FLAG_EAGER_FLAGS)";
         return FGPU_ERR_STATE;
     }
     return FGPU_OK;
@@ -514,6 +517,13 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
     for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
     ctx->prepared.clear();
     return rc;
+}
+
+int fgpu_scan_set_eager(fgpu_ctx* ctx, int on) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "fgpu_scan_set_eager while a pass is open"; return FGPU_ERR_STATE; }
+    ctx->eager_runtime = on != 0;
+    return FGPU_OK;
 }
 
 int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* n_out, int64_t* batch_seq) {

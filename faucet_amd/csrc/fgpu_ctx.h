@@ -169,6 +169,7 @@ struct fgpu_ctx {
     std::vector<BatchBufs*> pool;         // recycled BatchBufs (device buffers kept)
     std::vector<BatchBufs*> all_batches;  // every heap BatchBufs, for destruction
     bool record_stops = false;            // FGPU_FLAG_RECORD_STOPS
+    bool eager_runtime = false;           // fgpu_scan_set_eager: evaluate testForJunction everywhere in the following scans
     std::vector<BatchBufs*> to_harvest;   // walked batches whose stops are still on the device, in scan order
     std::deque<StopBatch> stop_queue;     // harvested, not yet taken
     uint64_t scan_batch_seq = 0;

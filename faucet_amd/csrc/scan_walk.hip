@@ -1012,7 +1012,7 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
 int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
-    if (ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) {   // evaluate testForJunction everywhere
+    if ((ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime) {   // evaluate testForJunction everywhere
         FGPU_HIP(hipMemsetAsync(bb.need.p, 0xFF, wb, ctx->stream));
         return FGPU_OK;
     }

@@ -476,60 +476,84 @@ int main(int argc, char** argv) {
 
     // ---- pass 2 (ReadScanner::scanReads, src/ReadScanner.cpp:284-359; printScanSummary :19-27)
     {
-        BatchSource src(o, o.read_scan_file);
-        if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_scan_file.c_str()); return 2; }
         time_t start, stop;
         time(&start);
         float w2 = 0;
         CHECK(fgpu_bloom_weight(ctx, FGPU_BLOO2, &w2));
         printf("Weight before read scan: %f \n", w2);
-        CHECK(fgpu_scan_begin(ctx));
-        uint64_t scanned = 0;
         PairLogic pairs;
-        pairs.k = o.k;
-        pairs.paired_ends = o.paired_ends;
-        pairs.no_cleaning = o.no_cleaning;
-        pairs.short_pf = &short_pf;
-        pairs.long_pf = o.paired_ends ? &long_pf : nullptr;
-        std::vector<uint64_t> batch_n_reads;
-        std::vector<fgpu_stop> stops;
-        // lists of the oldest batch whose walk is done (the newest one keeps walking while the next batch is prepared)
-        auto take = [&](bool& got) -> int {
-            got = false;
-            uint64_t n = 0;
-            int64_t seq = -1;
-            int rc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
-            if (rc == FGPU_ERR_CAPACITY) {
-                stops.resize(n);
-                rc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
+        fgpu_scan_stats ss;
+        // One scan of the file.  0 = done, 2 = fatal, -1 = the lazy-flag self-check of the library fired:
+        // the caller switches to eager flags and scans the file again.
+        auto scan_once = [&]() -> int {
+            BatchSource src(o, o.read_scan_file);
+            if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_scan_file.c_str()); return 2; }
+            auto failed = [&](const char* what, int rc) -> int {
+                const std::string msg = fgpu_last_error(ctx);
+                if (rc == FGPU_ERR_STATE && msg.find("lazy-flag") != std::string::npos) return -1;
+                fprintf(stderr, "%s failed (%d): %s\n", what, rc, msg.c_str());
+                return 2;
+            };
+            int rc = fgpu_scan_begin(ctx);
+            if (rc != FGPU_OK) return failed("fgpu_scan_begin", rc);
+            uint64_t scanned = 0;
+            pairs = PairLogic();
+            pairs.k = o.k;
+            pairs.paired_ends = o.paired_ends;
+            pairs.no_cleaning = o.no_cleaning;
+            pairs.short_pf = &short_pf;
+            pairs.long_pf = o.paired_ends ? &long_pf : nullptr;
+            std::fill(short_pf.bits.begin(), short_pf.bits.end(), 0);
+            std::fill(long_pf.bits.begin(), long_pf.bits.end(), 0);
+            std::vector<uint64_t> batch_n_reads;
+            std::vector<fgpu_stop> stops;
+            // lists of the oldest batch whose walk is done (the newest one keeps walking while the next batch is prepared)
+            auto take = [&](bool& got) -> int {
+                got = false;
+                uint64_t n = 0;
+                int64_t seq = -1;
+                int trc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
+                if (trc == FGPU_ERR_CAPACITY) {
+                    stops.resize(n);
+                    trc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
+                }
+                if (trc != FGPU_OK) return failed("fgpu_scan_take_stops", trc);
+                if (seq < 0) return 0;
+                got = true;
+                std::vector<fgpu_stop> view(stops.begin(), stops.begin() + n);
+                pairs.batch(view, batch_n_reads[(size_t)seq]);
+                return 0;
+            };
+            fgpu_reads r;
+            for (int more; (more = src.next(ctx, &r)) != 0;) {
+                if (more < 0) return failed("fgpu_text_split", -more);
+                if ((rc = fgpu_scan_batch(ctx, &r)) != FGPU_OK) return failed("fgpu_scan_batch", rc);
+                batch_n_reads.push_back(r.n_reads);
+                if (want_lists && batch_n_reads.size() > 1) {
+                    bool got;
+                    if (int trc = take(got)) return trc;
+                }
+                scanned += r.n_reads;
+                fprintf(stdout, "\rreads scanned: %lld", (long long)scanned);
+                fflush(stdout);
             }
-            if (rc != FGPU_OK) { fprintf(stderr, "fgpu_scan_take_stops failed (%d): %s\n", rc, fgpu_last_error(ctx)); return 2; }
-            if (seq < 0) return 0;
-            got = true;
-            std::vector<fgpu_stop> view(stops.begin(), stops.begin() + n);
-            pairs.batch(view, batch_n_reads[(size_t)seq]);
+            if ((rc = fgpu_scan_end(ctx, &ss)) != FGPU_OK) return failed("fgpu_scan_end", rc);
+            if (want_lists) {
+                bool got = true;
+                while (got)
+                    if (int trc = take(got)) return trc;
+            }
             return 0;
         };
-        fgpu_reads r;
-        for (int more; (more = src.next(ctx, &r)) != 0;) {
-            if (more < 0) { fprintf(stderr, "fgpu_text_split failed (%d): %s\n", -more, fgpu_last_error(ctx)); return 2; }
-            CHECK(fgpu_scan_batch(ctx, &r));
-            batch_n_reads.push_back(r.n_reads);
-            if (want_lists && batch_n_reads.size() > 1) {
-                bool got;
-                if (int rc = take(got)) return rc;
-            }
-            scanned += r.n_reads;
-            fprintf(stdout, "\rreads scanned: %lld", (long long)scanned);
-            fflush(stdout);
+        int src_rc = scan_once();
+        if (src_rc == -1) {
+            fprintf(stderr, "\nnote: the preview of the junction walk did not hold for this input; scanning again with every junction test evaluated\n");
+            fgpu_scan_end(ctx, nullptr);                 // closes the failed pass (its status is the failure itself)
+            CHECK(fgpu_scan_set_eager(ctx, 1));
+            src_rc = scan_once();
+            if (src_rc == -1) { fprintf(stderr, "scan failed: %s\n", fgpu_last_error(ctx)); return 2; }
         }
-        fgpu_scan_stats ss;
-        CHECK(fgpu_scan_end(ctx, &ss));
-        if (want_lists) {
-            bool got = true;
-            while (got)
-                if (int rc = take(got)) return rc;
-        }
+        if (src_rc) return src_rc;
         time(&stop);
         printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);
         printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);

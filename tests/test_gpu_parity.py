@@ -660,3 +660,42 @@ def test_fuzz_small_inputs_against_the_oracle(seed):
     sc = api.ReadScanner(ctx)
     sst = sc.scanReads(chunks(bases, offs, nsb))
     _scan_equals_oracle(sc, sst, osc)
+
+
+def test_callers_fall_back_to_eager_flags_when_the_lazy_check_fires(tmp_path, monkeypatch):
+    """FGPU_DEBUG_LAZY_FAIL=1 makes the library report the lazy-flag self-check as failed: the CLI and ReadScanner must finish
+    the pass, switch the preview off (fgpu_scan_set_eager) and deliver the same files / records."""
+    import os
+    import subprocess
+    c = Case("pe_fastq_k21")
+    reads = tmp_path / "reads.fq"
+    reads.write_bytes(c.reads_text())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    env = dict(os.environ, FGPU_DEBUG_LAZY_FAIL="1")
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
+                        "-batch_reads", "300"] + c.meta["args"], capture_output=True, text=True, env=env)
+    assert r.returncode == 3, r.stderr
+    assert "scanning again with every junction test evaluated" in r.stderr
+    assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
+    assert np.array_equal(np.fromfile(tmp_path / "out.short_pair_filter", dtype=np.uint8), c.pair_filter("short"))
+    assert np.array_equal(np.fromfile(tmp_path / "out.long_pair_filter", dtype=np.uint8), c.pair_filter("long"))
+    # the same through the Python mirror, in a child process (the knob is read once per process)
+    code = (
+        "import numpy as np\n"
+        "from faucet_amd import _lib as L, api\n"
+        "from oracle import pyoracle as po\n"
+        "from tests.golden_util import Case\n"
+        "c = Case('c1_k21')\n"
+        "bases, offs = po.reads_from_lines(c.lines())\n"
+        "tai, nh = api.load_filter_shape(c.E, c.S)\n"
+        "ctx = api.Context(c.k, tai, nh)\n"
+        "ctx.bloom_upload(L.BLOO2, c.bloom())\n"
+        "sc = api.ReadScanner(ctx)\n"
+        "st = sc.scanReads([api.ReadBatch(bases, offs)])\n"
+        "keys, recs = sc.junctions()\n"
+        "assert sc.fell_back_to_eager and st['flag_positions'] >= st['piece_positions']\n"
+        "assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())\n"
+        "print('fallback ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
