@@ -81,8 +81,14 @@ def load_sharded(backend, batches, rank: int, world: int):
 def scan_sharded(backend, batches, rank: int, world: int):
     """Returns (stats, is_last): on the last rank the stats are the whole run's and backend.junctions() is the final map."""
     backend.scan_begin()
-    for b in batches:
-        backend.scan_prepare(b)                            # pure stage: all ranks concurrently
+    if rank == 0:
+        # the first shard has nothing to wait for: it streams (pure stage of batch b+1 overlapped with the walk of batch b, lazy
+        # junction tests), which puts the table on its way ~50 ms per 10 M reads earlier than prepare-all + walk
+        for b in batches:
+            backend.scan_batch(b)
+    else:
+        for b in batches:
+            backend.scan_prepare(b)                        # pure stage while the earlier shards walk
     hdr = backend.header_tensor()
     if rank > 0:
         _recv(hdr, rank - 1)
@@ -92,7 +98,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
         _recv(buf, rank - 1)
         backend.fence()
         backend.import_table(buf, n_in, dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]])))
-    backend.scan_walk_prepared()                           # ordered walk of this shard
+    if rank > 0:
+        backend.scan_walk_prepared()                       # ordered walk of this shard
     stats = backend.scan_end()
     if rank < world - 1:
         n_out, buf = backend.export_table()
@@ -159,6 +166,9 @@ class GpuShard:
 
     def scan_prepare(self, batch):
         self.ctx.scan_prepare(batch)
+
+    def scan_batch(self, batch):
+        self.ctx.scan_batch(batch)
 
     def scan_walk_prepared(self):
         self.ctx.scan_walk_prepared()

@@ -65,6 +65,9 @@ class OracleShard:
     def scan_prepare(self, batch):
         self.prepared.append(batch)
 
+    def scan_batch(self, batch):
+        self.sc.scan_reads(batch[0], batch[1])
+
     def scan_walk_prepared(self):
         for b in self.prepared:
             self.sc.scan_reads(b[0], b[1])
