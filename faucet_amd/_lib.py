@@ -74,6 +74,8 @@ SIGNATURES = {
     "fgpu_bloom_weight": (C.c_int, [_vp, C.c_int, _P(_f32)]),
     "fgpu_bloom_devptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(_u64)]),
     "fgpu_bitmap_or": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "fgpu_host_alloc": (_vp, [_u64]),
+    "fgpu_host_free": (None, [_vp]),
     "fgpu_text_split": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, C.c_int, _P(Reads), _P(_u64)]),
     "fgpu_scan_begin": (C.c_int, [_vp]),
     "fgpu_scan_batch": (C.c_int, [_vp, _P(Reads)]),

@@ -137,3 +137,13 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     out->n_reads = n_rec;
     return FGPU_OK;
 }
+
+extern "C" void* fgpu_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+extern "C" void fgpu_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}

@@ -17,7 +17,10 @@
 #include <time.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <fstream>
+#include <mutex>
+#include <thread>
 #include <list>
 #include <string>
 #include <unordered_map>
@@ -39,7 +42,7 @@ struct Options {   // globals of src/Faucet.h:14-53
          node_graph = false, paired_ends = false, no_cleaning = false, high_cov = false;
     int max_spacer_dist = 100;
     uint64_t batch_reads = 0;         // not a reference flag: > 0 = split records on the host, this many reads per device call
-    uint64_t chunk_mb = 256;          // not a reference flag: file text handed to the device per call, records split there
+    uint64_t chunk_mb = 64;           // not a reference flag: file text handed to the device per call, records split there
 };
 
 void argument_error() {   // src/Faucet.cpp:50-54
@@ -143,35 +146,97 @@ private:
 // time, and carries the unconsumed tail (an incomplete record) over to the next call.  Works on non-seekable input.
 class TextSource {
 public:
-    TextSource(const std::string& path, bool fastq, uint64_t chunk) : f_(fopen(path.c_str(), "rb")), fastq_(fastq), chunk_(chunk) {}
-    ~TextSource() { if (f_) fclose(f_); }
-    bool is_open() const { return f_ != nullptr; }
+    TextSource(const std::string& path, bool fastq, uint64_t chunk) : f_(fopen(path.c_str(), "rb")), fastq_(fastq), chunk_(chunk) {
+        if (!f_) return;
+        for (Slot& sl : slot_) {
+            sl.base = (char*)fgpu_host_alloc(kPad + chunk_);          // pinned: the copy to the device runs at link speed
+            sl.pinned = sl.base != nullptr;
+            if (!sl.base) sl.base = (char*)malloc(kPad + chunk_);
+        }
+        reader_ = std::thread(&TextSource::read_ahead, this);
+    }
+    ~TextSource() {
+        if (!f_) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        reader_.join();
+        for (Slot& sl : slot_) { if (sl.pinned) fgpu_host_free(sl.base); else free(sl.base); }
+        fclose(f_);
+    }
+    bool is_open() const { return f_ != nullptr && slot_[0].base && slot_[1].base; }
     // 1 = a batch (device pointers, valid until the next call), 0 = input exhausted, < 0 = -status of a failed call
     int next(fgpu_ctx* ctx, fgpu_reads* out) {
         for (;;) {
-            if (eof_ && fill_ == 0) return 0;
-            if (!eof_) {
-                if (buf_.size() < fill_ + chunk_) buf_.resize(fill_ + chunk_);
-                const size_t got = fread(buf_.data() + fill_, 1, chunk_, f_);
-                fill_ += got;
-                if (got < chunk_) eof_ = true;
+            if (finished_) return 0;
+            Slot& sl = slot_[cur_];
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return sl.full; });
             }
+            // the unconsumed tail of the previous chunk sits right in front of this chunk's text
+            char* text = sl.base + kPad - tail_;
+            const uint64_t n = tail_ + sl.got;
             uint64_t used = 0;
-            const int rc = fgpu_text_split(ctx, buf_.data(), fill_, 0, fastq_ ? 1 : 0, eof_ ? 1 : 0, out, &used);
+            const int rc = fgpu_text_split(ctx, text, n, 0, fastq_ ? 1 : 0, sl.eof ? 1 : 0, out, &used);
             if (rc != FGPU_OK) return -rc;
-            memmove(buf_.data(), buf_.data() + used, fill_ - used);
-            fill_ -= used;
+            const uint64_t left = n - used;
+            if (sl.eof) {
+                finished_ = true;
+            } else {
+                if (left > kPad) return -FGPU_ERR_CAPACITY;   // a single line of more than 16 MB: use -batch_reads (host getline)
+                memcpy(slot_[cur_ ^ 1].base + kPad - left, text + used, left);
+                tail_ = left;
+                {
+                    std::lock_guard<std::mutex> g(m_);
+                    sl.full = false;
+                }
+                cv_.notify_all();
+                cur_ ^= 1;
+            }
             if (out->n_reads) return 1;
-            if (eof_) return 0;          // nothing but an empty tail
-            // no complete record inside a whole chunk (a very long line): keep the text and read on
+            // no complete record inside a whole chunk: its text has become the tail, read on
         }
     }
 private:
+    static constexpr uint64_t kPad = 16u << 20;
+    struct Slot {
+        char* base = nullptr;
+        bool pinned = false;
+        size_t got = 0;
+        bool eof = false, full = false;
+    };
+    void read_ahead() {   // reader thread: keeps the other slot filled while the device works on the current one
+        for (int i = 0;; i ^= 1) {
+            Slot& sl = slot_[i];
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || !sl.full; });
+                if (stop_) return;
+            }
+            const size_t got = fread(sl.base + kPad, 1, chunk_, f_);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                sl.got = got;
+                sl.eof = got < chunk_;
+                sl.full = true;
+            }
+            cv_.notify_all();
+            if (got < chunk_) return;
+        }
+    }
     FILE* f_;
-    bool fastq_, eof_ = false;
+    bool fastq_;
     uint64_t chunk_;
-    std::vector<char> buf_;
-    size_t fill_ = 0;
+    Slot slot_[2];
+    int cur_ = 0;
+    uint64_t tail_ = 0;
+    bool finished_ = false, stop_ = false;
+    std::thread reader_;
+    std::mutex m_;
+    std::condition_variable cv_;
 };
 
 // one interface over both ways of cutting the input into batches
@@ -350,23 +415,36 @@ struct PairLogic {
 };
 
 int write_junctions(const std::string& path, const std::unordered_map<uint64_t, Junction>& map, int k) {
-    // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596), Junction::toString (utils/Junction.cpp:74-89)
+    // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596), Junction::toString (utils/Junction.cpp:74-89):
+    //   "<kmer> d0 d1 d2 d3 d4  c0 c1 c2 c3 <sum>  l0 l1 l2 l3 l4 \n", formatted by hand into one buffer (a million lines)
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
-    std::string kmer(k, 'A');
+    std::vector<char> buf;
+    buf.reserve(1 << 22);
+    auto put_uint = [&](unsigned v) {
+        char tmp[12];
+        int n = 0;
+        do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) buf.push_back(tmp[--n]);
+        buf.push_back(' ');
+    };
     for (const auto& kv : map) {
         uint64_t x = kv.first;
-        for (int i = k - 1; i >= 0; i--) { kmer[i] = kDecode[x & 3]; x >>= 2; }
+        const size_t at = buf.size();
+        buf.resize(at + (size_t)k);
+        for (int i = k - 1; i >= 0; i--) { buf[at + (size_t)i] = kDecode[x & 3]; x >>= 2; }
+        buf.push_back(' ');
         const Junction& j = kv.second;
-        fprintf(f, "%s ", kmer.c_str());
-        for (int i = 0; i < 5; i++) fprintf(f, "%d ", j.dist[i]);
-        fprintf(f, " ");
-        for (int i = 0; i < 4; i++) fprintf(f, "%d ", j.cov[i]);
-        fprintf(f, "%d ", j.cov[0] + j.cov[1] + j.cov[2] + j.cov[3]);
-        fprintf(f, " ");
-        for (int i = 0; i < 5; i++) fprintf(f, "%d ", j.linked[i] ? 1 : 0);
-        fprintf(f, "\n");
+        for (int i = 0; i < 5; i++) put_uint(j.dist[i]);
+        buf.push_back(' ');
+        for (int i = 0; i < 4; i++) put_uint(j.cov[i]);
+        put_uint((unsigned)j.cov[0] + j.cov[1] + j.cov[2] + j.cov[3]);
+        buf.push_back(' ');
+        for (int i = 0; i < 5; i++) put_uint(j.linked[i] ? 1u : 0u);
+        buf.push_back('\n');
+        if (buf.size() > (1u << 22) - 256) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
     }
+    fwrite(buf.data(), 1, buf.size(), f);
     fclose(f);
     return 0;
 }

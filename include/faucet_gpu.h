@@ -173,6 +173,10 @@ int fgpu_bitmap_or(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t n
  * they occupy -- the caller prepends the rest to the next chunk.  final_chunk != 0: the text ends the file; a last line
  * without a newline, a missing sequence line (empty read) and missing FASTQ tail lines are handled as getline handles
  * them; *consumed = nbytes.  A carriage return before the newline stays part of the line, as it does in the reference. */
+/* Page-locked host memory for the text handed to fgpu_text_split (or for read batches): copies to the device then run at
+ * link speed and asynchronously.  NULL when it cannot be had; plain malloc'ed memory works too, only slower. */
+void* fgpu_host_alloc(uint64_t bytes);
+void  fgpu_host_free(void* p);
 int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
                     fgpu_reads* out, uint64_t* consumed);
 
