@@ -148,6 +148,89 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
     wave_add(&cnt->to_bloo2, n_pass);
 }
 
+// ---- --mercy (utils/Bloom.cpp:300-333) -----------------------------------------------------------------------------
+// With mercy the load also adds to bloo2 every run of low-coverage k-mers ("not contained in bloo1 when met") that sits
+// between two solid ones, unless the solid k-mer next to the run looks like a junction in bloo1 (isJunction, :249-265).  bloo1
+// evolves exactly as without mercy, and which occurrences were "contained" is the sure plane the two kernels above have
+// just written; what is left is a small sequential state machine per unambiguous segment plus a few TIME-AWARE membership
+// tests: bloo1 as it stood when occurrence t was processed = bits of the carried-in state or first set at a time <= t.
+__device__ __forceinline__ bool bloo1_contains_at(const uint2* __restrict__ pair, const uint32_t* __restrict__ first, uint64_t canon,
+                                                  uint32_t t, const FdParams& fp) {
+    uint64_t hA, hB;
+    fd_hash_pair(canon, fp.tai_mask, hA, hB);
+    uint64_t h = hA;
+    for (int i = 0; i < fp.n_hash; i++) {
+        if (!((pair[h >> 5].x >> (h & 31)) & 1u) && !(first[h] <= t)) return false;
+        h = (h + hB) & fp.tai_mask;
+    }
+    return true;
+}
+
+// isJunction(readKmer, bloo1, dir) as load_two_filters calls it: the cursor faces BACKWARD there, so the "real extension" is
+// the reverse complement of the window before, whatever dir says; dir only picks the strand the four candidates extend.
+__device__ __forceinline__ bool mercy_is_junction(const uint64_t* __restrict__ codes, const uint2* __restrict__ pair,
+                                                  const uint32_t* __restrict__ first, uint64_t pos, bool dir_forward, const FdParams& fp) {
+    const uint64_t km = fd_kmer_at(codes, pos, fp.k), rc = fd_revcomp(km, fp.k);
+    const uint64_t real_ext = ((rc << 2) | (uint64_t)(fd_base_at(codes, pos - 1) ^ 2)) & fp.kmask;
+    const uint64_t from = dir_forward ? km : rc;
+    for (int nt = 0; nt < 4; nt++) {
+        const uint64_t e = ((from << 2) | (uint64_t)nt) & fp.kmask;
+        if (e != real_ext && bloo1_contains_at(pair, first, fd_canon(e, fp.k), (uint32_t)pos, fp)) return true;
+    }
+    return false;
+}
+
+// one thread per 64-position word: the unambiguous segments (length >= k) that START in it
+__global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t n_words,
+                                                    FdParams fp, uint2* pair, const uint32_t* __restrict__ first,
+                                                    const uint64_t* __restrict__ sure) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t good = ~bad[w];
+        const uint64_t prev_good = w ? (~bad[w - 1]) >> 63 : 0;
+        uint64_t starts = good & ~((good << 1) | prev_good);
+        while (starts) {
+            const uint64_t p = w * 64 + __builtin_ctzll(starts);
+            starts &= starts - 1;
+            uint64_t len = 0;                       // segment length: bad padding past the end terminates the scan
+            for (;;) {
+                const uint64_t v = fd_bits_at(bad, p + len);
+                if (v) { len += __builtin_ctzll(v); break; }
+                len += 64;
+            }
+            if (len < (uint64_t)fp.k) continue;
+            const uint64_t n = len - fp.k + 1;      // windows p .. p+n-1, processed in this order (utils/Bloom.cpp:303)
+            bool have_last = false;
+            int64_t hv_lo = -1;                     // first window of the current hash_vals run, -1 = empty
+            uint64_t sbits = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                if ((i & 63) == 0) sbits = fd_bits_at(sure, p + i);
+                const bool contained = (sbits >> (i & 63)) & 1ULL;
+                const uint64_t pos = p + i;
+                if (contained) {
+                    have_last = true;
+                    if (hv_lo >= 0) {               // came from low to high (:311-318)
+                        if (!mercy_is_junction(codes, pair, first, pos, false, fp)) {
+                            for (uint64_t q = p + (uint64_t)hv_lo; q < pos; q++) {
+                                uint64_t hA, hB;
+                                fd_hash_pair(fd_canon(fd_kmer_at(codes, q, fp.k), fp.k), fp.tai_mask, hA, hB);
+                                uint64_t h = hA;
+                                for (int b = 0; b < fp.n_hash; b++) {
+                                    const uint32_t bit = 1u << (h & 31);
+                                    if (!(pair[h >> 5].y & bit)) atomicOr(&pair[h >> 5].y, bit);
+                                    h = (h + hB) & fp.tai_mask;
+                                }
+                            }
+                        }
+                        hv_lo = -1;
+                    }
+                } else if (have_last && hv_lo < 0) {   // came from high to low (:322-326); later low k-mers just join the run
+                    if (!mercy_is_junction(codes, pair, first, pos, true, fp)) hv_lo = (int64_t)i;
+                }
+            }
+        }
+    }
+}
+
 // pair[w] = {a[w], b[w]} (b == nullptr: zero) / the reverse / refresh of the carry half after a batch
 __global__ void __launch_bounds__(256) k_pair_join(uint2* __restrict__ pair, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                    uint64_t n32) {
@@ -324,6 +407,9 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
                 ctx->pair, ctx->first, ctx->bloo1_new, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
                 (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
+    if (ctx->prm.flags & FGPU_FLAG_MERCY)
+        FGPU_LAUNCH("load_mercy", k_load_mercy, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.n_words,
+                    ctx->fd, ctx->pair, (const uint32_t*)ctx->first, (const uint64_t*)bb.sure.p);
     // carry := carry | bits set during this batch
     if (ctx->bloo1_new) FGPU_LAUNCH("carry_update", k_carry_merge, 4096, 256, ctx->pair, (const uint32_t*)ctx->bloo1_new, ctx->bloom_bytes / 4);
     else FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);

@@ -456,7 +456,6 @@ int main(int argc, char** argv) {
     if (handle_arguments(argc, argv, o) == 1) return 1;
     fgpu_ctx* ctx = nullptr;
     if (o.k < 1 || o.k > 31) { fprintf(stderr, "k must be in 1..31 on this build\n"); return 1; }
-    if (o.mercy) { fprintf(stderr, "--mercy is not implemented on the device path (SURVEY.md 8f)\n"); return 1; }
     if (o.from_junctions) { fprintf(stderr, "-junctions_file restarts after the scan: nothing left for this build to do.\n"); return 1; }
 
     // ---- filter sizing: getBloomFilterFromReads / getBloomFilterFromFile (src/Faucet.cpp:185-219)
@@ -492,6 +491,7 @@ int main(int argc, char** argv) {
     prm.tai = tai;
     const bool want_lists = !o.no_cleaning || o.paired_ends;   // scanInputRead's lists feed the pair filters and the pair counts
     if (want_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
+    if (o.mercy) prm.flags |= FGPU_FLAG_MERCY;
     {
         int rc = fgpu_create(&prm, &ctx);
         if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(nullptr)); return 2; }
@@ -547,8 +547,9 @@ int main(int argc, char** argv) {
     PairFilter short_pf, long_pf;
     {
         const uint64_t E = o.estimated_kmers;
-        short_pf.create(o.high_cov ? E / 2 : E / 20, 0.01f);
-        if (o.paired_ends) long_pf.create(o.high_cov ? E / 2 : E / 10, 0.01f);
+        // mercy k-mers lead to more junctions: the reference doubles both filters (src/Faucet.cpp:268-271)
+        short_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 10 : E / 20, 0.01f);
+        if (o.paired_ends) long_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 5 : E / 10, 0.01f);
     }
     if (o.just_load) { fgpu_destroy(ctx); return 0; }
 

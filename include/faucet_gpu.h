@@ -58,6 +58,8 @@ typedef struct {
 } fgpu_params;
 
 #define FGPU_FLAG_PROFILE 1     /* bracket every kernel with HIP events (fgpu_kernel_times) */
+#define FGPU_FLAG_MERCY 16       /* load_two_filters(..., mercy = true): also add low-coverage k-mers between solid ones to bloo2
+                                 * (utils/Bloom.cpp:300-333; the reference's --mercy) */
 #define FGPU_FLAG_RECORD_STOPS 8 /* keep scanInputRead's return value for every read (fgpu_scan_take_stops) */
 #define FGPU_FLAG_NO_RESIDENT 4 /* do not keep the load batches in HBM for the scan pass (see fgpu_load_batch) */
 #define FGPU_FLAG_EAGER_FLAGS 2 /* evaluate testForJunction at every position instead of only where the walk can stop

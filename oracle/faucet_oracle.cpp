@@ -560,6 +560,63 @@ void fo_load_two_filters(fo_bloom* bloo1, fo_bloom* bloo2, const char* bases, co
     if (stats) *stats = st;
 }
 
+/* load_two_filters with mercy == true (utils/Bloom.cpp:300-333): low-coverage k-mers between two solid ones are added to bloo2
+ * as well unless the solid k-mer next to them looks like a junction in bloo1 (isJunction, :249-265).  Restated with its two
+ * peculiarities: `last_kmer` points at the loop's own cursor (so it always IS the current k-mer), and the cursor faces
+ * BACKWARD whenever the loop body runs (ReadKmer starts facing backward and is advanced two half-steps per iteration), so
+ * getRealExtension() is the real BACKWARD extension in both calls, whatever `dir` says. */
+static bool mercy_is_junction(const Cursor& c, fo_bloom* bloom, bool dir_forward) {
+    const uint64_t real_ext = c.real_ext();                        /* cursor faces backward: reverse complement of the window before */
+    for (int nt = 0; nt < 4; nt++) {
+        const uint64_t test_ext = (((dir_forward ? c.fwd : c.rc) << 2) | static_cast<uint64_t>(nt)) & c.mask;   /* DoubleKmer.cpp:10-17 */
+        if (real_ext != test_ext && bloom->old_contains(canon(test_ext, c.k))) return true;
+    }
+    return false;
+}
+
+void fo_load_two_filters_mercy(fo_bloom* bloo1, fo_bloom* bloo2, const char* bases, const uint64_t* offsets, uint64_t n,
+                               int k, fo_load_stats* stats) {
+    fo_load_stats st{0, 0, 0, 0};
+    std::vector<Seg> segs;
+    const uint64_t mask = bloo1->tai - 1;
+    for (uint64_t r = 0; r < n; r++) {
+        const char* line = bases + offsets[r];
+        unambiguous_segments(line, offsets[r + 1] - offsets[r], k, segs);
+        for (const Seg& sg : segs) {
+            st.unambiguous_reads++;
+            bool have_last = false;
+            std::vector<std::pair<uint64_t, uint64_t>> hash_vals;
+            Cursor c(line + sg.start, static_cast<int>(sg.len), k);
+            for (; c.dist_to_end() >= 0; c.step(), c.step()) {                       /* Bloom.cpp:303-331 */
+                uint64_t cn = c.canonical();
+                uint64_t ha = old_hash(cn, 0, mask), hb = old_hash(cn, 1, mask);
+                st.kmers++;
+                if (bloo1->contains(ha, hb)) {
+                    bloo2->add(ha, hb);
+                    st.to_bloo2++;
+                    have_last = true;
+                    if (!hash_vals.empty()) {                                        /* came from low to high */
+                        if (!mercy_is_junction(c, bloo1, false))
+                            for (const auto& v : hash_vals) bloo2->add(v.first, v.second);
+                        hash_vals.clear();
+                    }
+                } else {
+                    bloo1->add(ha, hb);
+                    if (have_last) {
+                        if (hash_vals.empty()) {                                     /* came from high to low */
+                            if (!mercy_is_junction(c, bloo1, true)) hash_vals.emplace_back(ha, hb);
+                        } else {
+                            hash_vals.emplace_back(ha, hb);
+                        }
+                    }
+                }
+            }
+        }
+        st.reads_processed++;
+    }
+    if (stats) *stats = st;
+}
+
 void fo_load_single_filter(fo_bloom* bloo1, const char* bases, const uint64_t* offsets, uint64_t n, int k,
                            fo_load_stats* stats) {
     fo_load_stats st{0, 0, 0, 0};

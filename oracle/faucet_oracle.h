@@ -81,6 +81,9 @@ typedef struct {
 } fo_load_stats;
 void fo_load_two_filters(fo_bloom* bloo1, fo_bloom* bloo2, const char* bases, const uint64_t* offsets,
                          uint64_t n, int k, fo_load_stats* stats);
+/* the same with mercy == true (Bloom.cpp:300-333) */
+void fo_load_two_filters_mercy(fo_bloom* bloo1, fo_bloom* bloo2, const char* bases, const uint64_t* offsets,
+                         uint64_t n, int k, fo_load_stats* stats);
 /* load_single_filter (Bloom.cpp:352-390): unconditional add of every k-mer */
 void fo_load_single_filter(fo_bloom* bloo1, const char* bases, const uint64_t* offsets, uint64_t n, int k,
                            fo_load_stats* stats);

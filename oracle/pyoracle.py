@@ -67,6 +67,7 @@ def lib():
         "fo_bloom_bit_sets": (u64, [vp]), "fo_bloom_reset_counters": (None, [vp]),
         "fo_reads_from_file": (i32, [cp, i32, C.POINTER(Reads)]), "fo_reads_free": (None, [C.POINTER(Reads)]),
         "fo_load_two_filters": (None, [vp, vp, vp, vp, u64, i32, C.POINTER(LoadStats)]),
+        "fo_load_two_filters_mercy": (None, [vp, vp, vp, vp, u64, i32, C.POINTER(LoadStats)]),
         "fo_load_single_filter": (None, [vp, vp, vp, u64, i32, C.POINTER(LoadStats)]),
         "fo_scanner_new": (vp, [i32, i32, i32, vp, vp, vp]), "fo_scanner_free": (None, [vp]),
         "fo_scan_reads": (None, [vp, vp, vp, u64, i32, i32]),
@@ -180,9 +181,10 @@ class Bloom:
         lib().fo_bloom_reset_counters(self.h)
 
 
-def load_two_filters(bloo1: Bloom, bloo2: Bloom, bases, offs, k) -> LoadStats:
+def load_two_filters(bloo1: Bloom, bloo2: Bloom, bases, offs, k, mercy=False) -> LoadStats:
     st = LoadStats()
-    lib().fo_load_two_filters(bloo1.h, bloo2.h, _p(bases), _p(offs), len(offs) - 1, k, C.byref(st))
+    fn = lib().fo_load_two_filters_mercy if mercy else lib().fo_load_two_filters
+    fn(bloo1.h, bloo2.h, _p(bases), _p(offs), len(offs) - 1, k, C.byref(st))
     return st
 
 

@@ -152,6 +152,16 @@ def main():
         run_case("j0_k15", p, False, ["-size_kmer", "15", "-max_read_length", "150", "-estimated_kmers", "50000",
                                       "-singletons", "10000", "-j", "0", "--no_cleaning"])
 
+        # --mercy: low coverage (4.5x), so that many true k-mers are seen once between solid ones and get rescued
+        g = synth.make_genome(20000, 41, repeats=2, repeat_len=150)
+        r = synth.make_reads(g, 900, 100, 0.01, 42, n_rate=0.001)
+        p = os.path.join(td, "mercy.fa")
+        synth.write_fasta(p, r)
+        run_case("mercy_k21", p, False, ["-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "100000",
+                                         "-singletons", "20000", "--no_cleaning", "--mercy"])
+        run_case("nomercy_k21", p, False, ["-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "100000",
+                                           "-singletons", "20000", "--no_cleaning"])
+
         # paired-end interleaved fastq (config 3 shape), with cleaning on: pair filters are written before Stage 3
         g = synth.make_genome(5000, 31, repeats=3, repeat_len=200)
         r = synth.make_pairs(g, 600, 100, 300, 30, 0.01, 32)

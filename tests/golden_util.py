@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21"]
+CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21", "mercy_k21", "nomercy_k21"]
 
 
 def _gz(path):
@@ -44,6 +44,7 @@ class Case:
         self.max_read_length = opt("-max_read_length")
         self.paired = "--paired_ends" in a
         self.no_cleaning = "--no_cleaning" in a
+        self.mercy = "--mercy" in a
         self.counters = self.meta["counters"]
 
     def reads_text(self) -> bytes:

@@ -74,7 +74,5 @@ def test_cli_argument_errors_exit_1():
             "-singletons", "20000", "-file_prefix", "/tmp/p"]
     r = _cli(*base, "-junctions_file", "j")
     assert r.returncode == 1 and "Cannot start from junctions without a bloom file." in r.stderr
-    r = _cli(*base, "--mercy")   # not on the device path: refuse instead of differing
-    assert r.returncode == 1 and "--mercy" in r.stderr
     r = _cli(*base[:-6], "-estimated_kmers", "100000", "-singletons", "0", "-file_prefix", "/tmp/p", "--no_cleaning")
     assert r.returncode == 1 and "singletons" in r.stderr

@@ -10,10 +10,10 @@ from tests.golden_util import CASES, Case, kat
 pytestmark = pytest.mark.gpu
 
 
-def oracle_run(lines_or_batch, k, tai, nh, j=1, spacer=100):
+def oracle_run(lines_or_batch, k, tai, nh, j=1, spacer=100, mercy=False):
     bases, offs = lines_or_batch
     b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
-    lst = po.load_two_filters(b1, b2, bases, offs, k)
+    lst = po.load_two_filters(b1, b2, bases, offs, k, mercy=mercy)
     sc = po.Scanner(k, j, spacer, b2)
     sc.scan_reads(bases, offs, paired_ends=False, no_cleaning=True)
     return b1, b2, lst, sc
@@ -67,11 +67,11 @@ def test_load_matches_reference_bloom(name, n_batches):
     c = Case(name)
     bases, offs = po.reads_from_lines(c.lines())
     tai, nh = api.load_filter_shape(c.E, c.S)
-    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer, mercy=c.mercy)
     st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, n_batches))
     got2 = ctx.bloom_download(L.BLOO2)
     assert np.array_equal(got2, c.bloom()), "bloo2 differs from the reference's .bloom file"
-    b1, b2, lst, _ = oracle_run((bases, offs), c.k, tai, nh, c.j, c.spacer)
+    b1, b2, lst, _ = oracle_run((bases, offs), c.k, tai, nh, c.j, c.spacer, mercy=c.mercy)
     assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
     assert st["reads_processed"] == c.counters["load_reads_processed"]
     assert st["unambiguous_reads"] == c.counters["load_unambiguous"]
@@ -346,7 +346,7 @@ def test_two_shard_scan_table_handover_is_exact():
 
 
 @pytest.mark.parametrize("how", [["-batch_reads", "400"], [], ["-chunk_mb", "1"]])
-@pytest.mark.parametrize("name", ["c1_k21", "ragged_k31", "j2_spacer20_k15"])
+@pytest.mark.parametrize("name", ["c1_k21", "ragged_k31", "j2_spacer20_k15", "mercy_k21"])
 def test_cli_writes_the_reference_files(name, how, tmp_path):
     """The stand-alone host: same flags as the reference, byte-identical .bloom and .junctions (dump order included)."""
     import os
@@ -699,3 +699,42 @@ def test_callers_fall_back_to_eager_flags_when_the_lazy_check_fires(tmp_path, mo
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n_batches", [1, 5])
+def test_mercy_load_matches_the_reference(n_batches):
+    """load_two_filters(..., mercy = true) (utils/Bloom.cpp:300-333): the reference's --mercy .bloom, byte for byte, and it does
+    differ from the plain load on this low-coverage fixture"""
+    c = Case("mercy_k21")
+    assert c.mercy and not np.array_equal(c.bloom(), Case("nomercy_k21").bloom())
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh, mercy=True)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, n_batches))
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), c.bloom())
+    w = c.counters["weights_after_load"]
+    assert f"{ctx.bloom_weight(L.BLOO1):f}" == w[0] and f"{ctx.bloom_weight(L.BLOO2):f}" == w[1]
+    # the scan over that filter (resident planes in use) gives the reference's junctions
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, n_batches))
+    keys, recs = sc.junctions()
+    assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
+    assert sst["n_junctions"] == c.counters["distinct_junctions"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mercy_random_inputs_vs_oracle(seed):
+    rng = np.random.default_rng(300 + seed)
+    k = int(rng.choice([11, 21, 31]))
+    G = int(rng.integers(3000, 30000))
+    cov = float(rng.choice([2.0, 5.0, 12.0]))
+    n = int(G * cov / 100)
+    bases, offs = _random_case(n, 100, k, G, float(rng.choice([0.0, 0.01, 0.03])), 900 + seed, float(rng.choice([0.0, 0.003])), int(rng.integers(0, 4)))
+    tai, nh = 1 << int(rng.integers(14, 20)), int(rng.integers(1, 5))
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    olst = po.load_two_filters(b1, b2, bases, offs, k, mercy=True)
+    ctx = api.Context(k, tai, nh, mercy=True)
+    st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, int(rng.integers(1, 6))))
+    assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits())
+    assert st["to_bloo2"] == olst.to_bloo2 and st["kmers"] == olst.kmers

@@ -88,7 +88,7 @@ def test_end_to_end_vs_reference(name):
     assert f"{p1:.6g}" == c.counters["p1"]
     assert bits == c.counters["bits_per_kmer"] and nh == c.counters["n_hash"]
     b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
-    st = po.load_two_filters(b1, b2, bases, offs, c.k)
+    st = po.load_two_filters(b1, b2, bases, offs, c.k, mercy=c.mercy)
     assert st.reads_processed == c.counters["load_reads_processed"]
     assert st.unambiguous_reads == c.counters["load_unambiguous"]
     assert np.array_equal(b2.bits(), c.bloom()), "bloo2 differs from the reference's .bloom"
