@@ -1046,6 +1046,10 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;
     const uint64_t ext = bb.max_piece_span;          // a piece that starts inside the window may reach this far beyond it
+    if (span + ext + 64 > ctx->wcap) {               // the per-position slot list of a window is sized for 4 x the largest span
+        ctx->err = "a read of " + std::to_string(ext) + " bases is longer than the walk's window tables allow";
+        return FGPU_ERR_CAPACITY;
+    }
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
     const unsigned walk_grid = fgpu_blocks(ctx->wmax, 64);
