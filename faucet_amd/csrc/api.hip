@@ -262,17 +262,11 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
             return FGPU_ERR_NOMEM;
         }
     }
-    // The carry of the next batch: filters up to 2^32 bits sweep first[] once per batch (4 bytes per bit, streaming: 4.4 ms per
-    // batch at 2^32 bits); beyond that the sweep costs more than a test-then-set per newly set bit on a second bitmap
-    // (measured equal at 2^32 bits with 1 M-read batches: +35 ms per 10 M reads either way; config 4 has 2^33 bits)
-    static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "collect": measurement aid
-    const bool collect = carry_env ? carry_env[0] == 'c' : ctx->prm.tai > (1ULL << 32);
-    if (collect && !ctx->bloo1_new) {
-        hipError_t e = hipMalloc(&ctx->bloo1_new, ctx->bloom_bytes);
-        if (e != hipSuccess) { (void)hipGetLastError(); ctx->bloo1_new = nullptr; }   // fall back to the sweep
-    }
-    if (!collect && ctx->bloo1_new) { hipFree(ctx->bloo1_new); ctx->bloo1_new = nullptr; }
-    if (ctx->bloo1_new) FGPU_HIP(hipMemsetAsync(ctx->bloo1_new, 0, ctx->bloom_bytes, ctx->stream));
+    // The carry of the next batch: one sweep of first[] per batch (4 bytes per filter bit, streaming) up to 2^30 bits; beyond
+    // that the sweep costs more than re-hashing the batch's new k-mers (k_carry_set): at 2^32 bits / 1 M-read batches 25 vs
+    // 44 ms per 10 M reads, at 2^33 bits the sweep would read 32 GiB per batch.
+    static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
+    ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai > (1ULL << 30);
     FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
     fgpu_resident_reset(ctx, true);
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));

@@ -54,8 +54,7 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
 // the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                    uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first,
-                                                   uint32_t* carry_next, uint64_t* __restrict__ pending, uint64_t* __restrict__ sure,
-                                                   DevCounters* cnt) {
+                                                   uint64_t* __restrict__ pending, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
@@ -89,13 +88,9 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 pend = true;
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
-                    if (missing & (1u << i)) {
-                        // the next carry is derived from first[] by a sweep (k_carry_from_first) or, for filters too large to
-                        // sweep per batch, collected here by whoever touches the bit first
-                        // (an atomic whose result is used is markedly slower than a fire-and-forget one: test-then-set instead)
-                        atomicMin(&first[h], (uint32_t)p);
-                        if (carry_next && !((carry_next[h >> 5] >> (h & 31)) & 1u)) atomicOr(&carry_next[h >> 5], 1u << (h & 31));
-                    }
+                    // the next carry is derived afterwards: from first[] by a sweep (k_carry_from_first) or by re-hashing the
+                    // occurrences that were not contained (k_carry_set)
+                    if (missing & (1u << i)) atomicMin(&first[h], (uint32_t)p);
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -271,11 +266,22 @@ __global__ void __launch_bounds__(256) k_carry_from_first(uint2* __restrict__ pa
     }
 }
 
-// carry |= bits collected in carry_next (streaming, tai/8 bytes; carry_next keeps accumulating: OR is idempotent)
-__global__ void __launch_bounds__(256) k_carry_merge(uint2* __restrict__ pair, const uint32_t* __restrict__ carry_next, uint64_t n32) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t v = carry_next[i];
-        if (v) pair[i].x |= v;
+// carry |= bits of every occurrence that was NOT contained when met (those are exactly the occurrences that set bits in
+// bloo1).  The alternative to the sweep when the filter is large: its cost follows the number of new k-mers of the batch
+// (3 test-then-set accesses each), not the size of first[] (32 GiB per sweep for config 4's 2^33-bit filters).
+__global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
+                                                   uint64_t n_words, FdParams fp, uint2* pair, const uint64_t* __restrict__ sure) {
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        if (!(p < T && fd_window_ok(bad, p, fp.k)) || ((sure[p >> 6] >> (p & 63)) & 1ULL)) continue;
+        uint64_t hA, hB;
+        fd_hash_pair(fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, hA, hB);
+        uint64_t h = hA;
+        for (int i = 0; i < fp.n_hash; i++) {
+            const uint32_t bit = 1u << (h & 31);
+            if (!(pair[h >> 5].x & bit)) atomicOr(&pair[h >> 5].x, bit);
+            h = (h + hB) & fp.tai_mask;
+        }
     }
 }
 
@@ -404,15 +410,18 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->first, ctx->bloo1_new, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
+                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
                 (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
     if (ctx->prm.flags & FGPU_FLAG_MERCY)
         FGPU_LAUNCH("load_mercy", k_load_mercy, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.n_words,
                     ctx->fd, ctx->pair, (const uint32_t*)ctx->first, (const uint64_t*)bb.sure.p);
     // carry := carry | bits set during this batch
-    if (ctx->bloo1_new) FGPU_LAUNCH("carry_update", k_carry_merge, 4096, 256, ctx->pair, (const uint32_t*)ctx->bloo1_new, ctx->bloom_bytes / 4);
-    else FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
+    if (ctx->carry_by_set)
+        FGPU_LAUNCH("carry_update", k_carry_set, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
+                    ctx->pair, (const uint64_t*)bb.sure.p);
+    else
+        FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
     return fgpu_resident_keep(ctx);
 }
 
