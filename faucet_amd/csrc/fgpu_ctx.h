@@ -115,7 +115,6 @@ struct fgpu_ctx {
 
     // pass 1 state
     uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
-    uint32_t* bloo1_new = nullptr;   // unused (kept for the destructor's list)
     bool carry_by_set = false;       // large filters: the carry is updated by re-hashing the new k-mers instead of sweeping first[]
     uint32_t* bloo2 = nullptr;
     uint32_t* first = nullptr;       // first-set time per Bloom bit, 4*tai bytes (allocated at load_begin)
