@@ -92,6 +92,9 @@ SIGNATURES = {
     "fgpu_scan_import_table": (C.c_int, [_vp, _vp, _u64, _P(ScanStats)]),
     "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
+    "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "fgpu_probe_valid_extension": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "fgpu_probe_bloom_junction": (C.c_int, [_vp, _vp, _u64, _vp]),
     "fgpu_kernel_times": (C.c_int, [_vp, _P(KernelTime), C.c_int]),
     "fgpu_kernel_times_reset": (C.c_int, [_vp]),
     "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),

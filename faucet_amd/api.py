@@ -252,6 +252,21 @@ class Context:
         self._c(self.lib.fgpu_scan_take_stops(self.h, out.ctypes.data, len(out), C.byref(n), C.byref(seq)))
         return int(seq.value), out[:int(n.value)]
 
+    def _probe_stage3(self, fn, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(len(kmers), dtype=np.int8)
+        self._c(fn(self.h, kmers.ctypes.data, len(kmers), out.ctypes.data))
+        return out
+
+    def probe_jcheck(self, kmers):                   # JChecker::jcheck(kmer_type), batched
+        return self._probe_stage3(self.lib.fgpu_probe_jcheck, kmers)
+
+    def probe_valid_extension(self, kmers):          # JunctionMap::getValidJExtension, batched
+        return self._probe_stage3(self.lib.fgpu_probe_valid_extension, kmers)
+
+    def probe_bloom_junction(self, kmers):           # JunctionMap::isBloomJunction, batched
+        return self._probe_stage3(self.lib.fgpu_probe_bloom_junction, kmers)
+
     def kernel_times(self) -> dict:
         arr = (L.KernelTime * 64)()
         n = self.lib.fgpu_kernel_times(self.h, arr, 64)

@@ -644,6 +644,23 @@ int fgpu_probe_contains(fgpu_ctx* ctx, int which, const uint64_t* canon_host, ui
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------------------
+static int probe_stage3(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int mode, int8_t* out) {
+    if (!ctx || !kmers_host || !out) return FGPU_ERR_ARG;
+    if (!n) return FGPU_OK;
+    DevBuf& b = ctx->probe_buf;
+    int rc = fgpu_ensure(ctx, &b, n * 16);
+    if (rc) return rc;
+    uint64_t* d = (uint64_t*)b.p;
+    FGPU_HIP(hipMemcpyAsync(d, kmers_host, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = fgpu_util_probe_stage3(ctx, d, n, mode, (signed char*)(d + n)))) return rc;
+    FGPU_HIP(hipMemcpyAsync(out, d + n, n, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+int fgpu_probe_jcheck(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 0, out); }
+int fgpu_probe_valid_extension(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 1, out); }
+int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 2, out); }
+
 int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap) {
     if (!ctx) return 0;
     if (fgpu_prof_collect(ctx) != FGPU_OK) return 0;

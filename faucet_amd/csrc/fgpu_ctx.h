@@ -234,6 +234,7 @@ int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned
 int fgpu_util_or(fgpu_ctx* ctx, void* dst, const void* src, uint64_t nbytes);
 int fgpu_util_probe_hash(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t* d_canon, uint64_t* d_hA, uint64_t* d_hB);
 int fgpu_util_probe_contains(fgpu_ctx* ctx, const uint32_t* bloom, const uint64_t* d_canon, uint64_t n, unsigned char* d_out);
+int fgpu_util_probe_stage3(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int mode, signed char* d_out);
 int fgpu_scan_alloc(fgpu_ctx* ctx);
 int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_scan_reset(fgpu_ctx* ctx);

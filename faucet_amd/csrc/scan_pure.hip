@@ -333,7 +333,41 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
     wave_add(&cnt->piece_positions, n_piece);
 }
 
+// ---- Stage 3's Bloom probes, batched: pure functions of bloo2, one k-mer per lane ----------------
+// mode 0  JChecker::jcheck(kmer_type)             utils/JChecker.cpp:51-80
+// mode 1  JunctionMap::getValidJExtension         utils/JunctionMap.cpp:474-490   (-1 none, -2 several, else the nucleotide)
+// mode 2  JunctionMap::isBloomJunction            utils/JunctionMap.cpp:494-504
+__global__ void __launch_bounds__(256) k_probe_stage3(const uint64_t* __restrict__ kmers, uint64_t n, int mode, FdParams fp,
+                                                      const uint32_t* __restrict__ bloom, signed char* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t km = kmers[i] & fp.kmask;
+    int r;
+    if (mode == 0) {
+        r = jcheck_dfs(km, fp, bloom) ? 1 : 0;
+    } else if (mode == 1) {
+        r = -1;
+        for (int nt = 0; nt < 4; nt++) {
+            const uint64_t e = ((km << 2) | (uint64_t)nt) & fp.kmask;
+            if (fd_bloom_contains_canon(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash) && jcheck_dfs(e, fp, bloom)) {
+                if (r != -1) { r = -2; break; }
+                r = nt;
+            }
+        }
+    } else {
+        int paths = 0;
+        for (int nt = 0; nt < 4; nt++) paths += jcheck_dfs(((km << 2) | (uint64_t)nt) & fp.kmask, fp, bloom) ? 1 : 0;
+        r = paths > 1 ? 1 : 0;
+    }
+    out[i] = (signed char)r;
+}
+
 }  // namespace
+
+int fgpu_util_probe_stage3(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int mode, signed char* d_out) {
+    FGPU_LAUNCH("probe_stage3", k_probe_stage3, fgpu_blocks(n, 256), 256, d_kmers, n, mode, ctx->fd, (const uint32_t*)ctx->bloo2, d_out);
+    return FGPU_OK;
+}
 
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     BatchBufs& bb = *ctx->cur;

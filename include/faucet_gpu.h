@@ -225,6 +225,18 @@ int fgpu_probe_hash(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, uint6
 /* Bloom::oldContains (utils/Bloom.h:162-173) of n canonical k-mers against filter `which`. */
 int fgpu_probe_contains(fgpu_ctx* ctx, int which, const uint64_t* canon_host, uint64_t n, uint8_t* out);
 
+/* ---- Stage 3's Bloom probes, batched -----------------------------------------
+ * The contig-graph stage walks the filter from every junction (JunctionMap::findNeighbor, utils/JunctionMap.cpp:231-412); its map
+ * look-ups and its control flow stay on the host, its filter work is these pure functions of bloo2, here for n forward-strand
+ * k-mers at once (one walk step of many junctions in lock-step):
+ *   jcheck            JChecker::jcheck(kmer_type)              utils/JChecker.cpp:51-80      -> 0 / 1
+ *   valid_extension   JunctionMap::getValidJExtension          utils/JunctionMap.cpp:474-490 -> -1 none, -2 several, else 0..3
+ *   bloom_junction    JunctionMap::isBloomJunction             utils/JunctionMap.cpp:494-504 -> 0 / 1
+ * (Bloom::oldContains itself is fgpu_probe_contains.) */
+int fgpu_probe_jcheck(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out);
+int fgpu_probe_valid_extension(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out);
+int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out);
+
 /* ---- profiling --------------------------------------------------------------------------------- */
 typedef struct {
     char     name[48];

@@ -617,6 +617,43 @@ void fo_load_two_filters_mercy(fo_bloom* bloo1, fo_bloom* bloo2, const char* bas
     if (stats) *stats = st;
 }
 
+/* ---- Stage 3's Bloom probes (pure functions of the filter) ---- */
+static bool stage3_jcheck(fo_bloom* b, uint64_t kmer, int k, int j) {                /* JChecker::jcheck(kmer_type), JChecker.cpp:51-80 */
+    const uint64_t mask = kmask(k);
+    std::vector<uint64_t> last{kmer}, next;
+    for (int lvl = 0; lvl < j; lvl++) {
+        next.clear();
+        for (uint64_t km : last)
+            for (int nt = 0; nt < 4; nt++) {
+                uint64_t e = ((km << 2) + static_cast<uint64_t>(nt)) & mask;
+                if (b->old_contains(canon(e, k))) next.push_back(e);
+            }
+        if (next.empty()) return false;
+        last.swap(next);
+    }
+    return true;
+}
+int fo_stage3_jcheck(fo_bloom* b, uint64_t kmer, int k, int j) { return stage3_jcheck(b, kmer, k, j) ? 1 : 0; }
+int fo_stage3_valid_extension(fo_bloom* b, uint64_t kmer, int k, int j) {            /* JunctionMap::getValidJExtension, JunctionMap.cpp:474-490 */
+    const uint64_t mask = kmask(k);
+    int answer = -1;
+    for (int i = 0; i < 4; i++) {
+        uint64_t e = ((kmer << 2) + static_cast<uint64_t>(i)) & mask;
+        if (b->old_contains(canon(e, k)) && stage3_jcheck(b, e, k, j)) {
+            if (answer != -1) return -2;
+            answer = i;
+        }
+    }
+    return answer;
+}
+int fo_stage3_bloom_junction(fo_bloom* b, uint64_t kmer, int k, int j) {             /* JunctionMap::isBloomJunction, JunctionMap.cpp:494-504 */
+    const uint64_t mask = kmask(k);
+    int paths = 0;
+    for (int i = 0; i < 4; i++)
+        if (stage3_jcheck(b, ((kmer << 2) + static_cast<uint64_t>(i)) & mask, k, j)) paths++;
+    return paths > 1 ? 1 : 0;
+}
+
 void fo_load_single_filter(fo_bloom* bloo1, const char* bases, const uint64_t* offsets, uint64_t n, int k,
                            fo_load_stats* stats) {
     fo_load_stats st{0, 0, 0, 0};

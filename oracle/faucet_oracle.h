@@ -72,6 +72,12 @@ typedef struct {
 int  fo_reads_from_file(const char* path, int fastq, fo_reads* out);
 void fo_reads_free(fo_reads*);
 
+/* ---- Stage 3's Bloom probes: JChecker::jcheck(kmer_type) (JChecker.cpp:51-80), JunctionMap::getValidJExtension (-1 none, -2 several;
+ * JunctionMap.cpp:474-490), JunctionMap::isBloomJunction (:494-504).  kmer = the forward-strand k-mer. */
+int fo_stage3_jcheck(fo_bloom* b, uint64_t kmer, int k, int j);
+int fo_stage3_valid_extension(fo_bloom* b, uint64_t kmer, int k, int j);
+int fo_stage3_bloom_junction(fo_bloom* b, uint64_t kmer, int k, int j);
+
 /* ---- pass 1: load_two_filters (Bloom.cpp:267-299,335-349) ------------------------------ */
 typedef struct {
     uint64_t reads_processed;      /* Bloom.cpp:335 */

@@ -66,6 +66,9 @@ def lib():
         "fo_bloom_contains_pair": (i32, [vp, u64, u64, i32]), "fo_bloom_bit_tests": (u64, [vp]),
         "fo_bloom_bit_sets": (u64, [vp]), "fo_bloom_reset_counters": (None, [vp]),
         "fo_reads_from_file": (i32, [cp, i32, C.POINTER(Reads)]), "fo_reads_free": (None, [C.POINTER(Reads)]),
+        "fo_stage3_jcheck": (i32, [vp, u64, i32, i32]),
+        "fo_stage3_valid_extension": (i32, [vp, u64, i32, i32]),
+        "fo_stage3_bloom_junction": (i32, [vp, u64, i32, i32]),
         "fo_load_two_filters": (None, [vp, vp, vp, vp, u64, i32, C.POINTER(LoadStats)]),
         "fo_load_two_filters_mercy": (None, [vp, vp, vp, vp, u64, i32, C.POINTER(LoadStats)]),
         "fo_load_single_filter": (None, [vp, vp, vp, u64, i32, C.POINTER(LoadStats)]),

@@ -67,7 +67,36 @@ static void scan_case(const char* name, int k, int j, int spacer, const std::vec
     dump_map(name, jm);
 }
 
+/* ref_kat stage3 <bloom file> <bloom size request> <n_hash> <k> <j> <file of hex k-mers>: the reference's own Stage-3 Bloom probes
+ * (Bloom::oldContains, JChecker::jcheck(kmer_type), JunctionMap::getValidJExtension, JunctionMap::isBloomJunction) for every k-mer */
+static int stage3_kat(int argc, char** argv) {
+    if (argc < 8) return 2;
+    const int k = atoi(argv[5]), j = atoi(argv[6]);
+    setSizeKmer(k);
+    Bloom bloom((uint64_t)atoll(argv[3]), k);
+    bloom.set_number_of_hash_func(atoi(argv[4]));
+    bloom.load(argv[2]);
+    JChecker jc(j, &bloom);
+    JunctionMap jm(&bloom, &jc, 100);
+    FILE* f = fopen(argv[7], "r");
+    if (!f) return 2;
+    unsigned long long x;
+    printf("{\"kat\":\"stage3\",\"k\":%d,\"j\":%d,\"tai\":%llu,\"probes\":[", k, j, (unsigned long long)bloom.tai);
+    bool first = true;
+    while (fscanf(f, "%llx", &x) == 1) {
+        kmer_type km = (kmer_type)x;
+        DoubleKmer dk(km);
+        printf("%s[\"%llx\",%d,%d,%d,%d]", first ? "" : ",", x, bloom.oldContains(get_canon(km)) ? 1 : 0, jc.jcheck(km) ? 1 : 0,
+               jm.getValidJExtension(dk), jm.isBloomJunction(km) ? 1 : 0);
+        first = false;
+    }
+    printf("]}\n");
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "stage3") return stage3_kat(argc, argv);
     /* ---- codec + hash KAT at k=31, tai=2^29 ---- */
     {
         setSizeKmer(31);

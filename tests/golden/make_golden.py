@@ -171,5 +171,48 @@ def main():
                                            "-singletons", "20000", "--fastq", "--paired_ends"], tolerate_crash=True)
 
 
+def stage3_kats():
+    """Stage 3's Bloom probes (oldContains, jcheck, getValidJExtension, isBloomJunction) by the reference's own functions
+    on the golden filters, for k-mers on and next to the reads: appended to kat.jsonl as "stage3" lines."""
+    sys.path.insert(0, ROOT)
+    from tests.golden_util import Case
+    from faucet_amd import api
+    lines = []
+    for name in ("c1_k21", "j2_spacer20_k15", "twohash_k31_L150", "j0_k15"):
+        c = Case(name)
+        k = c.k
+        mask = (1 << (2 * k)) - 1
+        code = {65: 0, 67: 1, 84: 2, 71: 3}
+        kmers = []
+        for line in c.lines()[:25]:
+            if len(line) < k or any(ch not in code for ch in line):
+                continue
+            x = 0
+            for i, ch in enumerate(line):
+                x = ((x << 2) | code[ch]) & mask
+                if i >= k - 1:
+                    kmers.append(x)
+                    if i % 7 == 0:                      # neighbours off the read: alternate extensions, mostly absent
+                        kmers.extend((((x << 2) | nt) & mask) for nt in range(4))
+        kmers = list(dict.fromkeys(kmers))[:4000]
+        tai = len(c.bloom()) * 8
+        nh = c.counters["n_hash"]
+        with tempfile.TemporaryDirectory() as td:
+            bf, kf = os.path.join(td, "b.bloom"), os.path.join(td, "kmers.txt")
+            c.bloom().tofile(bf)
+            with open(kf, "w") as f:
+                f.write("\n".join("%x" % x for x in kmers) + "\n")
+            out = subprocess.run([REF_KAT, "stage3", bf, str(tai - 1), str(nh), str(k), str(c.j), kf], capture_output=True, text=True, check=True).stdout
+        d = json.loads(out.strip().splitlines()[-1])
+        assert d["tai"] == tai and len(d["probes"]) == len(kmers)
+        d["case"], d["n_hash"] = name, nh
+        lines.append(json.dumps(d, separators=(",", ":")))
+    with open(os.path.join(HERE, "kat.jsonl"), "a") as f:
+        for ln in lines:
+            f.write(ln + "\n")
+    print("stage3 KATs:", [len(json.loads(ln)["probes"]) for ln in lines])
+
+
 if __name__ == "__main__":
     main()
+    stage3_kats()

@@ -738,3 +738,18 @@ def test_mercy_random_inputs_vs_oracle(seed):
     assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
     assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits())
     assert st["to_bloo2"] == olst.to_bloo2 and st["kmers"] == olst.kmers
+
+
+@pytest.mark.parametrize("d", kat("stage3"), ids=lambda d: d["case"])
+def test_stage3_probes_on_device_match_the_reference(d):
+    """the contig-graph stage's filter work (oldContains, jcheck, getValidJExtension, isBloomJunction), batched on the
+    device, against the reference's own functions on the golden filters"""
+    c = Case(d["case"])
+    ctx = api.Context(d["k"], d["tai"], d["n_hash"], j=d["j"])
+    ctx.bloom_upload(L.BLOO2, c.bloom())
+    kmers = np.array([int(p[0], 16) for p in d["probes"]], dtype=np.uint64)
+    canon = np.array([po.lib().fo_canon(int(x), d["k"]) for x in kmers], dtype=np.uint64)
+    assert list(ctx.probe_contains(L.BLOO2, canon)) == [p[1] for p in d["probes"]]
+    assert list(ctx.probe_jcheck(kmers)) == [p[2] for p in d["probes"]]
+    assert list(ctx.probe_valid_extension(kmers)) == [p[3] for p in d["probes"]]
+    assert list(ctx.probe_bloom_junction(kmers)) == [p[4] for p in d["probes"]]

@@ -135,3 +135,19 @@ def test_file_reader_matches_line_splitter(tmp_path):
         bases, offs = po.reads_from_file(str(p), c.fastq)
         b2, o2 = po.reads_from_lines(c.lines())
         assert np.array_equal(offs, o2) and np.array_equal(bases, b2)
+
+
+@pytest.mark.parametrize("d", kat("stage3"), ids=lambda d: d["case"])
+def test_stage3_probe_kats(d):
+    """Stage 3's Bloom probes restated in the oracle against the reference's own JChecker::jcheck, JunctionMap::getValidJExtension
+    and isBloomJunction on the golden filters"""
+    c = Case(d["case"])
+    b = po.Bloom(d["tai"], d["n_hash"])
+    b.set_bits(c.bloom())
+    lib = po.lib()
+    for hx, contains, jc, ext, bj in d["probes"]:
+        km = int(hx, 16)
+        assert lib.fo_bloom_old_contains(b.h, lib.fo_canon(km, d["k"])) == contains
+        assert lib.fo_stage3_jcheck(b.h, km, d["k"], d["j"]) == jc
+        assert lib.fo_stage3_valid_extension(b.h, km, d["k"], d["j"]) == ext
+        assert lib.fo_stage3_bloom_junction(b.h, km, d["k"], d["j"]) == bj
