@@ -18,24 +18,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (make_genome / make_reads: the bench's generators)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+fastq = len(sys.argv) > 2 and sys.argv[2] == "fastq"
 L, G = 100, 2 * n
 dev = torch.device("cuda", 0)
 reads = bench.make_reads(bench.make_genome(G, 2, dev), n, L, 0.01, 1000, dev).cpu().numpy()
-rec = np.empty((n, 10 + L + 1), dtype=np.uint8)
-rec[:, 0] = ord(">")
+rec = np.empty((n, 10 + L + 1 + ((2 + L + 1) if fastq else 0)), dtype=np.uint8)
+rec[:, 0] = ord("@") if fastq else ord(">")
 idx = np.arange(n, dtype=np.int64)
 for d in range(8):
     rec[:, 8 - d] = ord("0") + (idx // 10 ** d) % 10
 rec[:, 9] = ord("\n")
 rec[:, 10:10 + L] = reads
 rec[:, 10 + L] = ord("\n")
-path = "/tmp/e2e_reads.fa"
+if fastq:
+    rec[:, 11 + L] = ord("+")
+    rec[:, 12 + L] = ord("\n")
+    rec[:, 13 + L:13 + 2 * L] = ord("I")
+    rec[:, 13 + 2 * L] = ord("\n")
+path = "/tmp/e2e_reads.fq" if fastq else "/tmp/e2e_reads.fa"
 rec.tofile(path)
 print(f"{path}: {os.path.getsize(path) / 1e9:.2f} GB, {n} reads")
 del rec, reads
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
 base = ["-read_load_file", path, "-read_scan_file", path, "-size_kmer", "31", "-max_read_length", str(L),
-        "-estimated_kmers", str(10 * n), "-singletons", str(2 * n), "--no_cleaning"]
+        "-estimated_kmers", str(10 * n), "-singletons", str(2 * n), "--no_cleaning"] + (["--fastq"] if fastq else [])
 
 
 def digest(p):
