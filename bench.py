@@ -33,6 +33,7 @@ from faucet_amd import _lib as L  # noqa: E402
 from faucet_amd import api, sharded  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FALLBACKS = []      # steps in which the lazy-flag self-check fired and the scan was repeated with eager flags
 METRIC = "canonical k-mers/s (load+scan) at k=31, 100bp reads; % HBM roofline"
 
 
@@ -93,10 +94,12 @@ def step_single(ctx, batches):
         ctx.load_batch(b)
     lst = ctx.load_end()
     bloo2 = ctx.bloom_download(L.BLOO2)             # pass-1 output final in host memory
-    ctx.scan_begin()
-    for b in batches:
-        ctx.scan_batch(b)
-    sst = ctx.scan_end()
+    # ReadScanner.scanReads = scan_begin / scan_batch... / scan_end, plus the documented reaction to a failed lazy-flag self-check
+    # (DESIGN.md section 4): close the pass, switch to eager junction tests, scan again -- inside the timed region if it happens
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(batches)
+    if sc.fell_back_to_eager:
+        FALLBACKS.append(1)
     keys, recs = ctx.junctions()                    # pass-2 output final in host memory (creation order)
     return lst, sst, bloo2, keys, recs
 
@@ -329,12 +332,12 @@ def main():
                                f"filters 2 x {tai // 8 >> 20} MiB, {nh} hash functions",
                    "reads_per_gpu": args.reads, "read_len": L_, "k": k, "tai": tai, "n_hash": nh, "batch_reads": args.batch_reads,
                    "sharding": "reads in file order; prefix-OR(bloo1 presence) + OR-allreduce(bloo2); walk handed rank to rank" if world > 1 else "single GPU"},
-        "kmers_per_step": kmers_total,
+        "kmers_per_step": kmers_total, "lazy_flag_fallbacks": len(FALLBACKS),
         "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
                     "walk_max_cluster_rank0": int(sst["walk_max_cluster"]),
                     "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"]),
-                    "valid_reused_rank0": int(sst["valid_reused"]), "nb_processed_rank0": int(sst["nb_processed"]),
+                    "valid_reused_rank0": int(sst["valid_reused"]), "flags_filled_in_walk_rank0": int(sst["flags_filled"]), "nb_processed_rank0": int(sst["nb_processed"]),
                     "nb_skipped_rank0": int(sst["nb_skipped"]), "nb_jcheck_kmer_rank0": int(sst["nb_jcheck_kmer"])},
         "kernel_ms_per_step_rank0": {n: round(ms / args.steps, 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
     }

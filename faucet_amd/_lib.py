@@ -42,7 +42,7 @@ class LoadStats(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("reads_processed", "unambiguous_reads", "reads_no_errors", "nb_jcheck_kmer", "nb_no_juncs",
                                           "nb_processed", "nb_skipped", "n_junctions", "kmers", "walk_windows", "walk_followers",
-                                          "walk_max_cluster", "flag_positions", "piece_positions", "valid_reused")]
+                                          "walk_max_cluster", "flag_positions", "piece_positions", "valid_reused", "flags_filled")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

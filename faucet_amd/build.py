@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libfaucet_gpu.so")
 CLI = os.path.join(HERE, "faucet")
 HIP_SOURCES = ["api.hip", "pack.hip", "load.hip", "scan_pure.hip", "scan_walk.hip", "diag.hip", "text.hip"]
 CPP_SOURCES = ["sizing.cpp"]
-HEADERS = ["fgpu_ctx.h", "fgpu_device.h", os.path.join(ROOT, "include", "faucet_gpu.h")]
+HEADERS = ["fgpu_ctx.h", "fgpu_device.h", "fgpu_flags.h", os.path.join(ROOT, "include", "faucet_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 

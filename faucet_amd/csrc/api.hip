@@ -564,6 +564,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     s.flag_positions = c.flag_positions;
     s.piece_positions = c.piece_positions;
     s.valid_reused = c.valid_reused;
+    s.flags_filled = c.flags_filled;
     memset(&ctx->carried, 0, sizeof(ctx->carried));
     if (stats) *stats = s;
     return FGPU_OK;

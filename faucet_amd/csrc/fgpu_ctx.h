@@ -102,6 +102,7 @@ struct DevCounters {
     unsigned long long flag_positions;  // positions where the flags kernel evaluated testForJunction
     unsigned long long piece_positions; // positions inside valid pieces
     unsigned long long valid_reused;    // validity answers taken from the load pass' resident planes instead of probing
+    unsigned long long flags_filled;    // windows whose junction tests the walk evaluated itself (the preview had left them out)
 };
 
 struct fgpu_ctx {
@@ -229,6 +230,7 @@ void fgpu_resident_reset(fgpu_ctx* ctx, bool keep_going);
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_stage_scan_need(fgpu_ctx* ctx);
+int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx);
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);
 int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out);
 int fgpu_util_or(fgpu_ctx* ctx, void* dst, const void* src, uint64_t nbytes);

@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "fgpu_ctx.h"
+#include "fgpu_flags.h"
 
 namespace {
 
@@ -211,56 +212,6 @@ __global__ void __launch_bounds__(256) k_scan_piece_read(const uint2* __restrict
     piece_read[i] = (uint32_t)lo;
 }
 
-// JChecker::jcheck: depth-first search for one chain of j present extensions (same truth value as the
-// reference's level-by-level search; nothing else about it is observable).
-__device__ bool jcheck_dfs(uint64_t kmer, const FdParams& fp, const uint32_t* __restrict__ bloom) {
-    if (fp.j == 0) return true;
-    uint64_t stack_k[8];
-    int stack_nt[8];
-    int depth = 0;
-    stack_k[0] = kmer;
-    stack_nt[0] = 0;
-    const int J = fp.j < 8 ? fp.j : 8;
-    while (depth >= 0) {
-        if (stack_nt[depth] == 4) { depth--; continue; }
-        int nt = stack_nt[depth]++;
-        uint64_t e = ((stack_k[depth] << 2) | (uint64_t)nt) & fp.kmask;
-        if (fd_bloom_contains_canon_lazy(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
-            if (depth + 1 == J) return true;
-            depth++;
-            stack_k[depth] = e;
-            stack_nt[depth] = 0;
-        }
-    }
-    return false;
-}
-
-// testForJunction for the k-mer `key` (already oriented towards the extension) with real next base `real`
-__device__ __forceinline__ void test_for_junction(uint64_t key, int real, const FdParams& fp, const uint32_t* __restrict__ bloom,
-                                                  bool& flag, int& njc) {
-    flag = false;
-    njc = 0;
-    for (int nt = 0; nt < 4; nt++) {
-        if (nt == real) continue;
-        uint64_t e = ((key << 2) | (uint64_t)nt) & fp.kmask;
-        if (fd_bloom_contains_canon_lazy(bloom, fd_canon(e, fp.k), fp.tai_mask, fp.n_hash)) {
-            njc++;
-            if (jcheck_dfs(e, fp, bloom)) { flag = true; return; }
-        }
-    }
-}
-
-// position of the n-th set bit of x (n < popcount(x))
-__device__ __forceinline__ int select_bit(uint64_t x, int n) {
-    int pos = 0;
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) {
-        const int c = __popcll(x & ((1ULL << sh) - 1));
-        if (n >= c) { x >>= sh; pos += sh; n -= c; }
-    }
-    return pos;
-}
-
 // testForJunction where the walk may need it.  Work item = (position, direction) with the need bit set and a neighbour
 // window on that side.  Only a third to a half of the positions qualify, so a lane-per-position layout would leave most
 // lanes of a wave idle while the others wait for their probes: instead a wave takes 256 positions at a time, gathers the
@@ -441,6 +392,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
                     (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
                     (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,
                     (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters);
+        if ((rc = fgpu_stage_scan_debug_drop(ctx))) return rc;
     }
     return FGPU_OK;
 }

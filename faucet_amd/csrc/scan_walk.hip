@@ -31,6 +31,7 @@
 #include <algorithm>
 
 #include "fgpu_ctx.h"
+#include "fgpu_flags.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -338,8 +339,9 @@ struct WalkCtx {
     FdParams fp;
     JTable jt;
     DevCounters* cnt;
+    const uint32_t* bloom;   // bloo2, for the junction tests the preview did not order (walk_fill_flags)
     // per-thread accumulators
-    unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created;
+    unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
     // oriented keys this thread's cluster has created in the current window: the snapshot planes of phase A cannot
     // know them, every later in-map test of the cluster has to (tandem repeats inside a piece; later pieces of the cluster)
     static constexpr int NC = 16;
@@ -361,7 +363,12 @@ __device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
 __device__ __forceinline__ uint64_t pv_word(const PieceView& v, uint64_t r0, uint64_t r1, const uint64_t* plane, uint32_t c) {
     if (c == 0) return r0;
     if (c == 1) return r1;
-    return fd_bits_at(plane, v.p0 + 64ULL * c) & chunk_mask(v.nwin, c);
+    // beyond the 128 windows held in registers: agent-scope loads, because the walk may have patched these words itself
+    // (walk_fill_flags) and a plain load could be served from a stale L1 line
+    const uint64_t p = v.p0 + 64ULL * c;
+    const int o = (int)(p & 63);
+    const uint64_t lo = ld_agent(&plane[p >> 6]), hi = ld_agent(&plane[(p >> 6) + 1]);
+    return ((lo >> o) | ((hi << 1) << (63 - o))) & chunk_mask(v.nwin, c);
 }
 
 __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t p0, uint32_t nwin) {
@@ -482,11 +489,81 @@ __device__ __forceinline__ uint32_t jcheck_sum(const WalkCtx& wc, const PieceVie
            pv_popc(v, v.c0F0, v.c0F1, wc.pl.cf0, fq0, fq1) + 2 * pv_popc(v, v.c1F0, v.c1F1, wc.pl.cf1, fq0, fq1);
 }
 
-// every half-step in [t0, t1) is being scanned: its flags must have been evaluated (need plane); otherwise raise error bit 4
-__device__ __forceinline__ void check_scanned(WalkCtx& wc, const PieceView& v, int t0, int t1) {
-    if (t1 <= t0) return;
-    const uint32_t qa = (uint32_t)(t0 >> 1), qb = (uint32_t)((t1 - 1) >> 1) + 1;
-    if (pv_popc(v, v.nd0, v.nd1, wc.pl.need, qa, qb) != (qb < v.nwin ? qb : v.nwin) - qa) atomicOr(&wc.cnt->error_flags, 4ULL);
+// The preview of the pure stage (need plane) says where the walk may stop skipping; only there are testForJunction's
+// answers in the flag planes.  The preview is built on a junction map that keeps changing -- distances are also raised by
+// reads that travel the other way and link a junction to a farther one -- so now and then the walk scans a window the
+// preview left out.  Its junction tests are then evaluated right here (the same code the pure stage runs), patched into
+// the planes this walk reads, and the search that needed them is repeated: the result is exact whatever the preview said.
+__device__ __noinline__ void walk_fill_flags(const Planes pl, const FdParams fp, const uint32_t* bloom, uint64_t p0, uint32_t nwin, uint32_t q,
+                                             uint32_t& bits_out) {
+    const uint64_t pos = p0 + q;
+    const uint64_t km = fd_kmer_at(pl.codes, pos, fp.k);
+    bool f_f = false, f_b = false;
+    int c_f = 0, c_b = 0;
+    if (q + 1 < nwin) test_for_junction(km, fd_base_at(pl.codes, pos + fp.k), fp, bloom, f_f, c_f);            // a window follows: facing forward
+    if (q > 0) test_for_junction(fd_revcomp(km, fp.k), fd_base_at(pl.codes, pos - 1) ^ 2, fp, bloom, f_b, c_b);   // a window precedes: facing backward
+    bits_out = (f_f ? 1u : 0u) | (f_b ? 2u : 0u) | ((uint32_t)(c_f & 3) << 2) | ((uint32_t)(c_b & 3) << 4);
+    if (q >= 128) {   // these words are read from memory (pv_word): publish there
+        const unsigned long long bm = 1ULL << (pos & 63);
+        const uint64_t w = pos >> 6;
+        if (f_f) atomicOr((unsigned long long*)&pl.ff[w], bm);
+        if (f_b) atomicOr((unsigned long long*)&pl.fb[w], bm);
+        if (c_f & 1) atomicOr((unsigned long long*)&pl.cf0[w], bm);
+        if (c_f & 2) atomicOr((unsigned long long*)&pl.cf1[w], bm);
+        if (c_b & 1) atomicOr((unsigned long long*)&pl.cb0[w], bm);
+        if (c_b & 2) atomicOr((unsigned long long*)&pl.cb1[w], bm);
+        atomicOr((unsigned long long*)&pl.need[w], bm);
+    }
+}
+
+// every half-step in [t0, t1) is about to be scanned: evaluate the junction tests the preview left out; true if there were any
+__device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, int t1) {
+    if (t1 <= t0) return false;
+    uint32_t qa = (uint32_t)(t0 >> 1), qb = (uint32_t)((t1 - 1) >> 1) + 1;
+    if (qb > v.nwin) qb = v.nwin;
+    bool any = false;
+    while (qa < qb) {
+        const uint32_t c = qa >> 6;
+        const uint32_t n = min(qb - qa, 64u - (qa & 63));
+        uint64_t range = (n == 64 ? ~0ULL : ((1ULL << n) - 1)) << (qa & 63);
+        uint64_t missing = range & ~pv_word(v, v.nd0, v.nd1, wc.pl.need, c);
+        while (missing) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(missing);
+            missing &= missing - 1;
+            const uint32_t q = c * 64 + b;
+            uint32_t r;
+            walk_fill_flags(wc.pl, wc.fp, wc.bloom, v.p0, v.nwin, q, r);
+            wc.n_filled++;
+            any = true;
+            // A junction test that comes out TRUE here is a place where this piece may create a junction, and the window's
+            // dependency clusters were built without knowing that (only previewed flags are registered as candidates): the
+            // exactness argument of the parallel walk no longer covers this scan.  Rare squared; give up loudly -- the caller
+            // repeats the scan with every test evaluated up front (fgpu_scan_set_eager).
+            if (r & 3) atomicOr(&wc.cnt->error_flags, 4ULL);
+            if (q < 128) {   // the register copies this walk works from
+                const uint64_t bm = 1ULL << b;
+                if (c == 0) {
+                    v.nd0 |= bm;
+                    if (r & 1) v.fF0 |= bm;
+                    if (r & 2) v.fB0 |= bm;
+                    if (r & 4) v.c0F0 |= bm;
+                    if (r & 8) v.c1F0 |= bm;
+                    if (r & 16) v.c0B0 |= bm;
+                    if (r & 32) v.c1B0 |= bm;
+                } else {
+                    v.nd1 |= bm;
+                    if (r & 1) v.fF1 |= bm;
+                    if (r & 2) v.fB1 |= bm;
+                    if (r & 4) v.c0F1 |= bm;
+                    if (r & 8) v.c1F1 |= bm;
+                    if (r & 16) v.c0B1 |= bm;
+                    if (r & 32) v.c1B1 |= bm;
+                }
+            }
+        }
+        qa += n;
+    }
+    return any;
 }
 
 // A junction record held in two registers: dist[0..4] bytes 0-4, cov[0..3] bytes 5-8, linked mask byte 9.
@@ -573,54 +650,62 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         // ---- find_next_junction (ReadScanner.cpp:61-86): first t' >= t that is in the map, hits the spacer rule, or is flagged
         int t_sp = last_pos + spacer;
         if (t_sp < t) t_sp = t;
-        int t_ev = 0x7fffffff;
-        bool ev_in_map = false;
-        {
-            const uint32_t q0 = (uint32_t)(t >> 1);
-            const int t_stop = tmax < t_sp ? tmax : t_sp;
-            for (uint32_t c = q0 >> 6; c * 64 < nwin && 2 * (int)(c * 64) <= t_stop; c++) {
-                uint64_t mF, mB;
-                in_map_words(wc, v, c, mF, mB);
-                uint64_t eF = mF | pv_word(v, v.fF0, v.fF1, wc.pl.ff, c);
-                uint64_t eB = mB | pv_word(v, v.fB0, v.fB1, wc.pl.fb, c);
-                if (c == (q0 >> 6)) {               // nothing before q0; at q0 the backward half-step is behind us if t is odd
-                    const uint64_t from = ~0ULL << (q0 & 63);
-                    eF &= from;
-                    eB &= from;
-                    if (t & 1) eB &= ~(1ULL << (q0 & 63));
-                }
-                int tb = eB ? 2 * (int)(c * 64 + __builtin_ctzll(eB)) : 0x7fffffff;
-                int tf = eF ? 2 * (int)(c * 64 + __builtin_ctzll(eF)) + 1 : 0x7fffffff;
-                int te = tb < tf ? tb : tf;
-                if (te != 0x7fffffff) {
-                    t_ev = te;
-                    ev_in_map = ((te & 1) ? mF : mB) >> ((te >> 1) & 63) & 1ULL;
-                    break;
+        int tn;
+        uint32_t q = 0;
+        bool fwd = false, in_map = false, by_spacer = false;
+        for (;;) {   // repeated when junction tests had to be evaluated on the spot (fill_missing)
+            int t_ev = 0x7fffffff;
+            bool ev_in_map = false;
+            {
+                const uint32_t q0 = (uint32_t)(t >> 1);
+                const int t_stop = tmax < t_sp ? tmax : t_sp;
+                for (uint32_t c = q0 >> 6; c * 64 < nwin && 2 * (int)(c * 64) <= t_stop; c++) {
+                    uint64_t mF, mB;
+                    in_map_words(wc, v, c, mF, mB);
+                    uint64_t eF = mF | pv_word(v, v.fF0, v.fF1, wc.pl.ff, c);
+                    uint64_t eB = mB | pv_word(v, v.fB0, v.fB1, wc.pl.fb, c);
+                    if (c == (q0 >> 6)) {               // nothing before q0; at q0 the backward half-step is behind us if t is odd
+                        const uint64_t from = ~0ULL << (q0 & 63);
+                        eF &= from;
+                        eB &= from;
+                        if (t & 1) eB &= ~(1ULL << (q0 & 63));
+                    }
+                    int tb = eB ? 2 * (int)(c * 64 + __builtin_ctzll(eB)) : 0x7fffffff;
+                    int tf = eF ? 2 * (int)(c * 64 + __builtin_ctzll(eF)) + 1 : 0x7fffffff;
+                    int te = tb < tf ? tb : tf;
+                    if (te != 0x7fffffff) {
+                        t_ev = te;
+                        ev_in_map = ((te & 1) ? mF : mB) >> ((te >> 1) & 63) & 1ULL;
+                        break;
+                    }
                 }
             }
+            tn = t_ev < t_sp ? t_ev : t_sp;
+            if (tn > tmax) {   // runs off the end of the piece: everything up to tmax is scanned
+                if (fill_missing(wc, v, t, tmax + 1)) continue;
+                break;
+            }
+            q = (uint32_t)(tn >> 1);
+            fwd = tn & 1;
+            // why did we stop here?  (order of the tests in find_next_junction)
+            if (tn == t_ev) {
+                in_map = ev_in_map;
+            } else {           // stopped by the spacer rule before any event: the position itself may still be in the map
+                uint64_t mF, mB;
+                in_map_words(wc, v, q >> 6, mF, mB);
+                in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
+            }
+            by_spacer = !in_map && (tn - last_pos >= spacer);
+            if (fill_missing(wc, v, t, (in_map || by_spacer) ? tn : tn + 1)) continue;
+            break;
         }
-        int tn = t_ev < t_sp ? t_ev : t_sp;
         if (tn > tmax) {   // ran off the end of the piece
             wc.nb_processed += (unsigned long long)(tmax - t + 1);
             wc.nb_jcheck += jcheck_sum(wc, v, t, tmax + 1);
-            check_scanned(wc, v, t, tmax + 1);
             break;
         }
-        const uint32_t q = (uint32_t)(tn >> 1);
-        const bool fwd = tn & 1;
-        // why did we stop here?  (order of the tests in find_next_junction)
-        bool in_map;
-        if (tn == t_ev) {
-            in_map = ev_in_map;
-        } else {           // stopped by the spacer rule before any event: the position itself may still be in the map
-            uint64_t mF, mB;
-            in_map_words(wc, v, q >> 6, mF, mB);
-            in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
-        }
-        const bool by_spacer = !in_map && (tn - last_pos >= spacer);
         wc.nb_processed += (unsigned long long)(tn - t);
         wc.nb_jcheck += jcheck_sum(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
-        check_scanned(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
 
         // ---- junction at (q, fwd)  (ReadScanner.cpp:133-192)
         uint64_t km = pv_kmer(v, wc.pl.codes, p0 + q, k);
@@ -688,13 +773,13 @@ constexpr uint32_t LOCAL_MEMBERS = 16;
 __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root,
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
-                                             uint64_t piece_seq_base, DevCounters* cnt, int dbg) {
+                                             uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t created_keys[WalkCtx::NC];
     WalkCtx wc;
     wc.ckey = created_keys;
-    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt;
-    wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = 0;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
+    wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
     wc.nc = 0; wc.c_overflow = false; wc.created_now = false; wc.dbg = dbg;
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
@@ -728,8 +813,8 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         }
     }
     // wave-level reduction of the counters
-    unsigned long long v[6] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, wc.n_created, n_follow};
-    for (int c = 0; c < 6; c++)
+    unsigned long long v[7] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, wc.n_created, n_follow, wc.n_filled};
+    for (int c = 0; c < 7; c++)
         for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_down(v[c], o, 64);
     for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(biggest, o, 64); biggest = t > biggest ? t : biggest; }
     if (fd_lane() == 0) {
@@ -740,6 +825,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         if (v[2]) atomicAdd(&cnt->nb_jcheck, v[2]);
         if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
         if (v[4]) atomicAdd(&cnt->n_junctions, v[4]);
+        if (v[6]) atomicAdd(&cnt->flags_filled, v[6]);
     }
 }
 
@@ -779,6 +865,17 @@ __global__ void __launch_bounds__(256) k_iota_u32(uint32_t* p, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) p[i] = (uint32_t)i;
+}
+
+// FGPU_DEBUG_NEED_DROP=1 (tests): after the flags kernel, forget the evaluation of about half of the windows whose tests came out
+// false -- need bit and NbJCheckKmer bits cleared -- so that the walk has to evaluate them itself wherever it scans them.
+__global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, const uint64_t* __restrict__ ff, const uint64_t* __restrict__ fb,
+                                                         uint64_t* need, uint64_t* cf0, uint64_t* cf1, uint64_t* cb0, uint64_t* cb1) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t drop = need[w] & ~(ff[w] | fb[w]) & fd_mix(w * 0x9E3779B97F4A7C15ULL + 12345);
+        need[w] &= ~drop;
+        cf0[w] &= ~drop; cf1[w] &= ~drop; cb0[w] &= ~drop; cb1[w] &= ~drop;
+    }
 }
 
 // ---- lazy flags: which positions can the walk ever stop skipping at? -------------------------------------------
@@ -1018,11 +1115,21 @@ int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     }
     FGPU_HIP(hipMemsetAsync(bb.need.p, 0, wb, ctx->stream));
     if (!bb.n_pieces) return FGPU_OK;
+
     JTable jt = make_jt(ctx);
     FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
                 bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p);
     FGPU_LAUNCH("need_prewalk", k_need_prewalk, fgpu_grid(bb.n_pieces, 256), 256, (const uint64_t*)bb.codes.p, (const uint2*)bb.pieces.p,
                 bb.n_pieces, ctx->fd, jt, (const uint64_t*)bb.nF.p, (const uint64_t*)bb.nB.p, (unsigned long long*)bb.need.p);
+    return FGPU_OK;
+}
+
+int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx) {
+    static const bool drop = getenv("FGPU_DEBUG_NEED_DROP") && getenv("FGPU_DEBUG_NEED_DROP")[0] == '1';
+    BatchBufs& bb = *ctx->cur;
+    if (!drop || !bb.n_pieces) return FGPU_OK;
+    FGPU_LAUNCH("debug_need_drop", k_debug_need_drop, fgpu_grid(bb.n_words, 256), 256, bb.n_words, (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p,
+                (uint64_t*)bb.need.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p, (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p);
     return FGPU_OK;
 }
 
@@ -1079,7 +1186,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc);
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
                     (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
-                    seq_base, ctx->counters, dbg_walk);
+                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk);
         FGPU_LAUNCH("walk_clean", k_walk_clean, 2048, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
     }

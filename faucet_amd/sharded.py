@@ -84,8 +84,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
     if rank == 0:
         # the first shard has nothing to wait for: it streams (pure stage of batch b+1 overlapped with the walk of batch b, lazy
         # junction tests), which puts the table on its way ~50 ms per 10 M reads earlier than prepare-all + walk
-        for b in batches:
-            backend.scan_batch(b)
+        stats = backend.scan_stream(batches)               # ... and closes the pass
     else:
         for b in batches:
             backend.scan_prepare(b)                        # pure stage while the earlier shards walk
@@ -100,7 +99,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
         backend.import_table(buf, n_in, dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]])))
     if rank > 0:
         backend.scan_walk_prepared()                       # ordered walk of this shard
-    stats = backend.scan_end()
+        stats = backend.scan_end()
     if rank < world - 1:
         n_out, buf = backend.export_table()
         backend.fence()
@@ -167,8 +166,26 @@ class GpuShard:
     def scan_prepare(self, batch):
         self.ctx.scan_prepare(batch)
 
-    def scan_batch(self, batch):
-        self.ctx.scan_batch(batch)
+    def scan_stream(self, batches):
+        """scan_batch over all batches; when the lazy-flag self-check fires the pass is closed and repeated
+        with every junction test evaluated -- the table is reset by scan_begin, nothing has left this rank yet"""
+        from .api import FaucetGpuError
+        try:
+            for b in batches:
+                self.ctx.scan_batch(b)
+            return self.ctx.scan_end()
+        except FaucetGpuError as e:
+            if "lazy-flag" not in str(e):
+                raise
+            try:
+                self.ctx.scan_end()
+            except FaucetGpuError:
+                pass
+            self.ctx.scan_set_eager(True)
+            self.ctx.scan_begin()
+            for b in batches:
+                self.ctx.scan_batch(b)
+            return self.ctx.scan_end()
 
     def scan_walk_prepared(self):
         self.ctx.scan_walk_prepared()

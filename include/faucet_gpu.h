@@ -105,6 +105,7 @@ typedef struct {
     uint64_t flag_positions;     /* window positions at which testForJunction was evaluated (lazy flags: a subset of all) */
     uint64_t piece_positions;    /* window positions inside valid pieces */
     uint64_t valid_reused;       /* getValidReads answers taken from the load pass' resident planes (no filter probe) */
+    uint64_t flags_filled;       /* windows whose testForJunction the walk evaluated itself because the preview had left them out */
 } fgpu_scan_stats;
 
 /* One element of the list ReadScanner::scanInputRead returns for a read (src/ReadScanner.cpp:260-282): the real-extension

@@ -753,3 +753,36 @@ def test_stage3_probes_on_device_match_the_reference(d):
     assert list(ctx.probe_jcheck(kmers)) == [p[2] for p in d["probes"]]
     assert list(ctx.probe_valid_extension(kmers)) == [p[3] for p in d["probes"]]
     assert list(ctx.probe_bloom_junction(kmers)) == [p[4] for p in d["probes"]]
+
+
+def test_walk_evaluates_the_junction_tests_the_preview_left_out():
+    """The need plane is only a preview: where the walk scans a window outside it, it runs testForJunction itself (and gives up
+    loudly only if such a test comes out true, because the dependency clusters did not know that candidate).  With
+    FGPU_DEBUG_NEED_DROP=1 (read once per process: child pytest) the evaluation of about half of the windows whose tests are false
+    is thrown away after the flags kernel, so the walk re-evaluates them wherever it scans them -- long reads beyond the 128
+    windows held in registers included -- and every scan test still has to agree with the oracle and the goldens."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGPU_DEBUG_NEED_DROP="1")
+    sel = ("test_scan_matches_reference_junctions or test_random_inputs_vs_oracle or test_reads_of_two_thousand_bases or "
+           "test_periodic_genome or test_deeper_jcheck or test_scan_input_read_lists or test_many_tiny_reads")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # and the path was really taken: a scan in such a process reports the windows it tested itself
+    code = ("import numpy as np\n"
+            "from faucet_amd import _lib as L, api\n"
+            "from oracle import pyoracle as po\n"
+            "from tests.golden_util import Case\n"
+            "c = Case('c1_k21')\n"
+            "bases, offs = po.reads_from_lines(c.lines())\n"
+            "tai, nh = api.load_filter_shape(c.E, c.S)\n"
+            "ctx = api.Context(c.k, tai, nh)\n"
+            "ctx.bloom_upload(L.BLOO2, c.bloom())\n"
+            "st = api.ReadScanner(ctx).scanReads([api.ReadBatch(bases, offs)])\n"
+            "assert st['flags_filled'] > 1000 and st['nb_jcheck_kmer'] == c.counters['nb_jcheck_kmer'], st\n"
+            "print('filled', st['flags_filled'])\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "filled" in r.stdout, r.stdout + r.stderr

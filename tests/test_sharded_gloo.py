@@ -65,8 +65,10 @@ class OracleShard:
     def scan_prepare(self, batch):
         self.prepared.append(batch)
 
-    def scan_batch(self, batch):
-        self.sc.scan_reads(batch[0], batch[1])
+    def scan_stream(self, batches):
+        for batch in batches:
+            self.sc.scan_reads(batch[0], batch[1])
+        return self.scan_end()
 
     def scan_walk_prepared(self):
         for b in self.prepared:
