@@ -494,26 +494,14 @@ __device__ __forceinline__ uint32_t jcheck_sum(const WalkCtx& wc, const PieceVie
 // reads that travel the other way and link a junction to a farther one -- so now and then the walk scans a window the
 // preview left out.  Its junction tests are then evaluated right here (the same code the pure stage runs), patched into
 // the planes this walk reads, and the search that needed them is repeated: the result is exact whatever the preview said.
-__device__ __noinline__ void walk_fill_flags(const Planes pl, const FdParams fp, const uint32_t* bloom, uint64_t p0, uint32_t nwin, uint32_t q,
-                                             uint32_t& bits_out) {
-    const uint64_t pos = p0 + q;
-    const uint64_t km = fd_kmer_at(pl.codes, pos, fp.k);
+__device__ __noinline__ uint32_t walk_fill_flags(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ bloom, const FdParams fp,
+                                                 uint64_t pos, bool has_next, bool has_prev) {
+    const uint64_t km = fd_kmer_at(codes, pos, fp.k);
     bool f_f = false, f_b = false;
     int c_f = 0, c_b = 0;
-    if (q + 1 < nwin) test_for_junction(km, fd_base_at(pl.codes, pos + fp.k), fp, bloom, f_f, c_f);            // a window follows: facing forward
-    if (q > 0) test_for_junction(fd_revcomp(km, fp.k), fd_base_at(pl.codes, pos - 1) ^ 2, fp, bloom, f_b, c_b);   // a window precedes: facing backward
-    bits_out = (f_f ? 1u : 0u) | (f_b ? 2u : 0u) | ((uint32_t)(c_f & 3) << 2) | ((uint32_t)(c_b & 3) << 4);
-    if (q >= 128) {   // these words are read from memory (pv_word): publish there
-        const unsigned long long bm = 1ULL << (pos & 63);
-        const uint64_t w = pos >> 6;
-        if (f_f) atomicOr((unsigned long long*)&pl.ff[w], bm);
-        if (f_b) atomicOr((unsigned long long*)&pl.fb[w], bm);
-        if (c_f & 1) atomicOr((unsigned long long*)&pl.cf0[w], bm);
-        if (c_f & 2) atomicOr((unsigned long long*)&pl.cf1[w], bm);
-        if (c_b & 1) atomicOr((unsigned long long*)&pl.cb0[w], bm);
-        if (c_b & 2) atomicOr((unsigned long long*)&pl.cb1[w], bm);
-        atomicOr((unsigned long long*)&pl.need[w], bm);
-    }
+    if (has_next) test_for_junction(km, fd_base_at(codes, pos + fp.k), fp, bloom, f_f, c_f);                   // a window follows: facing forward
+    if (has_prev) test_for_junction(fd_revcomp(km, fp.k), fd_base_at(codes, pos - 1) ^ 2, fp, bloom, f_b, c_b);   // a window precedes: facing backward
+    return (f_f ? 1u : 0u) | (f_b ? 2u : 0u) | ((uint32_t)(c_f & 3) << 2) | ((uint32_t)(c_b & 3) << 4);
 }
 
 // every half-step in [t0, t1) is about to be scanned: evaluate the junction tests the preview left out; true if there were any
@@ -531,8 +519,7 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             const uint32_t b = (uint32_t)__builtin_ctzll(missing);
             missing &= missing - 1;
             const uint32_t q = c * 64 + b;
-            uint32_t r;
-            walk_fill_flags(wc.pl, wc.fp, wc.bloom, v.p0, v.nwin, q, r);
+            const uint32_t r = walk_fill_flags(wc.pl.codes, wc.bloom, wc.fp, v.p0 + q, q + 1 < v.nwin, q > 0);
             wc.n_filled++;
             any = true;
             // A junction test that comes out TRUE here is a place where this piece may create a junction, and the window's
@@ -540,7 +527,17 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             // exactness argument of the parallel walk no longer covers this scan.  Rare squared; give up loudly -- the caller
             // repeats the scan with every test evaluated up front (fgpu_scan_set_eager).
             if (r & 3) atomicOr(&wc.cnt->error_flags, 4ULL);
-            if (q < 128) {   // the register copies this walk works from
+            if (q >= 128) {   // these words are read from memory (pv_word): publish there
+                const unsigned long long gm = 1ULL << ((v.p0 + q) & 63);
+                const uint64_t gw = (v.p0 + q) >> 6;
+                if (r & 1) atomicOr((unsigned long long*)&wc.pl.ff[gw], gm);
+                if (r & 2) atomicOr((unsigned long long*)&wc.pl.fb[gw], gm);
+                if (r & 4) atomicOr((unsigned long long*)&wc.pl.cf0[gw], gm);
+                if (r & 8) atomicOr((unsigned long long*)&wc.pl.cf1[gw], gm);
+                if (r & 16) atomicOr((unsigned long long*)&wc.pl.cb0[gw], gm);
+                if (r & 32) atomicOr((unsigned long long*)&wc.pl.cb1[gw], gm);
+                atomicOr((unsigned long long*)&wc.pl.need[gw], gm);
+            } else {          // the register copies this walk works from
                 const uint64_t bm = 1ULL << b;
                 if (c == 0) {
                     v.nd0 |= bm;

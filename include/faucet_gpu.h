@@ -195,10 +195,12 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_scan_walk_prepared(fgpu_ctx* ctx);
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
-/* The scan evaluates testForJunction only where its preview of the walk says the walk can stop (lazy flags)
- * and the walk verifies that preview at every flag it reads.  Should the verification ever fail, the scan call (or
- * fgpu_scan_end) returns FGPU_ERR_STATE instead of a possibly different map: finish with fgpu_scan_end, switch the
- * preview off with fgpu_scan_set_eager(ctx, 1) and scan again (same results as FGPU_FLAG_EAGER_FLAGS, about 1.5x the probes). */
+/* The scan evaluates testForJunction only where its preview of the walk says the walk can stop (lazy
+ * flags); where the walk scans a window outside that preview it evaluates the tests itself, so the results are exact either
+ * way.  The one case it cannot absorb is such a late test coming out TRUE (a junction at a k-mer the window's dependency
+ * clusters did not know): the scan call (or fgpu_scan_end) then returns FGPU_ERR_STATE instead of a possibly different map --
+ * finish with fgpu_scan_end, switch the preview off with fgpu_scan_set_eager(ctx, 1) and scan again (same results as
+ * FGPU_FLAG_EAGER_FLAGS, about 1.5x the probes).  fgpu_scan_stats.flags_filled counts the windows evaluated inside the walk. */
 int fgpu_scan_set_eager(fgpu_ctx* ctx, int on);
 /* scanInputRead's lists of one scanned batch, flattened in processing order (reads in file order; inside a read the
  * valid pieces in the order scanInputRead walks them; inside a piece by half-step).  Batches come out in scan order,
