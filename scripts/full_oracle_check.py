@@ -1,7 +1,7 @@
 """BASELINE config 2 at FULL size against the oracle, bit for bit (diagnostic; GPU box; the oracle needs ~5 minutes on one core):
 bloo1/bloo2 bytes, junction records in creation order, every counter.
 
-    python scripts/full_oracle_check.py [n_reads]
+    python scripts/full_oracle_check.py [n_reads [genome_seed read_seed]]
 """
 import os
 import sys
@@ -17,8 +17,10 @@ from faucet_amd import api  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+gseed = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+rseed = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 dev = torch.device("cuda", 0)
-reads = bench.make_reads(bench.make_genome(2 * n, 2, dev), n, 100, 0.01, 1000, dev)
+reads = bench.make_reads(bench.make_genome(2 * n, gseed, dev), n, 100, 0.01, rseed, dev)
 tai, nh = api.load_filter_shape(10 * n, 2 * n)
 ctx = api.Context(31, tai, nh)
 lst, sst, b2, keys, recs = bench.step_single(ctx, bench.device_batches(reads, 1_000_000))
