@@ -509,6 +509,7 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
     if (t1 <= t0) return false;
     uint32_t qa = (uint32_t)(t0 >> 1), qb = (uint32_t)((t1 - 1) >> 1) + 1;
     if (qb > v.nwin) qb = v.nwin;
+    if (pv_popc(v, v.nd0, v.nd1, wc.pl.need, qa, qb) == qb - qa) return false;   // the usual case: the preview covered the stretch
     bool any = false;
     while (qa < qb) {
         const uint32_t c = qa >> 6;
