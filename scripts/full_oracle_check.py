@@ -19,8 +19,25 @@ from oracle import pyoracle as po  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 gseed = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rseed = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+repeats = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # planted copies of 500-base blocks: real branching, not only error junctions
 dev = torch.device("cuda", 0)
-reads = bench.make_reads(bench.make_genome(2 * n, gseed, dev), n, 100, 0.01, rseed, dev)
+if repeats:
+    from faucet_amd import synth
+    g = synth.make_genome(2 * n, gseed)
+    rng = np.random.default_rng(gseed + 1)
+    for _ in range(repeats // 4):           # families of 4 copies, each copy with a few private mutations
+        src = int(rng.integers(0, 2 * n - 500))
+        block = g[src:src + 500].copy()
+        for _c in range(4):
+            dst = int(rng.integers(0, 2 * n - 500))
+            cp = block.copy()
+            m = rng.random(500) < 0.01
+            cp[m] = synth._ACGT[rng.integers(0, 4, size=int(m.sum()))]
+            g[dst:dst + 500] = cp
+    genome = torch.from_numpy(g).to(dev)
+else:
+    genome = bench.make_genome(2 * n, gseed, dev)
+reads = bench.make_reads(genome, n, 100, 0.01, rseed, dev)
 tai, nh = api.load_filter_shape(10 * n, 2 * n)
 ctx = api.Context(31, tai, nh)
 lst, sst, b2, keys, recs = bench.step_single(ctx, bench.device_batches(reads, 1_000_000))
