@@ -20,6 +20,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 gseed = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rseed = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 repeats = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # planted copies of 500-base blocks: real branching, not only error junctions
+Lr = int(sys.argv[5]) if len(sys.argv) > 5 else 100
+err = float(sys.argv[6]) if len(sys.argv) > 6 else 0.01
+two_hash = len(sys.argv) > 7 and sys.argv[7] == "two_hash"
 dev = torch.device("cuda", 0)
 if repeats:
     from faucet_amd import synth
@@ -37,8 +40,11 @@ if repeats:
     genome = torch.from_numpy(g).to(dev)
 else:
     genome = bench.make_genome(2 * n, gseed, dev)
-reads = bench.make_reads(genome, n, 100, 0.01, rseed, dev)
-tai, nh = api.load_filter_shape(10 * n, 2 * n)
+reads = bench.make_reads(genome, n, Lr, err, rseed, dev)
+if two_hash:
+    _, tai, nh = api.size_two_hash(40 * n, 0.04)
+else:
+    tai, nh = api.load_filter_shape(10 * n, 2 * n)
 ctx = api.Context(31, tai, nh)
 lst, sst, b2, keys, recs = bench.step_single(ctx, bench.device_batches(reads, 1_000_000))
 b1 = ctx.bloom_download(L.BLOO1)
