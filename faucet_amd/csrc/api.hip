@@ -199,6 +199,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
     if (!rc && (e = hipMalloc(&ctx->counters, sizeof(DevCounters))) != hipSuccess) fail("hipMalloc counters", e);
     if (!rc && (e = hipHostMalloc(&ctx->counters_host, sizeof(DevCounters))) != hipSuccess) fail("hipHostMalloc", e);
+    if (!rc && (e = hipHostMalloc(&ctx->fb_host, 64)) != hipSuccess) fail("hipHostMalloc", e);
     if (!rc) {
         memset(ctx->counters_host, 0, sizeof(DevCounters));
         hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream);
@@ -225,6 +226,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
+    if (ctx->fb_host) hipHostFree(ctx->fb_host);
     if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     for (ResidentBatch* r : ctx->resident) delete r;
@@ -379,7 +381,9 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_piece_base = 0;
     ctx->scan_imported = 0;
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
-                                                 : std::min<uint64_t>(1ULL << 22, ctx->max_span);
+                                                 : std::min<uint64_t>(1ULL << 18, ctx->max_span);   // calibrated upwards window by window
+    ctx->calib_left = 16;
+    ctx->calib_f = ctx->calib_p = 0;
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
     ctx->walked_pieces = 0;
@@ -403,7 +407,7 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
-        if (f * 2 > p && ctx->window_span > 4096) ctx->window_span /= 2;
+        if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
         else if (f * 4 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;
     }
     ctx->adapt_followers = ctx->counters_host->followers;

@@ -103,6 +103,7 @@ struct DevCounters {
     unsigned long long piece_positions; // positions inside valid pieces
     unsigned long long valid_reused;    // validity answers taken from the load pass' resident planes instead of probing
     unsigned long long flags_filled;    // windows whose junction tests the walk evaluated itself (the preview had left them out)
+    unsigned long long walked_pieces;   // pieces of the windows walked so far (feedback for the window-span controller)
 };
 
 struct fgpu_ctx {
@@ -162,6 +163,9 @@ struct fgpu_ctx {
     uint64_t scan_pieces_seen = 0;   // pieces counted by previous batches of this scan
 
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
+    int calib_left = 0;              // windows the controller still waits for individually (start of a scan, after a bad batch)
+    uint64_t calib_f = 0, calib_p = 0;
+    unsigned long long* fb_host = nullptr;   // pinned: {followers, walked pieces} read back during calibration
     fgpu_scan_stats carried = {};    // counters handed over by the previous shard (multi-GPU)
 
     BatchBufs bb_default;                 // the batch of load_batch / scan_batch

@@ -302,10 +302,13 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
 // second launch; the leader of a cluster sorts its (short) list when it walks.
 __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict__ parent, uint32_t* count, uint32_t* head,
                                                       uint32_t* __restrict__ flat, uint32_t* __restrict__ next, Planes pl, uint64_t lo,
-                                                      uint64_t hi, WinDesc* wd_out) {
+                                                      uint64_t hi, WinDesc* wd_out, DevCounters* cnt) {
     const WinDesc wd = make_window(pl, lo, hi);
     const uint32_t n = wd.n;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *wd_out = wd;   // the walk kernel reads it with one uniform load
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *wd_out = wd;                  // the walk kernel reads it with one uniform load
+        cnt->walked_pieces += n;       // one writer per launch; feedback for the window-span controller
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t r = i;
         for (;;) { uint32_t pr = parent[r]; if (pr == r) break; r = pr; }
@@ -1151,7 +1154,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;
     const uint64_t ext = bb.max_piece_span;          // a piece that starts inside the window may reach this far beyond it
-    if (span + ext + 64 > ctx->wcap) {               // the per-position slot list of a window is sized for 4 x the largest span
+    if (ctx->max_span + ext + 64 > ctx->wcap) {      // the per-position slot list of a window is sized for 4 x the largest span
         ctx->err = "a read of " + std::to_string(ext) + " bases is longer than the walk's window tables allow";
         return FGPU_ERR_CAPACITY;
     }
@@ -1172,8 +1175,10 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     // thousands of tiny launches: by default one event pair around the whole stage
     const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
     ctx->prof_suppress = !ctx->prof_walk_detail;
-    for (uint64_t lo = 0; lo < T; lo += span) {
-        const uint64_t hi = std::min<uint64_t>(T, lo + span);
+    uint64_t span_now = span;
+    for (uint64_t lo = 0, step = 0; lo < T; lo += step) {
+        step = span_now;
+        const uint64_t hi = std::min<uint64_t>(T, lo + step);
         const uint64_t pos_end = std::min<uint64_t>(T, hi + ext);
         const unsigned grid = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) & ~63ULL, 256);
         const int parity = (int)(ctx->scan_windows & 1);
@@ -1181,13 +1186,32 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, lo, hi, pos_end);
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, 256, 256, (const uint32_t*)ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
-                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc);
+                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
         FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
                     (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk);
         FGPU_LAUNCH("walk_clean", k_walk_clean, 2048, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
+        // Calibration: at the start of a scan (and again whenever a batch came out with most of its pieces queueing) the host
+        // waits for the window it has just issued and looks at the share of pieces that had to queue behind an earlier piece of
+        // their cluster.  High coverage makes clusters percolate -- 250x reads of a small genome were 20x slower with the 4 M
+        // position windows that suit 50x data -- and a whole batch is too long to walk with the wrong size.
+        if (ctx->calib_left > 0 && !ctx->prm.walk_window_span) {
+            FGPU_HIP(hipMemcpyAsync(ctx->fb_host, &ctx->counters->followers, 8, hipMemcpyDeviceToHost, walk_stream));
+            FGPU_HIP(hipMemcpyAsync(ctx->fb_host + 1, &ctx->counters->walked_pieces, 8, hipMemcpyDeviceToHost, walk_stream));
+            FGPU_HIP(hipStreamSynchronize(walk_stream));
+            const uint64_t f = ctx->fb_host[0] - ctx->calib_f, p = ctx->fb_host[1] - ctx->calib_p;
+            if (p >= 64) {
+                ctx->calib_f = ctx->fb_host[0];
+                ctx->calib_p = ctx->fb_host[1];
+                if (f * 2 > p && span_now > 4096) span_now /= 2;
+                else if (f * 4 < p && span_now < ctx->max_span) span_now = std::min<uint64_t>(span_now * 4, ctx->max_span);
+                else ctx->calib_left = 1;          // settled
+                ctx->calib_left--;
+            }
+        }
     }
+    ctx->window_span = span_now;
     ctx->prof_suppress = false;
     fgpu_prof_end(ctx, stage_tok);
     if (bb.walk_done) {
