@@ -375,3 +375,26 @@ def junction_lines(keys, recs, k):
         out.append("%s %s  %s  %s " % (print_kmer(int(key), k), " ".join(str(int(x)) for x in r["dist"]),
                                        " ".join(str(x) for x in cv + [sum(cv)]), " ".join(str(int(x)) for x in r["linked"])))
     return out
+
+
+_ENC = {"A": 0, "C": 1, "T": 2, "G": 3}
+
+
+def parse_junction_lines(lines, k):
+    """Inverse of junction_lines: the `.junctions` text back to (keys, records), the way a restart with `-junctions_file` reads it
+    (JunctionMap::buildFromFile utils/JunctionMap.cpp:619-639 + Junction(string) utils/Junction.cpp:102-118: k-mer word, 5 dists,
+    4 coverages, one total that is skipped, 5 link flags, all whitespace-separated)."""
+    lines = [ln for ln in lines if ln.strip()]
+    keys = np.zeros(len(lines), dtype=np.uint64)
+    recs = np.zeros(len(lines), dtype=JUNC_DTYPE)
+    for i, ln in enumerate(lines):
+        w = ln.split()
+        if len(w) != 16 or len(w[0]) != k:
+            raise ValueError(f"junction line {i}: expected a {k}-mer and 15 numbers, got {ln!r}")
+        key = 0
+        for ch in w[0]:
+            key = (key << 2) | _ENC[ch]
+        keys[i] = key
+        v = [int(x) for x in w[1:]]
+        recs[i]["dist"], recs[i]["cov"], recs[i]["linked"] = v[0:5], v[5:9], v[10:15]
+    return keys, recs

@@ -1160,7 +1160,6 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     }
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
-    const unsigned walk_grid = fgpu_blocks(ctx->wmax, 64);
     static const int dbg_walk = getenv("FGPU_DEBUG_WALK") ? atoi(getenv("FGPU_DEBUG_WALK")) : 0;
     // the whole stage goes to the walk stream, behind the completion of this batch's pure stage
     static const bool no_overlap = getenv("FGPU_NO_OVERLAP") && getenv("FGPU_NO_OVERLAP")[0] == '1';   // measurement aid
@@ -1182,15 +1181,21 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const uint64_t pos_end = std::min<uint64_t>(T, hi + ext);
         const unsigned grid = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) & ~63ULL, 256);
         const int parity = (int)(ctx->scan_windows & 1);
+        // grids sized for THIS window (a window of w positions holds at most w/(k+1)+2 piece starts): small windows -- high
+        // coverage data -- must not pay for the launch of the thousands of empty blocks the largest window would need
+        const uint64_t max_pieces = std::min<uint64_t>((hi - lo) / (uint64_t)(ctx->fd.k + 1) + 2, ctx->wmax);
+        const unsigned walk_grid_w = fgpu_blocks(max_pieces, 64);
+        const unsigned cluster_grid = std::min(256u, fgpu_blocks(max_pieces, 256));
+        const unsigned clean_grid = std::min(2048u, fgpu_blocks(pos_end - (lo & ~63ULL), 256));
         FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, ctx->uf_parent, lo, hi, pos_end, ctx->counters, parity);
         FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, lo, hi, pos_end);
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
-        FGPU_LAUNCH("walk_cluster", k_walk_cluster, 256, 256, (const uint32_t*)ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
+        FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
-        FGPU_LAUNCH("walk", k_walk, walk_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
+        FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
                     (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk);
-        FGPU_LAUNCH("walk_clean", k_walk_clean, 2048, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
+        FGPU_LAUNCH("walk_clean", k_walk_clean, clean_grid, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
         ctx->scan_windows++;
         // Calibration: at the start of a scan (and again whenever a batch came out with most of its pieces queueing) the host
         // waits for the window it has just issued and looks at the share of pieces that had to queue behind an earlier piece of

@@ -76,3 +76,17 @@ def test_cli_argument_errors_exit_1():
     assert r.returncode == 1 and "Cannot start from junctions without a bloom file." in r.stderr
     r = _cli(*base[:-6], "-estimated_kmers", "100000", "-singletons", "0", "-file_prefix", "/tmp/p", "--no_cleaning")
     assert r.returncode == 1 and "singletons" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["c1_k21", "ragged_k31", "j2_spacer20_k15", "pe_fastq_k21"])
+def test_junction_file_text_round_trips(name):
+    """`.junctions` lines written by the compiled reference -> parse (what a -junctions_file restart reads) -> print: same text."""
+    from faucet_amd import api
+    from tests.golden_util import Case
+    c = Case(name)
+    lines = c.junction_lines()
+    keys, recs = api.parse_junction_lines(lines, c.k)
+    assert len(keys) == len(lines) > 0 and len(np.unique(keys)) == len(keys)
+    assert api.junction_lines(keys, recs, c.k) == lines
+    with pytest.raises(ValueError):
+        api.parse_junction_lines([lines[0][1:]], c.k)

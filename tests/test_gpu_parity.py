@@ -368,6 +368,39 @@ def test_cli_writes_the_reference_files(name, how, tmp_path):
     assert "Weights after load: %s, %s" % tuple(cn["weights_after_load"]) in r.stdout
 
 
+def test_cli_reads_both_passes_from_named_pipes(tmp_path):
+    """The reference's streaming scripts (src/stream_data_from_urls_list.sh) feed both passes through pipes: the host must read its
+    inputs strictly sequentially, never seek or ask for a size."""
+    import os
+    import subprocess
+    import threading
+    c = Case("ragged_k31")
+    text = c.reads_text()
+    pipes = [str(tmp_path / "load.fifo"), str(tmp_path / "scan.fifo")]
+    for p in pipes:
+        os.mkfifo(p)
+
+    def feed(path):
+        with open(path, "wb") as f:                      # blocks until the CLI opens its end
+            for lo in range(0, len(text), 777):          # odd-sized writes: short reads on the other side
+                f.write(text[lo:lo + 777])
+                f.flush()
+
+    feeders = [threading.Thread(target=feed, args=(p,), daemon=True) for p in pipes]
+    for t in feeders:
+        t.start()
+    args = [a for a in c.meta["args"] if not a.endswith(".fa")]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    r = subprocess.run([exe, "-read_load_file", pipes[0], "-read_scan_file", pipes[1], "-file_prefix", str(tmp_path / "out")] + args,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for t in feeders:
+        t.join(timeout=10)
+        assert not t.is_alive()
+    assert np.array_equal(np.fromfile(tmp_path / "out.bloom", dtype=np.uint8), c.bloom())
+    assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
+
+
 def _oracle_lists(bases, offs, k, j, spacer, bloom_bits, tai, nh):
     """scanInputRead's return value for every read, from the oracle driven read by read"""
     b2 = po.Bloom(tai, nh)
