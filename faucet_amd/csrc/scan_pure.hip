@@ -284,6 +284,163 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
     wave_add(&cnt->piece_positions, n_piece);
 }
 
+// The same work as k_scan_flags for j <= 1, organised as a per-lane state machine.  An item is a chain of 3 to ~20 DEPENDENT bit
+// tests with early exits (3 alternate extensions, each up to n_hash bits, each present one followed by up to 4 x n_hash bits of
+// jcheck), so in the kernel above a wave runs as long as its longest chain while most of its lanes have long finished: the
+// probes in flight -- the only thing a random-access-bound kernel has -- drop to under half of the lanes.  Here every lane
+// issues exactly one bit test per iteration and a lane whose chain has ended takes the next item in the same iteration.  Items
+// come from a pool the wave shares: 64 words (one per lane) of forward / backward work masks in LDS with their prefix counts;
+// item t is found by bisection over the prefix counts.  The pool rolls on to the next 64 words as soon as it is empty, while
+// unfinished chains of the previous words are still running (they hold everything they need in registers).
+struct FlagPool {
+    unsigned long long mf[64], mb[64];
+    int excl[64];
+};
+
+__global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
+                                                       const uint64_t* __restrict__ need, uint64_t T, uint64_t n_words, FdParams fp,
+                                                       const uint32_t* __restrict__ bloom, unsigned long long* ff, unsigned long long* fb,
+                                                       unsigned long long* cf0, unsigned long long* cf1, unsigned long long* cb0,
+                                                       unsigned long long* cb1, DevCounters* cnt) {
+    __shared__ FlagPool pools[4];
+    volatile FlagPool* pool = &pools[threadIdx.x >> 6];
+    const int lane = fd_lane();
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t wv = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_groups = (n_words + 63) / 64;
+    uint64_t grp = wv * n_groups / n_waves;
+    const uint64_t grp_end = (wv + 1) * n_groups / n_waves;
+    unsigned long long n_eval = 0, n_piece = 0;
+    int next = 0, total = 0;          // uniform: items of the pool handed out / in the pool
+    uint64_t pool_word0 = 0;          // uniform: first word of the pool
+
+    // per-lane chain state
+    bool active = false;
+    uint64_t key = 0, alt = 0, hA = 0, hB = 0, item_w = 0;
+    int real = 0, nt = 0, jnt = -1, h = 0, njc = 0, item_bit = 0;
+    bool backward = false, fresh = false;
+
+    for (;;) {
+        // ---- hand items to the lanes without one
+        uint64_t idle = __ballot(!active);
+        while (idle && (next < total || grp < grp_end)) {
+            if (next == total) {   // the pool is empty: the next 64 words
+                const uint64_t w = grp * 64 + lane;
+                uint64_t f = 0, b = 0;
+                if (w < n_words) {
+                    const uint64_t tmask = (w + 1) * 64 <= T ? ~0ULL : (T > w * 64 ? (1ULL << (T - w * 64)) - 1 : 0ULL);
+                    const uint64_t pmw = pm[w] & tmask, nd = need[w] & tmask;
+                    f = nd & pmw & ((pmw >> 1) | (pm[w + 1] << 63));              // a window follows: facing forward
+                    b = nd & pmw & ((pmw << 1) | (w ? pm[w - 1] >> 63 : 0ULL));   // a window precedes: facing backward
+                    n_eval += __popcll(nd);
+                    n_piece += __popcll(pmw);
+                }
+                const int c = __popcll(f) + __popcll(b);
+                int incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                pool->mf[lane] = f;
+                pool->mb[lane] = b;
+                pool->excl[lane] = incl - c;
+                total = __builtin_amdgcn_readlane(incl, 63);
+                next = 0;
+                pool_word0 = grp * 64;
+                grp++;
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            const int r = __popcll(idle & lt_mask);
+            const int avail = total - next;
+            if (!active && r < avail) {
+                const int t = next + r;
+                int s = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (pool->excl[s + step] <= t) s += step;   // largest s with excl[s] <= t (words without items share the excl of the next)
+                const uint64_t f = pool->mf[s], b = pool->mb[s];
+                const int within = t - pool->excl[s], cf = __popcll(f);
+                backward = within >= cf;
+                item_bit = backward ? select_bit(b, within - cf) : select_bit(f, within);
+                item_w = pool_word0 + s;
+                const uint64_t pos = item_w * 64 + item_bit;
+                const uint64_t km = fd_kmer_at(codes, pos, fp.k);
+                if (!backward) {   // real extension = base after the window (utils/ReadKmer.cpp:107-110)
+                    key = km;
+                    real = fd_base_at(codes, pos + fp.k);
+                } else {           // reverse complement, real extension = complement of the base before (:111-113)
+                    key = fd_revcomp(km, fp.k);
+                    real = fd_base_at(codes, pos - 1) ^ 2;
+                }
+                nt = real == 0 ? 1 : 0;
+                alt = ((key << 2) | (uint64_t)nt) & fp.kmask;
+                jnt = -1;
+                njc = 0;
+                fresh = true;
+                active = true;
+            }
+            next += min(__popcll(idle), avail);
+            idle = __ballot(!active);
+        }
+        if (!__ballot(active)) break;
+        if (active) {
+            if (fresh) {   // a new k-mer to look up: the alternate itself (jnt < 0) or one of its extensions (jcheck)
+                const uint64_t e = jnt < 0 ? alt : ((alt << 2) | (uint64_t)jnt) & fp.kmask;
+                fd_hash_pair(fd_canon(e, fp.k), fp.tai_mask, hA, hB);
+                h = 0;
+                fresh = false;
+            }
+            const uint64_t p = (hA + (uint64_t)h * hB) & fp.tai_mask;
+            const bool bit = (bloom[p >> 5] >> (p & 31)) & 1u;
+            bool done = false, flag = false;
+            if (bit && ++h < fp.n_hash) {
+                // next bit of the same k-mer
+            } else if (bit) {                       // the k-mer is in the filter
+                if (jnt < 0) {                      // an alternate extension exists (src/ReadScanner.cpp:44-49)
+                    njc++;
+                    if (fp.j == 0) { done = true; flag = true; }
+                    else { jnt = 0; fresh = true; }
+                } else {                            // and it continues: junction
+                    done = true;
+                    flag = true;
+                }
+            } else {                                // absent
+                if (jnt >= 0 && jnt < 3) {
+                    jnt++;
+                    fresh = true;
+                } else {                            // alternate absent, or none of its 4 extensions present: the next alternate
+                    nt++;
+                    if (nt == real) nt++;
+                    if (nt > 3) done = true;
+                    else {
+                        alt = ((key << 2) | (uint64_t)nt) & fp.kmask;
+                        jnt = -1;
+                        fresh = true;
+                    }
+                }
+            }
+            if (done) {
+                const unsigned long long bm = 1ULL << item_bit;
+                if (!backward) {
+                    if (flag) atomicOr(&ff[item_w], bm);
+                    if (njc & 1) atomicOr(&cf0[item_w], bm);
+                    if (njc & 2) atomicOr(&cf1[item_w], bm);
+                } else {
+                    if (flag) atomicOr(&fb[item_w], bm);
+                    if (njc & 1) atomicOr(&cb0[item_w], bm);
+                    if (njc & 2) atomicOr(&cb1[item_w], bm);
+                }
+                active = false;
+            }
+        }
+    }
+    wave_add(&cnt->flag_positions, n_eval);
+    wave_add(&cnt->piece_positions, n_piece);
+}
+
 // ---- Stage 3's Bloom probes, batched: pure functions of bloo2, one k-mer per lane ----------------
 // mode 0  JChecker::jcheck(kmer_type)             utils/JChecker.cpp:51-80
 // mode 1  JunctionMap::getValidJExtension         utils/JunctionMap.cpp:474-490   (-1 none, -2 several, else the nucleotide)
@@ -388,6 +545,14 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
         // twice the usual grid: shorter-lived blocks free wave slots more often, which lets the high-priority walk kernels of the
         // previous batch in sooner (walk stage 86 -> 80 ms per step; beyond 16 K blocks the flags kernel itself slows down)
         const unsigned flags_grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(bb.n_words / 16, 1), 2 * FGPU_GRID_BLOCKS);
+        static const int sm_blocks = getenv("FGPU_FLAGS_SM_BLOCKS") ? atoi(getenv("FGPU_FLAGS_SM_BLOCKS")) : 4096;
+        if (ctx->fd.j <= 1 && sm_blocks > 0) {
+            const unsigned sm_grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>((bb.n_words + 255) / 256, 1), (uint64_t)sm_blocks);
+            FGPU_LAUNCH("scan_flags", k_scan_flags_sm, sm_grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
+                        (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
+                        (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,
+                        (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters);
+        } else
         FGPU_LAUNCH("scan_flags", k_scan_flags, flags_grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
                     (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
                     (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,
