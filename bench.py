@@ -366,7 +366,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                traffic = json.load(f).get("bytes_per_launch", {}).get("k_" + name)
+                per_launch = json.load(f).get("bytes_per_launch", {})
+                traffic = per_launch.get("k_" + name, per_launch.get("k_" + name + "_sm"))   # scan_flags runs as k_scan_flags_sm for j <= 1
         res["device_time_share"] = {n: round(ms / (1e3 * elapsed), 4) for n, (c, ms) in ktimes.items() if ms / (1e3 * elapsed) > 0.01}
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
