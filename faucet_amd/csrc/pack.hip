@@ -29,95 +29,136 @@ __device__ __forceinline__ uint64_t spread32(uint32_t v) {
     return x;
 }
 
-// One LANE per stream position, one wave per 64-position word: the bases are read as coalesced 64-byte rows, the bad
-// word and the two code-bit planes come out of three ballots.  Every wave takes a contiguous run of words; the read
-// that contains a position is found once per run (binary search) and then followed with a cursor over a window of 64
-// read start positions held one per lane, so that the only memory access per word is the row of bases itself.
+// bit 7 of every byte of v that is zero (exact)
+__device__ __forceinline__ uint64_t zero_bytes(uint64_t v) {
+    return ~(((v & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | v) & 0x8080808080808080ULL;
+}
+
+// 8 characters (first in the low byte) -> their 2-bit codes (character q at bits 2q..2q+1) and "is A/C/G/T" bits (bit q)
+__device__ __forceinline__ void convert8(uint64_t x, uint32_t& code16, uint32_t& good8) {
+    uint64_t t = (x >> 1) & 0x0303030303030303ULL;
+    t = (t | (t >> 6)) & 0x000F000F000F000FULL;
+    t = (t | (t >> 12)) & 0x000000FF000000FFULL;
+    t = (t | (t >> 24)) & 0xFFFFULL;
+    code16 = (uint32_t)t;
+    const uint64_t g = zero_bytes(x ^ 0x4141414141414141ULL) | zero_bytes(x ^ 0x4343434343434343ULL) |
+                       zero_bytes(x ^ 0x4747474747474747ULL) | zero_bytes(x ^ 0x5454545454545454ULL);
+    good8 = (uint32_t)(((g >> 7) * 0x0102040810204080ULL) >> 56);
+}
+
+// One LANE per 32 stream positions = one 64-bit word of codes and half a word of the bad plane.  The positions of a lane are
+// at most a few runs of consecutive characters (a read, its separator, the next read ...); a run is fetched as the 16-byte
+// aligned chunks that hold it, funnel-shifted to its first byte and converted 8 characters at a time with SWAR arithmetic
+// (about a quarter of an instruction per position; one lane per position with ballots cost ten times that and ran at 5 % of
+// the streaming rate).  Every wave takes a contiguous run of lanes' worth of positions; the read that contains a position is
+// found by bisection over a window of 64 read start positions held one per lane (registers, no memory access), or over the
+// offsets in memory where reads are so short that 64 of them do not span the 2048 positions of a trip.
 __global__ void __launch_bounds__(256) k_pack(const unsigned char* __restrict__ bases, const uint64_t* __restrict__ offs,
                                               const uint64_t* __restrict__ starts, uint64_t n_reads, uint64_t T, uint64_t n_words, uint64_t* __restrict__ codes,
-                                              uint64_t* __restrict__ bad, unsigned char* __restrict__ readflag) {
-    const uint64_t total_words = n_words + FGPU_PADW;
+                                              uint32_t* __restrict__ bad32, unsigned char* __restrict__ readflag) {
+    const uint64_t total_hw = 2 * (n_words + FGPU_PADW);
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t per = (total_words + n_waves - 1) / n_waves;
-    const uint64_t w0 = wave * per, w1 = w0 + per < total_words ? w0 + per : total_words;
-    if (w0 >= w1) return;
+    const uint64_t per = (((total_hw + n_waves - 1) / n_waves) + 63) & ~63ULL;
+    const uint64_t h0 = wave * per, h1 = h0 + per < total_hw ? h0 + per : total_hw;
+    if (h0 >= h1) return;
     const int lane = fd_lane();
     const uint64_t off0 = offs[0];
     const uint64_t NEVER = ~0ULL;
     // largest i with S_i <= first position of the run (S_i = offs[i] - off0 + i; S_n = T); the same in every lane
     uint64_t cur = 0;
     {
-        const uint64_t s0 = w0 * 64;
+        const uint64_t s_first = h0 * 32;
         uint64_t lo = 0, hi = n_reads - 1;
         while (lo < hi) {
             uint64_t mid = (lo + hi + 1) >> 1;
-            if ((offs[mid] - off0) + mid <= s0) lo = mid; else hi = mid - 1;
+            if ((offs[mid] - off0) + mid <= s_first) lo = mid; else hi = mid - 1;
         }
         cur = lo;
     }
     uint64_t base = NEVER, Sreg = 0;   // lane l holds S_{base+l}
-    constexpr int U = 4;               // words per trip: the U rows of bases are loaded together (independent loads in flight)
-    for (uint64_t wb = w0; wb < w1; wb += U) {
-        uint64_t addr[U], rd[U];
-        bool chr[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t w = wb + u;
-            chr[u] = false;
-            addr[u] = 0;
-            rd[u] = 0;
-            if (w >= w1 || w >= n_words) continue;
-            if (base == NEVER || cur + 2 > base + 63) {
-                base = cur;
-                const uint64_t j = base + lane;
-                Sreg = j <= n_reads ? (offs[j] - off0) + j : NEVER;
-            }
-            const int r = (int)(cur - base);
-            const uint64_t S0 = __shfl(Sreg, r, 64), S1 = __shfl(Sreg, r + 1, 64), S2 = __shfl(Sreg, r + 2, 64);
-            const uint64_t s = w * 64 + lane;
-            uint64_t i, Si, Sn;   // read containing position s (its characters or its separator), its start, the next start
-            if (s < S1) { i = cur; Si = S0; Sn = S1; }
-            else if (s < S2) { i = cur + 1; Si = S1; Sn = S2; }
-            else {   // reads shorter than a word: follow the offsets in memory
-                i = cur + 2; Si = S2;
-                for (;;) {
-                    Sn = i + 1 <= n_reads ? (offs[i + 1] - off0) + (i + 1) : NEVER;
-                    if (s < Sn) break;
-                    i++;
-                    Si = Sn;
-                }
-            }
-            chr[u] = s < T && s + 1 < Sn;   // a character of read i (s + 1 == Sn: its separator)
-            // first byte of read i: offs[i] for contiguous batches, starts[i] when the reads lie inside raw text
-            addr[u] = (starts ? (chr[u] ? starts[i] : 0) : Si + off0 - i) + (s - Si);
-            rd[u] = i;
-            cur = __shfl(i, 63, 64);
-            if (cur > n_reads - 1) cur = n_reads - 1;
+    for (uint64_t hb = h0; hb < h1; hb += 64) {
+        const uint64_t hw = hb + lane;
+        const uint64_t s0 = hw * 32;
+        const uint64_t last_s0 = ((hb + 63 < h1 ? hb + 63 : h1 - 1)) * 32;
+        if (base == NEVER || __shfl(Sreg, 63, 64) <= last_s0) {   // the window does not reach the end of this trip: start it at cur
+            base = cur;
+            const uint64_t j = base + lane;
+            Sreg = j <= n_reads ? (offs[j] - off0) + j : NEVER;
         }
-        unsigned char ch[U];
+        uint64_t i;
+        if (__shfl(Sreg, 63, 64) > last_s0) {
+            int r = 0;
 #pragma unroll
-        for (int u = 0; u < U; u++) ch[u] = chr[u] ? bases[addr[u]] : (unsigned char)0;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t w = wb + u;
-            if (w >= w1) continue;
-            if (w >= n_words) {   // padding words so that funnel reads past the end see "bad"
-                if (lane == 0) { bad[w] = ~0ULL; codes[2 * w] = 0; codes[2 * w + 1] = 0; }
-                continue;
+            for (int step = 32; step > 0; step >>= 1) {
+                const uint64_t v = __shfl(Sreg, r + step, 64);
+                if (v <= s0) r += step;
             }
-            int code = 0;
-            bool isbad = true;
-            if (chr[u]) {
-                if (is_acgt(ch[u])) { isbad = false; code = (ch[u] >> 1) & 3; }
-                else readflag[rd[u]] = 1;   // benign same-value race between the lanes sharing a read
+            i = base + (uint64_t)r;
+        } else {                 // reads shorter than 32: bisection over the offsets themselves
+            uint64_t lo = cur, hi = n_reads - 1;
+            while (lo < hi) {
+                uint64_t mid = (lo + hi + 1) >> 1;
+                if ((offs[mid] - off0) + mid <= s0) lo = mid; else hi = mid - 1;
             }
-            const uint64_t badw = __ballot(isbad), hi = __ballot(code & 2), lo = __ballot(code & 1);
-            if (lane < 2) {   // lane t assembles code word t: position q of its half -> bits 63-2q (high code bit), 62-2q (low)
-                const uint32_t h32 = (uint32_t)(hi >> (32 * lane)), l32 = (uint32_t)(lo >> (32 * lane));
-                codes[2 * w + lane] = (spread32(__brev(h32)) << 1) | spread32(__brev(l32));
-                if (lane == 0) bad[w] = badw;
+            i = lo;
+        }
+        if (s0 >= T || i > n_reads - 1) i = n_reads - 1;
+        cur = __shfl(i, 63, 64);
+
+        uint64_t out_code = 0;
+        uint32_t out_good = 0;
+        if (hw < h1 && s0 < T) {
+            const uint64_t end = s0 + 32 < T ? s0 + 32 : T;
+            uint64_t pos = s0;
+            uint64_t Si = (offs[i] - off0) + i;
+            while (pos < end) {
+                const uint64_t Sn = (offs[i + 1] - off0) + (i + 1);   // i <= n_reads - 1; S_n = T
+                const uint64_t char_end = Sn - 1;                     // the separator behind read i
+                if (pos < char_end) {
+                    const uint64_t pos_b = char_end < end ? char_end : end;
+                    const uint32_t n = (uint32_t)(pos_b - pos), d = (uint32_t)(pos - s0);
+                    // first byte of read i: offs[i] for contiguous batches, starts[i] when the reads lie inside raw text
+                    const uint64_t A = (uint64_t)(uintptr_t)bases + (starts ? starts[i] : Si + off0 - i) + (pos - Si);
+                    const ulonglong2* c0 = (const ulonglong2*)(A & ~15ULL);
+                    const uint32_t sh = (uint32_t)(A & 15), need_bytes = sh + n;   // chunks that hold a needed byte are safe to load
+                    ulonglong2 q0 = c0[0], q1 = make_ulonglong2(0, 0), q2 = make_ulonglong2(0, 0);
+                    if (need_bytes > 16) q1 = c0[1];
+                    if (need_bytes > 32) q2 = c0[2];
+                    uint64_t b0 = q0.x, b1 = q0.y, b2 = q1.x, b3 = q1.y, b4 = q2.x, b5 = q2.y;
+                    if (sh & 8) { b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = b5; }
+                    const uint32_t bs = (sh & 7) * 8;
+                    if (bs) {
+                        b0 = (b0 >> bs) | (b1 << (64 - bs));
+                        b1 = (b1 >> bs) | (b2 << (64 - bs));
+                        b2 = (b2 >> bs) | (b3 << (64 - bs));
+                        b3 = (b3 >> bs) | (b4 << (64 - bs));
+                    }
+                    uint32_t c16[4], g8[4];
+                    convert8(b0, c16[0], g8[0]);
+                    convert8(b1, c16[1], g8[1]);
+                    convert8(b2, c16[2], g8[2]);
+                    convert8(b3, c16[3], g8[3]);
+                    const uint32_t keep = n == 32 ? ~0u : (1u << n) - 1;
+                    const uint32_t good = (g8[0] | (g8[1] << 8) | (g8[2] << 16) | (g8[3] << 24)) & keep;
+                    uint64_t cw = (uint64_t)c16[0] | ((uint64_t)c16[1] << 16) | ((uint64_t)c16[2] << 32) | ((uint64_t)c16[3] << 48);
+                    const uint64_t gs = spread32(good);
+                    cw &= gs | (gs << 1);                                  // characters that are not A/C/G/T carry code 0
+                    // character q at bits 2q..2q+1 -> first character in the two most significant bits
+                    uint64_t y = __builtin_bitreverse64(cw);
+                    y = ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+                    out_code |= y >> (2 * d);
+                    out_good |= good << d;
+                    if (good != keep) readflag[i] = 1;                     // benign same-value race between the lanes sharing a read
+                    pos = pos_b;
+                }
+                if (pos == char_end) pos++;
+                if (pos >= Sn) { i++; Si = Sn; }
             }
+        }
+        if (hw < h1) {
+            codes[hw] = out_code;
+            bad32[hw] = ~out_good;
         }
     }
 }
@@ -216,8 +257,9 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if ((rc = fgpu_ensure(ctx, &bb.bad, (bb.n_words + FGPU_PADW) * 8))) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.readflag, n + 16))) return rc;
     FGPU_HIP(hipMemsetAsync(bb.readflag.p, 0, n, ctx->stream));
-    FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) * 8, 256), 256, d_bases, d_offs, d_starts, n, T, bb.n_words, (uint64_t*)bb.codes.p,
-                (uint64_t*)bb.bad.p, (unsigned char*)bb.readflag.p);
+    // four trips of 64 x 32 positions per wave: the bisection that opens a wave's run is paid once per 8192 positions
+    FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) / 2 + 1, 256), 256, d_bases, d_offs, d_starts, n, T, bb.n_words, (uint64_t*)bb.codes.p,
+                (uint32_t*)bb.bad.p, (unsigned char*)bb.readflag.p);
     FGPU_LAUNCH("pack_fix", k_pack_fix, fgpu_blocks(n, 256), 256, d_bases, d_offs, d_starts, n, (unsigned long long*)bb.codes.p,
                 (unsigned long long*)bb.bad.p, (const unsigned char*)bb.readflag.p, &ctx->counters->max_read_len);
     return FGPU_OK;

@@ -659,6 +659,37 @@ def test_many_tiny_reads_and_small_spacer():
     _check_against_oracle(bases, offs, 11, 200_000, 50_000, 1, spacer=6, load_chunks=4, scan_chunks=5)
 
 
+@pytest.mark.parametrize("max_len", [12, 26, 45])
+def test_reads_shorter_than_a_code_word_contiguous_and_inside_raw_text(max_len):
+    """64 consecutive reads that do not span the 2048 positions of one trip of the pack kernel (its bisection over the offsets in
+    memory), several read boundaries inside the 32 positions of one lane, empty reads, bad characters -- as a contiguous batch and
+    as reads lying inside raw FASTA text (fgpu_reads.starts)."""
+    rng = np.random.default_rng(max_len)
+    g = synth.make_genome(3000, 21)
+    lines = []
+    for _ in range(40000):
+        ln = int(rng.integers(0, max_len + 1))
+        s = int(rng.integers(0, 3000 - max_len))
+        r = g[s:s + ln].copy()
+        if ln and rng.random() < 0.05:
+            r[int(rng.integers(0, ln))] = ord("N")
+        lines.append(bytes(r))
+    bases, offs = po.reads_from_lines(lines)
+    k = 7
+    _check_against_oracle(bases, offs, k, 100_000, 20_000, 1, spacer=5, load_chunks=3, scan_chunks=2)
+    tai, nh = api.load_filter_shape(100_000, 20_000)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 5)
+    text = b"".join(b">r%d\n" % i + ln + b"\n" for i, ln in enumerate(lines))
+    ctx = api.Context(k, tai, nh, j=1, max_spacer_dist=5)
+    st, n_reads = _load_split(ctx, text, False, 50_000)
+    assert n_reads == len(lines) and st["kmers"] == lst.kmers
+    assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits()) and np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+    rb, used = ctx.text_split(text, False, True)
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads([rb])
+    _scan_equals_oracle(sc, sst, osc)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_small_inputs_against_the_oracle(seed):
     """random k, j, spacer, read lengths, alphabets and batchings on small inputs (where corner cases live)"""
