@@ -152,7 +152,7 @@ class Bloom:
         self.tai, self.n_hash = tai, n_hash
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:   # `lib` is already gone when the interpreter shuts down
             lib().fo_bloom_free(self.h)
             self.h = None
 
@@ -205,7 +205,7 @@ class Scanner:
                                       long_pf.h if long_pf else None)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().fo_scanner_free(self.h)
             self.h = None
 
