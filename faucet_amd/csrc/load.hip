@@ -29,6 +29,7 @@
 #include <algorithm>
 
 #include "fgpu_ctx.h"
+#include "fgpu_flags.h"
 
 namespace {
 
@@ -52,14 +53,17 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
 // During a load pass the two filters live INTERLEAVED: pair[w] = {word w of the carried-in bloo1, word w of bloo2}.
 // Both filters use the same bit positions (same hashes, same size), so one 8-byte load serves the carry test and
 // the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
+constexpr int MISS_PLANES = 4;   // planes of "bit i was missing from the carry" kept for k_load_resolve (hash functions beyond are re-tested)
+
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                    uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first,
-                                                   uint64_t* __restrict__ pending, uint64_t* __restrict__ sure, DevCounters* cnt) {
+                                                   uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool ok = p < T && fd_window_ok(bad, p, fp.k);
         bool pend = false, hit = false;
+        uint32_t miss_bits = 0;
         if (ok) {
             n_ok++;
             uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
@@ -86,6 +90,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 }
             } else {
                 pend = true;
+                miss_bits = missing;
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
                     // the next carry is derived afterwards: from first[] by a sweep (k_carry_from_first) or by re-hashing the
@@ -96,9 +101,18 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
             }
         }
         uint64_t pm = __ballot(pend), hm = __ballot(hit);
+        // which of the first MISS_PLANES bits were missing from the carry: k_load_resolve starts from that instead of loading the
+        // same words again (1.5 of its ~2.5 accesses per pending occurrence)
+        uint64_t mm[MISS_PLANES];
+#pragma unroll
+        for (int i = 0; i < MISS_PLANES; i++) mm[i] = __ballot(pend && ((miss_bits >> i) & 1u));
         if (fd_lane() == 0) {
             pending[p >> 6] = pm;
             sure[p >> 6] = hm;
+            if (pm) {
+#pragma unroll
+                for (int i = 0; i < MISS_PLANES; i++) pending[(i + 1) * plane_stride + (p >> 6)] = mm[i];
+            }
         }
     }
     wave_add(&cnt->kmers, n_ok);
@@ -107,7 +121,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
                                                       uint2* pair, const uint32_t* __restrict__ first,
-                                                      const uint64_t* __restrict__ pending, uint64_t* __restrict__ sure, DevCounters* cnt) {
+                                                      const uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
@@ -115,30 +129,138 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
         if (!pw) continue;
         bool pass = false;
         if ((pw >> (p & 63)) & 1ULL) {
+            uint32_t missing = 0;                // what k_load_mark saw (the carry does not change between the two kernels)
+#pragma unroll
+            for (int i = 0; i < MISS_PLANES; i++)
+                missing |= (uint32_t)((pending[(i + 1) * plane_stride + (p >> 6)] >> (p & 63)) & 1ULL) << i;
             uint64_t canon = fd_canon(fd_kmer_at(codes, p, fp.k), fp.k);
             uint64_t hA, hB;
             fd_hash_pair(canon, fp.tai_mask, hA, hB);
             pass = true;
-            uint32_t b2_missing = 0;
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
-                const uint2 v = pair[h >> 5];
-                bool before = ((v.x >> (h & 31)) & 1u) || first[h] < (uint32_t)p;
-                if (!before) { pass = false; break; }
-                if (!((v.y >> (h & 31)) & 1u)) b2_missing |= 1u << i;
+                bool in_carry = i < MISS_PLANES ? !((missing >> i) & 1u) : ((pair[h >> 5].x >> (h & 31)) & 1u) != 0;
+                if (!in_carry && !(first[h] < (uint32_t)p)) { pass = false; break; }
                 h = (h + hB) & fp.tai_mask;
             }
-            if (pass) {
+            if (pass) {   // rare: every bit was set earlier in this very batch
                 n_pass++;
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
-                    if (b2_missing & (1u << i)) atomicOr(&pair[h >> 5].y, 1u << (h & 31));
+                    const uint32_t bit = 1u << (h & 31);
+                    if (!(pair[h >> 5].y & bit)) atomicOr(&pair[h >> 5].y, bit);   // a stale 0 only costs a redundant atomic
                     h = (h + hB) & fp.tai_mask;
                 }
             }
         }
         const uint64_t sm = __ballot(pass);
         if (fd_lane() == 0 && sm) sure[p >> 6] |= sm;
+    }
+    wave_add(&cnt->to_bloo2, n_pass);
+}
+
+// The same resolution with every lane busy.  Only a quarter of the positions are pending, so in the kernel above a wave has ~17
+// loads in flight instead of 64, and the loads go to first[] (4 bytes per filter bit: 2 GiB and more), the slowest table of the
+// path: the kernel sat at a third of the random-access rate.  Here a wave shares a pool of 64 pending words (LDS, prefix counts,
+// bisection -- the scheme of k_scan_flags_sm) and every lane carries one pending occurrence at a time: one first[] load per
+// iteration for its next missing bit, and a lane that is done (almost always after the first load: a k-mer that is new in this
+// batch set that time itself) takes the next occurrence in the same iteration.  Needs the missing planes to cover all hash
+// functions (n_hash <= MISS_PLANES).
+struct PendPool {
+    unsigned long long m[64];
+    unsigned long long miss[MISS_PLANES][64];   // the missing planes of the pool's words: read once per word, not once per occurrence
+    int excl[64];
+};
+
+__global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restrict__ codes, uint64_t n_words, FdParams fp, uint2* pair,
+                                                         const uint32_t* __restrict__ first, const uint64_t* __restrict__ pending,
+                                                         uint64_t plane_stride, unsigned long long* sure, DevCounters* cnt) {
+    // Plain LDS objects indexed directly, so that the accesses are ds_read / ds_write: those execute in order for a wave, which is
+    // what makes a word written by one lane visible to the lane that reads it next.  (Declared volatile, or reached through a
+    // generic pointer, they become FLAT accesses, whose order between the lanes of a wave is NOT guaranteed.)  The wavefront-scope
+    // fences around the refill keep the compiler from moving or caching the accesses across it.
+    __shared__ PendPool pools[4];
+    const int wid = (int)(threadIdx.x >> 6);
+    const int lane = fd_lane();
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t wv = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_groups = (n_words + 63) / 64;
+    uint64_t grp = wv * n_groups / n_waves;
+    const uint64_t grp_end = (wv + 1) * n_groups / n_waves;
+    unsigned long long n_pass = 0;
+    int next = 0, total = 0;
+    uint64_t pool_word0 = 0;
+    bool active = false;
+    uint64_t hA = 0, hB = 0, item_p = 0;
+    uint32_t missing = 0;
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        while (idle && (next < total || grp < grp_end)) {
+            if (next == total) {
+                const uint64_t w = grp * 64 + lane;
+                const uint64_t m = w < n_words ? pending[w] : 0ULL;
+                const int c = __popcll(m);
+                int incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                pools[wid].m[lane] = m;
+#pragma unroll
+                for (int i = 0; i < MISS_PLANES; i++) pools[wid].miss[i][lane] = m ? pending[(i + 1) * plane_stride + w] : 0ULL;
+                pools[wid].excl[lane] = incl - c;
+                total = __builtin_amdgcn_readlane(incl, 63);
+                next = 0;
+                pool_word0 = grp * 64;
+                grp++;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                continue;
+            }
+            const int r = __popcll(idle & lt_mask);
+            const int avail = total - next;
+            if (!active && r < avail) {
+                const int t = next + r;
+                int sl = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (pools[wid].excl[sl + step] <= t) sl += step;
+                const uint64_t w = pool_word0 + sl;
+                const int bit = select_bit(pools[wid].m[sl], t - pools[wid].excl[sl]);
+                item_p = w * 64 + bit;
+                missing = 0;
+#pragma unroll
+                for (int i = 0; i < MISS_PLANES; i++) missing |= (uint32_t)((pools[wid].miss[i][sl] >> bit) & 1ULL) << i;
+                fd_hash_pair(fd_canon(fd_kmer_at(codes, item_p, fp.k), fp.k), fp.tai_mask, hA, hB);
+                active = true;
+            }
+            next += min(__popcll(idle), avail);
+            idle = __ballot(!active);
+        }
+        if (!__ballot(active)) break;
+        if (active) {
+            const int i = __builtin_ctz(missing);            // pending => at least one bit was missing
+            const uint64_t h = (hA + (uint64_t)i * hB) & fp.tai_mask;
+            if (!(first[h] < (uint32_t)item_p)) {
+                active = false;                               // not set before this occurrence: it stays out of bloo2
+            } else {
+                missing &= missing - 1;
+                if (!missing) {                               // rare: every bit was set earlier in this very batch
+                    n_pass++;
+                    uint64_t hh = hA;
+                    for (int q = 0; q < fp.n_hash; q++) {
+                        const uint32_t b = 1u << (hh & 31);
+                        if (!(pair[hh >> 5].y & b)) atomicOr(&pair[hh >> 5].y, b);
+                        hh = (hh + hB) & fp.tai_mask;
+                    }
+                    atomicOr(&sure[item_p >> 6], 1ULL << (item_p & 63));
+                    active = false;
+                }
+            }
+        }
     }
     wave_add(&cnt->to_bloo2, n_pass);
 }
@@ -404,15 +526,22 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
 int fgpu_stage_load(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
-    int rc = fgpu_ensure(ctx, &bb.pending, (bb.n_words + FGPU_PADW) * 8);
+    const uint64_t plane_stride = bb.n_words + FGPU_PADW;   // plane 0: pending; planes 1..MISS_PLANES: bit i missing from the carry
+    int rc = fgpu_ensure(ctx, &bb.pending, (MISS_PLANES + 1) * plane_stride * 8);
     if (rc) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.sure, (bb.n_words + FGPU_PADW) * 8))) return rc;
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
+                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
+    static const int resolve_sm = getenv("FGPU_RESOLVE_SM") ? atoi(getenv("FGPU_RESOLVE_SM")) : 4096;
+    if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm)
+        FGPU_LAUNCH("load_resolve", k_load_resolve_sm, (unsigned)std::min<uint64_t>((bb.n_words + 255) / 256, (uint64_t)std::max(resolve_sm, 64)), 256, (const uint64_t*)bb.codes.p,
+                    bb.n_words, ctx->fd, ctx->pair, (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride,
+                    (unsigned long long*)bb.sure.p, ctx->counters);
+    else
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
-                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, (uint64_t*)bb.sure.p, ctx->counters);
+                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
     if (ctx->prm.flags & FGPU_FLAG_MERCY)
         FGPU_LAUNCH("load_mercy", k_load_mercy, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.n_words,
                     ctx->fd, ctx->pair, (const uint32_t*)ctx->first, (const uint64_t*)bb.sure.p);

@@ -302,8 +302,12 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
                                                        const uint32_t* __restrict__ bloom, unsigned long long* ff, unsigned long long* fb,
                                                        unsigned long long* cf0, unsigned long long* cf1, unsigned long long* cb0,
                                                        unsigned long long* cb1, DevCounters* cnt) {
+    // Plain LDS objects indexed directly, so that the accesses are ds_read / ds_write: those execute in order for a wave, which is
+    // what makes a word written by one lane visible to the lane that reads it next.  (Declared volatile, or reached through a
+    // generic pointer, they become FLAT accesses, whose order between the lanes of a wave is NOT guaranteed.)  The wavefront-scope
+    // fences around the refill keep the compiler from moving or caching the accesses across it.
     __shared__ FlagPool pools[4];
-    volatile FlagPool* pool = &pools[threadIdx.x >> 6];
+    const int wid = (int)(threadIdx.x >> 6);
     const int lane = fd_lane();
     const uint64_t lt_mask = (1ULL << lane) - 1;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -343,14 +347,16 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
                     const int o = __shfl_up(incl, d, 64);
                     if (lane >= d) incl += o;
                 }
-                pool->mf[lane] = f;
-                pool->mb[lane] = b;
-                pool->excl[lane] = incl - c;
+                pools[wid].mf[lane] = f;
+                pools[wid].mb[lane] = b;
+                pools[wid].excl[lane] = incl - c;
                 total = __builtin_amdgcn_readlane(incl, 63);
                 next = 0;
                 pool_word0 = grp * 64;
                 grp++;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 continue;
             }
             const int r = __popcll(idle & lt_mask);
@@ -360,9 +366,9 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
                 int s = 0;
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1)
-                    if (pool->excl[s + step] <= t) s += step;   // largest s with excl[s] <= t (words without items share the excl of the next)
-                const uint64_t f = pool->mf[s], b = pool->mb[s];
-                const int within = t - pool->excl[s], cf = __popcll(f);
+                    if (pools[wid].excl[s + step] <= t) s += step;   // largest s with excl[s] <= t (words without items share the excl of the next)
+                const uint64_t f = pools[wid].mf[s], b = pools[wid].mb[s];
+                const int within = t - pools[wid].excl[s], cf = __popcll(f);
                 backward = within >= cf;
                 item_bit = backward ? select_bit(b, within - cf) : select_bit(f, within);
                 item_w = pool_word0 + s;
