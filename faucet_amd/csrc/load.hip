@@ -172,6 +172,7 @@ struct PendPool {
     int excl[64];
 };
 
+template <int S>
 __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restrict__ codes, uint64_t n_words, FdParams fp, uint2* pair,
                                                          const uint32_t* __restrict__ first, const uint64_t* __restrict__ pending,
                                                          uint64_t plane_stride, unsigned long long* sure, DevCounters* cnt) {
@@ -191,12 +192,16 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
     unsigned long long n_pass = 0;
     int next = 0, total = 0;
     uint64_t pool_word0 = 0;
-    bool active = false;
-    uint64_t hA = 0, hB = 0, item_p = 0;
-    uint32_t missing = 0;
+    // S occurrences per lane (S independent first[] loads in flight): missing == 0 means the slot is free
+    uint64_t hA[S], hB[S], item_p[S];
+    uint32_t missing[S];
+#pragma unroll
+    for (int q = 0; q < S; q++) missing[q] = 0;
     for (;;) {
-        uint64_t idle = __ballot(!active);
-        while (idle && (next < total || grp < grp_end)) {
+        uint64_t idle[S], any_idle = 0;
+#pragma unroll
+        for (int q = 0; q < S; q++) { idle[q] = __ballot(missing[q] == 0); any_idle |= idle[q]; }
+        while (any_idle && (next < total || grp < grp_end)) {
             if (next == total) {
                 const uint64_t w = grp * 64 + lane;
                 const uint64_t m = w < n_words ? pending[w] : 0ULL;
@@ -220,44 +225,60 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 continue;
             }
-            const int r = __popcll(idle & lt_mask);
-            const int avail = total - next;
-            if (!active && r < avail) {
-                const int t = next + r;
-                int sl = 0;
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1)
-                    if (pools[wid].excl[sl + step] <= t) sl += step;
-                const uint64_t w = pool_word0 + sl;
-                const int bit = select_bit(pools[wid].m[sl], t - pools[wid].excl[sl]);
-                item_p = w * 64 + bit;
-                missing = 0;
+            for (int q = 0; q < S; q++) {
+                const int r = __popcll(idle[q] & lt_mask);
+                const int avail = total - next;
+                if (missing[q] == 0 && r < avail) {
+                    const int t = next + r;
+                    int sl = 0;
 #pragma unroll
-                for (int i = 0; i < MISS_PLANES; i++) missing |= (uint32_t)((pools[wid].miss[i][sl] >> bit) & 1ULL) << i;
-                fd_hash_pair(fd_canon(fd_kmer_at(codes, item_p, fp.k), fp.k), fp.tai_mask, hA, hB);
-                active = true;
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (pools[wid].excl[sl + step] <= t) sl += step;
+                    const uint64_t w = pool_word0 + sl;
+                    const int bit = select_bit(pools[wid].m[sl], t - pools[wid].excl[sl]);
+                    item_p[q] = w * 64 + bit;
+                    uint32_t ms = 0;
+#pragma unroll
+                    for (int i = 0; i < MISS_PLANES; i++) ms |= (uint32_t)((pools[wid].miss[i][sl] >> bit) & 1ULL) << i;
+                    missing[q] = ms;             // pending => at least one bit was missing
+                    fd_hash_pair(fd_canon(fd_kmer_at(codes, item_p[q], fp.k), fp.k), fp.tai_mask, hA[q], hB[q]);
+                }
+                next += min(__popcll(idle[q]), avail > 0 ? avail : 0);
             }
-            next += min(__popcll(idle), avail);
-            idle = __ballot(!active);
+            any_idle = 0;
+#pragma unroll
+            for (int q = 0; q < S; q++) { idle[q] = __ballot(missing[q] == 0); any_idle |= idle[q]; }
         }
-        if (!__ballot(active)) break;
-        if (active) {
-            const int i = __builtin_ctz(missing);            // pending => at least one bit was missing
-            const uint64_t h = (hA + (uint64_t)i * hB) & fp.tai_mask;
-            if (!(first[h] < (uint32_t)item_p)) {
-                active = false;                               // not set before this occurrence: it stays out of bloo2
+        bool mine = false;
+#pragma unroll
+        for (int q = 0; q < S; q++) mine |= missing[q] != 0;
+        if (!__ballot(mine)) break;
+        uint32_t seen[S];
+#pragma unroll
+        for (int q = 0; q < S; q++) {       // all S loads are issued before any result is looked at
+            seen[q] = 0;
+            if (missing[q]) {
+                const uint64_t h = (hA[q] + (uint64_t)__builtin_ctz(missing[q]) * hB[q]) & fp.tai_mask;
+                seen[q] = first[h];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            if (!missing[q]) continue;
+            if (!(seen[q] < (uint32_t)item_p[q])) {
+                missing[q] = 0;                               // not set before this occurrence: it stays out of bloo2
             } else {
-                missing &= missing - 1;
-                if (!missing) {                               // rare: every bit was set earlier in this very batch
+                missing[q] &= missing[q] - 1;
+                if (!missing[q]) {                            // rare: every bit was set earlier in this very batch
                     n_pass++;
-                    uint64_t hh = hA;
-                    for (int q = 0; q < fp.n_hash; q++) {
+                    uint64_t hh = hA[q];
+                    for (int i = 0; i < fp.n_hash; i++) {
                         const uint32_t b = 1u << (hh & 31);
                         if (!(pair[hh >> 5].y & b)) atomicOr(&pair[hh >> 5].y, b);
-                        hh = (hh + hB) & fp.tai_mask;
+                        hh = (hh + hB[q]) & fp.tai_mask;
                     }
-                    atomicOr(&sure[item_p >> 6], 1ULL << (item_p & 63));
-                    active = false;
+                    atomicOr(&sure[item_p[q] >> 6], 1ULL << (item_p[q] & 63));
                 }
             }
         }
@@ -536,9 +557,17 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
                 ctx->pair, ctx->first, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
     static const int resolve_sm = getenv("FGPU_RESOLVE_SM") ? atoi(getenv("FGPU_RESOLVE_SM")) : 4096;
     if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm)
-        FGPU_LAUNCH("load_resolve", k_load_resolve_sm, (unsigned)std::min<uint64_t>((bb.n_words + 255) / 256, (uint64_t)std::max(resolve_sm, 64)), 256, (const uint64_t*)bb.codes.p,
-                    bb.n_words, ctx->fd, ctx->pair, (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride,
-                    (unsigned long long*)bb.sure.p, ctx->counters);
+    {
+        static const int slots = getenv("FGPU_RESOLVE_SM_SLOTS") ? atoi(getenv("FGPU_RESOLVE_SM_SLOTS")) : 1;
+        const unsigned rgrid = (unsigned)std::min<uint64_t>((bb.n_words + 255) / 256, (uint64_t)std::max(resolve_sm, 64));
+#define FGPU_RESOLVE_SM(SLOTS)                                                                                                      \
+    FGPU_LAUNCH("load_resolve", k_load_resolve_sm<SLOTS>, rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, ctx->pair, \
+                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters)
+        if (slots <= 1) FGPU_RESOLVE_SM(1);
+        else if (slots == 2) FGPU_RESOLVE_SM(2);
+        else FGPU_RESOLVE_SM(4);
+#undef FGPU_RESOLVE_SM
+    }
     else
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
                 (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);

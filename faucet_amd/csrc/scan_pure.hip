@@ -297,6 +297,21 @@ struct FlagPool {
     int excl[64];
 };
 
+// chain state of one work item (8 registers): S of them per lane, so that a lane has S independent bit tests in flight
+struct FlagChain {
+    uint64_t key;        // the k-mer, oriented towards the extension under test
+    uint64_t hA, hB;     // hashes of the k-mer being looked up (the alternate, or one of its extensions during jcheck)
+    uint32_t w;          // word of the batch the item sits in
+    uint32_t st;         // packed: bit 0 active, 1 fresh, 2 backward, 3-4 real, 5-7 nt, 8-10 jnt+1 (0 = testing the alternate itself),
+                         //         11-14 h, 15-16 njc, 17-22 bit
+};
+#define FC_ACTIVE 1u
+#define FC_FRESH 2u
+#define FC_BACKWARD 4u
+#define FC_GET(st, sh, bits) (((st) >> (sh)) & ((1u << (bits)) - 1))
+#define FC_SET(st, sh, bits, v) ((st) = ((st) & ~(((1u << (bits)) - 1) << (sh))) | ((uint32_t)(v) << (sh)))
+
+template <int S>
 __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm,
                                                        const uint64_t* __restrict__ need, uint64_t T, uint64_t n_words, FdParams fp,
                                                        const uint32_t* __restrict__ bloom, unsigned long long* ff, unsigned long long* fb,
@@ -318,17 +333,17 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
     unsigned long long n_eval = 0, n_piece = 0;
     int next = 0, total = 0;          // uniform: items of the pool handed out / in the pool
     uint64_t pool_word0 = 0;          // uniform: first word of the pool
-
-    // per-lane chain state
-    bool active = false;
-    uint64_t key = 0, alt = 0, hA = 0, hB = 0, item_w = 0;
-    int real = 0, nt = 0, jnt = -1, h = 0, njc = 0, item_bit = 0;
-    bool backward = false, fresh = false;
+    FlagChain ch[S];
+#pragma unroll
+    for (int q = 0; q < S; q++) ch[q].st = 0;
 
     for (;;) {
-        // ---- hand items to the lanes without one
-        uint64_t idle = __ballot(!active);
-        while (idle && (next < total || grp < grp_end)) {
+        // ---- hand items to the slots without one
+        uint64_t idle[S];
+        uint64_t any_idle = 0;
+#pragma unroll
+        for (int q = 0; q < S; q++) { idle[q] = __ballot(!(ch[q].st & FC_ACTIVE)); any_idle |= idle[q]; }
+        while (any_idle && (next < total || grp < grp_end)) {
             if (next == total) {   // the pool is empty: the next 64 words
                 const uint64_t w = grp * 64 + lane;
                 uint64_t f = 0, b = 0;
@@ -359,88 +374,118 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 continue;
             }
-            const int r = __popcll(idle & lt_mask);
-            const int avail = total - next;
-            if (!active && r < avail) {
-                const int t = next + r;
-                int s = 0;
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1)
-                    if (pools[wid].excl[s + step] <= t) s += step;   // largest s with excl[s] <= t (words without items share the excl of the next)
-                const uint64_t f = pools[wid].mf[s], b = pools[wid].mb[s];
-                const int within = t - pools[wid].excl[s], cf = __popcll(f);
-                backward = within >= cf;
-                item_bit = backward ? select_bit(b, within - cf) : select_bit(f, within);
-                item_w = pool_word0 + s;
-                const uint64_t pos = item_w * 64 + item_bit;
-                const uint64_t km = fd_kmer_at(codes, pos, fp.k);
-                if (!backward) {   // real extension = base after the window (utils/ReadKmer.cpp:107-110)
-                    key = km;
-                    real = fd_base_at(codes, pos + fp.k);
-                } else {           // reverse complement, real extension = complement of the base before (:111-113)
-                    key = fd_revcomp(km, fp.k);
-                    real = fd_base_at(codes, pos - 1) ^ 2;
+            for (int q = 0; q < S; q++) {   // slot 0 of every lane first, then slot 1 ...: item t goes to the t-th idle slot in that order
+                const int r = __popcll(idle[q] & lt_mask);
+                const int avail = total - next;
+                if (!(ch[q].st & FC_ACTIVE) && r < avail) {
+                    const int t = next + r;
+                    int sl = 0;
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (pools[wid].excl[sl + step] <= t) sl += step;   // largest sl with excl[sl] <= t (words without items share the excl of the next)
+                    const uint64_t f = pools[wid].mf[sl], b = pools[wid].mb[sl];
+                    const int within = t - pools[wid].excl[sl], cf = __popcll(f);
+                    const bool backward = within >= cf;
+                    const int bit = backward ? select_bit(b, within - cf) : select_bit(f, within);
+                    const uint64_t iw = pool_word0 + sl;
+                    const uint64_t pos = iw * 64 + bit;
+                    const uint64_t km = fd_kmer_at(codes, pos, fp.k);
+                    int real;
+                    if (!backward) {   // real extension = base after the window (utils/ReadKmer.cpp:107-110)
+                        ch[q].key = km;
+                        real = fd_base_at(codes, pos + fp.k);
+                    } else {           // reverse complement, real extension = complement of the base before (:111-113)
+                        ch[q].key = fd_revcomp(km, fp.k);
+                        real = fd_base_at(codes, pos - 1) ^ 2;
+                    }
+                    ch[q].w = (uint32_t)iw;
+                    uint32_t st = FC_ACTIVE | FC_FRESH | (backward ? FC_BACKWARD : 0u);
+                    FC_SET(st, 3, 2, real);
+                    FC_SET(st, 5, 3, real == 0 ? 1 : 0);
+                    FC_SET(st, 17, 6, bit);
+                    ch[q].st = st;
                 }
-                nt = real == 0 ? 1 : 0;
-                alt = ((key << 2) | (uint64_t)nt) & fp.kmask;
-                jnt = -1;
-                njc = 0;
-                fresh = true;
-                active = true;
+                next += min(__popcll(idle[q]), avail > 0 ? avail : 0);
             }
-            next += min(__popcll(idle), avail);
-            idle = __ballot(!active);
+            any_idle = 0;
+#pragma unroll
+            for (int q = 0; q < S; q++) { idle[q] = __ballot(!(ch[q].st & FC_ACTIVE)); any_idle |= idle[q]; }
         }
-        if (!__ballot(active)) break;
-        if (active) {
-            if (fresh) {   // a new k-mer to look up: the alternate itself (jnt < 0) or one of its extensions (jcheck)
-                const uint64_t e = jnt < 0 ? alt : ((alt << 2) | (uint64_t)jnt) & fp.kmask;
-                fd_hash_pair(fd_canon(e, fp.k), fp.tai_mask, hA, hB);
-                h = 0;
-                fresh = false;
+        bool mine = false;
+#pragma unroll
+        for (int q = 0; q < S; q++) mine |= (ch[q].st & FC_ACTIVE) != 0;
+        if (!__ballot(mine)) break;
+        // ---- one bit test per active slot: all S loads are issued before any result is looked at
+        uint32_t word[S];
+        uint32_t sh[S];
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            word[q] = 0;
+            sh[q] = 0;
+            if (ch[q].st & FC_ACTIVE) {
+                if (ch[q].st & FC_FRESH) {   // a new k-mer to look up: the alternate itself (jnt+1 == 0) or one of its extensions (jcheck)
+                    const uint32_t jn = FC_GET(ch[q].st, 8, 3);
+                    const uint64_t alt = ((ch[q].key << 2) | (uint64_t)FC_GET(ch[q].st, 5, 3)) & fp.kmask;
+                    const uint64_t e = jn == 0 ? alt : ((alt << 2) | (uint64_t)(jn - 1)) & fp.kmask;
+                    fd_hash_pair(fd_canon(e, fp.k), fp.tai_mask, ch[q].hA, ch[q].hB);
+                    FC_SET(ch[q].st, 11, 4, 0);
+                    ch[q].st &= ~FC_FRESH;
+                }
+                const uint64_t p = (ch[q].hA + (uint64_t)FC_GET(ch[q].st, 11, 4) * ch[q].hB) & fp.tai_mask;
+                word[q] = bloom[p >> 5];
+                sh[q] = (uint32_t)(p & 31);
             }
-            const uint64_t p = (hA + (uint64_t)h * hB) & fp.tai_mask;
-            const bool bit = (bloom[p >> 5] >> (p & 31)) & 1u;
+        }
+#pragma unroll
+        for (int q = 0; q < S; q++) {
+            if (!(ch[q].st & FC_ACTIVE)) continue;
+            uint32_t st = ch[q].st;
+            const bool bit = (word[q] >> sh[q]) & 1u;
+            const uint32_t real = FC_GET(st, 3, 2);
+            uint32_t jn = FC_GET(st, 8, 3), h = FC_GET(st, 11, 4), njc = FC_GET(st, 15, 2), nt = FC_GET(st, 5, 3);
             bool done = false, flag = false;
-            if (bit && ++h < fp.n_hash) {
-                // next bit of the same k-mer
-            } else if (bit) {                       // the k-mer is in the filter
-                if (jnt < 0) {                      // an alternate extension exists (src/ReadScanner.cpp:44-49)
+            if (bit && h + 1 < (uint32_t)fp.n_hash) {
+                h++;                                    // next bit of the same k-mer
+            } else if (bit) {                           // the k-mer is in the filter
+                if (jn == 0) {                          // an alternate extension exists (src/ReadScanner.cpp:44-49)
                     njc++;
                     if (fp.j == 0) { done = true; flag = true; }
-                    else { jnt = 0; fresh = true; }
-                } else {                            // and it continues: junction
+                    else { jn = 1; st |= FC_FRESH; }
+                } else {                                // and it continues: junction
                     done = true;
                     flag = true;
                 }
-            } else {                                // absent
-                if (jnt >= 0 && jnt < 3) {
-                    jnt++;
-                    fresh = true;
-                } else {                            // alternate absent, or none of its 4 extensions present: the next alternate
+            } else {                                    // absent
+                if (jn >= 1 && jn < 4) {
+                    jn++;
+                    st |= FC_FRESH;
+                } else {                                // alternate absent, or none of its 4 extensions present: the next alternate
                     nt++;
                     if (nt == real) nt++;
                     if (nt > 3) done = true;
-                    else {
-                        alt = ((key << 2) | (uint64_t)nt) & fp.kmask;
-                        jnt = -1;
-                        fresh = true;
-                    }
+                    else { jn = 0; st |= FC_FRESH; }
                 }
             }
+            FC_SET(st, 8, 3, jn);
+            FC_SET(st, 11, 4, h);
+            FC_SET(st, 15, 2, njc);
+            FC_SET(st, 5, 3, nt & 7);
             if (done) {
-                const unsigned long long bm = 1ULL << item_bit;
-                if (!backward) {
-                    if (flag) atomicOr(&ff[item_w], bm);
-                    if (njc & 1) atomicOr(&cf0[item_w], bm);
-                    if (njc & 2) atomicOr(&cf1[item_w], bm);
+                const unsigned long long bm = 1ULL << FC_GET(st, 17, 6);
+                const uint32_t iw = ch[q].w;
+                if (!(st & FC_BACKWARD)) {
+                    if (flag) atomicOr(&ff[iw], bm);
+                    if (njc & 1) atomicOr(&cf0[iw], bm);
+                    if (njc & 2) atomicOr(&cf1[iw], bm);
                 } else {
-                    if (flag) atomicOr(&fb[item_w], bm);
-                    if (njc & 1) atomicOr(&cb0[item_w], bm);
-                    if (njc & 2) atomicOr(&cb1[item_w], bm);
+                    if (flag) atomicOr(&fb[iw], bm);
+                    if (njc & 1) atomicOr(&cb0[iw], bm);
+                    if (njc & 2) atomicOr(&cb1[iw], bm);
                 }
-                active = false;
+                st &= ~FC_ACTIVE;
             }
+            ch[q].st = st;
         }
     }
     wave_add(&cnt->flag_positions, n_eval);
@@ -554,10 +599,17 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
         static const int sm_blocks = getenv("FGPU_FLAGS_SM_BLOCKS") ? atoi(getenv("FGPU_FLAGS_SM_BLOCKS")) : 4096;
         if (ctx->fd.j <= 1 && sm_blocks > 0) {
             const unsigned sm_grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>((bb.n_words + 255) / 256, 1), (uint64_t)sm_blocks);
-            FGPU_LAUNCH("scan_flags", k_scan_flags_sm, sm_grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
-                        (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
-                        (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,
-                        (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters);
+            static const int sm_slots = getenv("FGPU_FLAGS_SM_SLOTS") ? atoi(getenv("FGPU_FLAGS_SM_SLOTS")) : 1;
+#define FGPU_FLAGS_SM(SLOTS)                                                                                                        \
+    FGPU_LAUNCH("scan_flags", k_scan_flags_sm<SLOTS>, sm_grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,           \
+                (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,    \
+                (unsigned long long*)bb.fb.p, (unsigned long long*)bb.cf0.p, (unsigned long long*)bb.cf1.p,                         \
+                (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters)
+            if (sm_slots <= 1) FGPU_FLAGS_SM(1);
+            else if (sm_slots == 2) FGPU_FLAGS_SM(2);
+            else if (sm_slots == 3) FGPU_FLAGS_SM(3);
+            else FGPU_FLAGS_SM(4);
+#undef FGPU_FLAGS_SM
         } else
         FGPU_LAUNCH("scan_flags", k_scan_flags, flags_grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
                     (const uint64_t*)bb.need.p, bb.T, bb.n_words, ctx->fd, (const uint32_t*)ctx->bloo2, (unsigned long long*)bb.ff.p,
