@@ -138,7 +138,6 @@ struct fgpu_ctx {
     // window table (candidate keys of the window being walked)
     uint64_t wcap = 0;
     uint64_t* wkeys = nullptr;
-    uint32_t* wowner = nullptr;
     uint32_t* wslots = nullptr;      // list of claimed slots, for the sparse clear
     uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
     // union-find / cluster scratch (per window)

@@ -439,8 +439,8 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
         }
 #pragma unroll
         for (int q = 0; q < S; q++) {
-            if (!(ch[q].st & FC_ACTIVE)) continue;
             uint32_t st = ch[q].st;
+            if (st & FC_ACTIVE) {
             const bool bit = (word[q] >> sh[q]) & 1u;
             const uint32_t real = FC_GET(st, 3, 2);
             uint32_t jn = FC_GET(st, 8, 3), h = FC_GET(st, 11, 4), njc = FC_GET(st, 15, 2), nt = FC_GET(st, 5, 3);
@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
                 st &= ~FC_ACTIVE;
             }
             ch[q].st = st;
+            }
         }
     }
     wave_add(&cnt->flag_positions, n_eval);

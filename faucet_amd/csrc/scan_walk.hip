@@ -54,8 +54,7 @@ struct JTable {
 __device__ __forceinline__ uint64_t jt_filter_bit(const JTable& jt, uint64_t canon) { return (fd_mix(canon) >> 24) & jt.filter_mask; }
 
 struct WTable {
-    uint64_t* keys;
-    uint32_t* owner;
+    uint64_t* keys;      // fingerprint << 24 | owner (see wt_register)
     uint32_t* slots;
     uint32_t* bits;      // 2^WBITS_LOG2-bit presence filter
     uint64_t mask;
@@ -161,24 +160,36 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 }
 
 // ---- window table -------------------------------------------------------------------------------
-// Returns the slot this call CLAIMED (the caller lists it for the sparse clean-up, one counter atomic per wave),
-// or U_INF when the key was already there.
+// One 64-bit word per slot: the upper 40 bits of the key's mix (a fingerprint) over the 24-bit index of the smallest piece that
+// registered the key (its owner).  A key that is new in the window -- most are -- costs ONE atomic (the CAS that claims the slot
+// carries the owner), a later one a load and an atomicMin; separate key and owner arrays took a CAS and an atomicMin each time.
+// Two keys with one fingerprint share an entry: their pieces end up in one cluster and the positions count as candidates of
+// each other, which only orders more than necessary -- every later use compares full k-mers (created_bits) or is a union.
+constexpr int W_OWNER_BITS = 24;
+constexpr uint64_t W_OWNER_MASK = (1ULL << W_OWNER_BITS) - 1;
+constexpr uint64_t W_EMPTY = ~0ULL;   // fingerprint and owner all ones: no piece index is that large
+
+// Returns the slot this call CLAIMED (the caller lists it for the sparse clean-up), or U_INF when the key was already there.
 __device__ __forceinline__ uint32_t wt_register(const WTable& wt, uint32_t* parent, uint64_t canon, uint32_t piece, DevCounters* cnt) {
-    uint64_t h = fd_mix(canon);
+    const uint64_t h = fd_mix(canon);
+    const uint64_t fp = h >> W_OWNER_BITS;
+    const unsigned long long mine = (unsigned long long)((fp << W_OWNER_BITS) | (uint64_t)piece);
     uint64_t s = h & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
-        unsigned long long old = atomicCAS((unsigned long long*)&wt.keys[s], (unsigned long long)J_EMPTY, (unsigned long long)canon);
-        uint32_t claimed = U_INF;
-        if (old == J_EMPTY) {
-            claimed = (uint32_t)s;
-            uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
-            atomicOr(&wt.bits[b >> 5], 1u << (b & 31));
-            old = canon;
+        unsigned long long v = wt.keys[s];                      // a stale value only costs the CAS / atomicMin below their effect
+        if (v == W_EMPTY) {
+            v = atomicCAS((unsigned long long*)&wt.keys[s], (unsigned long long)W_EMPTY, mine);
+            if (v == W_EMPTY) {
+                const uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
+                atomicOr(&wt.bits[b >> 5], 1u << (b & 31));
+                return (uint32_t)s;
+            }
         }
-        if (old == canon) {
-            uint32_t prev = atomicMin(&wt.owner[s], piece);
-            if (prev != U_INF && prev != piece) uf_union(parent, piece, prev);
-            return claimed;
+        if ((v >> W_OWNER_BITS) == fp) {
+            const unsigned long long prev = atomicMin((unsigned long long*)&wt.keys[s], mine);
+            const uint32_t prev_owner = (uint32_t)(prev & W_OWNER_MASK);
+            if (prev_owner != piece) uf_union(parent, piece, prev_owner);
+            return U_INF;
         }
         s = (s + 1) & wt.mask;
     }
@@ -187,14 +198,15 @@ __device__ __forceinline__ uint32_t wt_register(const WTable& wt, uint32_t* pare
 }
 
 __device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint64_t canon) {
-    uint64_t h = fd_mix(canon);
-    uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
+    const uint64_t h = fd_mix(canon);
+    const uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
     if (!((wt.bits[b >> 5] >> (b & 31)) & 1u)) return U_INF;
+    const uint64_t fp = h >> W_OWNER_BITS;
     uint64_t s = h & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
-        uint64_t w = wt.keys[s];
-        if (w == J_EMPTY) return U_INF;
-        if (w == canon) return wt.owner[s];
+        const uint64_t w = wt.keys[s];
+        if (w == W_EMPTY) return U_INF;
+        if ((w >> W_OWNER_BITS) == fp) return (uint32_t)(w & W_OWNER_MASK);
         s = (s + 1) & wt.mask;
     }
     return U_INF;
@@ -843,11 +855,10 @@ __global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent,
         uint32_t s = wt.slots[a];
         if (s == U_INF) continue;
         wt.slots[a] = U_INF;
-        uint64_t key = wt.keys[s];
-        uint32_t b = (uint32_t)(fd_mix(key) >> 40) & ((1u << WBITS_LOG2) - 1);
+        const uint64_t word = wt.keys[s];   // fingerprint = bits 24..63 of the key's mix; the filter bit comes from bits 40..61 of it
+        const uint32_t b = (uint32_t)(word >> 40) & ((1u << WBITS_LOG2) - 1);
         wt.bits[b >> 5] = 0;   // whole word: every bit of it belongs to a key that is being removed as well
-        wt.keys[s] = J_EMPTY;
-        wt.owner[s] = U_INF;
+        wt.keys[s] = W_EMPTY;
     }
     for (uint64_t a = i; a < n; a += stride) {
         parent[a] = (uint32_t)a;
@@ -1063,7 +1074,7 @@ __global__ void __launch_bounds__(256) k_import(JTable jt, FdParams fp, const Ex
 }
 
 JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1, ctx->jfilter, ctx->jcap * 2 - 1}; }
-WTable make_wt(fgpu_ctx* ctx) { return WTable{ctx->wkeys, ctx->wowner, ctx->wslots, ctx->wbits, ctx->wcap - 1}; }
+WTable make_wt(fgpu_ctx* ctx) { return WTable{ctx->wkeys, ctx->wslots, ctx->wbits, ctx->wcap - 1}; }
 
 }  // namespace
 
@@ -1077,11 +1088,11 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->jfilter, ctx->jcap * 2 / 8));
     // Scheduling windows span at most FGPU_MAX_SPAN positions (+ one piece length).  Worst case every position is a
     // candidate with a distinct k-mer, so the window table holds 2x that; piece starts are >= k+1 apart.
+    while (ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2 >= W_OWNER_MASK) ctx->max_span >>= 1;   // piece indices of a window fit the table's owner field
     ctx->wcap = 4 * ctx->max_span;
     ctx->wmax = (uint32_t)(ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2);
     FGPU_HIP(hipMalloc(&ctx->wdesc, 64));
     FGPU_HIP(hipMalloc(&ctx->wkeys, ctx->wcap * 8));
-    FGPU_HIP(hipMalloc(&ctx->wowner, ctx->wcap * 4));
     FGPU_HIP(hipMalloc(&ctx->wslots, ctx->wcap * 4));
     FGPU_HIP(hipMalloc(&ctx->wbits, (1ULL << WBITS_LOG2) / 8));
     FGPU_HIP(hipMalloc(&ctx->uf_parent, ctx->wmax * 4));
@@ -1097,7 +1108,6 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
-    FGPU_HIP(hipMemsetAsync(ctx->wowner, 0xFF, ctx->wcap * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wslots, 0xFF, ctx->wcap * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
