@@ -73,13 +73,40 @@ def make_reads(genome, n_reads, read_len, err, seed, device, chunk=1_000_000):
     return out
 
 
-def device_batches(reads, batch_reads):
+def batch_bounds(n, batch_reads, ramp):
+    """[lo, hi) read ranges of the batches, in file order.  Results do not depend on the batching (tests/test_gpu_parity.py);
+    its cost does: the first batches of both passes meet an empty carry / an empty junction map (everything pending, every
+    junction test evaluated), and the walk of the last batch overlaps nothing.  With `ramp` the batches therefore grow from
+    batch_reads / 2^ramp (the first two alike: the preview of batch b sees the map as of batch b-2) by doubling and shrink
+    again at the end."""
+    if ramp <= 0 or n < 4 * batch_reads:
+        sizes = [batch_reads] * (n // batch_reads)
+    else:
+        first = max(batch_reads >> ramp, 1)
+        head = [first] + [first << i for i in range(ramp)]            # f, f, 2f, ... batch/2
+        tail = [batch_reads >> i for i in range(1, min(ramp, 3) + 1)]  # batch/2, batch/4, batch/8
+        mid = n - sum(head) - sum(tail)
+        body = [batch_reads] * (mid // batch_reads)
+        rest = mid - sum(body)
+        sizes = head + ([rest] if rest else []) + body + tail
+    if sum(sizes) < n:
+        sizes.append(n - sum(sizes))
+    bounds, lo = [], 0
+    for s in sizes:
+        bounds.append((lo, lo + s))
+        lo += s
+    assert lo == n
+    return bounds
+
+
+def device_batches(reads, bounds):
     """ReadBatch views (device pointers) over consecutive row blocks of the read matrix"""
     n, ln = reads.shape
+    if isinstance(bounds, int):                        # equal batches of that many reads
+        bounds = batch_bounds(n, bounds, 0)
     offs = torch.arange(n + 1, dtype=torch.int64, device=reads.device) * ln
     out = []
-    for lo in range(0, n, batch_reads):
-        hi = min(n, lo + batch_reads)
+    for lo, hi in bounds:
         o = offs[lo:hi + 1]
         out.append(api.ReadBatch(reads.data_ptr(), o.data_ptr(), n_reads=hi - lo, on_device=True, keepalive=(reads, offs, o)))
     # the library runs on its own non-blocking stream: what torch's stream is still writing (reads, offsets) must be finished
@@ -224,6 +251,8 @@ def main():
     ap.add_argument("--singletons", type=int, default=20_000_000, help="per GPU")
     ap.add_argument("--err", type=float, default=0.01)
     ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--ramp", type=int, default=int(os.environ.get("FAUCET_BENCH_RAMP", "2")),
+                    help="grow the first batches from batch_reads / 2^RAMP by doubling and shrink the last ones (0 = equal batches)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (cpu_baseline and reference bit counts)")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the streaming-copy / random-access ceiling measurements")
@@ -272,11 +301,12 @@ def main():
     genome = make_genome(args.genome * world, 2, device)
     reads = make_reads(genome, args.reads, L_, args.err, 1000 + rank, device)
     del genome
+    bounds = batch_bounds(args.reads, args.batch_reads, args.ramp)
     if args.host_input:
         host = reads.cpu().numpy()
-        batches = [api.ReadBatch.from_matrix(host[lo:lo + args.batch_reads]) for lo in range(0, args.reads, args.batch_reads)]
+        batches = [api.ReadBatch.from_matrix(host[lo:hi]) for lo, hi in bounds]
     else:
-        batches = device_batches(reads, args.batch_reads)
+        batches = device_batches(reads, bounds)
     torch.cuda.synchronize()
 
     ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))

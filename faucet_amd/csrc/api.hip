@@ -3,6 +3,7 @@
 // Thin: argument checks, state machine (idle -> loading -> idle -> scanning -> idle), buffer management and the
 // order in which the stages of pack.hip / load.hip / scan_pure.hip / scan_walk.hip are put on the stream.
 // There is no CPU path in this library: with no usable gfx950 device fgpu_create fails with FGPU_ERR_HIP.
+#include <cstdio>
 #include <algorithm>
 #include <string>
 
@@ -269,6 +270,13 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     // 44 ms per 10 M reads, at 2^33 bits the sweep would read 32 GiB per batch.
     static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
     ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai > (1ULL << 30);
+    ctx->epoch_positions = ctx->swept_positions = 0;
+    ctx->sweep_num = ctx->sweep_den = 1;
+    const char* sweep_env = getenv("FGPU_SWEEP_RATIO");   // "num/den"; "0/1" = after every batch: measurement aid
+    if (sweep_env) {
+        unsigned n = 1, d = 1;
+        if (sscanf(sweep_env, "%u/%u", &n, &d) == 2 && d > 0) { ctx->sweep_num = n; ctx->sweep_den = d; }
+    }
     FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
     fgpu_resident_reset(ctx, true);
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));
@@ -314,7 +322,8 @@ int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
 int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 1) { ctx->err = "load_end without load_begin"; return FGPU_ERR_STATE; }
-    int rc = fgpu_load_pair_end(ctx);   // bloo1 / bloo2 back as the two raw bit arrays of the .bloom format
+    int rc = fgpu_load_sweep(ctx);          // bits set since the last sweep join bloo1
+    if (!rc) rc = fgpu_load_pair_end(ctx);   // bloo1 / bloo2 back as the two raw bit arrays of the .bloom format
     if (!rc) rc = pull_counters(ctx);
     ctx->phase = 0;
     if (rc) return rc;

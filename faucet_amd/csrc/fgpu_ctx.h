@@ -117,6 +117,9 @@ struct fgpu_ctx {
 
     // pass 1 state
     uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
+    uint64_t epoch_positions = 0;    // stream positions loaded since the last sweep of first[] (time base of the next batch)
+    uint64_t swept_positions = 0;    // stream positions the carry covers
+    uint32_t sweep_num = 1, sweep_den = 1;   // sweep when epoch_positions >= swept_positions * num / den (FGPU_SWEEP_RATIO=num/den)
     bool carry_by_set = false;       // large filters: the carry is updated by re-hashing the new k-mers instead of sweeping first[]
     uint32_t* bloo2 = nullptr;
     uint32_t* first = nullptr;       // first-set time per Bloom bit, 4*tai bytes (allocated at load_begin)
@@ -226,6 +229,7 @@ static inline unsigned fgpu_grid(uint64_t n, unsigned per_block) {
 // stage entry points implemented in the .hip files
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_stage_load(fgpu_ctx* ctx);
+int fgpu_load_sweep(fgpu_ctx* ctx);
 int fgpu_stage_presence(fgpu_ctx* ctx);
 int fgpu_load_pair_begin(fgpu_ctx* ctx);
 int fgpu_load_pair_end(fgpu_ctx* ctx);

@@ -56,7 +56,7 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
 constexpr int MISS_PLANES = 4;   // planes of "bit i was missing from the carry" kept for k_load_resolve (hash functions beyond are re-tested)
 
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                   uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first,
+                                                   uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first, uint32_t tb,
                                                    uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0;
     const uint64_t total = n_words * 64;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 for (int i = 0; i < fp.n_hash; i++) {
                     // the next carry is derived afterwards: from first[] by a sweep (k_carry_from_first) or by re-hashing the
                     // occurrences that were not contained (k_carry_set)
-                    if (missing & (1u << i)) atomicMin(&first[h], (uint32_t)p);
+                    if (missing & (1u << i)) atomicMin(&first[h], tb + (uint32_t)p);
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
-                                                      uint2* pair, const uint32_t* __restrict__ first,
+                                                      uint2* pair, const uint32_t* __restrict__ first, uint32_t tb,
                                                       const uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
                 bool in_carry = i < MISS_PLANES ? !((missing >> i) & 1u) : ((pair[h >> 5].x >> (h & 31)) & 1u) != 0;
-                if (!in_carry && !(first[h] < (uint32_t)p)) { pass = false; break; }
+                if (!in_carry && !(first[h] < tb + (uint32_t)p)) { pass = false; break; }
                 h = (h + hB) & fp.tai_mask;
             }
             if (pass) {   // rare: every bit was set earlier in this very batch
@@ -174,7 +174,7 @@ struct PendPool {
 
 template <int S>
 __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restrict__ codes, uint64_t n_words, FdParams fp, uint2* pair,
-                                                         const uint32_t* __restrict__ first, const uint64_t* __restrict__ pending,
+                                                         const uint32_t* __restrict__ first, uint32_t tb, const uint64_t* __restrict__ pending,
                                                          uint64_t plane_stride, unsigned long long* sure, DevCounters* cnt) {
     // Plain LDS objects indexed directly, so that the accesses are ds_read / ds_write: those execute in order for a wave, which is
     // what makes a word written by one lane visible to the lane that reads it next.  (Declared volatile, or reached through a
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
 #pragma unroll
         for (int q = 0; q < S; q++) {
             if (!missing[q]) continue;
-            if (!(seen[q] < (uint32_t)item_p[q])) {
+            if (!(seen[q] < tb + (uint32_t)item_p[q])) {
                 missing[q] = 0;                               // not set before this occurrence: it stays out of bloo2
             } else {
                 missing[q] &= missing[q] - 1;
@@ -307,20 +307,20 @@ __device__ __forceinline__ bool bloo1_contains_at(const uint2* __restrict__ pair
 // isJunction(readKmer, bloo1, dir) as load_two_filters calls it: the cursor faces BACKWARD there, so the "real extension" is
 // the reverse complement of the window before, whatever dir says; dir only picks the strand the four candidates extend.
 __device__ __forceinline__ bool mercy_is_junction(const uint64_t* __restrict__ codes, const uint2* __restrict__ pair,
-                                                  const uint32_t* __restrict__ first, uint64_t pos, bool dir_forward, const FdParams& fp) {
+                                                  const uint32_t* __restrict__ first, uint32_t tb, uint64_t pos, bool dir_forward, const FdParams& fp) {
     const uint64_t km = fd_kmer_at(codes, pos, fp.k), rc = fd_revcomp(km, fp.k);
     const uint64_t real_ext = ((rc << 2) | (uint64_t)(fd_base_at(codes, pos - 1) ^ 2)) & fp.kmask;
     const uint64_t from = dir_forward ? km : rc;
     for (int nt = 0; nt < 4; nt++) {
         const uint64_t e = ((from << 2) | (uint64_t)nt) & fp.kmask;
-        if (e != real_ext && bloo1_contains_at(pair, first, fd_canon(e, fp.k), (uint32_t)pos, fp)) return true;
+        if (e != real_ext && bloo1_contains_at(pair, first, fd_canon(e, fp.k), tb + (uint32_t)pos, fp)) return true;
     }
     return false;
 }
 
 // one thread per 64-position word: the unambiguous segments (length >= k) that START in it
 __global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t n_words,
-                                                    FdParams fp, uint2* pair, const uint32_t* __restrict__ first,
+                                                    FdParams fp, uint2* pair, const uint32_t* __restrict__ first, uint32_t tb,
                                                     const uint64_t* __restrict__ sure) {
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t good = ~bad[w];
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__
                 if (contained) {
                     have_last = true;
                     if (hv_lo >= 0) {               // came from low to high (:311-318)
-                        if (!mercy_is_junction(codes, pair, first, pos, false, fp)) {
+                        if (!mercy_is_junction(codes, pair, first, tb, pos, false, fp)) {
                             for (uint64_t q = p + (uint64_t)hv_lo; q < pos; q++) {
                                 uint64_t hA, hB;
                                 fd_hash_pair(fd_canon(fd_kmer_at(codes, q, fp.k), fp.k), fp.tai_mask, hA, hB);
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__
                         hv_lo = -1;
                     }
                 } else if (have_last && hv_lo < 0) {   // came from high to low (:322-326); later low k-mers just join the run
-                    if (!mercy_is_junction(codes, pair, first, pos, true, fp)) hv_lo = (int64_t)i;
+                    if (!mercy_is_junction(codes, pair, first, tb, pos, true, fp)) hv_lo = (int64_t)i;
                 }
             }
         }
@@ -544,6 +544,15 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
     return FGPU_OK;
 }
 
+// carry |= bits set since the last sweep; closes the epoch (times start at 0 again: every bit with a time is now in the carry)
+int fgpu_load_sweep(fgpu_ctx* ctx) {
+    if (ctx->epoch_positions == 0) return FGPU_OK;
+    FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
+    ctx->swept_positions += ctx->epoch_positions;
+    ctx->epoch_positions = 0;
+    return FGPU_OK;
+}
+
 int fgpu_stage_load(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
@@ -553,8 +562,17 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     if ((rc = fgpu_ensure(ctx, &bb.sure, (bb.n_words + FGPU_PADW) * 8))) return rc;
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
+    // Times are positions within the current EPOCH = the batches since the last sweep of first[] (k_carry_from_first).  A bit
+    // that is still 0 in the carry has first[bit] == never or a time of this epoch, so the carry does not have to be brought up
+    // to date after every batch: "set before t" = in the carry or first[bit] < t holds with any carry that is a subset of
+    // bloo1 as of the epoch's start.  A lagging carry only sends more occurrences through the resolve kernel, and once the carry
+    // holds a few coverages of the genome nearly every k-mer that will ever be in it already is: sweeps are made when an epoch
+    // has grown to sweep_num/sweep_den of what the carry already covers (after batches 0, 1, 3, 7 ... of equal batches).
+    const uint64_t span = bb.n_words * 64;
+    if (!ctx->carry_by_set && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
+    const uint32_t tb = ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->first, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
+                ctx->pair, ctx->first, tb, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
     static const int resolve_sm = getenv("FGPU_RESOLVE_SM") ? atoi(getenv("FGPU_RESOLVE_SM")) : 4096;
     if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm)
     {
@@ -562,7 +580,7 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
         const unsigned rgrid = (unsigned)std::min<uint64_t>((bb.n_words + 255) / 256, (uint64_t)std::max(resolve_sm, 64));
 #define FGPU_RESOLVE_SM(SLOTS)                                                                                                      \
     FGPU_LAUNCH("load_resolve", k_load_resolve_sm<SLOTS>, rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, ctx->pair, \
-                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters)
+                (const uint32_t*)ctx->first, tb, (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters)
         if (slots <= 1) FGPU_RESOLVE_SM(1);
         else if (slots == 2) FGPU_RESOLVE_SM(2);
         else FGPU_RESOLVE_SM(4);
@@ -570,16 +588,18 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     }
     else
     FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
-                (const uint32_t*)ctx->first, (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
+                (const uint32_t*)ctx->first, tb, (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
     if (ctx->prm.flags & FGPU_FLAG_MERCY)
         FGPU_LAUNCH("load_mercy", k_load_mercy, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.n_words,
-                    ctx->fd, ctx->pair, (const uint32_t*)ctx->first, (const uint64_t*)bb.sure.p);
-    // carry := carry | bits set during this batch
-    if (ctx->carry_by_set)
+                    ctx->fd, ctx->pair, (const uint32_t*)ctx->first, tb, (const uint64_t*)bb.sure.p);
+    // carry := carry | bits set during this batch -- or later: the carry may lag behind (see fgpu_load_sweep)
+    if (ctx->carry_by_set) {
         FGPU_LAUNCH("carry_update", k_carry_set, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
                     ctx->pair, (const uint64_t*)bb.sure.p);
-    else
-        FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
+    } else {
+        ctx->epoch_positions += span;
+        if (ctx->epoch_positions * ctx->sweep_den >= ctx->swept_positions * ctx->sweep_num && (rc = fgpu_load_sweep(ctx))) return rc;
+    }
     return fgpu_resident_keep(ctx);
 }
 

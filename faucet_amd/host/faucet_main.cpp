@@ -208,6 +208,14 @@ private:
         size_t got = 0;
         bool eof = false, full = false;
     };
+    // The first batches of both passes are the dear ones per read (empty carry: every occurrence goes through the resolve kernel;
+    // empty junction map: every junction test is evaluated), so the input starts with smaller chunks: 1/4, 1/4, 1/2 of a chunk,
+    // full chunks from then on.  A function of the chunk index only: both passes cut the same file into the same batches, which
+    // is what lets the scan reuse the planes the load kept.
+    size_t chunk_bytes(uint64_t i) const {
+        const uint64_t w = i < 2 ? chunk_ / 4 : i == 2 ? chunk_ / 2 : chunk_;
+        return (size_t)std::max<uint64_t>(w, std::min<uint64_t>(chunk_, 64u << 10));
+    }
     void read_ahead() {   // reader thread: keeps the other slot filled while the device works on the current one
         for (int i = 0;; i ^= 1) {
             Slot& sl = slot_[i];
@@ -216,15 +224,16 @@ private:
                 cv_.wait(g, [&] { return stop_ || !sl.full; });
                 if (stop_) return;
             }
-            const size_t got = fread(sl.base + kPad, 1, chunk_, f_);
+            const size_t want = chunk_bytes(n_chunks_++);
+            const size_t got = fread(sl.base + kPad, 1, want, f_);
             {
                 std::lock_guard<std::mutex> g(m_);
                 sl.got = got;
-                sl.eof = got < chunk_;
+                sl.eof = got < want;
                 sl.full = true;
             }
             cv_.notify_all();
-            if (got < chunk_) return;
+            if (got < want) return;
         }
     }
     FILE* f_;
@@ -232,7 +241,7 @@ private:
     uint64_t chunk_;
     Slot slot_[2];
     int cur_ = 0;
-    uint64_t tail_ = 0;
+    uint64_t tail_ = 0, n_chunks_ = 0;
     bool finished_ = false, stop_ = false;
     std::thread reader_;
     std::mutex m_;

@@ -62,10 +62,17 @@ def test_config2_filter_algebra_and_counters(config2):
     assert cov.min() >= 1                                               # every junction was visited by the read that created it
 
 
-@pytest.mark.parametrize("variant", ["batches_2.5M", "span_2^18", "eager_flags", "no_resident", "batches_333333"])
-def test_config2_is_invariant_under_scheduling_choices(config2, variant):
+@pytest.mark.parametrize("variant", ["batches_2.5M", "span_2^18", "eager_flags", "no_resident", "batches_333333", "ramped_batches",
+                                     "sweep_every_batch", "sweep_only_at_the_end"])
+def test_config2_is_invariant_under_scheduling_choices(config2, variant, monkeypatch):
     reads, tai, nh, base = config2
     kw, batch = {}, 1_000_000
+    if variant == "ramped_batches":                 # bench.py's default batching: small first and last batches
+        batch = bench.batch_bounds(reads.shape[0], 1_000_000, 2)
+    elif variant == "sweep_every_batch":            # the carry brought up to date after every batch / never before load_end
+        monkeypatch.setenv("FGPU_SWEEP_RATIO", "0/1")
+    elif variant == "sweep_only_at_the_end":
+        monkeypatch.setenv("FGPU_SWEEP_RATIO", "1000000/1")
     if variant == "batches_2.5M":
         batch = 2_500_000
     elif variant == "batches_333333":

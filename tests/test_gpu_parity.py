@@ -850,3 +850,26 @@ def test_walk_evaluates_the_junction_tests_the_preview_left_out():
             "print('filled', st['flags_filled'])\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0 and "filled" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("mercy", [False, True])
+@pytest.mark.parametrize("ratio", ["0/1", "1/1", "1/4", "1000000/1"])
+def test_load_with_a_lagging_carry_is_exact(ratio, mercy, monkeypatch):
+    """The carry is brought up to date (a sweep of first[]) only when an epoch has grown to FGPU_SWEEP_RATIO of what the carry
+    covers; in between, first-set times run on across batches.  Every policy -- after every batch, doubling, never before
+    load_end -- gives the oracle's two filters and counters on 13 uneven batches, with and without --mercy, and so does a second
+    load pass on the same context (first[] and the epoch are reset by load_begin)."""
+    monkeypatch.setenv("FGPU_SWEEP_RATIO", ratio)
+    k, tai, nh = 21, 1 << 18, 3
+    bases, offs = _random_case(1500, 100, k, 9000, 0.02, 4242, 0.003, 2)
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    olst = po.load_two_filters(b1, b2, bases, offs, k, mercy=mercy)
+    ctx = api.Context(k, tai, nh, mercy=mercy)
+    n = len(offs) - 1
+    cuts = [0, 1, 3, 40, 41, 200, 420, 421, 700, 900, 1100, 1101, 1400, n]
+    batches = [api.ReadBatch(bases, offs[a:b + 1].copy()) for a, b in zip(cuts[:-1], cuts[1:])]
+    for _ in range(2):
+        st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), batches)
+        assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
+        assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits())
+        assert st["to_bloo2"] == olst.to_bloo2 and st["kmers"] == olst.kmers
