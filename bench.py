@@ -115,19 +115,27 @@ def device_batches(reads, bounds):
 
 
 # ---------------------------------------------------------------------------------------------- one step
-def step_single(ctx, batches):
+def step_single(ctx, batches, pinned=False):
+    """pinned=True (what main() times): the outputs land in page-locked buffers owned by the context -- bloo2 on a copy stream
+    while the scan runs -- and are views that live as long as the context; pinned=False returns independent arrays."""
     ctx.load_begin()
     for b in batches:
         ctx.load_batch(b)
     lst = ctx.load_end()
-    bloo2 = ctx.bloom_download(L.BLOO2)             # pass-1 output final in host memory
+    # pass-1 output on its way to host memory (page-locked) while the scan runs; the reference keeps bloo2 for the dump and for
+    # Stage 3, the scan in between reads the device copy
+    if pinned:
+        bloo2 = ctx.bloom_download_begin(L.BLOO2, ctx._pinned_buffer("bloo2", ctx.tai // 8))
+    else:
+        bloo2 = ctx.bloom_download(L.BLOO2)
     # ReadScanner.scanReads = scan_begin / scan_batch... / scan_end, plus the documented reaction to a failed lazy-flag self-check
     # (DESIGN.md section 4): close the pass, switch to eager junction tests, scan again -- inside the timed region if it happens
     sc = api.ReadScanner(ctx)
     sst = sc.scanReads(batches)
     if sc.fell_back_to_eager:
         FALLBACKS.append(1)
-    keys, recs = ctx.junctions()                    # pass-2 output final in host memory (creation order)
+    keys, recs = ctx.junctions(pinned=pinned)       # pass-2 output final in host memory (creation order)
+    ctx.bloom_download_wait()                       # ... and so is pass 1's
     return lst, sst, bloo2, keys, recs
 
 
@@ -314,7 +322,7 @@ def main():
 
     def one_step():
         if world == 1 and not force_sharded:
-            return step_single(ctx, batches)
+            return step_single(ctx, batches, pinned=True)
         return step_multi(shard, batches, rank, world)
 
     def fence():

@@ -71,6 +71,8 @@ SIGNATURES = {
     "fgpu_load_end": (C.c_int, [_vp, _P(LoadStats)]),
     "fgpu_presence_batch": (C.c_int, [_vp, _P(Reads)]),
     "fgpu_bloom_download": (C.c_int, [_vp, C.c_int, _vp, _u64]),
+    "fgpu_bloom_download_begin": (C.c_int, [_vp, C.c_int, _vp, _u64]),
+    "fgpu_bloom_download_wait": (C.c_int, [_vp]),
     "fgpu_bloom_upload": (C.c_int, [_vp, C.c_int, _vp, _u64]),
     "fgpu_bloom_weight": (C.c_int, [_vp, C.c_int, _P(_f32)]),
     "fgpu_bloom_devptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(_u64)]),

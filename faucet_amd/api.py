@@ -97,6 +97,32 @@ STOP_DTYPE = np.dtype([("ext", "<u8"), ("read", "<u4"), ("info", "<u4")])
 JUNC_DTYPE = np.dtype([("cov", np.uint8, 4), ("dist", np.uint8, 5), ("linked", np.uint8, 5)])
 
 
+class HostBuffer:
+    """Page-locked host memory (fgpu_host_alloc) seen as numpy arrays: device-to-host copies into it run at link speed and
+    asynchronously.  The memory lives as long as this object; views must not outlive it."""
+
+    def __init__(self, nbytes: int):
+        self.lib = L.load()
+        self.nbytes = int(nbytes)
+        self.ptr = self.lib.fgpu_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise FaucetGpuError("fgpu_host_alloc failed")
+        self._raw = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+
+    def view(self, dtype=np.uint8, count=None) -> np.ndarray:
+        a = np.frombuffer(self._raw, dtype=dtype, count=-1 if count is None else count)
+        return a
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._raw = None
+            self.lib.fgpu_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
 class Context:
     """One fgpu_ctx: one MI355X, one pair of load filters, one junction map."""
 
@@ -117,6 +143,9 @@ class Context:
         if getattr(self, "h", None):
             self.lib.fgpu_destroy(self.h)
             self.h = None
+        for b in getattr(self, "_pinned", {}).values():
+            b.free()
+        self._pinned = {}
 
     def __del__(self):
         self.close()
@@ -145,6 +174,27 @@ class Context:
         out = np.empty(self.tai // 8, dtype=np.uint8)
         self._c(self.lib.fgpu_bloom_download(self.h, which, out.ctypes.data, out.nbytes))
         return out
+
+    def bloom_download_begin(self, which, into: HostBuffer) -> np.ndarray:
+        """Start the copy of a filter into page-locked memory; it runs beside whatever is submitted next (the scan).  The array
+        returned is complete after bloom_download_wait()."""
+        if into.nbytes < self.tai // 8:
+            raise ValueError("host buffer smaller than the filter")
+        self._c(self.lib.fgpu_bloom_download_begin(self.h, which, into.ptr, self.tai // 8))
+        return into.view(np.uint8, self.tai // 8)
+
+    def bloom_download_wait(self):
+        self._c(self.lib.fgpu_bloom_download_wait(self.h))
+
+    def _pinned_buffer(self, tag, nbytes) -> HostBuffer:
+        if not hasattr(self, "_pinned"):
+            self._pinned = {}
+        b = self._pinned.get(tag)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self._pinned[tag] = HostBuffer(nbytes + nbytes // 4)
+        return b
 
     def bloom_upload(self, which, data: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.uint8)
@@ -183,12 +233,18 @@ class Context:
         self._c(self.lib.fgpu_scan_end(self.h, C.byref(st)))
         return st.as_dict()
 
-    def junctions(self):
-        """(keys uint64[n], records[n]) in creation order."""
+    def junctions(self, pinned=False):
+        """(keys uint64[n], records[n]) in creation order.  pinned=True: into page-locked buffers owned by this context (the
+        copy then runs at link speed); the arrays are valid until the next such call or close()."""
         n = C.c_uint64()
         self._c(self.lib.fgpu_scan_junction_count(self.h, C.byref(n)))
-        keys = np.zeros(max(n.value, 1), dtype=np.uint64)
-        recs = np.zeros(max(n.value, 1), dtype=JUNC_DTYPE)
+        cap = max(n.value, 1)
+        if pinned:
+            keys = self._pinned_buffer("jkeys", cap * 8).view(np.uint64, cap)
+            recs = self._pinned_buffer("jrecs", cap * JUNC_DTYPE.itemsize).view(JUNC_DTYPE, cap)
+        else:
+            keys = np.zeros(cap, dtype=np.uint64)
+            recs = np.zeros(cap, dtype=JUNC_DTYPE)
         got = C.c_uint64()
         self._c(self.lib.fgpu_scan_download_junctions(self.h, keys.ctypes.data, recs.ctypes.data, len(keys), C.byref(got)))
         return keys[: got.value], recs[: got.value]

@@ -16,6 +16,8 @@ int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* r
 static std::string g_create_error;
 
 // ---- helpers declared in fgpu_ctx.h ---------------------------------------------------------------------------
+int g_fgpu_trace = getenv("FGPU_TRACE") && getenv("FGPU_TRACE")[0] == '1';
+
 int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes) {
     if (b->bytes >= bytes && b->p) return FGPU_OK;
     if (b->p) {
@@ -218,6 +220,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
 
 void fgpu_destroy(fgpu_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); hipEventDestroy(ctx->copy_after); }
     if (ctx->wstream) hipStreamSynchronize(ctx->wstream);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
@@ -249,6 +252,7 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 0) { ctx->err = "load_begin while another pass is open"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (int rc = fgpu_bloom_download_wait(ctx)) return rc;   // a download still in flight reads the filters this pass rewrites
     if (!ctx->first) {
         hipError_t e = hipMalloc(&ctx->first, ctx->prm.tai * 4);
         if (e != hipSuccess) {
@@ -343,8 +347,33 @@ int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nb
     return FGPU_OK;
 }
 
+int fgpu_bloom_download_wait(fgpu_ctx* ctx) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (!ctx->copy_pending) return FGPU_OK;
+    ctx->copy_pending = false;
+    FGPU_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return FGPU_OK;
+}
+
+int fgpu_bloom_download_begin(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes) {
+    if (!ctx || !host_out || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    if (ctx->phase == 1) { ctx->err = "bloom_download_begin inside a load pass: the filters are interleaved until load_end"; return FGPU_ERR_STATE; }
+    if (int rc = fgpu_bloom_download_wait(ctx)) return rc;
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (!ctx->copy_stream) {
+        FGPU_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        FGPU_HIP(hipEventCreateWithFlags(&ctx->copy_after, hipEventDisableTiming));
+    }
+    FGPU_HIP(hipEventRecord(ctx->copy_after, ctx->stream));
+    FGPU_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_after, 0));
+    FGPU_HIP(hipMemcpyAsync(host_out, bloom_ptr(ctx, which), nbytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    ctx->copy_pending = true;
+    return FGPU_OK;
+}
+
 int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t nbytes) {
     if (!ctx || !host_in || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    if (int rc = fgpu_bloom_download_wait(ctx)) return rc;
     if (which == FGPU_BLOO2) fgpu_resident_reset(ctx, false);   // the kept "routed to bloo2" planes speak about the filter this replaces
     FGPU_HIP(hipMemcpyAsync(bloom_ptr(ctx, which), host_in, nbytes, hipMemcpyHostToDevice, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
@@ -426,7 +455,8 @@ static void adapt_window(fgpu_ctx* ctx) {
 static BatchBufs* acquire_batch(fgpu_ctx* ctx) {
     // FIFO over (at least) two BatchBufs, so that the one handed out was last walked two batches ago
     BatchBufs* b;
-    if (ctx->pool.size() >= 2) { b = ctx->pool.front(); ctx->pool.erase(ctx->pool.begin()); }
+    static const size_t depth = getenv("FGPU_SCAN_BUFFERS") ? (size_t)std::max(2, atoi(getenv("FGPU_SCAN_BUFFERS"))) : 2;
+    if (ctx->pool.size() >= depth) { b = ctx->pool.front(); ctx->pool.erase(ctx->pool.begin()); }
     else {
         b = new BatchBufs();
         ctx->all_batches.push_back(b);
@@ -472,6 +502,8 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     BatchBufs* b = acquire_batch(ctx);
     rc = scan_pure_into(ctx, b, reads);          // main stream; overlaps the previous batch's walk on the walk stream
+    // records as of the pure stage's synchronisation (the previous walk may still be adding some): room for this batch's
+    if (!rc) rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported);
     if (!rc) {
         adapt_window(ctx);                       // counters as of the pure stage's synchronisation (the walk may lag one batch)
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
@@ -511,9 +543,10 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
     int rc = FGPU_OK;
     for (size_t i = 0; i < ctx->prepared.size() && !rc; i++) {
         BatchBufs* b = ctx->prepared[i];
-        if (i > 0 && !ctx->prm.walk_window_span) {   // feedback for the window controller between batches
+        if (i > 0) {   // feedback for the window controller and for the size of the junction table between batches
             if ((rc = pull_counters(ctx))) break;
-            adapt_window(ctx);
+            if (!ctx->prm.walk_window_span) adapt_window(ctx);
+            if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported))) break;
         }
         ctx->cur = b;
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
@@ -614,6 +647,7 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     if (ctx->phase != 2) { ctx->err = "import_table outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
     int rc = sync_all(ctx);
     if (rc) return rc;
+    if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported + n_entries))) return rc;
     rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
     if (rc) return rc;
     // the import runs on the main stream, the ordered walk on the walk stream behind events recorded BEFORE this call

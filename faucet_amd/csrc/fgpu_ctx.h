@@ -155,6 +155,7 @@ struct fgpu_ctx {
     uint64_t max_span = FGPU_MAX_SPAN;   // upper bound of window_span (sizes the window table)
     uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
     uint64_t scan_imported = 0;      // junction records imported from a previous shard
+    uint64_t scan_grown = 0;         // times the junction table was rehashed into a larger one
 
     DevCounters* counters = nullptr;      // device
     DevCounters* counters_host = nullptr; // pinned host mirror
@@ -182,6 +183,10 @@ struct fgpu_ctx {
     uint64_t scan_batch_seq = 0;
     uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;
+    DevBuf dl_entries, dl_stamps, dl_stamps_sorted, dl_idx, dl_idx_sorted, dl_keys, dl_recs, dl_tmp;   // junction download scratch
+    hipStream_t copy_stream = nullptr;    // fgpu_bloom_download_begin: a device-to-host copy next to the kernels
+    hipEvent_t copy_after = nullptr;      // main stream: everything the copy has to wait for
+    bool copy_pending = false;
     DevBuf text_buf, text_nl, text_rank, text_tmp, text_rec;   // fgpu_text_split: the text and the batch that points into it
     std::vector<DevBuf*> owned;
 
@@ -210,12 +215,17 @@ void fgpu_prof_end(fgpu_ctx* ctx, int token);
 int fgpu_prof_collect(fgpu_ctx* ctx);
 
 // Launch helper: brackets the launch with HIP events on ctx->stream when profiling is on.
+// FGPU_TRACE=1 (diagnostic): name and grid of every launch on stderr, and a synchronisation behind it -- finds the kernel
+// that does not come back
+extern int g_fgpu_trace;
 #define FGPU_LAUNCH(name, kernel, grid, block, ...)                                        \
     do {                                                                                   \
         int tok__ = fgpu_prof_begin(ctx, name);                                            \
+        if (g_fgpu_trace) { fprintf(stderr, "[fgpu] %s grid %u x %u ...", name, (unsigned)(grid), (unsigned)(block)); fflush(stderr); } \
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, ctx->launch_stream, __VA_ARGS__);  \
         fgpu_prof_end(ctx, tok__);                                                         \
         FGPU_HIP(hipGetLastError());                                                       \
+        if (g_fgpu_trace) { FGPU_HIP(hipStreamSynchronize(ctx->launch_stream)); fprintf(stderr, " done\n"); fflush(stderr); } \
     } while (0)
 
 static inline unsigned fgpu_blocks(uint64_t n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -247,3 +257,5 @@ int fgpu_util_probe_stage3(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, i
 int fgpu_scan_alloc(fgpu_ctx* ctx);
 int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_scan_reset(fgpu_ctx* ctx);
+int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap);
+int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records);

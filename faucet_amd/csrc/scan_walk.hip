@@ -40,6 +40,7 @@ namespace {
 constexpr uint64_t J_EMPTY = ~0ULL;
 constexpr uint64_t J_KEYMASK = (1ULL << 62) - 1;
 constexpr uint32_t U_INF = 0xFFFFFFFFu;
+constexpr uint64_t J_PROBE_LIMIT = 1ULL << 14;
 
 struct JTable {
     uint64_t* keys;
@@ -118,7 +119,13 @@ __device__ __forceinline__ bool jt_find_live(const JTable& jt, uint64_t canon, u
 __device__ __forceinline__ bool jt_find_or_claim(const JTable& jt, uint64_t canon, uint64_t home, uint64_t w_first, uint64_t& slot,
                                                  uint32_t& present, DevCounters* cnt) {
     uint64_t s = home;
-    for (uint64_t n = 0; n <= jt.mask; n++) {
+    // The host keeps the table below a quarter full between batches (fgpu_scan_grow); a probe sequence this long means one batch
+    // has outgrown it: report "full" now instead of crawling through a saturated table (16 M slots x millions of pieces)
+    const uint64_t limit = jt.mask < J_PROBE_LIMIT ? jt.mask : J_PROBE_LIMIT;
+    for (uint64_t n = 0; n <= limit; n++) {
+        // once some walk has reported the overflow this scan is void: the others stop crawling.  Looked at only on long probe
+        // sequences -- a load of that one word from every piece walk queues up in its L2 channel (+8 ms per step, measured)
+        if ((n & 255) == 255 && (ld_agent((const uint64_t*)&cnt->error_flags) & 1ULL)) return false;
         uint64_t w = n == 0 ? w_first : ld_agent(&jt.keys[s]);
         if (w == J_EMPTY) {
             unsigned long long old = atomicCAS((unsigned long long*)&jt.keys[s], (unsigned long long)J_EMPTY, (unsigned long long)canon);
@@ -938,7 +945,7 @@ __device__ __forceinline__ void need_mark(unsigned long long* need, uint64_t a, 
 
 __global__ void __launch_bounds__(256) k_need_prewalk(const uint64_t* __restrict__ codes, const uint2* __restrict__ pieces, uint64_t n_pieces,
                                                       FdParams fp, JTable jt, const uint64_t* __restrict__ nF, const uint64_t* __restrict__ nB,
-                                                      unsigned long long* need) {
+                                                      unsigned long long* need, int tight) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pieces; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint2 pc = pieces[i];
         const uint64_t p0 = pc.x;
@@ -964,7 +971,10 @@ __global__ void __launch_bounds__(256) k_need_prewalk(const uint64_t* __restrict
                 need_mark(need, p0 + (uint64_t)(t >> 1), p0 + (uint64_t)(tmax >> 1) + 1);
                 break;
             }
-            need_mark(need, p0 + (uint64_t)(t >> 1), p0 + (uint64_t)(t_ev >> 1) + 1);
+            // half-steps t .. t_ev - 1 are scanned (tested); the in-map junction's own half-step is not (find_next_junction looks the
+            // key up before it tests, ReadScanner.cpp:63-66) -- marking its position as well cost 7 % more junction tests
+            if (tight >= 1) { if (t < t_ev) need_mark(need, p0 + (uint64_t)(t >> 1), p0 + (uint64_t)((t_ev - 1) >> 1) + 1); }
+            else need_mark(need, p0 + (uint64_t)(t >> 1), p0 + (uint64_t)(t_ev >> 1) + 1);
             // the junction's current skip distance
             const uint32_t q = (uint32_t)(t_ev >> 1);
             const bool fwd = t_ev & 1;
@@ -990,7 +1000,12 @@ __global__ void __launch_bounds__(256) k_need_prewalk(const uint64_t* __restrict
             if (land > tmax) break;                       // jumps off the piece: nothing more is scanned
             const uint32_t lq = (uint32_t)(land >> 1);
             const uint64_t lbits = (land & 1) ? fd_bits_at(nF, p0 + lq) : fd_bits_at(nB, p0 + lq);
-            if (!(lbits & 1ULL)) {                        // distance not converged yet: anything up to the end may be scanned
+            // Lands between junctions (the distance still points at the end of an earlier read): the walk scans on from there.
+            // Distances only grow, so the real landing is this one or later and the stretch marked from here covers it -- unless the
+            // distance has meanwhile grown PAST the next junction of the snapshot, which the walk notices and repairs itself
+            // (fill_missing).  tight < 2 is the older, conservative form: mark the rest of the piece (5 % more junction tests; the
+            // repairs were as rare with either form: 0-4 windows per 10-20 M reads, scripts/lazy_flag_frequency.py).
+            if (!(lbits & 1ULL) && tight < 2) {
                 need_mark(need, p0 + lq, p0 + (uint64_t)(tmax >> 1) + 1);
                 break;
             }
@@ -1073,7 +1088,12 @@ __global__ void __launch_bounds__(256) k_import(JTable jt, FdParams fp, const Ex
     atomicOr(&jt.filter[hb >> 5], 1u << (hb & 31));
 }
 
-JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1, ctx->jfilter, ctx->jcap * 2 - 1}; }
+static uint64_t jfilter_bits(fgpu_ctx* ctx) {
+    static const int lg = getenv("FGPU_JFILTER_LOG2") ? atoi(getenv("FGPU_JFILTER_LOG2")) : 0;   // measurement aid
+    const uint64_t full = ctx->jcap * 2;
+    return lg >= 10 && (1ULL << lg) < full ? 1ULL << lg : full;
+}
+JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1, ctx->jfilter, jfilter_bits(ctx) - 1}; }
 WTable make_wt(fgpu_ctx* ctx) { return WTable{ctx->wkeys, ctx->wslots, ctx->wbits, ctx->wcap - 1}; }
 
 }  // namespace
@@ -1103,6 +1123,53 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     return FGPU_OK;
 }
 
+int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries, uint64_t* d_stamps, uint64_t* n_entries);
+int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n);
+
+// Rehash the junction table into new_cap slots.  Both streams are drained first; records, creation stamps and presence bits
+// travel through the export format of the multi-GPU hand-over (k_export / k_import), so nothing about a junction changes.
+int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap) {
+    if (new_cap <= ctx->jcap) return FGPU_OK;
+    if (ctx->wstream) FGPU_HIP(hipStreamSynchronize(ctx->wstream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->n_junctions, &ctx->counters->n_junctions, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->error_flags, &ctx->counters->error_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->counters_host->error_flags & 1ULL) return FGPU_OK;   // already overflowed: the scan is void, the caller reports it
+    const uint64_t n_max = ctx->counters_host->n_junctions + ctx->scan_imported;
+    int rc;
+    if ((rc = fgpu_ensure(ctx, &ctx->dl_entries, (n_max + 1) * sizeof(ExportEntry))) || (rc = fgpu_ensure(ctx, &ctx->dl_stamps, (n_max + 1) * 8))) return rc;
+    uint64_t n = 0;
+    if (n_max && (rc = fgpu_scan_export_impl(ctx, ctx->dl_entries.p, n_max, (uint64_t*)ctx->dl_stamps.p, &n))) return rc;
+    if (n != n_max) { ctx->err = "junction count mismatch between counters and table (grow)"; return FGPU_ERR_STATE; }
+    uint64_t* nk = nullptr; uint8_t* nr = nullptr; uint64_t* ns = nullptr; uint32_t* nf = nullptr;
+    if (hipMalloc(&nk, new_cap * 8) != hipSuccess || hipMalloc(&nr, new_cap * 32) != hipSuccess || hipMalloc(&ns, new_cap * 16) != hipSuccess ||
+        hipMalloc(&nf, new_cap * 2 / 8) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(nk); hipFree(nr); hipFree(ns); hipFree(nf);
+        ctx->err = "junction table: no memory to grow to " + std::to_string(new_cap) + " slots";
+        return FGPU_ERR_NOMEM;
+    }
+    hipFree(ctx->jkeys); hipFree(ctx->jrecs); hipFree(ctx->jstamps); hipFree(ctx->jfilter);
+    ctx->jkeys = nk; ctx->jrecs = nr; ctx->jstamps = ns; ctx->jfilter = nf;
+    ctx->jcap = new_cap;
+    FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
+    if ((rc = fgpu_scan_import_impl(ctx, ctx->dl_entries.p, n))) return rc;
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));   // the walk stream starts on the new table
+    ctx->scan_grown++;
+    return FGPU_OK;
+}
+
+// called where the host holds a fresh count of the records (batch boundaries): keep the table below a quarter full
+int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records) {
+    if (!ctx->jkeys || records * 4 <= ctx->jcap) return FGPU_OK;
+    uint64_t want = ctx->jcap;
+    while (want < records * 16 && want < (1ULL << 31)) want <<= 1;
+    return fgpu_scan_grow(ctx, want);
+}
+
 int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
@@ -1127,11 +1194,12 @@ int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(bb.need.p, 0, wb, ctx->stream));
     if (!bb.n_pieces) return FGPU_OK;
 
+    static const int need_tight = getenv("FGPU_NEED_TIGHT") ? atoi(getenv("FGPU_NEED_TIGHT")) : 2;   // measurement aid, see k_need_prewalk
     JTable jt = make_jt(ctx);
     FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
                 bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p);
     FGPU_LAUNCH("need_prewalk", k_need_prewalk, fgpu_grid(bb.n_pieces, 256), 256, (const uint64_t*)bb.codes.p, (const uint2*)bb.pieces.p,
-                bb.n_pieces, ctx->fd, jt, (const uint64_t*)bb.nF.p, (const uint64_t*)bb.nB.p, (unsigned long long*)bb.need.p);
+                bb.n_pieces, ctx->fd, jt, (const uint64_t*)bb.nF.p, (const uint64_t*)bb.nB.p, (unsigned long long*)bb.need.p, need_tight);
     return FGPU_OK;
 }
 
@@ -1368,40 +1436,30 @@ int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* r
     *n_out = n_max;
     if (!n_max || !keys_host || !recs_host) return FGPU_OK;
     if (cap < n_max) { ctx->err = "junction buffer too small"; return FGPU_ERR_CAPACITY; }
-    ExportEntry* d_entries = nullptr;
-    uint64_t *d_stamps = nullptr, *d_stamps_sorted = nullptr, *d_keys = nullptr;
-    uint32_t *d_idx = nullptr, *d_idx_sorted = nullptr;
-    fgpu_junction* d_recs = nullptr;
-    void* d_tmp = nullptr;
-    int rc = FGPU_OK;
-    hipError_t e;
-#define DL_HIP(call) do { e = (call); if (e != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e); rc = FGPU_ERR_HIP; goto done; } } while (0)
-    DL_HIP(hipMalloc(&d_entries, n_max * sizeof(ExportEntry)));
-    DL_HIP(hipMalloc(&d_stamps, n_max * 8));
-    DL_HIP(hipMalloc(&d_stamps_sorted, n_max * 8));
-    DL_HIP(hipMalloc(&d_idx, n_max * 4));
-    DL_HIP(hipMalloc(&d_idx_sorted, n_max * 4));
-    DL_HIP(hipMalloc(&d_keys, n_max * 8));
-    DL_HIP(hipMalloc(&d_recs, n_max * sizeof(fgpu_junction)));
-    {
-        uint64_t n = 0;
-        rc = fgpu_scan_export_impl(ctx, d_entries, n_max, d_stamps, &n);
-        if (rc) goto done;
-        if (n != n_max) { ctx->err = "junction count mismatch between counters and table"; rc = FGPU_ERR_STATE; goto done; }
-        hipLaunchKernelGGL(k_iota_u32, dim3(256), dim3(256), 0, ctx->stream, d_idx, n);
-        size_t tmp_bytes = 0;
-        DL_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_stamps, d_stamps_sorted, d_idx, d_idx_sorted, n, 0, 64, ctx->stream));
-        DL_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-        DL_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_stamps, d_stamps_sorted, d_idx, d_idx_sorted, n, 0, 64, ctx->stream));
-        hipLaunchKernelGGL(k_gather_sorted, dim3(fgpu_blocks(n, 256)), dim3(256), 0, ctx->stream, (const ExportEntry*)d_entries,
-                           (const uint32_t*)d_idx_sorted, n, d_keys, d_recs);
-        DL_HIP(hipMemcpyAsync(keys_host, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        DL_HIP(hipMemcpyAsync(recs_host, d_recs, n * sizeof(fgpu_junction), hipMemcpyDeviceToHost, ctx->stream));
-        DL_HIP(hipStreamSynchronize(ctx->stream));
-    }
-done:
-#undef DL_HIP
-    hipFree(d_entries); hipFree(d_stamps); hipFree(d_stamps_sorted); hipFree(d_idx); hipFree(d_idx_sorted);
-    hipFree(d_keys); hipFree(d_recs); hipFree(d_tmp);
-    return rc;
+    // scratch lives with the context: eight hipMalloc / hipFree pairs per call cost more than the sort they served
+    int rc;
+    if ((rc = fgpu_ensure(ctx, &ctx->dl_entries, n_max * sizeof(ExportEntry))) || (rc = fgpu_ensure(ctx, &ctx->dl_stamps, n_max * 8)) ||
+        (rc = fgpu_ensure(ctx, &ctx->dl_stamps_sorted, n_max * 8)) || (rc = fgpu_ensure(ctx, &ctx->dl_idx, n_max * 4)) ||
+        (rc = fgpu_ensure(ctx, &ctx->dl_idx_sorted, n_max * 4)) || (rc = fgpu_ensure(ctx, &ctx->dl_keys, n_max * 8)) ||
+        (rc = fgpu_ensure(ctx, &ctx->dl_recs, n_max * sizeof(fgpu_junction))))
+        return rc;
+    ExportEntry* d_entries = (ExportEntry*)ctx->dl_entries.p;
+    uint64_t *d_stamps = (uint64_t*)ctx->dl_stamps.p, *d_stamps_sorted = (uint64_t*)ctx->dl_stamps_sorted.p, *d_keys = (uint64_t*)ctx->dl_keys.p;
+    uint32_t *d_idx = (uint32_t*)ctx->dl_idx.p, *d_idx_sorted = (uint32_t*)ctx->dl_idx_sorted.p;
+    fgpu_junction* d_recs = (fgpu_junction*)ctx->dl_recs.p;
+    uint64_t n = 0;
+    if ((rc = fgpu_scan_export_impl(ctx, d_entries, n_max, d_stamps, &n))) return rc;
+    if (n != n_max) { ctx->err = "junction count mismatch between counters and table"; return FGPU_ERR_STATE; }
+    hipLaunchKernelGGL(k_iota_u32, dim3(256), dim3(256), 0, ctx->stream, d_idx, n);
+    size_t tmp_bytes = 0;
+    FGPU_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_stamps, d_stamps_sorted, d_idx, d_idx_sorted, n, 0, 64, ctx->stream));
+    if ((rc = fgpu_ensure(ctx, &ctx->dl_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
+    FGPU_HIP(rocprim::radix_sort_pairs(ctx->dl_tmp.p, tmp_bytes, d_stamps, d_stamps_sorted, d_idx, d_idx_sorted, n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(fgpu_blocks(n, 256)), dim3(256), 0, ctx->stream, (const ExportEntry*)d_entries,
+                       (const uint32_t*)d_idx_sorted, n, d_keys, d_recs);
+    // page-locked destinations (fgpu_host_alloc) receive this at link speed; pageable ones through the runtime's staging
+    FGPU_HIP(hipMemcpyAsync(keys_host, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(recs_host, d_recs, n * sizeof(fgpu_junction), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
 }

@@ -50,7 +50,10 @@ typedef struct {
     uint64_t tai;               /* bits per load filter, power of two (utils/Bloom.cpp:173-175) */
     int32_t  device;            /* HIP device ordinal */
     int32_t  flags;             /* FGPU_FLAG_* */
-    uint64_t junction_capacity; /* slots of the device junction table, power of two; 0 = default */
+    uint64_t junction_capacity; /* INITIAL slots of the device junction table, power of two; 0 = default (tai / 32).  The table is
+                                 * rehashed into a larger one between batches whenever it is more than a quarter full (the
+                                 * reference's unordered_map grows the same way); a single batch that outgrows it ends the scan
+                                 * with FGPU_ERR_CAPACITY: hand over smaller batches or start larger. */
     uint64_t max_batch_bases;   /* largest batch (bases + one separator per read); 0 = default 2^30 */
     void*    stream;            /* hipStream_t to run on, or NULL for a private stream */
     uint64_t walk_window_span;  /* stream positions per scheduling window of the ordered walk; 0 = adaptive.
@@ -159,6 +162,13 @@ int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
 
 /* filters: raw bit arrays, tai/8 bytes, exactly the .bloom file body (utils/Bloom.cpp:571-587) */
 int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes);
+/* The same copy, started now and finished by fgpu_bloom_download_wait: it runs on its own copy stream behind the work
+ * submitted so far, next to whatever the caller submits afterwards (the reference's bloo2 stays in host memory for the dump
+ * and for Stage 3, src/Faucet.cpp:220-245 -- the scan in between does not read the host copy).  host_out should be page-locked
+ * (fgpu_host_alloc); with pageable memory the call simply blocks until the copy is done.  The filter must not be rewritten
+ * (load_begin, bloom_upload) before the wait: those calls wait themselves.  One download in flight per context. */
+int fgpu_bloom_download_begin(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes);
+int fgpu_bloom_download_wait(fgpu_ctx* ctx);
 int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t nbytes);   /* -bloom_file restart */
 int fgpu_bloom_weight(fgpu_ctx* ctx, int which, float* weight);                             /* Bloom::weight, Bloom.cpp:191-203 */
 int fgpu_bloom_devptr(fgpu_ctx* ctx, int which, void** dptr, uint64_t* nbytes);

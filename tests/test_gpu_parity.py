@@ -873,3 +873,87 @@ def test_load_with_a_lagging_carry_is_exact(ratio, mercy, monkeypatch):
         assert np.array_equal(ctx.bloom_download(L.BLOO1), b1.bits())
         assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits())
         assert st["to_bloo2"] == olst.to_bloo2 and st["kmers"] == olst.kmers
+
+
+def test_page_locked_and_overlapped_downloads_equal_the_plain_ones():
+    """fgpu_bloom_download_begin / _wait (copy stream, page-locked destination, the scan submitted in between) and the junction
+    download into page-locked buffers return what the blocking calls return; a load_begin issued while a download is in flight
+    waits for it instead of rewriting the filter under the copy."""
+    c = Case("ragged_k31")
+    bases, offs = po.reads_from_lines(c.lines())
+    tai, nh = api.load_filter_shape(c.E, c.S)
+    ctx = api.Context(c.k, tai, nh, j=c.j, max_spacer_dist=c.spacer)
+    batches = chunks(bases, offs, 3)
+    api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), batches)
+    buf = api.HostBuffer(tai // 8)
+    early = ctx.bloom_download_begin(L.BLOO2, buf)
+    sc = api.ReadScanner(ctx)
+    sc.scanReads(batches)
+    keys_p, recs_p = ctx.junctions(pinned=True)
+    ctx.bloom_download_wait()
+    assert np.array_equal(early, c.bloom()) and np.array_equal(early, ctx.bloom_download(L.BLOO2))
+    keys, recs = ctx.junctions()
+    assert np.array_equal(keys, keys_p) and recs.tobytes() == recs_p.tobytes()
+    assert sorted(api.junction_lines(keys_p, recs_p, c.k)) == sorted(c.junction_lines())
+    # a download in flight when the next load pass starts
+    first = ctx.bloom_download_begin(L.BLOO2, buf).copy
+    ctx.load_begin()
+    snapshot = first()
+    ctx.load_end()
+    assert np.array_equal(snapshot, c.bloom())
+    with pytest.raises(ValueError):
+        ctx.bloom_download_begin(L.BLOO2, api.HostBuffer(16))
+    ctx.close()
+
+
+def _saturated_filter_case(n_reads, seed):
+    """10x reads over a genome whose k-mers overfill the filter they are given: bloo2 ends up ~40 % full, its false positives
+    make every few positions look like a junction, and the scan creates several junction records PER READ (the data set on
+    which a fixed-size table crawled: 34 M records from 10 M reads)"""
+    k, G = 31, n_reads * 10
+    bases, offs = _random_case(n_reads, 100, k, G, 0.01, seed)
+    tai, nh = api.load_filter_shape(10 * n_reads, 2 * n_reads)
+    return k, bases, offs, tai, nh
+
+
+def test_junction_table_grows_between_batches():
+    k, bases, offs, tai, nh = _saturated_filter_case(60_000, 77)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh)
+    n_ref = osc.stats()["n_junctions"]
+    assert n_ref > 40_000                                   # the better part of a record per read
+    ctx = api.Context(k, tai, nh, junction_capacity=1 << 14)   # a quarter of it is passed with the first of 12 batches
+    batches = chunks(bases, offs, 12)
+    api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), batches)
+    sc = api.ReadScanner(ctx)
+    for _ in range(2):                                      # the second scan starts on the grown table
+        sst = sc.scanReads(batches)
+        _scan_equals_oracle(sc, sst, osc)
+        assert sst["n_junctions"] == n_ref
+    # the same through prepare-all + ordered walk (the multi-GPU ranks' path) on a fresh, small table
+    ctx2 = api.Context(k, tai, nh, junction_capacity=1 << 14)
+    api.load_two_filters(api.Bloom(ctx2, L.BLOO1), api.Bloom(ctx2, L.BLOO2), batches)
+    ctx2.scan_begin()
+    for b in batches:
+        ctx2.scan_prepare(b)
+    ctx2.scan_walk_prepared()
+    sst2 = ctx2.scan_end()
+    keys, recs = ctx2.junctions()
+    k1, r1 = sc.junctions()
+    assert sst2["n_junctions"] == n_ref and np.array_equal(keys, k1) and recs.tobytes() == r1.tobytes()
+
+
+def test_a_batch_that_outgrows_the_junction_table_fails_promptly():
+    """one batch, far more records than slots: FGPU_ERR_CAPACITY with the advice, not a crawl through a saturated table"""
+    k, bases, offs, tai, nh = _saturated_filter_case(30_000, 78)
+    ctx = api.Context(k, tai, nh, junction_capacity=1 << 12)
+    batch = chunks(bases, offs, 1)
+    api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), batch)
+    ctx.scan_begin()
+    with pytest.raises(api.FaucetGpuError, match="junction table full"):
+        ctx.scan_batch(batch[0])
+        ctx.scan_end()
+    try:
+        ctx.scan_end()
+    except api.FaucetGpuError:
+        pass
+    ctx.close()
