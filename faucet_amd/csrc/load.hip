@@ -38,7 +38,8 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
     if (fd_lane() == 0 && v) atomicAdd(dst, v);
 }
 
-// one atomic per BLOCK (for short kernels whose tail would otherwise be a queue of same-address atomics)
+// one atomic per BLOCK: the waves of a grid-stride kernel retire together, and 16 K of them adding to one word is a queue of
+// ~10 ns same-address atomics at the tail of every launch (k_scan_pieces spent most of its time in it).  All threads must call.
 __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long long v) {
     __shared__ unsigned long long part[4];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -48,6 +49,7 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
         const unsigned long long t = part[0] + part[1] + part[2] + part[3];
         if (t) atomicAdd(dst, t);
     }
+    __syncthreads();   // part[] is reused by the next call
 }
 
 // During a load pass the two filters live INTERLEAVED: pair[w] = {word w of the carried-in bloo1, word w of bloo2}.
@@ -115,8 +117,8 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
             }
         }
     }
-    wave_add(&cnt->kmers, n_ok);
-    wave_add(&cnt->to_bloo2, n_hit);
+    block_add(&cnt->kmers, n_ok);
+    block_add(&cnt->to_bloo2, n_hit);
 }
 
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
         const uint64_t sm = __ballot(pass);
         if (fd_lane() == 0 && sm) sure[p >> 6] |= sm;
     }
-    wave_add(&cnt->to_bloo2, n_pass);
+    block_add(&cnt->to_bloo2, n_pass);
 }
 
 // The same resolution with every lane busy.  Only a quarter of the positions are pending, so in the kernel above a wave has ~17
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
             }
         }
     }
-    wave_add(&cnt->to_bloo2, n_pass);
+    block_add(&cnt->to_bloo2, n_pass);
 }
 
 // ---- --mercy (utils/Bloom.cpp:300-333) -----------------------------------------------------------------------------
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(256) k_presence(const uint64_t* __restrict__ c
         fd_hash_pair(canon, fp.tai_mask, hA, hB);
         fd_bloom_set(bitmap, hA, hB, fp.tai_mask, fp.n_hash);
     }
-    wave_add(&cnt->kmers, n_ok);
+    block_add(&cnt->kmers, n_ok);
 }
 
 // unambiguous segments of length >= minlen (utils/Kmer.cpp:77; ReadScanner.cpp:268).  One thread per 64-position
@@ -626,7 +628,7 @@ int fgpu_stage_presence(fgpu_ctx* ctx) {
 // ---- small utilities used by api.hip and scan_pure.hip --------------------------------------------
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen) {
     BatchBufs& bb = *ctx->cur;
-    FGPU_LAUNCH("count_segments", k_count_segments, std::min(fgpu_grid(bb.n_words, 256), 1024u), 256, (const uint64_t*)bb.bad.p, bb.n_words, minlen,
+    FGPU_LAUNCH("count_segments", k_count_segments, std::min(fgpu_grid(bb.n_words, 256), 256u), 256, (const uint64_t*)bb.bad.p, bb.n_words, minlen,
                 &ctx->counters->segments);
     return FGPU_OK;
 }

@@ -168,10 +168,18 @@ __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restric
                                                   const uint64_t* __restrict__ starts, uint64_t n_reads, unsigned long long* codes, unsigned long long* bad,
                                                   const unsigned char* __restrict__ readflag, unsigned long long* max_len) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    {   // longest read of the batch: an atomic only when the wave raises the maximum (same-address atomics serialise)
+    {   // longest read of the batch: one look at the running maximum per BLOCK, an atomic only when the block raises it (loads of
+        // one address from every wave queue up in its L2 channel just like same-address atomics do)
+        __shared__ unsigned long long wave_max[4];
         unsigned long long l = i < n_reads ? (unsigned long long)(offs[i + 1] - offs[i]) : 0;
         for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(l, o, 64); l = t > l ? t : l; }
-        if ((threadIdx.x & 63) == 0 && l > *(volatile unsigned long long*)max_len) atomicMax(max_len, l);
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long m = wave_max[0];
+            for (int w = 1; w < 4; w++) m = wave_max[w] > m ? wave_max[w] : m;
+            if (m > *(volatile unsigned long long*)max_len) atomicMax(max_len, m);
+        }
     }
     if (i >= n_reads || !readflag[i]) return;
     const uint64_t off0 = offs[0];

@@ -28,6 +28,19 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
     if (fd_lane() == 0 && v) atomicAdd(dst, v);
 }
 
+// one atomic per BLOCK of 256 threads (see load.hip); every thread of the block must call
+__device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long long v) {
+    __shared__ unsigned long long part[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (fd_lane() == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(dst, t);
+    }
+    __syncthreads();
+}
+
 // Is this batch, word for word, the load batch kept under the same index?  *same starts non-zero; any differing word clears it.
 __global__ void __launch_bounds__(256) k_scan_same(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ kept_codes, uint64_t n_code_words,
                                                    const uint64_t* __restrict__ bad, const uint64_t* __restrict__ kept_bad, uint64_t n_words,
@@ -65,8 +78,8 @@ __global__ void __launch_bounds__(256) k_scan_valid(const uint64_t* __restrict__
         uint64_t vm = __ballot(v);
         if (fd_lane() == 0) valid[p >> 6] = vm;
     }
-    wave_add(&cnt->kmers, n_ok);
-    wave_add(&cnt->valid_reused, n_reused);
+    block_add(&cnt->kmers, n_ok);
+    block_add(&cnt->valid_reused, n_reused);
 }
 
 // One thread per 64-position word of the valid plane: run starts by bit arithmetic; each start measures its run and,
@@ -123,7 +136,7 @@ __global__ void __launch_bounds__(256) k_scan_pieces(const uint64_t* __restrict_
         }
         ps[w] = psw;
     }
-    wave_add(&cnt->pieces, n_pieces);
+    block_add(&cnt->pieces, n_pieces);
 }
 
 // exclusive prefix sum of popcount(ps[w]) over the words of the batch: three small kernels
@@ -280,8 +293,8 @@ __global__ void __launch_bounds__(256) k_scan_flags(const uint64_t* __restrict__
             }
         }
     }
-    wave_add(&cnt->flag_positions, n_eval);
-    wave_add(&cnt->piece_positions, n_piece);
+    block_add(&cnt->flag_positions, n_eval);
+    block_add(&cnt->piece_positions, n_piece);
 }
 
 // The same work as k_scan_flags for j <= 1, organised as a per-lane state machine.  An item is a chain of 3 to ~20 DEPENDENT bit
@@ -489,8 +502,8 @@ __global__ void __launch_bounds__(256) k_scan_flags_sm(const uint64_t* __restric
             }
         }
     }
-    wave_add(&cnt->flag_positions, n_eval);
-    wave_add(&cnt->piece_positions, n_piece);
+    block_add(&cnt->flag_positions, n_eval);
+    block_add(&cnt->piece_positions, n_piece);
 }
 
 // ---- Stage 3's Bloom probes, batched: pure functions of bloo2, one k-mer per lane ----------------
