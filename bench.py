@@ -142,11 +142,14 @@ def step_single(ctx, batches, pinned=False):
 def step_multi(shard, batches, rank, world):
     """The read-sharded pipeline of faucet_amd/sharded.py on this rank's GPU."""
     lst = sharded.load_sharded(shard, batches, rank, world)
-    bloo2 = shard.ctx.bloom_download(L.BLOO2) if rank == 0 else None      # pass-1 output final in host memory
+    ctx = shard.ctx
+    # pass-1 output on its way to (page-locked) host memory while rank 0 starts the scan: it heads the chain of walks
+    bloo2 = ctx.bloom_download_begin(L.BLOO2, ctx._pinned_buffer("bloo2", ctx.tai // 8)) if rank == 0 else None
     sst, last = sharded.scan_sharded(shard, batches, rank, world)
     keys = recs = None
     if last:
-        keys, recs = shard.junctions()                                     # pass-2 output final in host memory
+        keys, recs = ctx.junctions(pinned=True)                            # pass-2 output final in host memory
+    ctx.bloom_download_wait()
     return lst, sst, bloo2, keys, recs
 
 

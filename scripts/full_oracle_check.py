@@ -46,7 +46,8 @@ if two_hash:
 else:
     tai, nh = api.load_filter_shape(10 * n, 2 * n)
 ctx = api.Context(31, tai, nh)
-lst, sst, b2, keys, recs = bench.step_single(ctx, bench.device_batches(reads, 1_000_000))
+# the step bench.py times: ramped batches, outputs into page-locked buffers, bloo2 copied while the scan runs
+lst, sst, b2, keys, recs = bench.step_single(ctx, bench.device_batches(reads, bench.batch_bounds(n, 1_000_000, 2)), pinned=True)
 b1 = ctx.bloom_download(L.BLOO1)
 print("device done:", sst["n_junctions"], "junctions; running the oracle on one host core ...", flush=True)
 bases, offs = po.reads_from_matrix(reads.cpu().numpy())
