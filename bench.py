@@ -108,7 +108,8 @@ def device_batches(reads, bounds):
     out = []
     for lo, hi in bounds:
         o = offs[lo:hi + 1]
-        out.append(api.ReadBatch(reads.data_ptr(), o.data_ptr(), n_reads=hi - lo, on_device=True, keepalive=(reads, offs, o)))
+        out.append(api.ReadBatch(reads.data_ptr(), o.data_ptr(), n_reads=hi - lo, on_device=True, keepalive=(reads, offs, o),
+                                 n_positions=(hi - lo) * (ln + 1)))
     # the library runs on its own non-blocking stream: what torch's stream is still writing (reads, offsets) must be finished
     torch.cuda.synchronize(reads.device)
     return out

@@ -27,6 +27,9 @@ class Params(C.Structure):
                 ("max_batch_bases", C.c_uint64), ("stream", C.c_void_p), ("walk_window_span", C.c_uint64)]
 
 
+LOAD_KEEP_CARRY, LOAD_SHARD_TIMES = 1, 2
+
+
 class Reads(C.Structure):
     _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("on_device", C.c_int32),
                 ("reserved", C.c_int32), ("starts", C.c_void_p)]
@@ -70,6 +73,7 @@ SIGNATURES = {
     "fgpu_load_batch": (C.c_int, [_vp, _P(Reads)]),
     "fgpu_load_end": (C.c_int, [_vp, _P(LoadStats)]),
     "fgpu_presence_batch": (C.c_int, [_vp, _P(Reads)]),
+    "fgpu_load_fixup": (C.c_int, [_vp, _vp, _P(LoadStats)]),
     "fgpu_bloom_download": (C.c_int, [_vp, C.c_int, _vp, _u64]),
     "fgpu_bloom_download_begin": (C.c_int, [_vp, C.c_int, _vp, _u64]),
     "fgpu_bloom_download_wait": (C.c_int, [_vp]),

@@ -61,8 +61,9 @@ def load_filter_shape(estimated_kmers: int, singletons: int, fp: float = 0.04):
 class ReadBatch:
     """Sequence lines in file order.  Host numpy arrays or device pointers (e.g. torch tensors' data_ptr())."""
 
-    def __init__(self, bases, offsets, n_reads=None, on_device=False, keepalive=None, starts=None):
+    def __init__(self, bases, offsets, n_reads=None, on_device=False, keepalive=None, starts=None, n_positions=None):
         self.on_device = bool(on_device)
+        self.n_positions = n_positions          # bases + one separator per read, when the caller knows it (device batches)
         self._keep = (bases, offsets, keepalive)
         self.starts_ptr = int(starts) if starts else None      # device batches whose reads lie inside raw text
         if on_device:
@@ -74,6 +75,7 @@ class ReadBatch:
             self.bases_ptr = self.bases.ctypes.data
             self.offsets_ptr = self.offsets.ctypes.data
             self.n_reads = len(self.offsets) - 1
+            self.n_positions = int(self.offsets[-1] - self.offsets[0]) + self.n_reads
 
     @classmethod
     def from_lines(cls, lines):
@@ -154,8 +156,14 @@ class Context:
         _check(rc, self.h)
 
     # pass 1
-    def load_begin(self, keep_carry=False):
-        self._c(self.lib.fgpu_load_begin(self.h, int(keep_carry)))
+    def load_begin(self, keep_carry=False, shard_times=False):
+        self._c(self.lib.fgpu_load_begin(self.h, (L.LOAD_KEEP_CARRY if keep_carry else 0) | (L.LOAD_SHARD_TIMES if shard_times else 0)))
+
+    def load_fixup(self, prefix_dev_ptr) -> dict:
+        """multi-GPU: re-evaluate what this shard's own pass kept out of bloo2 against the OR of the lower ranks' bloo1"""
+        st = L.LoadStats()
+        self._c(self.lib.fgpu_load_fixup(self.h, prefix_dev_ptr, C.byref(st)))
+        return st.as_dict()
 
     def load_batch(self, batch: ReadBatch):
         s = batch.c_struct()

@@ -274,6 +274,11 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     // 44 ms per 10 M reads, at 2^33 bits the sweep would read 32 GiB per batch.
     static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
     ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai > (1ULL << 30);
+    ctx->shard_times = (keep_carry & FGPU_LOAD_SHARD_TIMES) != 0;
+    ctx->fixup_ready = false;
+    ctx->pass_positions = ctx->pass_batches = 0;
+    ctx->pass_empty_carry = !(keep_carry & FGPU_LOAD_KEEP_CARRY);
+    keep_carry &= FGPU_LOAD_KEEP_CARRY;
     ctx->epoch_positions = ctx->swept_positions = 0;
     ctx->sweep_num = ctx->sweep_den = 1;
     const char* sweep_env = getenv("FGPU_SWEEP_RATIO");   // "num/den"; "0/1" = after every batch: measurement aid
@@ -306,6 +311,7 @@ int fgpu_load_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     if ((rc = fgpu_stage_pack(ctx, reads))) return rc;
     if ((rc = fgpu_stage_load(ctx))) return rc;
+    if (ctx->cur->T) ctx->pass_batches++;
     ctx->load_stats.reads_processed += reads->n_reads;
     if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));   // caller may reuse its host buffers
     return FGPU_OK;
@@ -334,6 +340,27 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     ctx->load_stats.kmers = ctx->counters_host->kmers;
     ctx->load_stats.to_bloo2 = ctx->counters_host->to_bloo2;
     ctx->load_stats.unambiguous_reads = ctx->counters_host->segments;
+    if (stats) *stats = ctx->load_stats;
+    ctx->fixup_ready = ctx->shard_times && ctx->pass_empty_carry && ctx->resident_count == ctx->pass_batches &&
+                       !(ctx->prm.flags & FGPU_FLAG_MERCY);
+    return FGPU_OK;
+}
+
+int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stats) {
+    if (!ctx || !prefix_dev) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "load_fixup while a pass is open"; return FGPU_ERR_STATE; }
+    if (!ctx->fixup_ready) {
+        ctx->err = "load_fixup needs a finished load pass begun with FGPU_LOAD_SHARD_TIMES and an empty carry, every batch kept resident, no --mercy";
+        return FGPU_ERR_STATE;
+    }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (int rc = fgpu_bloom_download_wait(ctx)) return rc;
+    int rc = fgpu_stage_fixup(ctx, (const uint32_t*)prefix_dev);
+    if (!rc) rc = fgpu_util_or(ctx, ctx->bloo1, prefix_dev, ctx->bloom_bytes);
+    if (!rc) rc = pull_counters(ctx);
+    if (rc) return rc;
+    ctx->fixup_ready = false;                       // once per pass: the planes now speak about the global filter
+    ctx->load_stats.to_bloo2 = ctx->counters_host->to_bloo2;
     if (stats) *stats = ctx->load_stats;
     return FGPU_OK;
 }
@@ -411,6 +438,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     int rc = fgpu_scan_alloc(ctx);
     if (rc) return rc;
     if ((rc = fgpu_scan_reset(ctx))) return rc;
+    ctx->fixup_ready = false;   // the load pass' counters go with this reset
     FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
     memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
     memset(ctx->counters_host, 0, sizeof(DevCounters));

@@ -61,6 +61,7 @@ struct BatchBufs {
 struct ResidentBatch {
     DevBuf codes, bad, sure;
     uint64_t T = 0, n_words = 0;
+    uint32_t tb = 0;             // time base of the batch's first-set times (FGPU_LOAD_SHARD_TIMES: position within the pass)
 };
 
 struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_scan_take_stops
@@ -119,6 +120,12 @@ struct fgpu_ctx {
     uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
     uint64_t epoch_positions = 0;    // stream positions loaded since the last sweep of first[] (time base of the next batch)
     uint64_t swept_positions = 0;    // stream positions the carry covers
+    bool shard_times = false;        // FGPU_LOAD_SHARD_TIMES: times count from the start of the pass (fgpu_load_fixup compares them later)
+    bool fixup_ready = false;        // the last load pass ran that way with an empty carry and every batch resident
+    uint64_t pass_positions = 0;     // stream positions of the pass so far
+    uint32_t cur_tb = 0;             // time base of the batch being loaded
+    bool pass_empty_carry = true;
+    uint64_t pass_batches = 0;       // batches of the pass (all of them must be resident for fgpu_load_fixup)
     uint32_t sweep_num = 1, sweep_den = 1;   // sweep when epoch_positions >= swept_positions * num / den (FGPU_SWEEP_RATIO=num/den)
     bool carry_by_set = false;       // large filters: the carry is updated by re-hashing the new k-mers instead of sweeping first[]
     uint32_t* bloo2 = nullptr;
@@ -240,6 +247,7 @@ static inline unsigned fgpu_grid(uint64_t n, unsigned per_block) {
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_stage_load(fgpu_ctx* ctx);
 int fgpu_load_sweep(fgpu_ctx* ctx);
+int fgpu_stage_fixup(fgpu_ctx* ctx, const uint32_t* prefix);
 int fgpu_stage_presence(fgpu_ctx* ctx);
 int fgpu_load_pair_begin(fgpu_ctx* ctx);
 int fgpu_load_pair_end(fgpu_ctx* ctx);

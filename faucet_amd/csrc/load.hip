@@ -430,6 +430,36 @@ __global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ 
     }
 }
 
+// multi-GPU, fgpu_load_fixup: the occurrences the shard's own pass kept out of bloo2, looked at again with the lower ranks' bits.
+// bit set before t  <=>  in the prefix (set by a lower rank: all of those come earlier in file order) or first set locally before t.
+__global__ void __launch_bounds__(256) k_load_fixup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
+                                                    uint64_t n_words, FdParams fp, const uint32_t* __restrict__ prefix,
+                                                    const uint32_t* __restrict__ first, uint32_t tb, uint32_t* bloo2,
+                                                    unsigned long long* sure, DevCounters* cnt) {
+    unsigned long long n_pass = 0;
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool pass = false;
+        if (p < T && fd_window_ok(bad, p, fp.k) && !((sure[p >> 6] >> (p & 63)) & 1ULL)) {
+            uint64_t hA, hB;
+            fd_hash_pair(fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, hA, hB);
+            pass = true;
+            uint64_t h = hA;
+            for (int i = 0; i < fp.n_hash; i++) {
+                if (!((prefix[h >> 5] >> (h & 31)) & 1u) && !(first[h] < tb + (uint32_t)p)) { pass = false; break; }
+                h = (h + hB) & fp.tai_mask;
+            }
+            if (pass) {
+                n_pass++;
+                fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+            }
+        }
+        const uint64_t sm = __ballot(pass);   // lanes = the 64 positions of one plane word
+        if (fd_lane() == 0 && sm) sure[p >> 6] |= sm;
+    }
+    block_add(&cnt->to_bloo2, n_pass);
+}
+
 // multi-GPU helper: OR the bits of every k-mer into a bitmap, no ordering
 __global__ void __launch_bounds__(256) k_presence(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                   uint64_t T, uint64_t n_words, FdParams fp, uint32_t* bitmap, DevCounters* cnt) {
@@ -538,6 +568,7 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
     }
     r.T = bb.T;
     r.n_words = bb.n_words;
+    r.tb = ctx->cur_tb;
     FGPU_HIP(hipMemcpyAsync(r.codes.p, bb.codes.p, cb, hipMemcpyDeviceToDevice, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(r.bad.p, bb.bad.p, pb, hipMemcpyDeviceToDevice, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(r.sure.p, bb.sure.p, pb, hipMemcpyDeviceToDevice, ctx->stream));
@@ -571,8 +602,15 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     // holds a few coverages of the genome nearly every k-mer that will ever be in it already is: sweeps are made when an epoch
     // has grown to sweep_num/sweep_den of what the carry already covers (after batches 0, 1, 3, 7 ... of equal batches).
     const uint64_t span = bb.n_words * 64;
-    if (!ctx->carry_by_set && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
-    const uint32_t tb = ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
+    if (!ctx->carry_by_set && !ctx->shard_times && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
+    if (ctx->shard_times && ctx->pass_positions + span >= 0xFFFFFFF0ULL) {
+        ctx->err = "FGPU_LOAD_SHARD_TIMES: the pass exceeds 2^32 stream positions";
+        return FGPU_ERR_CAPACITY;
+    }
+    // shard times: one time base for the whole pass (sweeps still bring the carry up to date; they just do not restart the clock)
+    const uint32_t tb = ctx->shard_times ? (uint32_t)ctx->pass_positions : ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
+    ctx->cur_tb = tb;
+    ctx->pass_positions += span;
     FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
                 ctx->pair, ctx->first, tb, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
     static const int resolve_sm = getenv("FGPU_RESOLVE_SM") ? atoi(getenv("FGPU_RESOLVE_SM")) : 4096;
@@ -612,6 +650,16 @@ int fgpu_load_pair_begin(fgpu_ctx* ctx) {
 }
 int fgpu_load_pair_end(fgpu_ctx* ctx) {
     FGPU_LAUNCH("pair_split", k_pair_split, 2048, 256, (const uint2*)ctx->pair, ctx->bloo1, ctx->bloo2, ctx->bloom_bytes / 4);
+    return FGPU_OK;
+}
+
+int fgpu_stage_fixup(fgpu_ctx* ctx, const uint32_t* prefix) {
+    for (uint64_t i = 0; i < ctx->resident_count; i++) {
+        ResidentBatch& r = *ctx->resident[i];
+        if (!r.T) continue;
+        FGPU_LAUNCH("load_fixup", k_load_fixup, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
+                    r.n_words, ctx->fd, prefix, (const uint32_t*)ctx->first, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+    }
     return FGPU_OK;
 }
 

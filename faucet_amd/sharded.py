@@ -5,7 +5,8 @@ The reference is single-process; this is the multi-GPU host logic that SURVEY.md
 backend on CPU.  It talks to a *backend* object; the product backend is `GpuShard` below (libfaucet_gpu.so through
 `api.Context`); the CPU tests plug in an oracle-backed stand-in with the same methods.
 
-Pass 1 (exact):
+Pass 1 (exact), one of
+    load of the shard alone -> all-gather of bloo1 -> fix-up against the OR of the lower ranks' bloo1 -> bloo2 := OR over ranks
     presence bitmap of the shard  ->  all-gather  ->  carried-in bloo1 of rank r = OR of the bitmaps of ranks < r
     ->  ordered load of the shard ->  bloo2 := OR over ranks (all-gather + local OR; RCCL has no bitwise-OR reduction)
 Pass 2:
@@ -13,6 +14,8 @@ Pass 2:
     recv table from r-1, import, walk own shard, export, send to r+1.  The last rank holds the final map.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -51,8 +54,63 @@ def _recv(t, src):
         dist.recv(t, src=src)
 
 
+def _agree(flag: bool, device=None) -> bool:
+    """True iff it is True on every rank (the ranks must take the same protocol: their collectives have to match)"""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if dist.get_backend() != "gloo" else None)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def load_sharded(backend, batches, rank: int, world: int):
-    """Returns this shard's load stats; afterwards every rank holds the global bloo2."""
+    """Returns this shard's load stats; afterwards every rank holds the global bloo2.  Two exact protocols for pass 1:
+    the fix-up one (no presence pass: every rank loads its shard alone, then re-evaluates what it kept out of bloo2 against the
+    lower ranks' bits) where every rank can run it, else the presence one."""
+    # Which one: measured on one MI355X with the per-rank shapes of bench.py (scripts/shard_protocol_times.py; 10 M reads per rank):
+    # 2 ranks (2^30-bit filters, 25x coverage per shard): presence 43 + load 56 ms  vs  own load 70 + fix-up 18 ms  -> fix-up;
+    # 8 ranks (2^32 bits, 6x per shard): presence 53 + load 88 ms  vs  own load 146 + fix-up 34 ms -> presence: a shard that thin finds
+    # little in its own carry, and every occurrence it cannot settle alone costs first-set-time atomics into a 16 GiB array.
+    # FAUCET_SHARD_PROTOCOL=fixup|presence overrides the choice.
+    want = os.environ.get("FAUCET_SHARD_PROTOCOL", "auto")
+    prefer = want == "fixup" or (want == "auto" and world <= 2)
+    can = getattr(backend, "fixup_possible", None)
+    if _agree(bool(prefer and can and can(batches)), getattr(backend, "device", None)):
+        return load_sharded_fixup(backend, batches, rank, world)
+    return load_sharded_presence(backend, batches, rank, world)
+
+
+def load_sharded_fixup(backend, batches, rank: int, world: int):
+    """own shard alone (first-set times kept)  ->  all-gather of bloo1  ->  prefix = OR of the lower ranks' bloo1  ->  fix-up:
+    an occurrence the local pass kept out of bloo2 goes there iff each of its bits is in the prefix or was set locally before it
+    ->  bloo2 := OR over ranks.  Exact for the same reason as the presence protocol: what the sequential run has in
+    bloo1 when it reaches shard r IS that prefix, and within the shard "set before t" is what the first-set times say."""
+    stats = backend.load(batches, keep_carry=False, shard_times=True)
+    b1 = backend.bloom_tensor(L.BLOO1)
+    nbytes = b1.numel()
+    gathered = backend.scratch(world * nbytes)
+    backend.fence()
+    _all_gather(gathered, b1)
+    backend.fence()
+    if rank > 0:
+        prefix = backend.scratch(nbytes, tag="prefix")
+        prefix.zero_()
+        backend.fence()
+        for q in range(rank):                                  # exclusive prefix-OR
+            backend.or_tensor(prefix, gathered[q * nbytes:(q + 1) * nbytes])
+        stats = backend.load_fixup(prefix)
+    b2 = backend.bloom_tensor(L.BLOO2)
+    backend.fence()
+    _all_gather(gathered, b2)
+    backend.fence()
+    for q in range(world):                                     # OR-allreduce
+        if q != rank:
+            backend.or_into(L.BLOO2, gathered[q * nbytes:(q + 1) * nbytes])
+    backend.fence()
+    return stats
+
+
+def load_sharded_presence(backend, batches, rank: int, world: int):
+    """presence bitmap of the shard  ->  all-gather  ->  carried-in bloo1 of rank r = OR of the bitmaps of ranks < r  ->  ordered load
+    of the shard  ->  bloo2 := OR over ranks"""
     backend.clear_filters()
     for b in batches:
         backend.presence(b)
@@ -154,11 +212,25 @@ class GpuShard:
         ptr, nbytes = self.ctx.bloom_devptr(which)
         self.ctx.bitmap_or(ptr, src.data_ptr(), nbytes)
 
-    def load(self, batches, keep_carry):
-        self.ctx.load_begin(keep_carry=keep_carry)
+    def load(self, batches, keep_carry, shard_times=False):
+        self.ctx.load_begin(keep_carry=keep_carry, shard_times=shard_times)
         for b in batches:
             self.ctx.load_batch(b)
         return self.ctx.load_end()
+
+    def fixup_possible(self, batches):
+        """the fix-up protocol needs first-set times that count through the whole shard (32 bits) and every batch kept in HBM"""
+        pos = [getattr(b, "n_positions", None) for b in batches]
+        if any(p is None for p in pos):
+            return False
+        free, total = torch.cuda.mem_get_info(self.device)
+        return sum(pos) + 64 * len(pos) < 0xFFF00000 and sum(pos) // 2 + (64 << 20) < total // 8
+
+    def or_tensor(self, dst, src):
+        self.ctx.bitmap_or(dst.data_ptr(), src.data_ptr(), dst.numel())
+
+    def load_fixup(self, prefix):
+        return self.ctx.load_fixup(prefix.data_ptr())
 
     def scan_begin(self):
         self.ctx.scan_begin()

@@ -957,3 +957,84 @@ def test_a_batch_that_outgrows_the_junction_table_fails_promptly():
     except api.FaucetGpuError:
         pass
     ctx.close()
+
+
+@pytest.mark.parametrize("n_shards,batches_per_shard,ratio", [(2, 1, None), (3, 4, None), (4, 3, "0/1"), (3, 5, "1000000/1")])
+def test_shard_fixup_protocol_is_exact(n_shards, batches_per_shard, ratio, monkeypatch):
+    """Multi-GPU pass 1 without the presence pass (fgpu_load_fixup), emulated with one context per shard on this device: every shard
+    loads its reads alone with first-set times that count through the shard, then re-evaluates what it kept out of bloo2 against the OR
+    of the lower shards' bloo1.  The OR of the shards' bloo2 is the oracle's bloo2, the last shard's bloo1 the oracle's bloo1, the
+    to_bloo2 counts add up, and the scan of every shard reuses the fixed-up planes (valid_reused == to_bloo2 of the shard)."""
+    import torch
+    if ratio:
+        monkeypatch.setenv("FGPU_SWEEP_RATIO", ratio)
+    k, tai, nh = 21, 1 << 18, 3
+    bases, offs = _random_case(2400, 100, k, 9000, 0.02, 99, 0.003, 2)
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    olst = po.load_two_filters(b1, b2, bases, offs, k)
+    n = len(offs) - 1
+    cuts = np.linspace(0, n, n_shards + 1).astype(int)
+    ctxs, shards, stats = [], [], []
+    for a, z in zip(cuts[:-1], cuts[1:]):
+        sub = np.linspace(a, z, batches_per_shard + 1).astype(int)
+        shards.append([api.ReadBatch(bases, offs[x:y + 1].copy()) for x, y in zip(sub[:-1], sub[1:])])
+        ctxs.append(api.Context(k, tai, nh))
+    for ctx, sh in zip(ctxs, shards):
+        ctx.load_begin(shard_times=True)
+        for b in sh:
+            ctx.load_batch(b)
+        stats.append(ctx.load_end())
+    local_b1 = [torch.from_numpy(ctx.bloom_download(L.BLOO1)).cuda() for ctx in ctxs]
+    prefix = torch.zeros(tai // 8, dtype=torch.uint8, device="cuda")
+    total = stats[0]["to_bloo2"]
+    for r in range(1, n_shards):
+        prefix |= local_b1[r - 1]
+        torch.cuda.synchronize()
+        st = ctxs[r].load_fixup(prefix.data_ptr())
+        assert st["to_bloo2"] >= stats[r]["to_bloo2"]
+        stats[r] = st
+        total += st["to_bloo2"]
+        with pytest.raises(api.FaucetGpuError):      # once per pass
+            ctxs[r].load_fixup(prefix.data_ptr())
+    assert total == olst.to_bloo2
+    merged = np.zeros(tai // 8, dtype=np.uint8)
+    for ctx in ctxs:
+        merged |= ctx.bloom_download(L.BLOO2)
+    assert np.array_equal(merged, b2.bits())
+    assert np.array_equal(ctxs[-1].bloom_download(L.BLOO1), b1.bits())
+    # every shard scans with the global filter; its validity answers come from the fixed-up planes
+    for ctx, sh, st in zip(ctxs, shards, stats):
+        ctx.bloom_upload(L.BLOO2, merged)                       # (an upload forgets the planes ...
+    ctx = ctxs[-1]
+    ctx.load_begin(shard_times=True)                            # ... so load the last shard again and fix it up: the planes are kept)
+    for b in shards[-1]:
+        ctx.load_batch(b)
+    ctx.load_end()
+    st = ctx.load_fixup(prefix.data_ptr())
+    q, nbytes = ctx.bloom_devptr(L.BLOO2)
+    m = torch.from_numpy(merged).cuda()
+    torch.cuda.synchronize()
+    ctx.bitmap_or(q, m.data_ptr(), nbytes)
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(shards[-1])
+    assert sst["valid_reused"] == st["to_bloo2"]
+    osc = po.Scanner(k, 1, 100, b2)
+    for b in shards[-1]:
+        osc.scan_reads(b.bases, b.offsets)
+    _scan_equals_oracle(sc, sst, osc)
+
+
+def test_load_fixup_refuses_passes_it_cannot_speak_for():
+    k, tai, nh = 21, 1 << 16, 3
+    bases, offs = _random_case(300, 100, k, 3000, 0.01, 5)
+    import torch
+    prefix = torch.zeros(tai // 8, dtype=torch.uint8, device="cuda")
+    for kw, begin in (({}, {}), ({"keep_resident": False}, {"shard_times": True}), ({"mercy": True}, {"shard_times": True}),
+                      ({}, {"shard_times": True, "keep_carry": True})):
+        ctx = api.Context(k, tai, nh, **kw)
+        ctx.load_begin(**begin)
+        ctx.load_batch(api.ReadBatch(bases, offs))
+        ctx.load_end()
+        with pytest.raises(api.FaucetGpuError, match="load_fixup needs"):
+            ctx.load_fixup(prefix.data_ptr())
+        ctx.close()

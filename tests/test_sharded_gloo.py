@@ -23,8 +23,8 @@ assert ENTRY.itemsize == L.TABLE_ENTRY_BYTES
 class OracleShard:
     """CPU stand-in with the method set of sharded.GpuShard (TEST ONLY: the product backend is GpuShard)."""
 
-    def __init__(self, k, tai, nh, j, spacer):
-        self.k, self.tai, self.nh, self.j, self.spacer = k, tai, nh, j, spacer
+    def __init__(self, k, tai, nh, j, spacer, protocol="fixup"):
+        self.k, self.tai, self.nh, self.j, self.spacer, self.protocol = k, tai, nh, j, spacer, protocol
         self.b1, self.b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
         self.sc = None
         self.prepared = []
@@ -51,11 +51,33 @@ class OracleShard:
     def or_into(self, which, src):
         (self.b1 if which == L.BLOO1 else self.b2).bits()[:] |= src.numpy()
 
-    def load(self, batches, keep_carry):
-        assert keep_carry
+    def load(self, batches, keep_carry, shard_times=False):
+        if not keep_carry:
+            self.clear_filters()
+        self._batches = batches
         st = None
         for b in batches:
             st = po.load_two_filters(self.b1, self.b2, b[0], b[1], self.k)
+        return {"kmers": int(st.kmers)}
+
+    def fixup_possible(self, batches):
+        self.asked = True
+        return True
+
+    def or_tensor(self, dst, src):
+        dst.numpy()[:] |= src.numpy()
+
+    def load_fixup(self, prefix):
+        # what the device's fix-up must amount to: the shard loaded with the prefix as the carried-in state (the device gets there
+        # from its own first-set times; the parity of THAT kernel with this is tests/test_gpu_parity.py's business)
+        self.fixed_up = True
+        local = self.b1.bits().copy()
+        self.b1.bits()[:] = prefix.numpy()
+        self.b2.bits()[:] = 0
+        st = None
+        for b in self._batches:
+            st = po.load_two_filters(self.b1, self.b2, b[0], b[1], self.k)
+        assert np.array_equal(self.b1.bits(), local | prefix.numpy())
         return {"kmers": int(st.kmers)}
 
     def scan_begin(self):
@@ -110,7 +132,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, out_dir):
+def _worker(rank, world, port, name, out_dir, protocol):
+    os.environ["FAUCET_SHARD_PROTOCOL"] = protocol
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -121,8 +144,9 @@ def _worker(rank, world, port, name, out_dir):
     lo, hi = cuts[rank], cuts[rank + 1]
     mine = [(bases, offs[lo:(lo + hi) // 2 + 1].copy()), (bases, offs[(lo + hi) // 2:hi + 1].copy())]   # two batches per shard
     tai, nh, _, _ = po.sizing_from_cli(c.E, c.S)
-    be = OracleShard(c.k, tai, nh, c.j, c.spacer)
+    be = OracleShard(c.k, tai, nh, c.j, c.spacer, protocol)
     sharded.load_sharded(be, mine, rank, world)
+    assert getattr(be, "fixed_up", False) == ((protocol == "fixup" or (protocol == "auto" and world <= 2)) and rank > 0)
     np.save(os.path.join(out_dir, f"bloo2_{rank}.npy"), be.b2.bits().copy())
     st, last = sharded.scan_sharded(be, mine, rank, world)
     if last:
@@ -136,9 +160,10 @@ def _worker(rank, world, port, name, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("protocol", ["fixup", "presence", "auto"])
 @pytest.mark.parametrize("name,world", [("c1_k21", 2), ("ragged_k31", 2), ("j2_spacer20_k15", 3)])
-def test_sharded_protocol_matches_single_process(name, world, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+def test_sharded_protocol_matches_single_process(name, world, protocol, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), protocol), nprocs=world, join=True)
     c = Case(name)
     for r in range(world):      # every rank ends up with the reference's bloo2
         assert np.array_equal(np.load(tmp_path / f"bloo2_{r}.npy"), c.bloom())
