@@ -177,7 +177,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     ctx->bloom_bytes = p->tai / 8;
     if (const char* e = getenv("FGPU_MAX_SPAN_LOG2")) {   // experiment knob
         int l = atoi(e);
-        if (l >= 12 && l <= 26) ctx->max_span = 1ULL << l;
+        if (l >= 12 && l <= 28) ctx->max_span = 1ULL << l;
     }
     memset(&ctx->load_stats, 0, sizeof(ctx->load_stats));
     memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
@@ -474,7 +474,8 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
         if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
-        else if (f * 4 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;
+        else if (f * 4 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN)) ctx->window_span *= 2;
+        else if (f * 16 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;   // thin coverage per window: see FGPU_MAX_SPAN
     }
     ctx->adapt_followers = ctx->counters_host->followers;
     ctx->adapt_pieces = ctx->walked_pieces;
@@ -621,6 +622,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     while (!rc && !ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());   // every walk has finished
     ctx->phase = 0;
     if (rc) return rc;
+    ctx->wt_clean = true;   // every window was walked to its end: its clean-up kernel has left the window tables empty
     const DevCounters& c = *ctx->counters_host;
     fgpu_scan_stats& s = ctx->scan_stats;
     s.unambiguous_reads = c.segments + ctx->carried.unambiguous_reads;

@@ -16,7 +16,13 @@
 // every per-position plane / code array carries this many padding words past ceil(T/64): kernels run
 // whole 256-thread blocks and funnel-read one word ahead
 #define FGPU_PADW 8
-#define FGPU_MAX_SPAN (1ULL << 24)   // largest scheduling window of the ordered walk, in stream positions
+// Scheduling windows of the ordered walk, in stream positions.  Up to FGPU_USUAL_SPAN a window grows while fewer than a quarter of its
+// pieces queue behind another piece of their cluster (50x data settles there: 2^25 and 2^26 measured no better on config 2).  Beyond, up
+// to FGPU_MAX_SPAN, only while fewer than 1/16 do: reads of a large genome -- 10 M reads of 160 Mb, the per-rank shape of an 8-GPU run --
+// barely meet inside a window, and there 2^26 takes the walk stage from 28.8 to 25.9 ms per 10 M reads.  The window tables are sized for
+// FGPU_MAX_SPAN (3 GiB).
+#define FGPU_USUAL_SPAN (1ULL << 24)
+#define FGPU_MAX_SPAN (1ULL << 26)
 
 // A growable device buffer (hipMalloc'd; freed with the context).
 struct DevBuf {
@@ -150,6 +156,7 @@ struct fgpu_ctx {
     uint64_t* wkeys = nullptr;
     uint32_t* wslots = nullptr;      // list of claimed slots, for the sparse clear
     uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
+    bool wt_clean = false;           // the window tables are known to be empty (fresh memset, or the last scan ran to its end)
     // union-find / cluster scratch (per window)
     uint32_t wmax = 0;               // max pieces per window
     uint32_t* uf_parent = nullptr;

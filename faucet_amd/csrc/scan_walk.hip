@@ -1174,9 +1174,12 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
-    FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
-    FGPU_HIP(hipMemsetAsync(ctx->wslots, 0xFF, ctx->wcap * 4, ctx->stream));
-    FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
+    if (!ctx->wt_clean) {   // 3 GiB: only for new tables and after a scan that did not reach its end (every window cleans up after itself)
+        FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
+        FGPU_HIP(hipMemsetAsync(ctx->wslots, 0xFF, ctx->wcap * 4, ctx->stream));
+        FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
+    }
+    ctx->wt_clean = false;   // until this scan's fgpu_scan_end says otherwise
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
     FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, ctx->wmax * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->cl_offset, 0xFF, ctx->wmax * 4, ctx->stream));
@@ -1288,7 +1291,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                 ctx->calib_f = ctx->fb_host[0];
                 ctx->calib_p = ctx->fb_host[1];
                 if (f * 2 > p && span_now > 4096) span_now /= 2;
-                else if (f * 4 < p && span_now < ctx->max_span) span_now = std::min<uint64_t>(span_now * 4, ctx->max_span);
+                else if (f * 4 < p && span_now < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN))
+                    span_now = std::min<uint64_t>(span_now * 4, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
+                else if (f * 16 < p && span_now < ctx->max_span) span_now = std::min<uint64_t>(span_now * 4, ctx->max_span);
                 else ctx->calib_left = 1;          // settled
                 ctx->calib_left--;
             }
