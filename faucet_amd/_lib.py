@@ -96,6 +96,7 @@ SIGNATURES = {
     "fgpu_scan_table_entries": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_scan_export_table": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "fgpu_scan_import_table": (C.c_int, [_vp, _vp, _u64, _P(ScanStats)]),
+    "fgpu_scan_import_hint": (C.c_int, [_vp, _vp, _u64]),
     "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
     "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),

@@ -267,6 +267,10 @@ class Context:
         self._c(self.lib.fgpu_scan_export_table(self.h, dev_ptr, nbytes, C.byref(n)))
         return n.value
 
+    def import_hint(self, dev_ptr, n_entries):
+        """a preview of the table this shard will be handed (an earlier state of it): lets scan_prepare evaluate lazily"""
+        self._c(self.lib.fgpu_scan_import_hint(self.h, dev_ptr, n_entries))
+
     def import_table(self, dev_ptr, n_entries, carried: dict = None):
         st = None
         if carried is not None:

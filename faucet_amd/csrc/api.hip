@@ -446,6 +446,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_pieces_seen = 0;
     ctx->scan_piece_base = 0;
     ctx->scan_imported = 0;
+    ctx->hint_in_table = false;
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
                                                  : std::min<uint64_t>(1ULL << 18, ctx->max_span);   // calibrated upwards window by window
     ctx->calib_left = 16;
@@ -526,6 +527,7 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_batch outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
     if (!ctx->prepared.empty()) { ctx->err = "scan_batch while prepared batches are waiting: call fgpu_scan_walk_prepared first"; return FGPU_ERR_STATE; }
+    if (ctx->hint_in_table) { ctx->err = "the junction table holds a preview (fgpu_scan_import_hint): import the real table before walking"; return FGPU_ERR_STATE; }
     int rc = check_reads(ctx, reads);
     if (rc) return rc;
     FGPU_HIP(hipSetDevice(ctx->prm.device));
@@ -568,6 +570,7 @@ int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
 int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_walk_prepared outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    if (ctx->hint_in_table) { ctx->err = "the junction table holds a preview (fgpu_scan_import_hint): import the real table before walking"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     int rc = FGPU_OK;
     for (size_t i = 0; i < ctx->prepared.size() && !rc; i++) {
@@ -677,6 +680,10 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     if (ctx->phase != 2) { ctx->err = "import_table outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
     int rc = sync_all(ctx);
     if (rc) return rc;
+    if (ctx->hint_in_table) {   // the preview has done its work (the prepared batches' planes): the real table takes its place
+        if ((rc = fgpu_scan_clear_table(ctx))) return rc;
+        ctx->hint_in_table = false;
+    }
     if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported + n_entries))) return rc;
     rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
     if (rc) return rc;
@@ -687,6 +694,22 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     if (carried) ctx->carried = *carried;
     // creation stamps of this shard must sort after everything imported
     ctx->scan_piece_base = std::max<uint64_t>(ctx->scan_piece_base, carried ? carried->reads_no_errors : 0);
+    return FGPU_OK;
+}
+
+int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries) {
+    if (!ctx || (n_entries && !dev_buf)) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "import_hint outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    if (ctx->scan_windows || ctx->scan_imported || ctx->hint_in_table) {
+        ctx->err = "import_hint comes before any walk and before the real table (batches prepared earlier have simply seen an empty table)";
+        return FGPU_ERR_STATE;
+    }
+    int rc = sync_all(ctx);
+    if (rc) return rc;
+    if ((rc = fgpu_scan_reserve(ctx, n_entries))) return rc;
+    if ((rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries))) return rc;
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->hint_in_table = true;
     return FGPU_OK;
 }
 

@@ -169,6 +169,7 @@ struct fgpu_ctx {
     uint64_t max_span = FGPU_MAX_SPAN;   // upper bound of window_span (sizes the window table)
     uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
     uint64_t scan_imported = 0;      // junction records imported from a previous shard
+    bool hint_in_table = false;      // fgpu_scan_import_hint: the table holds a preview, not the state to walk on
     uint64_t scan_grown = 0;         // times the junction table was rehashed into a larger one
 
     DevCounters* counters = nullptr;      // device
@@ -274,3 +275,4 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_scan_reset(fgpu_ctx* ctx);
 int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap);
 int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records);
+int fgpu_scan_clear_table(fgpu_ctx* ctx);

@@ -1162,6 +1162,14 @@ int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap) {
     return FGPU_OK;
 }
 
+// empty junction table (a preview is being replaced by the real state); both streams idle
+int fgpu_scan_clear_table(fgpu_ctx* ctx) {
+    FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
+    return FGPU_OK;
+}
+
 // called where the host holds a fresh count of the records (batch boundaries): keep the table below a quarter full
 int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records) {
     if (!ctx->jkeys || records * 4 <= ctx->jcap) return FGPU_OK;

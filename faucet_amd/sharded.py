@@ -136,16 +136,109 @@ def load_sharded_presence(backend, batches, rank: int, world: int):
     return stats
 
 
+HINT_AFTER = 0.25      # share of the first shard's reads after which its table is shown to the other ranks
+
+
+def _n_reads(b):
+    return b.n_reads if hasattr(b, "n_reads") else len(b[1]) - 1
+
+
+def _bcast(t, src, rank):
+    if _staged(t):
+        h = t.cpu() if rank == src else torch.empty(t.shape, dtype=t.dtype)
+        dist.broadcast(h, src=src)
+        if rank != src:
+            t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
+class _HintReceiver:
+    """the two broadcasts of the hint (count, then entries) posted asynchronously and looked at between batches"""
+
+    def __init__(self, backend, hdr, rank):
+        self.backend, self.hdr, self.rank = backend, hdr, rank
+        self.stage, self.buf, self.n = 0, None, 0
+        self.work, self.host = self._post(hdr)
+
+    def _post(self, t):
+        if _staged(t):
+            h = torch.empty(t.shape, dtype=t.dtype)
+            return dist.broadcast(h, src=0, async_op=True), h
+        return dist.broadcast(t, src=0, async_op=True), None
+
+    def _landed(self, t):
+        if self.host is not None:
+            t.copy_(self.host)
+
+    def _advance(self):
+        if self.stage == 0:
+            self._landed(self.hdr)
+            self.n = int(self.hdr.cpu()[0])
+            self.buf = self.backend.scratch(max(self.n, 1) * L.TABLE_ENTRY_BYTES, tag="table_hint")
+            self.work, self.host = self._post(self.buf)
+            self.stage = 1
+        elif self.stage == 1:
+            self._landed(self.buf)
+            self.stage = 2
+            return True
+        return False
+
+    def poll(self):
+        while self.stage < 2 and self.work.is_completed():
+            self.work.wait()
+            if self._advance():
+                self.backend.fence()
+                self.backend.import_hint(self.buf, self.n)
+
+    def finish(self):
+        while self.stage < 2:
+            self.work.wait()
+            self._advance()
+
+
 def scan_sharded(backend, batches, rank: int, world: int):
-    """Returns (stats, is_last): on the last rank the stats are the whole run's and backend.junctions() is the final map."""
+    """Returns (stats, is_last): on the last rank the stats are the whole run's and backend.junctions() is the final map.
+
+    The ranks behind the first one have no junction table while they run their pure stage, and with an empty table every junction test
+    of every position is evaluated (105-116 ms per 10 M reads instead of ~50).  So the first rank shows them its table once it has
+    walked HINT_AFTER of its reads -- an earlier state of the very table they will be handed, which is all the preview of the pure stage
+    needs (faucet_gpu.h, fgpu_scan_import_hint) -- and they prepare against that.  The hint is replaced by the real table before a walk."""
     backend.scan_begin()
+    hinting = world > 1
+    hint_hdr = backend.header_tensor()[:1] if hinting else None
     if rank == 0:
+        total, done, sent = sum(_n_reads(b) for b in batches), 0, [False]
+        marks = []
+        for b in batches:
+            done += _n_reads(b)
+            marks.append(done >= HINT_AFTER * total)
+        hint_index = marks.index(True) if True in marks else len(batches) - 1
+
+        def show(i):
+            if hinting and not sent[0] and i >= hint_index:
+                sent[0] = True
+                n, buf = backend.export_table()
+                backend.fence()
+                hint_hdr[0] = n
+                _bcast(hint_hdr, 0, rank)
+                _bcast(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 0, rank)
+
         # the first shard has nothing to wait for: it streams (pure stage of batch b+1 overlapped with the walk of batch b, lazy
         # junction tests), which puts the table on its way ~50 ms per 10 M reads earlier than prepare-all + walk
-        stats = backend.scan_stream(batches)               # ... and closes the pass
+        stats = backend.scan_stream(batches, after_batch=show)   # ... and closes the pass
+        show(len(batches))                                        # (a shard without batches still owes the others their broadcast)
     else:
+        # pure stage while the earlier shards walk.  It does not wait for the hint: the receive is posted, the batches prepared until it
+        # has landed see an empty table (every test evaluated), the others the hint.  Measured with the per-rank shapes
+        # (scripts/rank_stage_times.py, 10 M reads): 2 ranks 117 ms without a hint, 75 ms with it from the start; 8 ranks 107 and 93 ms.
+        rx = _HintReceiver(backend, hint_hdr, rank) if hinting else None
         for b in batches:
-            backend.scan_prepare(b)                        # pure stage while the earlier shards walk
+            if rx:
+                rx.poll()
+            backend.scan_prepare(b)
+        if rx:
+            rx.finish()                                    # the collective is completed even when it came too late to be of use
     hdr = backend.header_tensor()
     if rank > 0:
         _recv(hdr, rank - 1)
@@ -154,10 +247,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
         buf = backend.scratch(max(n_in, 1) * L.TABLE_ENTRY_BYTES, tag="table_in")
         _recv(buf, rank - 1)
         backend.fence()
-        backend.import_table(buf, n_in, dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]])))
-    if rank > 0:
-        backend.scan_walk_prepared()                       # ordered walk of this shard
-        stats = backend.scan_end()
+        carried = dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]]))
+        stats = backend.walk_shard(batches, buf, n_in, carried)   # import (replaces the hint) + ordered walk of this shard + scan_end
     if rank < world - 1:
         n_out, buf = backend.export_table()
         backend.fence()
@@ -238,25 +329,55 @@ class GpuShard:
     def scan_prepare(self, batch):
         self.ctx.scan_prepare(batch)
 
-    def scan_stream(self, batches):
-        """scan_batch over all batches; when the lazy-flag self-check fires the pass is closed and repeated
-        with every junction test evaluated -- the table is reset by scan_begin, nothing has left this rank yet"""
+    def _restart_eager(self):
         from .api import FaucetGpuError
         try:
-            for b in batches:
+            self.ctx.scan_end()
+        except FaucetGpuError:
+            pass
+        self.ctx.scan_set_eager(True)
+        self.ctx.scan_begin()
+
+    def scan_stream(self, batches, after_batch=None):
+        """scan_batch over all batches (after_batch(i) is called behind each); when the lazy-flag self-check fires
+        the pass is closed and repeated with every junction test evaluated -- the table is reset by scan_begin, and what has left this
+        rank so far is at most a preview of the table (an earlier state of the same table in the repeated scan as well)"""
+        from .api import FaucetGpuError
+        try:
+            for i, b in enumerate(batches):
                 self.ctx.scan_batch(b)
+                if after_batch:
+                    after_batch(i)
             return self.ctx.scan_end()
         except FaucetGpuError as e:
             if "lazy-flag" not in str(e):
                 raise
-            try:
-                self.ctx.scan_end()
-            except FaucetGpuError:
-                pass
-            self.ctx.scan_set_eager(True)
-            self.ctx.scan_begin()
-            for b in batches:
+            self._restart_eager()
+            for i, b in enumerate(batches):
                 self.ctx.scan_batch(b)
+                if after_batch:
+                    after_batch(i)
+            return self.ctx.scan_end()
+
+    def import_hint(self, buf, n):
+        self.ctx.import_hint(buf.data_ptr(), n)
+
+    def walk_shard(self, batches, buf, n, carried):
+        """the handed-over table takes the place of the preview, then the ordered walk of the prepared batches.  Should the walk find
+        the preview wanting in a way it cannot repair the shard is prepared again with every test evaluated."""
+        from .api import FaucetGpuError
+        try:
+            self.import_table(buf, n, carried)
+            self.ctx.scan_walk_prepared()
+            return self.ctx.scan_end()
+        except FaucetGpuError as e:
+            if "lazy-flag" not in str(e):
+                raise
+            self._restart_eager()
+            for b in batches:
+                self.ctx.scan_prepare(b)
+            self.import_table(buf, n, carried)
+            self.ctx.scan_walk_prepared()
             return self.ctx.scan_end()
 
     def scan_walk_prepared(self):

@@ -239,6 +239,13 @@ int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* r
 int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries);
 int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries);
 int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries, const fgpu_scan_stats* carried);
+/* A PREVIEW of the table a later shard will be handed: an earlier state of the same ordered table (what the first shard has built
+ * after part of its reads).  Imported before (or between) the calls of fgpu_scan_prepare -- before any walk --, it lets the pure stage evaluate the junction tests only where the walk
+ * may stop, as it does in a streaming scan -- with an empty table every test of every position is evaluated (2.5x the probes).  Valid
+ * because the table only grows along the file (keys are never removed, distances only rise), the same reason a batch may be previewed
+ * against the table as of two batches earlier; the walk verifies the preview as always.  The hint is not part of the result: the
+ * fgpu_scan_import_table that must follow replaces it, and the walk refuses to start while it is in place (FGPU_ERR_STATE). */
+int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries);
 #define FGPU_TABLE_ENTRY_BYTES 32
 
 /* ---- probes for tests (pure, no state change) ------------------------------------------------- */

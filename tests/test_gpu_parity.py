@@ -1038,3 +1038,76 @@ def test_load_fixup_refuses_passes_it_cannot_speak_for():
         with pytest.raises(api.FaucetGpuError, match="load_fixup needs"):
             ctx.load_fixup(prefix.data_ptr())
         ctx.close()
+
+
+def test_table_hint_lets_a_later_shard_prepare_lazily_and_never_enters_the_result():
+    """fgpu_scan_import_hint: shard B prepares against the table shard A had after a third of its reads (a preview), is then handed A's
+    final table and walks.  Records, order and counters are the oracle's; fewer junction tests were evaluated than without the hint;
+    walking on the hint itself is refused."""
+    import torch
+    k, G = 21, 30_000
+    bases, offs = _random_case(12_000, 100, k, G, 0.01, 4711, 0.002, 3)     # 40x
+    tai, nh = api.load_filter_shape(20 * G, 4 * G)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh)
+    n = len(offs) - 1
+    half = n // 2
+    part_a = [api.ReadBatch(bases, offs[x:y + 1].copy()) for x, y in ((0, half // 3), (half // 3, half))]
+    part_b = [api.ReadBatch(bases, offs[x:y + 1].copy()) for x, y in ((half, half + half // 2), (half + half // 2, n))]
+    a, b = api.Context(k, tai, nh), api.Context(k, tai, nh)
+    for ctx in (a, b):
+        ctx.bloom_upload(L.BLOO2, b2.bits())
+
+    def export(ctx):
+        m = ctx.table_entries()
+        buf = torch.empty(max(m, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device="cuda")
+        assert ctx.export_table(buf.data_ptr(), buf.numel()) == m
+        torch.cuda.synchronize()
+        return m, buf
+
+    a.scan_begin()
+    a.scan_batch(part_a[0])
+    n_hint, hint = export(a)                                   # mid-scan: an earlier state of A's table
+    a.scan_batch(part_a[1])
+    st_a = a.scan_end()
+    n_real, real = export(a)
+    assert 0 < n_hint < n_real
+
+    def run_b(with_hint):
+        b.scan_begin()
+        if with_hint:
+            b.import_hint(hint.data_ptr(), n_hint)
+        for p in part_b:
+            b.scan_prepare(p)
+        if with_hint:
+            with pytest.raises(api.FaucetGpuError, match="preview"):
+                b.scan_walk_prepared()
+        b.import_table(real.data_ptr(), n_real, carried=st_a)
+        b.scan_walk_prepared()
+        st = b.scan_end()
+        return st, b.junctions()
+
+    st_plain, (k_plain, r_plain) = run_b(False)
+    st_hint, (k_hint, r_hint) = run_b(True)
+    assert st_hint["flag_positions"] < 0.8 * st_plain["flag_positions"]
+    for st, keys, recs in ((st_plain, k_plain, r_plain), (st_hint, k_hint, r_hint)):
+        ost = osc.stats()
+        for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors"):
+            assert st[key] == ost[key], key
+        okeys, orecs = osc.junctions("creation")
+        assert np.array_equal(keys, okeys) and np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
+    # the hint may land between two prepares (the batches before it have seen an empty table) but not once a walk has been issued
+    b.scan_begin()
+    b.scan_prepare(part_b[0])
+    b.import_hint(hint.data_ptr(), n_hint)
+    b.scan_prepare(part_b[1])
+    b.import_table(real.data_ptr(), n_real, carried=st_a)
+    b.scan_walk_prepared()
+    st_mid = b.scan_end()
+    k_mid, r_mid = b.junctions()
+    assert np.array_equal(k_mid, k_plain) and r_mid.tobytes() == r_plain.tobytes()
+    assert st_hint["flag_positions"] <= st_mid["flag_positions"] <= st_plain["flag_positions"]
+    b.scan_begin()
+    b.scan_batch(part_b[0])
+    with pytest.raises(api.FaucetGpuError, match="before any walk"):
+        b.import_hint(hint.data_ptr(), n_hint)
+    b.scan_end()

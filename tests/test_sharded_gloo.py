@@ -87,9 +87,26 @@ class OracleShard:
     def scan_prepare(self, batch):
         self.prepared.append(batch)
 
-    def scan_stream(self, batches):
-        for batch in batches:
+    def scan_stream(self, batches, after_batch=None):
+        for i, batch in enumerate(batches):
             self.sc.scan_reads(batch[0], batch[1])
+            if after_batch:
+                after_batch(i)
+        return self.scan_end()
+
+    def import_hint(self, buf, n):
+        # the oracle has no preview to feed; what matters here is that the hint is a state of rank 0's table and never part of a result
+        self.hint = buf.numpy()[: n * L.TABLE_ENTRY_BYTES].view(ENTRY).copy()
+
+    def walk_shard(self, batches, buf, n, carried):
+        self.import_table(buf, n, carried)
+        if getattr(self, "hint", None) is not None and len(self.hint):   # the hint is an EARLIER state of the first shard's table
+            real = buf.numpy()[: n * L.TABLE_ENTRY_BYTES].view(ENTRY)
+            pos = {int(k): i for i, k in enumerate(real["key"])}
+            for e in self.hint:
+                r = real[pos[int(e["key"])]]                              # every key is still there ...
+                assert (e["dist"] <= r["dist"]).all()                     # ... and distances have only grown
+        self.scan_walk_prepared()
         return self.scan_end()
 
     def scan_walk_prepared(self):
