@@ -1022,37 +1022,57 @@ struct ExportEntry {   // FGPU_TABLE_ENTRY_BYTES = 32
 };
 
 __global__ void __launch_bounds__(256) k_export(JTable jt, FdParams fp, ExportEntry* out, uint64_t* stamps_out, unsigned long long* n_out) {
-    // one same-address atomic per BLOCK (they serialise at ~10 ns each): ranks inside the block come from ballots
+    // Every block owns a contiguous range of slots and reserves its output space ONCE: a first pass over the key words counts the
+    // records of the range, one atomic claims that many entries, a second pass writes them (ranks from ballots and wave totals).
+    // One same-address atomic per 256 slots, as before, cost 5 ms at 2^27 slots -- they serialise at ~10 ns each -- and the export is
+    // on the path of every hand-over between ranks; the key words read twice are 1 GiB of streaming there.
     __shared__ unsigned wave_total[4];
     __shared__ unsigned long long block_base;
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t w = s <= jt.mask ? jt.keys[s] : J_EMPTY;
-    const bool has0 = w != J_EMPTY && ((w >> 62) & 1ULL), has1 = w != J_EMPTY && ((w >> 63) & 1ULL);
-    const uint64_t m0 = __ballot(has0), m1 = __ballot(has1);
-    const uint64_t below = (1ULL << fd_lane()) - 1;
-    unsigned rank = (unsigned)(__popcll(m0 & below) + __popcll(m1 & below));
+    const uint64_t n_slots = jt.mask + 1;
+    const uint64_t per_block = ((n_slots + gridDim.x - 1) / gridDim.x + 255) & ~255ULL;
+    const uint64_t lo = (uint64_t)blockIdx.x * per_block;
+    const uint64_t hi = lo + per_block < n_slots ? lo + per_block : n_slots;
     const int wave = (int)(threadIdx.x >> 6);
-    if (fd_lane() == 0) wave_total[wave] = (unsigned)(__popcll(m0) + __popcll(m1));
+    unsigned long long mine = 0;
+    for (uint64_t s = lo + threadIdx.x; s < hi; s += 256) {
+        const uint64_t w = jt.keys[s];
+        if (w != J_EMPTY) mine += ((w >> 62) & 1ULL) + ((w >> 63) & 1ULL);
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (fd_lane() == 0) wave_total[wave] = (unsigned)mine;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
-        block_base = total ? atomicAdd(n_out, (unsigned long long)total) : 0ULL;
+        const unsigned long long total = (unsigned long long)wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        block_base = total ? atomicAdd(n_out, total) : 0ULL;
     }
     __syncthreads();
-    for (int q = 0; q < wave; q++) rank += wave_total[q];
-    unsigned long long idx = block_base + rank;
-    const uint64_t canon = w & J_KEYMASK;
-    for (int o = 0; o < 2; o++) {
-        if (!(o == 0 ? has0 : has1)) continue;
-        ExportEntry e;
-        e.key = o == 0 ? canon : fd_revcomp(canon, fp.k);
-        e.stamp = jt.stamps[s * 2 + o];
-        const uint64_t* r = (const uint64_t*)(jt.recs + (s * 2 + o) * 16);
-        ((uint64_t*)e.rec)[0] = r[0];
-        ((uint64_t*)e.rec)[1] = r[1];
-        out[idx] = e;
-        stamps_out[idx] = e.stamp;
-        idx++;
+    unsigned long long base = block_base;
+    for (uint64_t s0 = lo; s0 < hi; s0 += 256) {     // uniform trip count: hi - lo is a multiple of 256 except in the last block
+        const uint64_t s = s0 + threadIdx.x;
+        const uint64_t w = s < hi ? jt.keys[s] : J_EMPTY;
+        const bool has0 = w != J_EMPTY && ((w >> 62) & 1ULL), has1 = w != J_EMPTY && ((w >> 63) & 1ULL);
+        const uint64_t m0 = __ballot(has0), m1 = __ballot(has1);
+        const uint64_t below = (1ULL << fd_lane()) - 1;
+        unsigned rank = (unsigned)(__popcll(m0 & below) + __popcll(m1 & below));
+        __syncthreads();                               // the totals of the previous chunk have been read by everybody
+        if (fd_lane() == 0) wave_total[wave] = (unsigned)(__popcll(m0) + __popcll(m1));
+        __syncthreads();
+        for (int q = 0; q < wave; q++) rank += wave_total[q];
+        unsigned long long idx = base + rank;
+        base += (unsigned long long)wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        const uint64_t canon = w & J_KEYMASK;
+        for (int o = 0; o < 2; o++) {
+            if (!(o == 0 ? has0 : has1)) continue;
+            ExportEntry e;
+            e.key = o == 0 ? canon : fd_revcomp(canon, fp.k);
+            e.stamp = jt.stamps[s * 2 + o];
+            const uint64_t* r = (const uint64_t*)(jt.recs + (s * 2 + o) * 16);
+            ((uint64_t*)e.rec)[0] = r[0];
+            ((uint64_t*)e.rec)[1] = r[1];
+            out[idx] = e;
+            stamps_out[idx] = e.stamp;
+            idx++;
+        }
     }
 }
 
@@ -1427,7 +1447,8 @@ int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries
     unsigned long long* d_n = &ctx->counters->pad;
     FGPU_HIP(hipMemsetAsync(d_n, 0, 8, ctx->stream));
     (void)cap_entries;
-    FGPU_LAUNCH("export", k_export, fgpu_blocks(ctx->jcap, 256), 256, make_jt(ctx), ctx->fd, (ExportEntry*)dev_entries, d_stamps, d_n);
+    FGPU_LAUNCH("export", k_export, (unsigned)std::min<uint64_t>(fgpu_blocks(ctx->jcap, 256), 4096), 256, make_jt(ctx), ctx->fd, (ExportEntry*)dev_entries,
+                d_stamps, d_n);
     FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->pad, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     *n_entries = ctx->counters_host->pad;

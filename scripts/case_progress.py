@@ -1,5 +1,6 @@
 """One data set through load + lazy scan + eager scan with a progress line after every stage (diagnostic; GPU box).
     python scripts/case_progress.py <reads> <genome> [seed] [log2 junction capacity]"""
+import hashlib
 import os
 import sys
 import time
@@ -41,3 +42,5 @@ for i, b in enumerate(batches):
 sst = ctx.scan_end()
 say(f"scan done: junctions {sst['n_junctions']} windows {sst['walk_windows']} max cluster {sst['walk_max_cluster']} filled {sst['flags_filled']}")
 say(str({k: round(v[1], 1) for k, v in ctx.kernel_times().items() if v[1] > 5}))
+keys, recs = ctx.junctions()
+say("junction records in creation order: sha256 " + hashlib.sha256(keys.tobytes() + recs.tobytes()).hexdigest()[:16])
