@@ -218,7 +218,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
         def show(i):
             if hinting and not sent[0] and i >= hint_index:
                 sent[0] = True
-                n, buf = backend.export_table()
+                n, buf = backend.export_table(tag="table_hint_out")   # its own buffer: the broadcast may still be reading it at the final export
                 backend.fence()
                 hint_hdr[0] = n
                 _bcast(hint_hdr, 0, rank)
@@ -389,9 +389,9 @@ class GpuShard:
     def import_table(self, buf, n, carried):
         self.ctx.import_table(buf.data_ptr(), n, carried=carried)
 
-    def export_table(self):
+    def export_table(self, tag="table_out"):
         n = self.ctx.table_entries()
-        buf = self.scratch(max(n, 1) * L.TABLE_ENTRY_BYTES, tag="table_out")
+        buf = self.scratch(max(n, 1) * L.TABLE_ENTRY_BYTES, tag=tag)
         got = self.ctx.export_table(buf.data_ptr(), buf.numel())
         assert got == n
         return n, buf

@@ -128,7 +128,7 @@ class OracleShard:
         oc.update(empty_count=0, not_empty_count=0, n_junctions=0)
         self.sc.import_junctions(e["key"][order], recs[order], oc)
 
-    def export_table(self):
+    def export_table(self, tag="table_out"):
         keys, recs = self.sc.junctions("creation")
         e = np.zeros(max(len(keys), 1), dtype=ENTRY)
         e["key"][: len(keys)] = keys
