@@ -20,3 +20,18 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     # value is consistent with the step time it was derived from
     assert abs(d["value"] - d["kmers_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_batch_bounds_cover_the_reads_once_in_order():
+    """bench.py's batching (host logic): contiguous, complete, in file order; the ramp starts and ends small"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n, batch, ramp in ((10_000_000, 1_000_000, 2), (10_000_000, 1_000_000, 0), (10_000_003, 1_000_000, 3), (3_000_000, 1_000_000, 2),
+                           (999, 1000, 2), (25_000_000, 1_000_000, 5), (7, 2, 1)):
+        b = bench.batch_bounds(n, batch, ramp)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b[:-1], b[1:])) and all(lo < hi for lo, hi in b)
+        assert max(hi - lo for lo, hi in b) <= batch
+    sizes = [hi - lo for lo, hi in bench.batch_bounds(10_000_000, 1_000_000, 2)]
+    assert sizes[:3] == [250_000, 250_000, 500_000] and sizes[-2:] == [500_000, 250_000] and sizes.count(1_000_000) == 8
