@@ -98,12 +98,14 @@ static int check_errors(fgpu_ctx* ctx) {
 // everything issued so far, on both streams, has completed
 static int sync_all(fgpu_ctx* ctx) {
     FGPU_HIP(hipStreamSynchronize(ctx->wstream));
+    FGPU_HIP(hipStreamSynchronize(ctx->cstream));   // the side stream's last resets (nothing waits for them but the next window of their parity)
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     return FGPU_OK;
 }
 
 static int pull_counters(fgpu_ctx* ctx) {
     FGPU_HIP(hipStreamSynchronize(ctx->wstream));
+    FGPU_HIP(hipStreamSynchronize(ctx->cstream));
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     return check_errors(ctx);
@@ -197,6 +199,12 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
         if ((e = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (walk)", e);
+        if (!rc && (e = hipStreamCreateWithPriority(&ctx->cstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (clean)", e);
+        if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_linked, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
+        if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_cleaned, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
+        if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_walked, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
+        for (int q = 0; q < 2 && !rc; q++)
+            if ((e = hipEventCreateWithFlags(&ctx->ev_uf_reset[q], hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
     }
     if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
@@ -232,6 +240,11 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
     if (ctx->fb_host) hipHostFree(ctx->fb_host);
     if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
+    if (ctx->cstream) { hipStreamSynchronize(ctx->cstream); hipStreamDestroy(ctx->cstream); }
+    if (ctx->ev_linked) hipEventDestroy(ctx->ev_linked);
+    if (ctx->ev_cleaned) hipEventDestroy(ctx->ev_cleaned);
+    if (ctx->ev_walked) hipEventDestroy(ctx->ev_walked);
+    for (int q = 0; q < 2; q++) if (ctx->ev_uf_reset[q]) hipEventDestroy(ctx->ev_uf_reset[q]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     for (ResidentBatch* r : ctx->resident) delete r;
     for (BatchBufs* b : ctx->all_batches) {

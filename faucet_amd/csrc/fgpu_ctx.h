@@ -118,6 +118,8 @@ struct fgpu_ctx {
     FdParams fd;
     hipStream_t stream = nullptr;          // main stream: pack, load, pure scan stage, transfers
     hipStream_t wstream = nullptr;         // walk stream: the ordered walk of batch b overlaps the pure stage of batch b+1
+    hipStream_t cstream = nullptr;         // clean stream: the window table of window w is emptied while w is clustered and walked
+    hipEvent_t ev_linked = nullptr, ev_cleaned = nullptr, ev_walked = nullptr, ev_uf_reset[2] = {nullptr, nullptr};
     hipStream_t launch_stream = nullptr;   // where FGPU_LAUNCH puts kernels (and profiling events) right now
     bool own_stream = false;
     std::string err;

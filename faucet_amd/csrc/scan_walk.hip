@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *wd_out = wd;                  // the walk kernel reads it with one uniform load
         cnt->walked_pieces += n;       // one writer per launch; feedback for the window-span controller
+        cnt->pad2 = 0;                 // pool cursor of the giant-cluster lists of the walk kernel that follows
     }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t r = i;
@@ -808,6 +809,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     const uint32_t ii = i < n ? i : 0;
     const uint32_t my_root = root[ii], my_count = count[ii], my_head = head[ii];
     const uint2 my_piece = pl.pieces[first_piece + ii];
+
     if (i < n && my_root == i) {
         const uint32_t nm = (dbg & 2) ? 0 : my_count;
         uint32_t local_mem[LOCAL_MEMBERS];
@@ -851,10 +853,9 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
 
 // ---- E: sparse reset of the window table ----------------------------------------------------------------
 // wt.slots is indexed by position relative to the window's (word-aligned) start: U_INF = that position claimed nothing.
-__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent, uint32_t* count, uint32_t* head, DevCounters* cnt, Planes pl,
-                                                    uint64_t lo, uint64_t hi, uint64_t pos_end) {
-    const uint32_t n = make_window(pl, lo, hi).n;
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->pad2 = 0;   // pool cursor of the giant-cluster lists
+__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint64_t lo, uint64_t pos_end) {
+    // Nothing reads the window table once the link kernel is done (the walk works from the lk plane), so this runs on a stream of its
+    // own beside the cluster and walk kernels of the same window; the union-find and list entries are reset by k_walk_reset_uf.
     const uint64_t span = pos_end - (lo & ~63ULL);
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -867,13 +868,18 @@ __global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint32_t* parent,
         wt.bits[b >> 5] = 0;   // whole word: every bit of it belongs to a key that is being removed as well
         wt.keys[s] = W_EMPTY;
     }
-    for (uint64_t a = i; a < n; a += stride) {
-        parent[a] = (uint32_t)a;
+}
+
+
+// union-find and list entries of a window's pieces back to "every piece its own cluster": the arrays exist twice and consecutive
+// windows alternate, so this runs on the side stream while the NEXT window is already being looked up and linked
+__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t n) {
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
+        parent[a] = a;
         count[a] = 0;
         head[a] = U_INF;
     }
 }
-
 
 __global__ void __launch_bounds__(256) k_fill_u64(uint64_t* p, uint64_t n, uint64_t v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1135,9 +1141,9 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->wkeys, ctx->wcap * 8));
     FGPU_HIP(hipMalloc(&ctx->wslots, ctx->wcap * 4));
     FGPU_HIP(hipMalloc(&ctx->wbits, (1ULL << WBITS_LOG2) / 8));
-    FGPU_HIP(hipMalloc(&ctx->uf_parent, ctx->wmax * 4));
-    FGPU_HIP(hipMalloc(&ctx->cl_count, ctx->wmax * 4));
-    FGPU_HIP(hipMalloc(&ctx->cl_offset, ctx->wmax * 4));
+    FGPU_HIP(hipMalloc(&ctx->uf_parent, 2 * ctx->wmax * 4));   // two sets each: consecutive windows alternate (k_walk_reset_uf)
+    FGPU_HIP(hipMalloc(&ctx->cl_count, 2 * ctx->wmax * 4));
+    FGPU_HIP(hipMalloc(&ctx->cl_offset, 2 * ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_fill, ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_members, ctx->wmax * 4 * 2));
     return FGPU_OK;
@@ -1209,8 +1215,9 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     }
     ctx->wt_clean = false;   // until this scan's fgpu_scan_end says otherwise
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
-    FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, ctx->wmax * 4, ctx->stream));
-    FGPU_HIP(hipMemsetAsync(ctx->cl_offset, 0xFF, ctx->wmax * 4, ctx->stream));
+    FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent + ctx->wmax, (uint64_t)ctx->wmax);
+    FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, 2 * ctx->wmax * 4, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->cl_offset, 0xFF, 2 * ctx->wmax * 4, ctx->stream));
     return FGPU_OK;
 }
 
@@ -1270,6 +1277,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
     static const int dbg_walk = getenv("FGPU_DEBUG_WALK") ? atoi(getenv("FGPU_DEBUG_WALK")) : 0;
+    static const bool serial_clean = getenv("FGPU_SERIAL_CLEAN") && getenv("FGPU_SERIAL_CLEAN")[0] == '1';
     // the whole stage goes to the walk stream, behind the completion of this batch's pure stage
     static const bool no_overlap = getenv("FGPU_NO_OVERLAP") && getenv("FGPU_NO_OVERLAP")[0] == '1';   // measurement aid
     hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
@@ -1296,15 +1304,35 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const unsigned walk_grid_w = fgpu_blocks(max_pieces, 64);
         const unsigned cluster_grid = std::min(256u, fgpu_blocks(max_pieces, 256));
         const unsigned clean_grid = std::min(2048u, fgpu_blocks(pos_end - (lo & ~63ULL), 256));
-        FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, ctx->uf_parent, lo, hi, pos_end, ctx->counters, parity);
-        FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, ctx->uf_parent, lo, hi, pos_end);
+        uint32_t* const uf_parent = ctx->uf_parent + parity * (uint64_t)ctx->wmax;     // this window's set of the union-find / list arrays
+        uint32_t* const cl_count = ctx->cl_count + parity * (uint64_t)ctx->wmax;
+        uint32_t* const cl_offset = ctx->cl_offset + parity * (uint64_t)ctx->wmax;
+        FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));        // reset since the window before last used it
+        FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, uf_parent, lo, hi, pos_end, ctx->counters, parity);
+        FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end);
+        // the window table has done its work: emptied on the side stream while this window is clustered and walked
+        FGPU_HIP(hipEventRecord(ctx->ev_linked, walk_stream));
+        FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_linked, 0));
+        ctx->launch_stream = ctx->cstream;
+        FGPU_LAUNCH("walk_clean", k_walk_clean, clean_grid, 256, wt, lo, pos_end);
+        ctx->launch_stream = walk_stream;
+        FGPU_HIP(hipEventRecord(ctx->ev_cleaned, ctx->cstream));
+        if (serial_clean) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_cleaned, 0));   // measurement aid: the old, serial order
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
-        FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill,
+        FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
-        FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)ctx->cl_count,
-                    (const uint32_t*)ctx->cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
+        FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
+                    (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk);
-        FGPU_LAUNCH("walk_clean", k_walk_clean, clean_grid, 256, wt, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->counters, pl, lo, hi, pos_end);
+        // this window's set is reset on the side stream while the next window (the other set) is looked up and linked
+        FGPU_HIP(hipEventRecord(ctx->ev_walked, walk_stream));
+        FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_walked, 0));
+        ctx->launch_stream = ctx->cstream;
+        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, (uint32_t)max_pieces);
+        ctx->launch_stream = walk_stream;
+        FGPU_HIP(hipEventRecord(ctx->ev_uf_reset[parity], ctx->cstream));
+        if (serial_clean) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));
+        FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_cleaned, 0));   // the next window registers into an empty table
         ctx->scan_windows++;
         // Calibration: at the start of a scan (and again whenever a batch came out with most of its pieces queueing) the host
         // waits for the window it has just issued and looks at the share of pieces that had to queue behind an earlier piece of
