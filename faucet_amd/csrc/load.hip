@@ -14,10 +14,13 @@
 //                                                    flag the occurrence as pending.
 //   k_load_resolve (pending only)   bit is "set before t" iff it is in the carry or first[bit] < t;
 //                                   all bits set before t -> bloo2.
-//   k_carry_from_first              carry |= bits whose first-set time is no longer "never" (one sweep of first[]).
+//   k_carry_from_first              carry |= bits whose first-set time is no longer "never" (one sweep of first[]) -- not after
+//                                   every batch: the carry may lag (fgpu_stage_load), a sweep closes an EPOCH of batches.
 // Both kernels also write the `sure` plane (occurrence routed to bloo2), which the scan of the same reads reuses.
-// t is the stream position (pack.hip makes position order == processing order); times are batch-local
-// because a bit that is still 0 in the carry has first[bit] == 0xFFFFFFFF at batch start.
+// t is the stream position within the epoch (pack.hip makes position order == processing order); first[] never needs a
+// reset because a bit that is still 0 in the carry has first[bit] == 0xFFFFFFFF or a time of the current epoch.
+// Multi-GPU shards may ask for times that count through the whole pass instead (FGPU_LOAD_SHARD_TIMES) and re-evaluate
+// afterwards what they kept out of bloo2 against the lower ranks' bits (k_load_fixup).
 //
 // Launch shape: a fixed grid of FGPU_GRID_BLOCKS x 256 threads strides over the stream, lanes = consecutive
 // positions (so every per-position plane is written as one 8-byte ballot word per wave) and counters are
