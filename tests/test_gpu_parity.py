@@ -412,16 +412,17 @@ def _oracle_lists(bases, offs, k, j, spacer, bloom_bits, tai, nh):
     return osc, lists
 
 
-@pytest.mark.parametrize("n_batches", [1, 4])
+@pytest.mark.parametrize("n_batches,capacity", [(1, 0), (4, 0), (12, 1 << 10)])
 @pytest.mark.parametrize("n_rate", [0.0, 0.004])
-def test_scan_input_read_lists_match_the_oracle(n_batches, n_rate):
-    """fgpu_scan_take_stops = the list scanInputRead returns per read (src/ReadScanner.cpp:260-282), batch by batch."""
+def test_scan_input_read_lists_match_the_oracle(n_batches, n_rate, capacity):
+    """fgpu_scan_take_stops = the list scanInputRead returns per read (src/ReadScanner.cpp:260-282), batch by batch -- also
+    when the junction table is rehashed into larger ones between the batches (capacity: its initial slots)."""
     k, E, S = 25, 1_000_000, 200_000
     bases, offs = _random_case(12000, 110, k, 30000, 0.012, 99, n_rate, 3)
     tai, nh = api.load_filter_shape(E, S)
     b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
     _, want = _oracle_lists(bases, offs, k, 1, 100, b2.bits(), tai, nh)
-    ctx = api.Context(k, tai, nh, record_stops=True)
+    ctx = api.Context(k, tai, nh, record_stops=True, junction_capacity=capacity)
     ctx.bloom_upload(L.BLOO2, b2.bits())
     parts = chunks(bases, offs, n_batches)
     got = []
