@@ -136,7 +136,10 @@ def load_sharded_presence(backend, batches, rank: int, world: int):
     return stats
 
 
-HINT_AFTER = 0.25      # share of the first shard's reads after which its table is shown to the other ranks
+# share of the first shard's reads after which its table is shown to the other ranks.  Earlier means a thinner preview, later means more
+# batches prepared without one: with the 2-rank shapes the pure stage of a later rank takes 91.8 ms behind a hint taken at 10 %, 75.0 ms
+# at 25 % (117 without); 25 % arrives ~20 ms into the scan, 10 % ~8 ms (scripts/rank_stage_times.py, HINT_AFTER=...)
+HINT_AFTER = 0.25
 
 
 def _n_reads(b):

@@ -31,7 +31,7 @@ done, n_hint, hint = 0, 0, None
 for b in lower:
     ctx.scan_batch(b)
     done += b.n_reads
-    if hint is None and done >= 0.25 * n:        # what sharded.scan_sharded broadcasts: the table after a quarter of the first shard
+    if hint is None and done >= float(os.environ.get("HINT_AFTER", "0.25")) * n:        # what sharded.scan_sharded broadcasts: the table after a quarter of the first shard
         n_hint = ctx.table_entries()
         hint = torch.empty(max(n_hint, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device=dev)
         ctx.export_table(hint.data_ptr(), hint.numel())
