@@ -182,6 +182,10 @@ def reference_binary_baseline(reads_host, k, E, S):
     exe = os.path.join(ROOT, "oracle", "_ref", "faucet_ref")
     if not os.path.exists(exe) or shutil.which("stdbuf") is None:
         return None
+    # under a profiler the child would inherit its preload: stdbuf would initialise the GPU and then exec the reference, the
+    # exec hop this pool forbids.  The port's number stands in then.
+    if any(k.startswith(("ROCP", "ROCPROF", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     n, ln = reads_host.shape
     td = tempfile.mkdtemp(prefix="faucet_ref_")
     try:

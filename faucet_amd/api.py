@@ -140,6 +140,7 @@ class Context:
         _check(self.lib.fgpu_create(C.byref(p), C.byref(h)))
         self.h = h
         self.k, self.tai, self.n_hash, self.j = k, tai, n_hash, j
+        self.mercy = bool(mercy)
 
     def close(self):
         if getattr(self, "h", None):

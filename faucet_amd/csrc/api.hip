@@ -200,8 +200,6 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
         if ((e = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (walk)", e);
         if (!rc && (e = hipStreamCreateWithPriority(&ctx->cstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (clean)", e);
-        if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_linked, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
-        if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_cleaned, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
         if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_walked, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
         for (int q = 0; q < 2 && !rc; q++)
             if ((e = hipEventCreateWithFlags(&ctx->ev_uf_reset[q], hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
@@ -234,15 +232,13 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
     void* ptrs[] = {ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
-                    ctx->wslots, ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_members, ctx->counters,
+                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_members, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
     if (ctx->fb_host) hipHostFree(ctx->fb_host);
     if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
     if (ctx->cstream) { hipStreamSynchronize(ctx->cstream); hipStreamDestroy(ctx->cstream); }
-    if (ctx->ev_linked) hipEventDestroy(ctx->ev_linked);
-    if (ctx->ev_cleaned) hipEventDestroy(ctx->ev_cleaned);
     if (ctx->ev_walked) hipEventDestroy(ctx->ev_walked);
     for (int q = 0; q < 2; q++) if (ctx->ev_uf_reset[q]) hipEventDestroy(ctx->ev_uf_reset[q]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -382,6 +378,7 @@ static uint32_t* bloom_ptr(fgpu_ctx* ctx, int which) { return which == FGPU_BLOO
 
 int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes) {
     if (!ctx || !host_out || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    if (ctx->phase == 1) { ctx->err = "bloom_download inside a load pass: the filters are interleaved until load_end"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipMemcpyAsync(host_out, bloom_ptr(ctx, which), nbytes, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     return FGPU_OK;
@@ -413,6 +410,7 @@ int fgpu_bloom_download_begin(fgpu_ctx* ctx, int which, uint8_t* host_out, uint6
 
 int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t nbytes) {
     if (!ctx || !host_in || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "bloom_upload while a pass is open (a load pass would overwrite it at load_end, a scan is reading bloo2)"; return FGPU_ERR_STATE; }
     if (int rc = fgpu_bloom_download_wait(ctx)) return rc;
     if (which == FGPU_BLOO2) fgpu_resident_reset(ctx, false);   // the kept "routed to bloo2" planes speak about the filter this replaces
     FGPU_HIP(hipMemcpyAsync(bloom_ptr(ctx, which), host_in, nbytes, hipMemcpyHostToDevice, ctx->stream));
@@ -422,6 +420,7 @@ int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t
 
 int fgpu_bloom_weight(fgpu_ctx* ctx, int which, float* weight) {
     if (!ctx || !weight || !bloom_ptr(ctx, which)) return FGPU_ERR_ARG;
+    if (ctx->phase == 1) { ctx->err = "bloom_weight inside a load pass: the filters are interleaved until load_end"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipMemsetAsync(&ctx->counters->pad, 0, 8, ctx->stream));
     int rc = fgpu_util_popcount(ctx, bloom_ptr(ctx, which), ctx->bloom_bytes, &ctx->counters->pad);
     if (rc) return rc;
@@ -638,7 +637,6 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     while (!rc && !ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());   // every walk has finished
     ctx->phase = 0;
     if (rc) return rc;
-    ctx->wt_clean = true;   // every window was walked to its end: its clean-up kernel has left the window tables empty
     const DevCounters& c = *ctx->counters_host;
     fgpu_scan_stats& s = ctx->scan_stats;
     s.unambiguous_reads = c.segments + ctx->carried.unambiguous_reads;

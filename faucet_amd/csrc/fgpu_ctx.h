@@ -42,6 +42,7 @@ struct BatchBufs {
     DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
     DevBuf lk;                     // walk: positions whose k-mer is a registered candidate of the current window
     DevBuf nF, nB, need;           // lazy flags: in-map snapshot planes of the pure stage, positions whose flags get evaluated
+    DevBuf kh;                     // uint32 per stream position: hash of the canonical k-mer (positions inside pieces; see jt_h32)
     DevBuf ps_prefix;              // exclusive prefix of popcount(ps) per 64-bit word (uint32)
     DevBuf pieces;                 // uint2 {start position, windows} per valid piece, in stream order
     // FGPU_FLAG_RECORD_STOPS: where the walk stopped (junction visits), for scanInputRead's return value
@@ -119,7 +120,7 @@ struct fgpu_ctx {
     hipStream_t stream = nullptr;          // main stream: pack, load, pure scan stage, transfers
     hipStream_t wstream = nullptr;         // walk stream: the ordered walk of batch b overlaps the pure stage of batch b+1
     hipStream_t cstream = nullptr;         // clean stream: the window table of window w is emptied while w is clustered and walked
-    hipEvent_t ev_linked = nullptr, ev_cleaned = nullptr, ev_walked = nullptr, ev_uf_reset[2] = {nullptr, nullptr};
+    hipEvent_t ev_walked = nullptr, ev_uf_reset[2] = {nullptr, nullptr};
     hipStream_t launch_stream = nullptr;   // where FGPU_LAUNCH puts kernels (and profiling events) right now
     bool own_stream = false;
     std::string err;
@@ -156,9 +157,8 @@ struct fgpu_ctx {
     // window table (candidate keys of the window being walked)
     uint64_t wcap = 0;
     uint64_t* wkeys = nullptr;
-    uint32_t* wslots = nullptr;      // list of claimed slots, for the sparse clear
     uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
-    bool wt_clean = false;           // the window tables are known to be empty (fresh memset, or the last scan ran to its end)
+    uint32_t wt_epoch = 0;           // epoch of the window table's newest entries (1..255; 0 = table not initialised yet)
     // union-find / cluster scratch (per window)
     uint32_t wmax = 0;               // max pieces per window
     uint32_t* uf_parent = nullptr;

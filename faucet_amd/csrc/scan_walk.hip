@@ -41,6 +41,11 @@ constexpr uint64_t J_EMPTY = ~0ULL;
 constexpr uint64_t J_KEYMASK = (1ULL << 62) - 1;
 constexpr uint32_t U_INF = 0xFFFFFFFFu;
 constexpr uint64_t J_PROBE_LIMIT = 1ULL << 14;
+// creation stamp = (global piece number << STAMP_SHIFT) | half-step of the visit (STAMP_FAKE for add_fake_junction's record, which
+// is created after every half-step of its piece): half-steps run to 2 x windows, so a piece may span up to 2^19 - 1 windows
+// (fgpu_stage_scan_walk refuses longer reads with FGPU_ERR_CAPACITY); 44 bits are left for the piece number.
+constexpr int STAMP_SHIFT = 20;
+constexpr uint64_t STAMP_FAKE = (1ULL << STAMP_SHIFT) - 1;
 
 struct JTable {
     uint64_t* keys;
@@ -51,14 +56,23 @@ struct JTable {
     uint64_t filter_mask;  // filter bits - 1
 };
 
-// filter bit of a canonical k-mer: other hash bits than the slot index uses
-__device__ __forceinline__ uint64_t jt_filter_bit(const JTable& jt, uint64_t canon) { return (fd_mix(canon) >> 24) & jt.filter_mask; }
+// The 32-bit hash of a canonical k-mer that every table of the walk stage works from: h32 = low half of fd_mix(canon).  It is computed
+// ONCE per position and batch (k_need_lookup writes the plane `kh`, 4 bytes per position); the per-window kernels read it back
+// instead of extracting, reverse-complementing and mixing the k-mer again -- those 64-bit multiplies were most of what
+// k_walk_lookup / k_walk_link executed (lookup 11.9 -> 6.x ms, link 7.1 -> 3.x ms per step on config 2).
+__device__ __forceinline__ uint32_t jt_h32(uint64_t canon) { return (uint32_t)fd_mix(canon); }
+// junction-table slot (capacities up to 2^32) and filter bit (a multiplicative scramble: other bits than the slot's low ones decide)
+__device__ __forceinline__ uint64_t jt_home(const JTable& jt, uint32_t h32) { return (uint64_t)h32 & jt.mask; }
+__device__ __forceinline__ uint64_t jt_filter_bit_h(const JTable& jt, uint32_t h32) {
+    return (((uint64_t)(h32 * 0x9E3779B1u) << 16) ^ (uint64_t)(h32 >> 7)) & jt.filter_mask;
+}
+__device__ __forceinline__ uint64_t jt_filter_bit(const JTable& jt, uint64_t canon) { return jt_filter_bit_h(jt, jt_h32(canon)); }
 
 struct WTable {
-    uint64_t* keys;      // fingerprint << 24 | owner (see wt_register)
-    uint32_t* slots;
-    uint32_t* bits;      // 2^WBITS_LOG2-bit presence filter
+    uint64_t* keys;      // epoch << 56 | h32 << 24 | owner (see wt_register)
+    uint32_t* bits;      // 2^WBITS_LOG2-bit presence filter (cleared by a memset before every window)
     uint64_t mask;
+    uint64_t epoch;      // number of the window (1..255) << 56: entries of any other epoch count as empty slots
 };
 constexpr int WBITS_LOG2 = 22;   // 4 Mbit = 512 KiB
 
@@ -80,6 +94,7 @@ struct Planes {
     uint64_t* lk;
     const uint64_t* need;
     unsigned long long *sF, *sB;   // junction visits (FGPU_FLAG_RECORD_STOPS), else nullptr
+    const uint32_t* kh;            // 32-bit hash of the canonical k-mer of every position inside a piece (k_need_lookup)
 };
 
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
@@ -167,53 +182,51 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 }
 
 // ---- window table -------------------------------------------------------------------------------
-// One 64-bit word per slot: the upper 40 bits of the key's mix (a fingerprint) over the 24-bit index of the smallest piece that
-// registered the key (its owner).  A key that is new in the window -- most are -- costs ONE atomic (the CAS that claims the slot
-// carries the owner), a later one a load and an atomicMin; separate key and owner arrays took a CAS and an atomicMin each time.
-// Two keys with one fingerprint share an entry: their pieces end up in one cluster and the positions count as candidates of
-// each other, which only orders more than necessary -- every later use compares full k-mers (created_bits) or is a union.
+// One 64-bit word per slot: the window's epoch (8 bits) over the key's 32-bit hash over the 24-bit index of the smallest piece
+// that registered the key (its owner).  A key that is new in the window -- most are -- costs ONE atomic (the CAS that claims the
+// slot carries the owner), a later one a load and an atomicMin.  Two keys with one hash share an entry: their pieces end up in one
+// cluster and the positions count as candidates of each other, which only orders more than necessary -- every later use compares
+// full k-mers (created_bits) or is a union.
+// The epoch makes the clean-up kernel of earlier versions unnecessary (3.8 ms per step plus a launch and two cross-stream events
+// per window): an entry written by another window is simply an empty slot -- the table is wiped once every 255 windows.
 constexpr int W_OWNER_BITS = 24;
 constexpr uint64_t W_OWNER_MASK = (1ULL << W_OWNER_BITS) - 1;
-constexpr uint64_t W_EMPTY = ~0ULL;   // fingerprint and owner all ones: no piece index is that large
+constexpr uint64_t W_EPOCH_MASK = 0xFFULL << 56;
+__device__ __forceinline__ uint32_t wt_filter_bit(uint32_t h32) { return (h32 * 0x85EBCA6Bu) >> (32 - WBITS_LOG2); }
 
-// Returns the slot this call CLAIMED (the caller lists it for the sparse clean-up), or U_INF when the key was already there.
-__device__ __forceinline__ uint32_t wt_register(const WTable& wt, uint32_t* parent, uint64_t canon, uint32_t piece, DevCounters* cnt) {
-    const uint64_t h = fd_mix(canon);
-    const uint64_t fp = h >> W_OWNER_BITS;
-    const unsigned long long mine = (unsigned long long)((fp << W_OWNER_BITS) | (uint64_t)piece);
-    uint64_t s = h & wt.mask;
+__device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, uint32_t h32, uint32_t piece, DevCounters* cnt) {
+    const unsigned long long mine = (unsigned long long)(wt.epoch | ((uint64_t)h32 << W_OWNER_BITS) | (uint64_t)piece);
+    uint64_t s = (uint64_t)h32 & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
         unsigned long long v = wt.keys[s];                      // a stale value only costs the CAS / atomicMin below their effect
-        if (v == W_EMPTY) {
-            v = atomicCAS((unsigned long long*)&wt.keys[s], (unsigned long long)W_EMPTY, mine);
-            if (v == W_EMPTY) {
-                const uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
+        if ((v & W_EPOCH_MASK) != wt.epoch) {                   // left by an earlier window: free
+            const unsigned long long old = atomicCAS((unsigned long long*)&wt.keys[s], v, mine);
+            if (old == v) {
+                const uint32_t b = wt_filter_bit(h32);
                 atomicOr(&wt.bits[b >> 5], 1u << (b & 31));
-                return (uint32_t)s;
+                return;
             }
+            v = old;                                            // somebody of this window was faster
         }
-        if ((v >> W_OWNER_BITS) == fp) {
+        if ((v & W_EPOCH_MASK) == wt.epoch && (uint32_t)(v >> W_OWNER_BITS) == h32) {
             const unsigned long long prev = atomicMin((unsigned long long*)&wt.keys[s], mine);
             const uint32_t prev_owner = (uint32_t)(prev & W_OWNER_MASK);
             if (prev_owner != piece) uf_union(parent, piece, prev_owner);
-            return U_INF;
+            return;
         }
         s = (s + 1) & wt.mask;
     }
     atomicOr(&cnt->error_flags, 2ULL);
-    return U_INF;
 }
 
-__device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint64_t canon) {
-    const uint64_t h = fd_mix(canon);
-    const uint32_t b = (uint32_t)(h >> 40) & ((1u << WBITS_LOG2) - 1);
+__device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint32_t h32) {
+    const uint32_t b = wt_filter_bit(h32);
     if (!((wt.bits[b >> 5] >> (b & 31)) & 1u)) return U_INF;
-    const uint64_t fp = h >> W_OWNER_BITS;
-    uint64_t s = h & wt.mask;
+    uint64_t s = (uint64_t)h32 & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
         const uint64_t w = wt.keys[s];
-        if (w == W_EMPTY) return U_INF;
-        if ((w >> W_OWNER_BITS) == fp) return (uint32_t)(w & W_OWNER_MASK);
+        if ((w & W_EPOCH_MASK) != wt.epoch) return U_INF;
+        if ((uint32_t)(w >> W_OWNER_BITS) == h32) return (uint32_t)(w & W_OWNER_MASK);
         s = (s + 1) & wt.mask;
     }
     return U_INF;
@@ -261,34 +274,33 @@ __global__ void __launch_bounds__(256) k_walk_lookup(Planes pl, FdParams fp, JTa
     bool inF = false, inB = false;
     uint32_t li;
     uint2 pc;
-    uint32_t claimed = U_INF;
     if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL) && piece_in_window(pl, wd, p, li, pc)) {
-        uint64_t km = fd_kmer_at(pl.codes, p, fp.k);
-        uint64_t rc = fd_revcomp(km, fp.k);
-        uint64_t canon = km < rc ? km : rc;
-        // most k-mers own no junction: one bit of a small (cache-resident) filter answers that without touching the table
-        const uint64_t hb = jt_filter_bit(jt, canon);
-        uint32_t present = ((jt.filter[hb >> 5] >> (hb & 31)) & 1u) ? jt_present_snapshot(jt, canon) : 0;
-        int oF = km == canon ? 0 : 1;   // orientation of the forward-facing key (the k-mer itself)
-        int oB = rc == canon ? 0 : 1;   // orientation of the backward-facing key (its reverse complement)
-        inF = (present >> oF) & 1u;
-        inB = (present >> oB) & 1u;
+        const uint32_t h32 = pl.kh[p];
+        // most k-mers own no junction: one bit of a small (cache-resident) filter answers that without touching the table --
+        // or the k-mer: it is only extracted where the filter says "maybe"
+        const uint64_t hb = jt_filter_bit_h(jt, h32);
+        uint32_t present = 0;
+        if ((jt.filter[hb >> 5] >> (hb & 31)) & 1u) {
+            const uint64_t km = fd_kmer_at(pl.codes, p, fp.k);
+            const uint64_t rc = fd_revcomp(km, fp.k);
+            const uint64_t canon = km < rc ? km : rc;
+            present = jt_present_snapshot(jt, canon);
+            inF = (present >> (km == canon ? 0 : 1)) & 1u;   // forward-facing key = the k-mer itself
+            inB = (present >> (rc == canon ? 0 : 1)) & 1u;   // backward-facing key = its reverse complement
+        }
         uint32_t q = (uint32_t)(p - pc.x);
         uint32_t len = pc.y + fp.k - 1;
         bool cand = present != 0;
         cand |= ((pl.ff[p >> 6] | pl.fb[p >> 6]) >> (p & 63)) & 1ULL;
         cand |= q == len / 2 - (uint32_t)fp.k / 2;                       // add_fake_junction's k-mer (ReadScanner.cpp:94)
         cand |= 2 * q + 1 >= (uint32_t)(2 * fp.max_spacer - 1);           // spacer rule can fire here (ReadScanner.cpp:72)
-        if (cand) claimed = wt_register(wt, parent, canon, li, cnt);
+        if (cand) wt_register(wt, parent, h32, li, cnt);
     }
     uint64_t mF = __ballot(inF), mB = __ballot(inB);
     if (fd_lane() == 0) {
         pl.inF[p >> 6] = mF;
         pl.inB[p >> 6] = mB;
     }
-    // remember which window-table slot this position claimed (for the sparse clean-up).  Indexed by position, NOT
-    // appended through a shared counter: one same-address atomic per wave would serialise the whole kernel.
-    if (claimed != U_INF) wt.slots[p - (wd.lo & ~63ULL)] = claimed;
 }
 
 // ---- B: link every piece to the owners of the candidate k-mers that occur on it ---------------------
@@ -298,8 +310,7 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
     uint64_t p = (wd.lo & ~63ULL) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hit = false;
     if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL)) {
-        uint64_t canon = fd_canon(fd_kmer_at(pl.codes, p, fp.k), fp.k);
-        uint32_t owner = wt_owner(wt, canon);
+        uint32_t owner = wt_owner(wt, pl.kh[p]);
         if (owner != U_INF) {
             uint32_t li;
             uint2 pc;
@@ -635,8 +646,8 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
         wc.jt.stamps[slot * 2 + orient] = stamp;
         atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
         // presence filter in front of the table (phase A of later windows tests it before probing)
-        uint64_t hb = fd_mix(canon) >> 24;
-        atomicOr(&wc.jt.filter[(hb & wc.jt.filter_mask) >> 5], 1u << (hb & 31));
+        const uint64_t hb = jt_filter_bit(wc.jt, canon);
+        atomicOr(&wc.jt.filter[hb >> 5], 1u << (hb & 31));
         wc.n_created++;
     } else if (slot == home) {
         out.lo = spec_lo;
@@ -733,7 +744,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         uint64_t key = fwd ? km : fd_revcomp(km, k);
         int real = fwd ? pv_base(v, wc.pl.codes, p0 + q + k) : (pv_base(v, wc.pl.codes, p0 + q - 1) ^ 2);
         RecRegs cur;
-        if (!junction_get(wc, key, (piece_seq << 16) | (uint64_t)tn, cur)) return;
+        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, cur)) return;
         if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
         if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
             created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
@@ -778,7 +789,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         uint64_t key = pv_kmer(v, wc.pl.codes, p0 + m, k);
         int real = pv_base(v, wc.pl.codes, p0 + m + k);
         RecRegs rec;
-        if (!junction_get(wc, key, (piece_seq << 16) | 0xFFFFULL, rec)) return;
+        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, rec)) return;
         rr_add_cov(rec, real);
         const int tm = 2 * m + 1;
         rr_update(rec, 4, tm - 2 * j);
@@ -851,34 +862,17 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     }
 }
 
-// ---- E: sparse reset of the window table ----------------------------------------------------------------
-// wt.slots is indexed by position relative to the window's (word-aligned) start: U_INF = that position claimed nothing.
-__global__ void __launch_bounds__(256) k_walk_clean(WTable wt, uint64_t lo, uint64_t pos_end) {
-    // Nothing reads the window table once the link kernel is done (the walk works from the lk plane), so this runs on a stream of its
-    // own beside the cluster and walk kernels of the same window; the union-find and list entries are reset by k_walk_reset_uf.
-    const uint64_t span = pos_end - (lo & ~63ULL);
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t a = i; a < span; a += stride) {
-        uint32_t s = wt.slots[a];
-        if (s == U_INF) continue;
-        wt.slots[a] = U_INF;
-        const uint64_t word = wt.keys[s];   // fingerprint = bits 24..63 of the key's mix; the filter bit comes from bits 40..61 of it
-        const uint32_t b = (uint32_t)(word >> 40) & ((1u << WBITS_LOG2) - 1);
-        wt.bits[b >> 5] = 0;   // whole word: every bit of it belongs to a key that is being removed as well
-        wt.keys[s] = W_EMPTY;
-    }
-}
-
-
 // union-find and list entries of a window's pieces back to "every piece its own cluster": the arrays exist twice and consecutive
 // windows alternate, so this runs on the side stream while the NEXT window is already being looked up and linked
-__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t n) {
+__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t n, uint4* wbits) {
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
         parent[a] = a;
         count[a] = 0;
         head[a] = U_INF;
     }
+    // ... and the window table's presence filter of this parity (a memset on the walk stream took 47 us per window when the
+    // pure stage of the next batch ran beside it: 3.6 ms per step on the critical queue)
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < (1u << WBITS_LOG2) / 128; a += gridDim.x * blockDim.x) wbits[a] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ void __launch_bounds__(256) k_fill_u64(uint64_t* p, uint64_t n, uint64_t v) {
@@ -917,7 +911,8 @@ __global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, const
 // scanning: they do not change which positions are visited.  The walk double-checks: scanning a position whose need bit
 // is clear raises error bit 4 (surfaced as FGPU_ERR_STATE), it never silently uses a flag that was not computed.
 __global__ void __launch_bounds__(256) k_need_lookup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm, uint64_t n_words,
-                                                     FdParams fp, JTable jt, uint64_t* __restrict__ nF, uint64_t* __restrict__ nB) {
+                                                     FdParams fp, JTable jt, uint64_t* __restrict__ nF, uint64_t* __restrict__ nB,
+                                                     uint32_t* __restrict__ kh) {
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool inF = false, inB = false;
@@ -925,7 +920,9 @@ __global__ void __launch_bounds__(256) k_need_lookup(const uint64_t* __restrict_
             uint64_t km = fd_kmer_at(codes, p, fp.k);
             uint64_t rc = fd_revcomp(km, fp.k);
             uint64_t canon = km < rc ? km : rc;
-            const uint64_t hb = jt_filter_bit(jt, canon);
+            const uint32_t h32 = jt_h32(canon);
+            kh[p] = h32;                     // the walk stage's kernels take the hash from here (see jt_h32)
+            const uint64_t hb = jt_filter_bit_h(jt, h32);
             if ((jt.filter[hb >> 5] >> (hb & 31)) & 1u) {
                 uint32_t present = jt_present_snapshot(jt, canon);
                 inF = (present >> (km == canon ? 0 : 1)) & 1u;
@@ -1120,7 +1117,9 @@ static uint64_t jfilter_bits(fgpu_ctx* ctx) {
     return lg >= 10 && (1ULL << lg) < full ? 1ULL << lg : full;
 }
 JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1, ctx->jfilter, jfilter_bits(ctx) - 1}; }
-WTable make_wt(fgpu_ctx* ctx) { return WTable{ctx->wkeys, ctx->wslots, ctx->wbits, ctx->wcap - 1}; }
+WTable make_wt(fgpu_ctx* ctx, uint64_t epoch, int parity) {
+    return WTable{ctx->wkeys, ctx->wbits + parity * ((1ULL << WBITS_LOG2) / 32), ctx->wcap - 1, epoch << 56};
+}
 
 }  // namespace
 
@@ -1139,8 +1138,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     ctx->wmax = (uint32_t)(ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2);
     FGPU_HIP(hipMalloc(&ctx->wdesc, 64));
     FGPU_HIP(hipMalloc(&ctx->wkeys, ctx->wcap * 8));
-    FGPU_HIP(hipMalloc(&ctx->wslots, ctx->wcap * 4));
-    FGPU_HIP(hipMalloc(&ctx->wbits, (1ULL << WBITS_LOG2) / 8));
+    FGPU_HIP(hipMalloc(&ctx->wbits, 2 * (1ULL << WBITS_LOG2) / 8));   // two filters: consecutive windows alternate
     FGPU_HIP(hipMalloc(&ctx->uf_parent, 2 * ctx->wmax * 4));   // two sets each: consecutive windows alternate (k_walk_reset_uf)
     FGPU_HIP(hipMalloc(&ctx->cl_count, 2 * ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_offset, 2 * ctx->wmax * 4));
@@ -1208,12 +1206,8 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jkeys, 0xFF, ctx->jcap * 8, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
-    if (!ctx->wt_clean) {   // 3 GiB: only for new tables and after a scan that did not reach its end (every window cleans up after itself)
-        FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0xFF, ctx->wcap * 8, ctx->stream));
-        FGPU_HIP(hipMemsetAsync(ctx->wslots, 0xFF, ctx->wcap * 4, ctx->stream));
-        FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, (1ULL << WBITS_LOG2) / 8, ctx->stream));
-    }
-    ctx->wt_clean = false;   // until this scan's fgpu_scan_end says otherwise
+    if (!ctx->wt_epoch) FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0, ctx->wcap * 8, ctx->stream));   // a new table: epoch 0 = no window's entry
+    FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, 2 * (1ULL << WBITS_LOG2) / 8, ctx->stream));        // (a scan that broke off may have left bits behind)
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent + ctx->wmax, (uint64_t)ctx->wmax);
     FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, 2 * ctx->wmax * 4, ctx->stream));
@@ -1225,17 +1219,17 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
 int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
-    if ((ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime) {   // evaluate testForJunction everywhere
-        FGPU_HIP(hipMemsetAsync(bb.need.p, 0xFF, wb, ctx->stream));
-        return FGPU_OK;
-    }
-    FGPU_HIP(hipMemsetAsync(bb.need.p, 0, wb, ctx->stream));
+    const bool eager = (ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime;   // evaluate testForJunction everywhere
+    FGPU_HIP(hipMemsetAsync(bb.need.p, eager ? 0xFF : 0, wb, ctx->stream));
     if (!bb.n_pieces) return FGPU_OK;
+    if (int rc = fgpu_ensure(ctx, &bb.kh, (bb.n_words + FGPU_PADW) * 64 * 4)) return rc;
 
     static const int need_tight = getenv("FGPU_NEED_TIGHT") ? atoi(getenv("FGPU_NEED_TIGHT")) : 2;   // measurement aid, see k_need_prewalk
     JTable jt = make_jt(ctx);
+    // also with eager flags: this kernel writes the hash plane the walk stage's kernels work from
     FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
-                bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p);
+                bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p);
+    if (eager) return FGPU_OK;
     FGPU_LAUNCH("need_prewalk", k_need_prewalk, fgpu_grid(bb.n_pieces, 256), 256, (const uint64_t*)bb.codes.p, (const uint2*)bb.pieces.p,
                 bb.n_pieces, ctx->fd, jt, (const uint64_t*)bb.nF.p, (const uint64_t*)bb.nB.p, (unsigned long long*)bb.need.p, need_tight);
     return FGPU_OK;
@@ -1258,7 +1252,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     Planes pl{(const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.ps.p, (const uint32_t*)bb.ps_prefix.p,
               (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p, (const uint64_t*)bb.cf0.p, (const uint64_t*)bb.cf1.p,
               (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p,
-              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p, nullptr, nullptr};
+              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p, nullptr, nullptr, (const uint32_t*)bb.kh.p};
     if (ctx->record_stops) {
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
         int rc;
@@ -1267,17 +1261,20 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         pl.sB = (unsigned long long*)bb.sB.p;
     }
     JTable jt = make_jt(ctx);
-    WTable wt = make_wt(ctx);
     const uint64_t span = ctx->window_span;
     const uint64_t ext = bb.max_piece_span;          // a piece that starts inside the window may reach this far beyond it
     if (ctx->max_span + ext + 64 > ctx->wcap) {      // the per-position slot list of a window is sized for 4 x the largest span
         ctx->err = "a read of " + std::to_string(ext) + " bases is longer than the walk's window tables allow";
         return FGPU_ERR_CAPACITY;
     }
+    if (ext >= (1ULL << (STAMP_SHIFT - 1)) - 64) {   // half-steps of a piece must fit the creation stamp's low bits (dump order)
+        ctx->err = "a read of " + std::to_string(ext) + " bases is longer than the junction creation stamps allow (2^19 windows)";
+        return FGPU_ERR_CAPACITY;
+    }
     const uint64_t T = bb.T;
     const uint64_t seq_base = ctx->scan_piece_base;
     static const int dbg_walk = getenv("FGPU_DEBUG_WALK") ? atoi(getenv("FGPU_DEBUG_WALK")) : 0;
-    static const bool serial_clean = getenv("FGPU_SERIAL_CLEAN") && getenv("FGPU_SERIAL_CLEAN")[0] == '1';
+    static const bool serial_clean = getenv("FGPU_SERIAL_CLEAN") && getenv("FGPU_SERIAL_CLEAN")[0] == '1';   // measurement aid: union-find reset in line
     // the whole stage goes to the walk stream, behind the completion of this batch's pure stage
     static const bool no_overlap = getenv("FGPU_NO_OVERLAP") && getenv("FGPU_NO_OVERLAP")[0] == '1';   // measurement aid
     hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
@@ -1303,21 +1300,18 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const uint64_t max_pieces = std::min<uint64_t>((hi - lo) / (uint64_t)(ctx->fd.k + 1) + 2, ctx->wmax);
         const unsigned walk_grid_w = fgpu_blocks(max_pieces, 64);
         const unsigned cluster_grid = std::min(256u, fgpu_blocks(max_pieces, 256));
-        const unsigned clean_grid = std::min(2048u, fgpu_blocks(pos_end - (lo & ~63ULL), 256));
         uint32_t* const uf_parent = ctx->uf_parent + parity * (uint64_t)ctx->wmax;     // this window's set of the union-find / list arrays
         uint32_t* const cl_count = ctx->cl_count + parity * (uint64_t)ctx->wmax;
         uint32_t* const cl_offset = ctx->cl_offset + parity * (uint64_t)ctx->wmax;
         FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));        // reset since the window before last used it
+        // the window table of this window: entries carry the window's epoch, everything older counts as empty (wiped every 255 windows)
+        if (++ctx->wt_epoch > 255) {
+            FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0, ctx->wcap * 8, walk_stream));
+            ctx->wt_epoch = 1;
+        }
+        const WTable wt = make_wt(ctx, ctx->wt_epoch, parity);   // its presence filter was zeroed by the reset kernel of the window before last
         FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, uf_parent, lo, hi, pos_end, ctx->counters, parity);
         FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end);
-        // the window table has done its work: emptied on the side stream while this window is clustered and walked
-        FGPU_HIP(hipEventRecord(ctx->ev_linked, walk_stream));
-        FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_linked, 0));
-        ctx->launch_stream = ctx->cstream;
-        FGPU_LAUNCH("walk_clean", k_walk_clean, clean_grid, 256, wt, lo, pos_end);
-        ctx->launch_stream = walk_stream;
-        FGPU_HIP(hipEventRecord(ctx->ev_cleaned, ctx->cstream));
-        if (serial_clean) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_cleaned, 0));   // measurement aid: the old, serial order
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
@@ -1328,11 +1322,10 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_HIP(hipEventRecord(ctx->ev_walked, walk_stream));
         FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_walked, 0));
         ctx->launch_stream = ctx->cstream;
-        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, (uint32_t)max_pieces);
+        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, (uint32_t)max_pieces, (uint4*)wt.bits);
         ctx->launch_stream = walk_stream;
         FGPU_HIP(hipEventRecord(ctx->ev_uf_reset[parity], ctx->cstream));
         if (serial_clean) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));
-        FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_cleaned, 0));   // the next window registers into an empty table
         ctx->scan_windows++;
         // Calibration: at the start of a scan (and again whenever a batch came out with most of its pieces queueing) the host
         // waits for the window it has just issued and looks at the share of pieces that had to queue behind an earlier piece of

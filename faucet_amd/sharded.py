@@ -315,7 +315,7 @@ class GpuShard:
     def fixup_possible(self, batches):
         """the fix-up protocol needs first-set times that count through the whole shard (32 bits) and every batch kept in HBM"""
         pos = [getattr(b, "n_positions", None) for b in batches]
-        if any(p is None for p in pos):
+        if any(p is None for p in pos) or getattr(self.ctx, "mercy", False):    # --mercy: fgpu_load_end leaves no fix-up state
             return False
         free, total = torch.cuda.mem_get_info(self.device)
         return sum(pos) + 64 * len(pos) < 0xFFF00000 and sum(pos) // 2 + (64 << 20) < total // 8

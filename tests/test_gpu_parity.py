@@ -271,7 +271,15 @@ def test_state_machine_errors():
     ctx.load_begin()
     with pytest.raises(api.FaucetGpuError):
         ctx.scan_begin()
+    # during a load pass both filters live interleaved: the raw bit arrays are neither readable nor writable
+    with pytest.raises(api.FaucetGpuError):
+        ctx.bloom_download(L.BLOO2)
+    with pytest.raises(api.FaucetGpuError):
+        ctx.bloom_upload(L.BLOO1, np.zeros((1 << 19) // 8, dtype=np.uint8))
+    with pytest.raises(api.FaucetGpuError):
+        ctx.bloom_weight(L.BLOO1)
     ctx.load_end()
+    assert ctx.bloom_weight(L.BLOO1) == 0.0
     with pytest.raises(api.FaucetGpuError):
         api.Context(32, 1 << 19, 3)
     with pytest.raises(api.FaucetGpuError):
