@@ -10,6 +10,9 @@ minutes per configuration at these sizes, so it checks a sample; everything else
 * a prefix sample against the oracle: the load of the first reads alone (exactly what the oracle computes).
 """
 import hashlib
+import json
+import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -18,9 +21,48 @@ import torch
 import bench
 from faucet_amd import _lib as L
 from faucet_amd import api
+from faucet_amd import synth_det as sd
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# digests of what the ORACLE / the COMPILED REFERENCE produce on the full-size configurations (tests/golden/make_fullsize.py, run
+# once in the build container); the reads are regenerated here, on the device, by the same counter-based generator
+with open(os.path.join(ROOT, "tests", "golden", "fullsize.json")) as _f:
+    FULL = json.load(_f)
+
+
+def _case_reads(name, dev):
+    c = FULL[name]["params"]
+    g = sd.make_genome(c["genome"], c["genome_seed"], dev)
+    if "repeats" in c:
+        sd.plant_repeats(g, c["genome_seed"] + 100, *c["repeats"])
+    if "pairs" in c:
+        r = sd.make_pairs(g, c["pairs"], c["read_len"], c["insert"][0], c["insert"][1], c["err"], c["read_seed"], dev)
+    else:
+        r = sd.make_reads(g, c["reads"], c["read_len"], c["err"], c["read_seed"], dev)
+    return r
+
+
+def _sha_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _assert_equals_oracle_fixture(name, lst, sst, bloo1, bloo2, keys, recs):
+    fx = FULL[name]
+    assert lst["kmers"] == fx["kmers"] and lst["to_bloo2"] == fx["to_bloo2"]
+    assert _digest(bloo1) == fx["bloo1_sha256"], "bloo1 differs from the oracle's at full size"
+    assert _digest(bloo2) == fx["bloo2_sha256"], "bloo2 (the .bloom file) differs from the oracle's at full size"
+    for key, want in fx["counters"].items():
+        assert sst[key] == want, key
+    assert _digest(keys) == fx["keys_sha256"], "junction keys / creation order differ from the oracle's at full size"
+    assert _digest(recs["dist"]) == fx["dist_sha256"] and _digest(recs["cov"]) == fx["cov_sha256"] and _digest(recs["linked"]) == fx["linked_sha256"]
+    assert _digest(recs) == fx["recs_sha256"]
 
 
 def _digest(a: np.ndarray) -> str:
@@ -41,10 +83,19 @@ def _run(reads, k, tai, nh, batch_reads, **ctx_kw):
 def config2():
     """10 M x 100 bp, k = 31, estimated_kmers 1e8 / singletons 2e7 (BASELINE config 2), in HBM"""
     dev = torch.device("cuda", 0)
-    reads = bench.make_reads(bench.make_genome(20_000_000, 2, dev), 10_000_000, 100, 0.01, 1000, dev)
+    reads = _case_reads("config2", dev)
+    assert _digest(reads.cpu().numpy()) == FULL["config2"]["reads_sha256"], "the read generator gives other bytes here than in the build container"
     tai, nh = api.load_filter_shape(100_000_000, 20_000_000)
     base = _run(reads, 31, tai, nh, 1_000_000)
     return reads, tai, nh, base
+
+
+def test_config2_full_size_equals_the_oracle(config2):
+    """BASELINE config 2 at its FULL size, bit for bit against the oracle (pinned on the reference): bloo1 and bloo2 bytes, the
+    973 k junction records in creation order, every counter -- by digest (the oracle needs 5 minutes of one core for this)."""
+    reads, tai, nh, (lst, sst, bloo1, bloo2, keys, recs, w2) = config2
+    assert (tai, nh) == (FULL["config2"]["tai"], FULL["config2"]["n_hash"])
+    _assert_equals_oracle_fixture("config2", lst, sst, bloo1, bloo2, keys, recs)
 
 
 def test_config2_filter_algebra_and_counters(config2):
@@ -194,3 +245,84 @@ def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank):
                        capture_output=True, text=True, cwd=root, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "RESULT PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif("config5" not in FULL, reason="tests/golden/fullsize.json has no config5 entry yet (make_fullsize.py config5: ~1.5 h of one core)")
+def test_config5_full_size_equals_the_oracle():
+    """BASELINE config 5 at its FULL size -- 50 M reads of 150 bases, 5 % errors, S/E = 0.5 so that the reference's own sizing gives two
+    hash functions and 2 x 1 GiB filters -- bit for bit against the oracle, by digest."""
+    dev = torch.device("cuda", 0)
+    fx = FULL["config5"]
+    c = fx["params"]
+    reads = _case_reads("config5", dev)
+    assert _digest(reads.cpu().numpy()) == fx["reads_sha256"]
+    tai, nh = api.load_filter_shape(c["E"], c["S"])
+    assert (tai, nh) == (fx["tai"], fx["n_hash"]) and nh == 2
+    lst, sst, bloo1, bloo2, keys, recs, _ = _run(reads, c["k"], tai, nh, bench.batch_bounds(c["reads"], 2_000_000, 2))
+    _assert_equals_oracle_fixture("config5", lst, sst, bloo1, bloo2, keys, recs)
+
+
+def _run_cli(name, tmp_path):
+    """the reads of a full-size case as a FASTA / FASTQ file through the `faucet` command line; returns the output prefix"""
+    dev = torch.device("cuda", 0)
+    fx = FULL[name]
+    reads = _case_reads(name, dev)
+    assert _digest(reads.cpu().numpy()) == fx["reads_sha256"]
+    paired = "pairs" in fx["params"]
+    text = sd.fasta_bytes(reads, fastq=paired).cpu().numpy()
+    del reads
+    assert _digest(text) == fx["text_sha256"]
+    inp = str(tmp_path / ("reads.fq" if paired else "reads.fa"))
+    text.tofile(inp)
+    del text
+    prefix = str(tmp_path / "out")
+    cli = os.path.join(ROOT, "faucet_amd", "faucet")
+    r = subprocess.run([cli, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + fx["args"], capture_output=True, text=True, timeout=800)
+    assert r.returncode == (0 if "--no_cleaning" in fx["args"] else 3), r.stdout[-2000:] + r.stderr[-2000:]
+    os.remove(inp)
+    return prefix, r.stdout
+
+
+@pytest.mark.skipif("config3" not in FULL, reason="no config3 entry in tests/golden/fullsize.json")
+def test_config3_paired_end_fastq_through_the_cli_equals_the_reference(tmp_path):
+    """BASELINE config 3's shape at its real size: 2.5 M pairs of 100-base reads of a 4.6 Mb genome with planted repeats as an interleaved
+    FASTQ file, `--fastq --paired_ends`.  All four files the hot path writes are byte-identical to the COMPILED REFERENCE's (by digest)."""
+    fx = FULL["config3"]
+    prefix, out = _run_cli("config3", tmp_path)
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        assert os.path.getsize(prefix + "." + ext) == fx[ext + "_bytes"], ext
+        assert _sha_file(prefix + "." + ext) == fx[ext + "_sha256"], "." + ext + " differs from the reference's"
+    for label, key in (("Distinct junctions: ", "distinct_junctions"), ("Number of kmers that we j-checked: ", "nb_jcheck_kmer"),
+                       ("Number of reads with no junctions: ", "nb_no_juncs"), ("Number of processed kmers: ", "nb_processed"),
+                       ("Number of skipped kmers: ", "nb_skipped"), ("Reads without errors: ", "reads_no_errors")):
+        assert f"{label}{fx[key]}" in out, label
+
+
+@pytest.mark.skipif("config2_cli" not in FULL, reason="no config2_cli entry in tests/golden/fullsize.json")
+def test_config2_fasta_through_the_cli_equals_the_reference(tmp_path):
+    """config 2 as a 1.1 GB FASTA file, file to files: `.bloom` and `.junctions` (dump order included) equal the compiled reference's"""
+    fx = FULL["config2_cli"]
+    prefix, out = _run_cli("config2_cli", tmp_path)
+    for ext in ("bloom", "junctions"):
+        assert _sha_file(prefix + "." + ext) == fx[ext + "_sha256"], "." + ext + " differs from the reference's"
+
+
+def test_config4_per_gpu_shape_is_invariant_under_scheduling_choices():
+    """BASELINE config 4 on one of its eight GPUs: 25 M of the 200 M reads (a 6x shard of a 400 Mb genome) against filters sized for the whole
+    run (-estimated_kmers 1e9 -singletons 2e8: 2 x 1 GiB, 32 GiB of first-set times).  No oracle at this size: the result must not depend on the
+    batching, the walk's window span or the carry policy, and the filter algebra must hold."""
+    dev = torch.device("cuda", 0)
+    n = 25_000_000
+    g = sd.make_genome(400_000_000, 4, dev)
+    reads = sd.make_reads(g, n, 100, 0.01, 4000, dev)
+    del g
+    tai, nh = api.load_filter_shape(1_000_000_000, 200_000_000)
+    assert (tai, nh) == (1 << 33, 3)
+    a = _run(reads, 31, tai, nh, bench.batch_bounds(n, 2_500_000, 2))
+    b = _run(reads, 31, tai, nh, 1_777_777, walk_window_span=1 << 22)
+    assert a[0]["kmers"] == n * 70 and a[0]["to_bloo2"] == b[0]["to_bloo2"]
+    assert _digest(a[3]) == _digest(b[3]) and _digest(a[2]) == _digest(b[2])        # bloo2, bloo1
+    assert np.array_equal(a[4], b[4]) and _digest(a[5]) == _digest(b[5])            # junction records, creation order
+    for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors"):
+        assert a[1][key] == b[1][key], key
+    assert not np.any(a[3] & ~a[2])                                                  # bloo2's bits are a subset of bloo1's
