@@ -12,6 +12,7 @@
 // scanInputRead's per-read lists (fgpu_scan_take_stops) exactly as ReadScanner does it.
 #include <stdint.h>
 #include <stdio.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -633,7 +634,21 @@ int main(int argc, char** argv) {
             }
             return 0;
         };
+        // The fall-back below reads the scan input a second time.  A pipe or a process substitution (how the reference is fed when it
+        // streams, src/stream_data_from_urls_list.sh:12-15) cannot be read twice -- re-opening a FIFO blocks for ever, /dev/fd/N yields an
+        // empty second scan -- so such input is scanned with every junction test evaluated from the start (same results, about 1.5x the
+        // junction-test probes), and a fall-back that is asked for nonetheless fails loudly instead of rescanning.
+        struct stat scan_sb;
+        const bool rereadable = stat(o.read_scan_file.c_str(), &scan_sb) == 0 && S_ISREG(scan_sb.st_mode);
+        if (!rereadable) {
+            fprintf(stderr, "note: %s is not a regular file: it cannot be scanned twice, so every junction test is evaluated up front\n", o.read_scan_file.c_str());
+            CHECK(fgpu_scan_set_eager(ctx, 1));
+        }
         int src_rc = scan_once();
+        if (src_rc == -1 && !rereadable) {
+            fprintf(stderr, "scan failed and the input is not re-readable: %s\n", fgpu_last_error(ctx));
+            return 2;
+        }
         if (src_rc == -1) {
             fprintf(stderr, "\nnote: the preview of the junction walk did not hold for this input; scanning again with every junction test evaluated\n");
             fgpu_scan_end(ctx, nullptr);                 // closes the failed pass (its status is the failure itself)

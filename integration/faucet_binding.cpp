@@ -1,0 +1,138 @@
+// faucet_binding.cpp — the patch a Faucet maintainer adds to src/Faucet.cpp to run the two hot passes on libfaucet_gpu.so.
+//
+// Written against the reference's OWN headers (Bloom.h, JunctionMap.h, Junction.h, Kmer.h): tests/test_abi_cpu.py compiles this
+// file with `g++ -std=c++11 -fsyntax-only -I/root/reference/src -I/root/reference/utils -Iinclude` wherever the reference tree is
+// mounted, so the members it touches (Bloom::tai, ::blooma, ::getNumHash, JunctionMap::createJunction / getJunction,
+// Junction::setCoverage / dist / linked) are checked against the real declarations.  It replaces
+//     load_two_filters(bloo1, bloo2, read_load_file, fastq, mercy)        src/Faucet.cpp:220   (def utils/Bloom.cpp:267)
+//     scanner->scanReads(fastq, paired_ends, no_cleaning)                  src/Faucet.cpp:241-245 (def src/ReadScanner.cpp:284)
+// Every fgpu_* status is checked; the one status a caller has to ACT on is FGPU_ERR_STATE from the scan with "lazy-flag" in
+// fgpu_last_error (faucet_gpu.h, fgpu_scan_set_eager): close the pass, switch the preview off, scan the reads again.  An input that
+// cannot be read twice (a pipe, a process substitution -- src/stream_data_from_urls_list.sh feeds Faucet that way) must therefore be
+// scanned with the preview off from the start.
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../utils/Bloom.h"
+#include "../utils/JunctionMap.h"
+#include "../utils/Junction.h"
+#include "../utils/Kmer.h"
+#include "faucet_gpu.h"
+
+extern int j;               // src/Faucet.h:15
+extern int maxSpacerDist;   // src/Faucet.h:48
+
+static fgpu_ctx* g_ctx;
+
+static void gpu_die(const char* what, int rc) {
+    fprintf(stderr, "%s failed (%d): %s\n", what, rc, fgpu_last_error(g_ctx));
+    exit(2);
+}
+#define GPU_CHECK(call) do { int rc__ = (call); if (rc__ != FGPU_OK) gpu_die(#call, rc__); } while (0)
+
+// The reference's record loop (utils/Bloom.cpp:280-282,340; src/ReadScanner.cpp:306-308,349), cut into batches of sequence lines.
+// `each` returns an fgpu status; the first failure ends the loop and is returned.
+template <class F>
+static int for_each_batch(const std::string& filename, bool fastq, F each) {
+    std::ifstream in(filename.c_str());
+    std::string line, bases;
+    std::vector<uint64_t> offs(1, 0);
+    auto flush = [&]() -> int {
+        fgpu_reads r;
+        memset(&r, 0, sizeof(r));
+        r.bases = bases.data();
+        r.offsets = offs.data();
+        r.n_reads = offs.size() - 1;
+        const int rc = each(&r);
+        bases.clear();
+        offs.assign(1, 0);
+        return rc;
+    };
+    while (getline(in, line)) {
+        line.clear();
+        getline(in, line);
+        bases += line;
+        offs.push_back(bases.size());
+        if (fastq) { getline(in, line); getline(in, line); }
+        if (offs.size() > 1000000)
+            if (int rc = flush()) return rc;
+    }
+    return offs.size() > 1 ? flush() : FGPU_OK;
+}
+
+// replaces the call of load_two_filters in getBloomFilterFromReads() (src/Faucet.cpp:220); bloo1 / bloo2 are the two Bloom objects
+// create_bloom_filter_optimal has just made (same tai, same number of hash functions)
+void gpu_load_two_filters(Bloom* bloo1, Bloom* bloo2, std::string reads_filename, bool fastq, bool mercy) {
+    fgpu_params p;
+    memset(&p, 0, sizeof(p));
+    p.k = sizeKmer;
+    p.j = j;
+    p.max_spacer_dist = maxSpacerDist;
+    p.n_hash = bloo1->getNumHash();
+    p.tai = bloo1->tai;
+    p.flags = mercy ? FGPU_FLAG_MERCY : 0;
+    int rc = fgpu_create(&p, &g_ctx);
+    if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(NULL)); exit(2); }
+    GPU_CHECK(fgpu_load_begin(g_ctx, 0));
+    GPU_CHECK(for_each_batch(reads_filename, fastq, [&](const fgpu_reads* r) { return fgpu_load_batch(g_ctx, r); }));
+    fgpu_load_stats st;
+    GPU_CHECK(fgpu_load_end(g_ctx, &st));
+    // the caller deletes bloo1 and keeps bloo2 for the dump and for Stage 3 (src/Faucet.cpp:221-222,262,285-288)
+    GPU_CHECK(fgpu_bloom_download(g_ctx, FGPU_BLOO1, bloo1->blooma, bloo1->tai / 8));
+    GPU_CHECK(fgpu_bloom_download(g_ctx, FGPU_BLOO2, bloo2->blooma, bloo2->tai / 8));
+    printf("Reads processed: %llu\nUnambiguous reads: %llu\n", (unsigned long long)st.reads_processed, (unsigned long long)st.unambiguous_reads);
+}
+
+static bool is_regular_file(const std::string& path) {
+    struct stat sb;
+    return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+}
+
+// one pass over the scan file; FGPU_OK, or the status of the first call that failed
+static int gpu_scan_pass(const std::string& read_scan_file, bool fastq, fgpu_scan_stats* st) {
+    int rc = fgpu_scan_begin(g_ctx);
+    if (rc != FGPU_OK) return rc;
+    rc = for_each_batch(read_scan_file, fastq, [&](const fgpu_reads* r) { return fgpu_scan_batch(g_ctx, r); });
+    const int end_rc = fgpu_scan_end(g_ctx, st);      // always closes the pass, also after a failed batch
+    return rc != FGPU_OK ? rc : end_rc;
+}
+
+// replaces buildJunctionMapFromReads() (src/Faucet.cpp:240-246) for the --no_cleaning / single-end flow
+void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq) {
+    // The library evaluates testForJunction only where its preview of the walk expects the walk to look, and checks that preview while
+    // walking.  A preview it cannot repair ends the pass with FGPU_ERR_STATE ("lazy-flag ..."): scan again with every test evaluated.
+    // Reads that cannot be read a second time are scanned that way from the start.
+    if (!is_regular_file(read_scan_file)) GPU_CHECK(fgpu_scan_set_eager(g_ctx, 1));
+    fgpu_scan_stats st;
+    int rc = gpu_scan_pass(read_scan_file, fastq, &st);
+    if (rc == FGPU_ERR_STATE && strstr(fgpu_last_error(g_ctx), "lazy-flag") && is_regular_file(read_scan_file)) {
+        GPU_CHECK(fgpu_scan_set_eager(g_ctx, 1));
+        rc = gpu_scan_pass(read_scan_file, fastq, &st);
+    }
+    if (rc != FGPU_OK) gpu_die("junction scan", rc);
+
+    uint64_t n = 0;
+    GPU_CHECK(fgpu_scan_junction_count(g_ctx, &n));
+    std::vector<uint64_t> keys(n ? n : 1);
+    std::vector<fgpu_junction> recs(n ? n : 1);
+    GPU_CHECK(fgpu_scan_download_junctions(g_ctx, keys.data(), recs.data(), keys.size(), &n));
+    for (uint64_t i = 0; i < n; i++) {                // creation order -> the reference's unordered_map iteration (= dump) order
+        junctionMap->createJunction((kmer_type)keys[i]);
+        Junction* jn = junctionMap->getJunction((kmer_type)keys[i]);
+        for (int e = 0; e < 4; e++) jn->setCoverage(e, recs[i].cov[e]);
+        for (int e = 0; e < 5; e++) { jn->dist[e] = recs[i].dist[e]; jn->linked[e] = recs[i].linked[e] != 0; }
+    }
+    printf("Reads processed: %llu\nUnambiguous reads: %llu\n", (unsigned long long)st.reads_processed, (unsigned long long)st.unambiguous_reads);
+    printf("\nDistinct junctions: %llu \n", (unsigned long long)st.n_junctions);
+    printf("Number of kmers that we j-checked: %llu \n", (unsigned long long)st.nb_jcheck_kmer);
+    printf("Number of reads with no junctions: %llu \n", (unsigned long long)st.nb_no_juncs);
+    printf("Number of processed kmers: %llu \n", (unsigned long long)st.nb_processed);
+    printf("Number of skipped kmers: %llu \n", (unsigned long long)st.nb_skipped);
+    printf("Reads without errors: %llu\n", (unsigned long long)st.reads_no_errors);
+}

@@ -90,3 +90,19 @@ def test_junction_file_text_round_trips(name):
     assert api.junction_lines(keys, recs, c.k) == lines
     with pytest.raises(ValueError):
         api.parse_junction_lines([lines[0][1:]], c.k)
+
+
+def test_integration_binding_compiles_against_the_reference_headers():
+    """integration/faucet_binding.cpp -- the patch INTEGRATION.md shows a Faucet maintainer, status checks and the lazy-flag retry
+    included -- must be valid C++11 against the reference's own Bloom.h / JunctionMap.h / Junction.h (only where that tree is mounted)."""
+    import os
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "utils")) or shutil.which("g++") is None:
+        pytest.skip("reference tree not mounted here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-include", "vector", "-include", "cmath", "-I", os.path.join(ref, "src"),
+                        "-I", os.path.join(ref, "utils"), "-I", os.path.join(root, "include"), os.path.join(root, "integration", "faucet_binding.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

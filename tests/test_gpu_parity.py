@@ -376,9 +376,12 @@ def test_cli_writes_the_reference_files(name, how, tmp_path):
     assert "Weights after load: %s, %s" % tuple(cn["weights_after_load"]) in r.stdout
 
 
-def test_cli_reads_both_passes_from_named_pipes(tmp_path):
+@pytest.mark.parametrize("force_lazy_fail", [False, True])
+def test_cli_reads_both_passes_from_named_pipes(tmp_path, force_lazy_fail):
     """The reference's streaming scripts (src/stream_data_from_urls_list.sh) feed both passes through pipes: the host must read its
-    inputs strictly sequentially, never seek or ask for a size."""
+    inputs strictly sequentially, never seek or ask for a size -- and never need them twice: with FGPU_DEBUG_LAZY_FAIL=1 every lazy scan
+    reports the failure that regular files answer by scanning again; on a pipe that second scan would hang or find nothing,
+    so the CLI scans pipes with every junction test evaluated up front and the forced failure cannot occur."""
     import os
     import subprocess
     import threading
@@ -399,9 +402,11 @@ def test_cli_reads_both_passes_from_named_pipes(tmp_path):
         t.start()
     args = [a for a in c.meta["args"] if not a.endswith(".fa")]
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    env = dict(os.environ, FGPU_DEBUG_LAZY_FAIL="1") if force_lazy_fail else None
     r = subprocess.run([exe, "-read_load_file", pipes[0], "-read_scan_file", pipes[1], "-file_prefix", str(tmp_path / "out")] + args,
-                       capture_output=True, text=True, timeout=120)
+                       capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
+    assert "not a regular file" in r.stderr
     for t in feeders:
         t.join(timeout=10)
         assert not t.is_alive()
