@@ -169,6 +169,32 @@ def cpu_baseline(reads_host, k, tai, nh):
     return lst.kmers / dt, dt, int(lst.kmers)
 
 
+def _cpu_replica(args):
+    """one worker of cpu_all_cores: the oracle on its own shard of the sample, with filters of the run's size"""
+    reads_host, k, tai, nh = args
+    v, dt, nk = cpu_baseline(reads_host, k, tai, nh)
+    return nk, dt
+
+
+def cpu_all_cores(reads_host, k, tai, nh, workers):
+    """SURVEY 8d(ii)'s second CPU figure.  The reference is single-threaded and so is the oracle; what an ideal parallel port could do on
+    this host is bounded by `workers` independent single-threaded replicas, each running load + scan over its own slice of the sample with
+    its own full-size filters (no exchange between them: NOT the reference's result for the whole sample, only its work rate).  Returns
+    (aggregate k-mers/s, wall seconds, k-mers)."""
+    import multiprocessing as mp
+    n = reads_host.shape[0]
+    per = n // workers
+    if per < 1000:
+        return None
+    parts = [(np.ascontiguousarray(reads_host[i * per:(i + 1) * per]), k, tai, nh) for i in range(workers)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(workers) as pool:      # spawn: the children must not inherit this process' GPU state
+        res = pool.map(_cpu_replica, parts)
+    dt = time.perf_counter() - t0
+    nk = sum(r[0] for r in res)
+    return nk / max(max(r[1] for r in res), 1e-9), dt, nk
+
+
 def reference_binary_baseline(reads_host, k, E, S):
     """The COMPILED REFERENCE itself (oracle/_ref/faucet_ref, built from the reference's own sources by oracle/Makefile where
     they are mounted; it travels to the GPU box as a prebuilt binary) on a bounded sample written to a FASTA file, with the
@@ -275,6 +301,8 @@ def main():
     ap.add_argument("--profile-walk", action="store_true", help="time the per-window walk kernels individually")
     ap.add_argument("--host-input", action="store_true",
                     help="hand the reads over as HOST buffers (PCIe copy inside the timed region); diagnostic only, never the headline value")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the extra PCIe-inclusive steps reported as `host_input` (N = 1)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="replicas of the all-cores CPU leg (0 = min(host cores, 16))")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL prints its version banner there) go to stderr
@@ -399,13 +427,22 @@ def main():
         kmers_per_launch = kmers_local * args.steps * (2 if name == "pack" else 1) / launches
         base_bytes = L_ / (L_ - k + 1)
         rho = lst["to_bloo2"] / max(kmers_local, 1)
+        split = ctx.diag_load_split()                          # last load pass: occurrences routed to bloo2 by k_load_mark itself / left pending
+        rho_mark = split["in_mark"] / max(kmers_local, 1)
+        reused = sst["valid_reused"] / max(kmers_local, 1)     # validity answers taken from the load pass' planes: no filter access at all
+        # ALGORITHMIC bytes per k-mer of each kernel: the reference's counted bit accesses (SURVEY 8d, 64 B each) charged to the kernel
+        # that PERFORMS them: the bloo2 sets of an occurrence whose bits are all in the carry happen inside
+        # k_load_mark (the interleaved {bloo1, bloo2} word serves both), only the rest in k_load_resolve; a validity answer read from
+        # the resident `sure` plane moves no filter bytes (the reference's n_hash tests of those occurrences are charged to nobody)
         per_kmer = {
             "pack": base_bytes,                                  # each base read once per pass (1 B/base in HBM)
-            "load_mark": 64.0 * nh,                              # test-and-set of n_hash bits of bloo1
-            "load_resolve": 64.0 * nh * rho,                     # sets on bloo2 (rho = occurrences routed to bloo2 / N)
-            "scan_valid": 64.0 * (T["T_valid"] if T else nh),    # validity bit tests the reference performs (early exit)
+            "load_mark": 64.0 * nh * (1.0 + rho_mark),           # test-and-set of n_hash bits of bloo1 + the bloo2 sets done here
+            "load_resolve": 64.0 * nh * max(rho - rho_mark, 0.0),  # the bloo2 sets of the occurrences it settles
+            "scan_valid": 64.0 * max((T["T_valid"] if T else nh) - nh * reused, 0.0),   # validity bit tests that still reach the filter
             "scan_flags": 64.0 * (T["T_junc"] if T else 0.0),    # alternate-extension + jcheck bit tests WITH the reference's skipping
         }[name]
+        per_kmer_r1 = {"pack": base_bytes, "load_mark": 64.0 * nh, "load_resolve": 64.0 * nh * rho,
+                       "scan_valid": 64.0 * (T["T_valid"] if T else nh), "scan_flags": 64.0 * (T["T_junc"] if T else 0.0)}[name]
         avg_ms = total_ms / launches
         achieved = per_kmer * kmers_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None          # HBM bytes per launch from rocprofv3 PMC passes, when a summary for this kernel is committed
@@ -417,13 +454,41 @@ def main():
         res["device_time_share"] = {n: round(ms / (1e3 * elapsed), 4) for n, (c, ms) in ktimes.items() if ms / (1e3 * elapsed) > 0.01}
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
-                           "algorithmic_bytes_per_kmer": per_kmer, "kmers_per_launch": kmers_per_launch}
+                           "algorithmic_bytes_per_kmer": per_kmer, "kmers_per_launch": kmers_per_launch,
+                           "attribution": "reference bit accesses charged to the kernel that performs them (64 B each): "
+                                          f"n_hash bloo1 test-and-sets + the bloo2 sets of the {rho_mark:.3f} of occurrences settled inside this kernel",
+                           "frac_bloo1_accesses_only": per_kmer_r1 * kmers_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,   # round 1's charge (64 * n_hash)
+                           "rho_settled_in_mark": rho_mark, "rho_settled_in_resolve": max(rho - rho_mark, 0.0)}
+        # ---- what the counters say: FETCH_SIZE + WRITE_SIZE of every kernel of a step, from the committed PMC passes
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pl = json.load(f).get("bytes_per_launch", {})
+            alias = {"scan_flags": "k_scan_flags_sm", "load_resolve": "k_load_resolve_sm", "carry_update": "k_carry_from_first"}
+            tot, missing = 0.0, []
+            for n, (c, ms) in ktimes.items():
+                b = pl.get("k_" + n, pl.get(alias.get(n, "")))
+                if b is None:
+                    if ms / (1e3 * elapsed) > 0.01 and n != "walk_stage":
+                        missing.append(n)
+                    continue
+                tot += b * c / args.steps
+            for n in ("k_walk_lookup", "k_walk_link", "k_walk", "k_walk_cluster", "k_walk_reset_uf"):   # the walk stage is timed as one entry
+                if n in pl and "walk_stage" in ktimes:
+                    tot += pl[n] * sst["walk_windows"]
+            res["pipeline_measured"] = {"hbm_bytes_per_step": tot, "GBps": tot / (elapsed / args.steps) / 1e9, "frac_of_hbm_peak": tot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                                        "source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, separate passes) x launches of this run",
+                                        "kernels_without_counters": missing}
     if T:
         tsum = T["T_load"] + T["T_valid"] + T["T_junc"]
         ab64 = 2 * L_ / (L_ - k + 1) + 64.0 * tsum
         res["pipeline_ab64"] = {"bytes_per_kmer": ab64, "ab32_bytes_per_kmer": ab64 - 32.0 * tsum, "ab128_bytes_per_kmer": ab64 + 64.0 * tsum, "achieved_GBps": ab64 * value / 1e9, "frac_of_hbm_peak": ab64 * value / 1e9 / HBM_PEAK_GBPS,
                                 "T_load": T["T_load"], "T_valid": T["T_valid"], "T_junc": T["T_junc"], "rho_sample": T["rho"],
                                 "rho_gpu_run": lst["to_bloo2"] / max(kmers_local, 1),
+                                # the device's own counters beside the sample's: validity probes it still sends to the filter, half-steps whose
+                                # junction tests it evaluates (the preview's superset) against those the reference's walk tests
+                                "T_valid_probed_gpu_run": max(T["T_valid"] - nh * sst["valid_reused"] / max(kmers_local, 1), 0.0),
+                                "junction_test_halfsteps_gpu_run_per_kmer": 2.0 * sst["flag_positions"] / max(kmers_local, 1),
+                                "junction_test_halfsteps_reference_per_kmer": sst["nb_processed"] / max(kmers_local, 1),
                                 "counted_on": f"oracle, {T['sample_reads']} reads of a {T['sample_genome']} bp genome (same coverage, error rate, bits per estimated k-mer)"}
 
     # ---- measured ceilings of this device for the two access patterns of the path, ~1 s in total
@@ -461,6 +526,30 @@ def main():
                                    "port": {"value": v, "seconds": dt}}
         else:
             res["cpu_baseline"] = port
+        # the all-cores figure SURVEY 8d(ii) asks for beside the one-thread one: independent single-threaded replicas (see cpu_all_cores)
+        workers = args.cpu_workers or min(os.cpu_count() or 1, 16)
+        if workers > 1:
+            ac = cpu_all_cores(sample, k, tai, nh, workers)
+            if ac:
+                res["cpu_baseline"]["all_cores"] = {"value": ac[0], "unit": "k-mers/s", "cores": workers, "kind": "port",
+                                                    "sample": f"{workers} independent single-threaded replicas of the oracle, each load+scan over 1/{workers} of the "
+                                                              f"same {n_s} reads with its own 2 x {tai // 8 >> 20} MiB filters ({ac[2]} k-mers in {ac[1]:.1f} s wall): the "
+                                                              "work rate an ideal parallel port is bounded by, not the reference's result for the whole sample"}
+    # ---- the PCIe-inclusive rate: the same step with the reads handed over as HOST buffers, 2 x 1 GB of copies inside
+    # the timed region.  Reported beside `value`, never as `value`.
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+        host = reads.cpu().numpy()
+        hb = [api.ReadBatch.from_matrix(host[lo:hi]) for lo, hi in bounds]
+        step_single(ctx, hb, pinned=True)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        n_h = 3
+        for _ in range(n_h):
+            step_single(ctx, hb, pinned=True)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / n_h
+        res["host_input"] = {"value": kmers_local / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt, "steps": n_h,
+                             "note": "reads handed over as pageable host buffers: both passes copy them to the device inside the timed region"}
     emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

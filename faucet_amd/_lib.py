@@ -107,6 +107,7 @@ SIGNATURES = {
     "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),
     "fgpu_diag_random_access": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_int, _P(_f64)]),
     "fgpu_diag_device_attr": (C.c_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
+    "fgpu_diag_load_split": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
 }
 
 _lib = None

@@ -350,6 +350,12 @@ class Context:
         self._c(self.lib.fgpu_diag_stream_copy(self.h, nbytes, iters, C.byref(out)))
         return out.value
 
+    def diag_load_split(self) -> dict:
+        """where the last load pass settled its occurrences: routed to bloo2 by the marking kernel itself / left to the resolution"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._c(self.lib.fgpu_diag_load_split(self.h, C.byref(a), C.byref(b)))
+        return {"in_mark": int(a.value), "pending": int(b.value)}
+
     def diag_device_attr(self) -> dict:
         v = [C.c_int32(0) for _ in range(4)]
         self._c(self.lib.fgpu_diag_device_attr(self.h, *[C.byref(x) for x in v]))

@@ -348,6 +348,8 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     if (rc) return rc;
     ctx->load_stats.kmers = ctx->counters_host->kmers;
     ctx->load_stats.to_bloo2 = ctx->counters_host->to_bloo2;
+    ctx->load_mark_hits = ctx->counters_host->mark_hits;
+    ctx->load_mark_pending = ctx->counters_host->mark_pending;
     ctx->load_stats.unambiguous_reads = ctx->counters_host->segments;
     if (stats) *stats = ctx->load_stats;
     ctx->fixup_ready = ctx->shard_times && ctx->pass_empty_carry && ctx->resident_count == ctx->pass_batches &&
@@ -772,6 +774,13 @@ static int probe_stage3(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, i
 int fgpu_probe_jcheck(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 0, out); }
 int fgpu_probe_valid_extension(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 1, out); }
 int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 2, out); }
+
+int fgpu_diag_load_split(fgpu_ctx* ctx, uint64_t* in_mark, uint64_t* pending) {
+    if (!ctx || !in_mark || !pending) return FGPU_ERR_ARG;
+    *in_mark = ctx->load_mark_hits;
+    *pending = ctx->load_mark_pending;
+    return FGPU_OK;
+}
 
 int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap) {
     if (!ctx) return 0;

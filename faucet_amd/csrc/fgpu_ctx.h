@@ -112,6 +112,8 @@ struct DevCounters {
     unsigned long long valid_reused;    // validity answers taken from the load pass' resident planes instead of probing
     unsigned long long flags_filled;    // windows whose junction tests the walk evaluated itself (the preview had left them out)
     unsigned long long walked_pieces;   // pieces of the windows walked so far (feedback for the window-span controller)
+    unsigned long long mark_hits;       // pass 1: occurrences k_load_mark itself routed to bloo2 (all bits already in the carry)
+    unsigned long long mark_pending;    // pass 1: occurrences left to k_load_resolve
 };
 
 struct fgpu_ctx {
@@ -178,6 +180,7 @@ struct fgpu_ctx {
     DevCounters* counters_host = nullptr; // pinned host mirror
 
     fgpu_load_stats load_stats;
+    uint64_t load_mark_hits = 0, load_mark_pending = 0;   // fgpu_diag_load_split
     fgpu_scan_stats scan_stats;
     uint64_t scan_windows = 0;
     uint64_t scan_pieces_seen = 0;   // pieces counted by previous batches of this scan

@@ -63,7 +63,7 @@ constexpr int MISS_PLANES = 4;   // planes of "bit i was missing from the carry"
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
                                                    uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first, uint32_t tb,
                                                    uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
-    unsigned long long n_ok = 0, n_hit = 0;
+    unsigned long long n_ok = 0, n_hit = 0, n_pend = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool ok = p < T && fd_window_ok(bad, p, fp.k);
@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 }
             } else {
                 pend = true;
+                n_pend++;
                 miss_bits = missing;
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
@@ -122,6 +123,8 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
     }
     block_add(&cnt->kmers, n_ok);
     block_add(&cnt->to_bloo2, n_hit);
+    block_add(&cnt->mark_hits, n_hit);
+    block_add(&cnt->mark_pending, n_pend);
 }
 
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,

@@ -101,7 +101,8 @@ int handle_arguments(int argc, char** argv, Options& o) {
         argument_error();
         return 1;
     }
-    if (o.from_bloom) printf("Starting from after bloom load based on bloom file.\n");
+    if (o.from_junctions) printf("Starting from after read scan based on bloom and junction files.\n");
+    else if (o.from_bloom) printf("Starting from after bloom load based on bloom file.\n");
     else printf("Starting at the beginning: will load bloom and find junctions from the read set.\n");
     if (o.just_load) printf("Only loading bloom, dumping and termination.\n");
     printf("Read load file name: %s\n", o.read_load_file.c_str());
@@ -459,6 +460,51 @@ int write_junctions(const std::string& path, const std::unordered_map<uint64_t, 
     return 0;
 }
 
+// JunctionMap::buildFromFile (utils/JunctionMap.cpp:619-639) with Junction's parsing constructor (utils/Junction.cpp:102-118): the k-mer as
+// text (getFirstKmerFromRead: A0 C1 T2 G3), five distances, four coverages, their sum (skipped), five link flags; a later line with the same
+// k-mer replaces the earlier one (junctionMap[kmer] = junc).  Returns -1 when the file cannot be opened or a line does not parse.
+long read_junctions(const std::string& path, int k, std::unordered_map<uint64_t, Junction>& map) {
+    std::ifstream in(path.c_str());
+    if (!in.is_open()) return -1;
+    std::string line;
+    long n_lines = 0;
+    while (std::getline(in, line)) {
+        if ((int)line.size() < k + 1) return -1;
+        uint64_t kmer = 0;
+        for (int i = 0; i < k; i++) {
+            const char c = line[(size_t)i];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return -1;
+            kmer = (kmer << 2) | (uint64_t)((c >> 1) & 3);
+        }
+        int v[15];
+        const char* p = line.c_str() + k;
+        for (int i = 0; i < 15; i++) {
+            char* end = nullptr;
+            const long x = strtol(p, &end, 10);
+            if (end == p) return -1;
+            v[i] = (int)x;
+            p = end;
+        }
+        Junction j;
+        for (int i = 0; i < 5; i++) j.dist[i] = (uint8_t)v[i];
+        for (int i = 0; i < 4; i++) j.cov[i] = (uint8_t)v[5 + i];
+        for (int i = 0; i < 5; i++) j.linked[i] = (uint8_t)(v[10 + i] != 0);
+        map[kmer] = j;
+        n_lines++;
+    }
+    return n_lines;
+}
+
+int load_pair_filter(PairFilter& pf, const std::string& path) {   // Bloom::load (utils/Bloom.cpp:580-587), with the size checked
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); return 2; }
+    const size_t got = fread(pf.bits.data(), 1, pf.bits.size(), f);
+    const bool more = fgetc(f) != EOF;
+    fclose(f);
+    if (got != pf.bits.size() || more) { fprintf(stderr, "%s is not %llu bytes\n", path.c_str(), (unsigned long long)pf.bits.size()); return 2; }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -466,7 +512,6 @@ int main(int argc, char** argv) {
     if (handle_arguments(argc, argv, o) == 1) return 1;
     fgpu_ctx* ctx = nullptr;
     if (o.k < 1 || o.k > 31) { fprintf(stderr, "k must be in 1..31 on this build\n"); return 1; }
-    if (o.from_junctions) { fprintf(stderr, "-junctions_file restarts after the scan: nothing left for this build to do.\n"); return 1; }
 
     // ---- filter sizing: getBloomFilterFromReads / getBloomFilterFromFile (src/Faucet.cpp:185-219)
     uint64_t tai = 0;
@@ -562,6 +607,26 @@ int main(int argc, char** argv) {
         if (o.paired_ends) long_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 5 : E / 10, 0.01f);
     }
     if (o.just_load) { fgpu_destroy(ctx); return 0; }
+
+    // ---- -junctions_file <prefix> (src/Faucet.cpp:104-109,289-293): the scan's three files are reloaded instead of being made.  What the
+    // reference does next is its contig graph, which is not part of this build: the files are parsed and checked (sizes as the flags imply),
+    // the lines the reference prints after reloading are printed, and the program stops where every run of this build stops (exit code 3).
+    if (o.from_junctions) {
+        std::unordered_map<uint64_t, Junction> junction_map;
+        printf("Reading from Junction file to build junction map.\n");
+        const long n_lines = read_junctions(o.junctions_prefix + ".junctions", o.k, junction_map);
+        if (n_lines < 0) { fprintf(stderr, "cannot read %s.junctions (missing, or not in the .junctions format for k = %d)\n", o.junctions_prefix.c_str(), o.k); return 2; }
+        if (int rc = load_pair_filter(short_pf, o.junctions_prefix + ".short_pair_filter")) return rc;
+        if (o.paired_ends)
+            if (int rc = load_pair_filter(long_pf, o.junctions_prefix + ".long_pair_filter")) return rc;
+        printf("Weight of short pair filter: %f\n", short_pf.weight());
+        if (o.paired_ends) printf("Weight of long pair filter: %f\n", long_pf.weight());
+        printf("Number of junctions: %llu\n", (unsigned long long)junction_map.size());
+        fgpu_destroy(ctx);
+        fprintf(stderr, "The contig-graph stage is not part of this build: -bloom_file / -junctions_file inputs have been read and checked; the\n"
+                        "reference continues from them.\n");
+        return 3;
+    }
 
     // ---- pass 2 (ReadScanner::scanReads, src/ReadScanner.cpp:284-359; printScanSummary :19-27)
     {

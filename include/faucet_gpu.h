@@ -283,6 +283,10 @@ int fgpu_diag_stream_copy(fgpu_ctx* ctx, uint64_t bytes, int iters, double* gb_p
 /* n_access independent random 32-bit accesses into a table of table_bytes (power of two) per iteration.
  * mode 0 = load, 1 = atomicMin (the load pass' first-set times), 2 = test-then-atomicOr (Bloom::add). */
 int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_access, int mode, int iters, double* access_per_s);
+/* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
+ * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
+ * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */
+int fgpu_diag_load_split(fgpu_ctx* ctx, uint64_t* in_mark, uint64_t* pending);
 /* Memory clock (kHz), bus width (bits), L2 bytes and CU count as the HIP runtime reports them. */
 int fgpu_diag_device_attr(fgpu_ctx* ctx, int32_t* mem_clock_khz, int32_t* mem_bus_bits, int32_t* l2_bytes, int32_t* compute_units);
 

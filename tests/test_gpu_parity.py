@@ -376,6 +376,73 @@ def test_cli_writes_the_reference_files(name, how, tmp_path):
     assert "Weights after load: %s, %s" % tuple(cn["weights_after_load"]) in r.stdout
 
 
+@pytest.mark.parametrize("name", ["restart_bloomfile_k21", "restart_bloomfile_twohash_k21"])
+def test_cli_restarts_from_a_bloom_file_like_the_reference(name, tmp_path):
+    """-bloom_file (src/Faucet.cpp:97-100,185-195,257-258): pass 1 is skipped, the filter is loaded from a file into a Bloom sized with
+    create_bloom_filter_optimal(estimated_kmers, fpRate) -- fpRate, NOT the p1 a load from reads is sized with -- or, with --two_hash,
+    create_bloom_filter_2_hash.  Golden: the compiled reference restarted from the .bloom of a normal run (tests/golden/make_restart_golden.py).
+    The plain case pins the reference's quirk: the file holds 3 bits per k-mer, the restarted run asks for 4, nearly nothing is "present"
+    and the junction file comes out empty; the --two_hash case (2 of the 3 bits asked for) finds 158 junctions."""
+    import gzip
+    import json
+    import os
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    meta = json.load(open(os.path.join(d, "case.json")))
+    reads, bloom = tmp_path / "reads.fa", tmp_path / "in.bloom"
+    reads.write_bytes(gzip.open(os.path.join(d, "reads.fa.gz")).read())
+    bloom.write_bytes(gzip.open(os.path.join(d, "in.bloom.gz")).read())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"), "-bloom_file", str(bloom)]
+                       + meta["args"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Starting from after bloom load based on bloom file." in r.stdout
+    want = gzip.open(os.path.join(d, "out.junctions.gz")).read()
+    assert (tmp_path / "out.junctions").read_bytes() == want                      # dump order included
+    assert not (tmp_path / "out.bloom").exists()                                  # the reference dumps no .bloom on this path
+    cn = meta["counters"]
+    assert f"Bits per kmer: {cn['bits_per_kmer']} " in r.stdout
+    for label, key in (("Distinct junctions: ", "distinct_junctions"), ("Number of kmers that we j-checked: ", "nb_jcheck_kmer"),
+                       ("Number of processed kmers: ", "nb_processed"), ("Number of skipped kmers: ", "nb_skipped"), ("Reads without errors: ", "reads_no_errors")):
+        assert f"{label}{cn[key]}" in r.stdout, label
+    # a .bloom of another size is refused, not half-read (the reference freads what is there and goes on)
+    (tmp_path / "short.bloom").write_bytes(bloom.read_bytes()[:1000])
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out2"), "-bloom_file",
+                        str(tmp_path / "short.bloom")] + meta["args"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "is not" in r.stderr
+
+
+def test_cli_restarts_from_junction_files_like_the_reference(tmp_path):
+    """-junctions_file <prefix> (needs -bloom_file; src/Faucet.cpp:104-109,130-134,289-293): both passes are skipped, <prefix>.junctions and the two
+    pair filters are reloaded (JunctionMap::buildFromFile, utils/JunctionMap.cpp:619-639; Bloom::load).  The contig graph that follows in the
+    reference is not part of this build: the CLI reloads and checks the files, prints what the reference prints after reloading them (pair
+    filter weights, number of junctions: golden = the compiled reference's own lines) and stops with its "contig graph not built" code 3."""
+    import gzip
+    import json
+    import os
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "restart_junctions_k21")
+    meta = json.load(open(os.path.join(d, "case.json")))
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        (tmp_path / ("pe." + ext)).write_bytes(gzip.open(os.path.join(d, "in." + ext + ".gz")).read())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    base = [exe, "-read_load_file", "unused.fq", "-read_scan_file", "unused.fq", "-file_prefix", str(tmp_path / "again"), "-bloom_file", str(tmp_path / "pe.bloom")]
+    r = subprocess.run(base + ["-junctions_file", str(tmp_path / "pe")] + meta["args"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, r.stdout[-1500:] + r.stderr[-1500:]
+    for line in meta["stdout_after_reload"]:
+        if line.startswith("Size of junction"):        # sizeof(Junction), a debugging print of the reference
+            continue
+        assert line in r.stdout, line
+    assert not (tmp_path / "again.junctions").exists()
+    # without -bloom_file the reference refuses (exit code 1); a truncated pair filter is an error here (the reference would half-read it)
+    r = subprocess.run([exe, "-read_load_file", "u", "-read_scan_file", "u", "-file_prefix", "x", "-junctions_file", str(tmp_path / "pe")] + meta["args"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Cannot start from junctions without a bloom file." in r.stderr
+    (tmp_path / "pe.long_pair_filter").write_bytes(b"\0" * 100)
+    r = subprocess.run(base + ["-junctions_file", str(tmp_path / "pe")] + meta["args"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2
+
+
 @pytest.mark.parametrize("force_lazy_fail", [False, True])
 def test_cli_reads_both_passes_from_named_pipes(tmp_path, force_lazy_fail):
     """The reference's streaming scripts (src/stream_data_from_urls_list.sh) feed both passes through pipes: the host must read its
