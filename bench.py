@@ -8,8 +8,8 @@ A step = one pass of the hot path (Bloom load pass + junction scan pass) over th
 which is resident in HBM before the timed region starts.  N = 1: BASELINE.json configs[1] — 10 M synthetic
 100 bp reads, k = 31, -estimated_kmers 1e8 -singletons 2e7 (64 MiB filters, 3 hash functions).  N > 1: weak
 scaling — every rank holds 10 M reads of an N x 20 Mb genome and the filters are sized for N x 1e8 k-mers; reads
-are sharded in file order, the shards' k-mer presence bitmaps are exchanged for the exclusive prefix-OR, the
-shards' bloo2 are OR-all-reduced (RCCL all-gather + local OR kernel), the pure scan stage runs on every rank
+are sharded in file order, the exclusive prefix-OR of the shards' bloo1 and the OR-all-reduce of their bloo2 run as
+slice-wise reduce-scatter / all-gather (grouped RCCL send/recv + local OR kernel), the pure scan stage runs on every rank
 at once and the ordered junction walk is handed from rank to rank (table export -> send/recv -> import).
 
 The timed region of a step ends when the pass outputs are final in HOST memory: the bloo2 bit array and the
@@ -353,8 +353,17 @@ def main():
         batches = device_batches(reads, bounds)
     torch.cuda.synchronize()
 
-    ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
-    shard = sharded.GpuShard(ctx, device) if (world > 1 or force_sharded) else None
+    if world > 1 or force_sharded:
+        # the library on the stream the collectives are ordered with: kernels, local OR steps and RCCL calls follow each other on the device,
+        # the host never waits between them (sharded.GpuShard.fence is a no-op then)
+        tstream = torch.cuda.Stream(device)
+        torch.cuda.set_stream(tstream)
+        ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")), stream=tstream.cuda_stream)
+        ctx.on_torch_stream = True
+        shard = sharded.GpuShard(ctx, device)
+    else:
+        ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
+        shard = None
 
     def one_step():
         if world == 1 and not force_sharded:
@@ -405,7 +414,7 @@ def main():
                                f"estimated_kmers={E}, singletons={S}, genome {args.genome * world} bp, {args.err:.0%} substitutions; "
                                f"filters 2 x {tai // 8 >> 20} MiB, {nh} hash functions",
                    "reads_per_gpu": args.reads, "read_len": L_, "k": k, "tai": tai, "n_hash": nh, "batch_reads": args.batch_reads,
-                   "sharding": "reads in file order; prefix-OR(bloo1 presence) + OR-allreduce(bloo2); walk handed rank to rank" if world > 1 else "single GPU"},
+                   "sharding": "reads in file order; slice-wise prefix-OR(bloo1) + OR-allreduce(bloo2) over RCCL send/recv; walk handed rank to rank" if world > 1 else "single GPU"},
         "kmers_per_step": kmers_total, "lazy_flag_fallbacks": len(FALLBACKS),
         "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),

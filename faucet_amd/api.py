@@ -141,6 +141,7 @@ class Context:
         self.h = h
         self.k, self.tai, self.n_hash, self.j = k, tai, n_hash, j
         self.mercy = bool(mercy)
+        self.on_torch_stream = False     # set by callers that create the context on torch's current stream (sharded.GpuShard)
 
     def close(self):
         if getattr(self, "h", None):

@@ -6,9 +6,14 @@ backend on CPU.  It talks to a *backend* object; the product backend is `GpuShar
 `api.Context`); the CPU tests plug in an oracle-backed stand-in with the same methods.
 
 Pass 1 (exact), one of
-    load of the shard alone -> all-gather of bloo1 -> fix-up against the OR of the lower ranks' bloo1 -> bloo2 := OR over ranks
-    presence bitmap of the shard  ->  all-gather  ->  carried-in bloo1 of rank r = OR of the bitmaps of ranks < r
-    ->  ordered load of the shard ->  bloo2 := OR over ranks (all-gather + local OR; RCCL has no bitwise-OR reduction)
+    load of the shard alone -> exclusive prefix-OR of the shards' bloo1 -> fix-up against it -> bloo2 := OR over ranks
+    presence bitmap of the shard  ->  exclusive prefix-OR over ranks = carried-in bloo1 of rank r
+    ->  ordered load of the shard ->  bloo2 := OR over ranks
+  Both exchanges work on SLICES of the bit arrays (RCCL has no bitwise-OR reduction): rank q collects slice q of every rank (grouped
+  send/recv), reduces it with the local OR kernel -- a running OR for the exclusive prefix, whose r-th intermediate goes back to rank r --
+  and the reduced slices are gathered.  Each rank receives 2 (N-1)/N of a bitmap per exchange instead of the N-1 bitmaps of an
+  all-gather + local OR (0.9 instead of 3.5 GiB at N = 8 with 2^32-bit filters), and nothing waits on the host: the library runs on the
+  stream the collectives are ordered with (GpuShard).
 Pass 2:
     pure stage on every rank at once (no collective)  ->  the ordered junction walk is handed from rank to rank:
     recv table from r-1, import, walk own shard, export, send to r+1.  The last rank holds the final map.
@@ -78,60 +83,120 @@ def load_sharded(backend, batches, rank: int, world: int):
     return load_sharded_presence(backend, batches, rank, world)
 
 
+def _slices(nbytes: int, world: int):
+    """[lo, hi) byte ranges of the `world` slices of a bitmap: equal, 16-byte aligned (the OR kernel's granule), the last one short"""
+    step = -(-nbytes // world)
+    step = (step + 15) & ~15
+    return [(min(q * step, nbytes), min((q + 1) * step, nbytes)) for q in range(world)]
+
+
+def _exchange(sends, recvs):
+    """grouped point-to-point: sends = [(tensor, dst)], recvs = [(tensor, src)].  RCCL moves device tensors directly (one grouped
+    launch: every rank talks to every other over its own xGMI link); gloo stages device tensors through host memory."""
+    if not sends and not recvs:
+        return
+    ops, landing = [], []
+    for t, dst in sends:
+        ops.append(dist.P2POp(dist.isend, t.cpu() if _staged(t) else t, dst))
+    for t, src in recvs:
+        if _staged(t):
+            h = torch.empty(t.shape, dtype=t.dtype)
+            landing.append((t, h))
+            ops.append(dist.P2POp(dist.irecv, h, src))
+        else:
+            ops.append(dist.P2POp(dist.irecv, t, src))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for t, h in landing:
+        t.copy_(h)
+
+
+def or_allreduce(backend, bitmap, rank: int, world: int):
+    """bitmap := OR over ranks, in place on every rank: reduce-scatter by slices (grouped send/recv + local OR) + all-gather of the slices"""
+    if world == 1:
+        return
+    nbytes = bitmap.numel()
+    sl = _slices(nbytes, world)
+    lo, hi = sl[rank]
+    mine = hi - lo
+    stage = backend.scratch(max(mine, 16) * (world - 1), tag="rs_stage")
+    others = [q for q in range(world) if q != rank]
+    backend.fence()      # (no-op when the library runs on the collectives' stream)
+    # reduce-scatter: slice q of this rank's bitmap goes to rank q; slice `rank` of everybody else's comes here
+    _exchange([(bitmap[sl[q][0]:sl[q][1]], q) for q in others if sl[q][1] > sl[q][0]],
+              [(stage[i * mine:(i + 1) * mine], q) for i, q in enumerate(others)] if mine else [])
+    for i in range(len(others) if mine else 0):
+        backend.or_tensor(bitmap[lo:hi], stage[i * mine:(i + 1) * mine])
+    backend.fence()
+    # all-gather: the reduced slice to everybody, theirs straight into place
+    _exchange([(bitmap[lo:hi], q) for q in others] if mine else [],
+              [(bitmap[sl[q][0]:sl[q][1]], q) for q in others if sl[q][1] > sl[q][0]])
+
+
+def exclusive_prefix_or(backend, bitmap, out, rank: int, world: int):
+    """out := OR of the bitmaps of all ranks < rank (zero on rank 0); `bitmap` is left as it was.  Slice q of every rank is collected on
+    rank q, which ORs them up in rank order and sends the running value BEFORE rank r's contribution back to rank r."""
+    nbytes = bitmap.numel()
+    if world == 1:
+        out.zero_()
+        return
+    sl = _slices(nbytes, world)
+    lo, hi = sl[rank]
+    mine = hi - lo
+    others = [q for q in range(world) if q != rank]
+    stage = backend.scratch(max(mine, 16) * world, tag="px_stage")      # slice `rank` of every rank, in rank order
+    pref = backend.scratch(max(mine, 16) * world, tag="px_prefix")      # what goes back to rank r: OR over ranks < r of that slice
+    backend.fence()
+    if mine:
+        stage[rank * mine:(rank + 1) * mine].copy_(bitmap[lo:hi])
+    _exchange([(bitmap[sl[q][0]:sl[q][1]], q) for q in others if sl[q][1] > sl[q][0]],
+              [(stage[q * mine:(q + 1) * mine], q) for q in others] if mine else [])
+    if mine:
+        pref[:mine].zero_()
+        for r in range(1, world):                                        # running OR: pref[r] = pref[r-1] | stage[r-1]
+            pref[r * mine:(r + 1) * mine].copy_(pref[(r - 1) * mine:r * mine])
+            backend.fence()
+            backend.or_tensor(pref[r * mine:(r + 1) * mine], stage[(r - 1) * mine:r * mine])
+            backend.fence()
+    # rank 0's prefix is empty: nothing is sent to it, it zero-fills
+    sends = [(pref[q * mine:(q + 1) * mine], q) for q in others if q != 0] if mine else []
+    recvs = [(out[sl[q][0]:sl[q][1]], q) for q in others if sl[q][1] > sl[q][0]] if rank != 0 else []
+    _exchange(sends, recvs)
+    if rank == 0:
+        out.zero_()
+    elif mine:
+        out[lo:hi].copy_(pref[rank * mine:(rank + 1) * mine])
+    backend.fence()
+
+
 def load_sharded_fixup(backend, batches, rank: int, world: int):
-    """own shard alone (first-set times kept)  ->  all-gather of bloo1  ->  prefix = OR of the lower ranks' bloo1  ->  fix-up:
+    """own shard alone (first-set times kept)  ->  prefix = OR of the lower ranks' bloo1 (exclusive prefix-OR by slices)  ->  fix-up:
     an occurrence the local pass kept out of bloo2 goes there iff each of its bits is in the prefix or was set locally before it
     ->  bloo2 := OR over ranks.  Exact for the same reason as the presence protocol: what the sequential run has in
     bloo1 when it reaches shard r IS that prefix, and within the shard "set before t" is what the first-set times say."""
     stats = backend.load(batches, keep_carry=False, shard_times=True)
     b1 = backend.bloom_tensor(L.BLOO1)
-    nbytes = b1.numel()
-    gathered = backend.scratch(world * nbytes)
-    backend.fence()
-    _all_gather(gathered, b1)
-    backend.fence()
+    prefix = backend.scratch(b1.numel(), tag="prefix")
+    exclusive_prefix_or(backend, b1, prefix, rank, world)
     if rank > 0:
-        prefix = backend.scratch(nbytes, tag="prefix")
-        prefix.zero_()
-        backend.fence()
-        for q in range(rank):                                  # exclusive prefix-OR
-            backend.or_tensor(prefix, gathered[q * nbytes:(q + 1) * nbytes])
         stats = backend.load_fixup(prefix)
-    b2 = backend.bloom_tensor(L.BLOO2)
-    backend.fence()
-    _all_gather(gathered, b2)
-    backend.fence()
-    for q in range(world):                                     # OR-allreduce
-        if q != rank:
-            backend.or_into(L.BLOO2, gathered[q * nbytes:(q + 1) * nbytes])
+    or_allreduce(backend, backend.bloom_tensor(L.BLOO2), rank, world)
     backend.fence()
     return stats
 
 
 def load_sharded_presence(backend, batches, rank: int, world: int):
-    """presence bitmap of the shard  ->  all-gather  ->  carried-in bloo1 of rank r = OR of the bitmaps of ranks < r  ->  ordered load
-    of the shard  ->  bloo2 := OR over ranks"""
+    """presence bitmap of the shard  ->  exclusive prefix-OR over ranks = carried-in bloo1 of rank r  ->  ordered load of the shard  ->
+    bloo2 := OR over ranks"""
     backend.clear_filters()
     for b in batches:
         backend.presence(b)
     b1 = backend.bloom_tensor(L.BLOO1)
-    nbytes = b1.numel()
-    gathered = backend.scratch(world * nbytes)
-    backend.fence()
-    _all_gather(gathered, b1)
-    backend.fence()
-    b1.zero_()
-    backend.fence()
-    for q in range(rank):                                  # exclusive prefix-OR
-        backend.or_into(L.BLOO1, gathered[q * nbytes:(q + 1) * nbytes])
+    prefix = backend.scratch(b1.numel(), tag="prefix")
+    exclusive_prefix_or(backend, b1, prefix, rank, world)
+    b1.copy_(prefix)
     stats = backend.load(batches, keep_carry=True)
-    b2 = backend.bloom_tensor(L.BLOO2)
-    backend.fence()
-    _all_gather(gathered, b2)
-    backend.fence()
-    for q in range(world):                                 # OR-allreduce
-        if q != rank:
-            backend.or_into(L.BLOO2, gathered[q * nbytes:(q + 1) * nbytes])
+    or_allreduce(backend, backend.bloom_tensor(L.BLOO2), rank, world)
     backend.fence()
     return stats
 
@@ -271,13 +336,19 @@ class _DevView:
 
 
 class GpuShard:
-    """The product backend: one api.Context on one MI355X."""
+    """The product backend: one api.Context on one MI355X.  The context should run on torch's current stream (api.Context(stream=
+    torch.cuda.current_stream().cuda_stream), as bench.py creates it for N > 1): the library's kernels, the local OR steps and the
+    collectives torch orders with that stream then follow each other without the host waiting in between.  A context on a stream of its
+    own (stream_ordered=False) is fenced on the host around every exchange, as in round 1."""
 
-    def __init__(self, ctx, device):
+    def __init__(self, ctx, device, stream_ordered=None):
         self.ctx, self.device = ctx, device
         self._scratch = {}
+        self.stream_ordered = bool(getattr(ctx, "on_torch_stream", False)) if stream_ordered is None else stream_ordered
 
     def fence(self):
+        if self.stream_ordered:
+            return
         self.ctx.synchronize()
         torch.cuda.synchronize(self.device)
 

@@ -95,8 +95,54 @@ static int stage3_kat(int argc, char** argv) {
     return 0;
 }
 
+/* ref_kat neighbors <bloom file> <bloom size request> <n_hash> <k> <j> <junctions file> <max read length>: the reference's own
+ * JunctionMap::findNeighbor (utils/JunctionMap.cpp:231-412) from every junction of a reloaded map along every extension a contig would be
+ * built on, on the STATIC map (buildContigGraph removes junctions as it goes; the walk itself is what is pinned here).  One JSON line per
+ * call: start k-mer, index, then the result's k-mer, isNode, index, distance and contig length.  The reference's asserts stay armed: a call
+ * that trips one (a filter false positive off the real sequence) is reported as "abort" instead of ending the harness. */
+#include <csetjmp>
+#include <csignal>
+#include <algorithm>
+static jmp_buf g_abort_jmp;
+static void on_abort(int) { longjmp(g_abort_jmp, 1); }
+
+static int neighbors_kat(int argc, char** argv) {
+    if (argc < 9) return 2;
+    const int k = atoi(argv[5]), j = atoi(argv[6]);
+    setSizeKmer(k);
+    Bloom bloom((uint64_t)atoll(argv[3]), k);
+    bloom.set_number_of_hash_func(atoi(argv[4]));
+    bloom.load(argv[2]);
+    JChecker jc(j, &bloom);
+    JunctionMap jm(&bloom, &jc, atoi(argv[8]));
+    jm.buildFromFile(argv[7]);
+    std::vector<kmer_type> keys;
+    for (auto& kv : jm.junctionMap) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    signal(SIGABRT, on_abort);
+    FILE* devnull = fopen("/dev/null", "w");
+    for (kmer_type key : keys) {
+        Junction junc = jm.junctionMap[key];
+        for (int i = 0; i < 5; i++) {
+            if (junc.dist[i] == 0 || (i < 4 && junc.getCoverage(i) == 0)) continue;
+            fflush(stdout);
+            if (setjmp(g_abort_jmp)) {
+                signal(SIGABRT, on_abort);
+                printf("{\"kat\":\"neighbor\",\"start\":\"%llx\",\"index\":%d,\"abort\":1}\n", (unsigned long long)key, i);
+                continue;
+            }
+            BfSearchResult r = jm.findNeighbor(junc, key, i);
+            printf("{\"kat\":\"neighbor\",\"start\":\"%llx\",\"index\":%d,\"kmer\":\"%llx\",\"node\":%d,\"rindex\":%d,\"dist\":%d,\"len\":%d}\n",
+                   (unsigned long long)key, i, (unsigned long long)r.kmer, r.isNode ? 1 : 0, r.index, r.distance, (int)r.contig.size());
+        }
+    }
+    fclose(devnull);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "stage3") return stage3_kat(argc, argv);
+    if (argc > 1 && std::string(argv[1]) == "neighbors") return neighbors_kat(argc, argv);
     /* ---- codec + hash KAT at k=31, tai=2^29 ---- */
     {
         setSizeKmer(31);

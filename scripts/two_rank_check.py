@@ -29,7 +29,13 @@ tai, nh = api.load_filter_shape(10 * n * world, 2 * n * world)
 genome = bench.make_genome(2 * n * world, 2, dev)
 reads = bench.make_reads(genome, n, Lr, 0.01, 1000 + rank, dev)
 batches = bench.device_batches(reads, 1_000_000)
-ctx = api.Context(k, tai, nh, device=0)
+if os.environ.get("FAUCET_TORCH_STREAM", "0") == "1":      # the library on torch's stream, no host fences (what bench.py does for N > 1)
+    ts = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(ts)
+    ctx = api.Context(k, tai, nh, device=0, stream=ts.cuda_stream)
+    ctx.on_torch_stream = True
+else:
+    ctx = api.Context(k, tai, nh, device=0)
 shard = sharded.GpuShard(ctx, dev)
 lst = sharded.load_sharded(shard, batches, rank, world)
 bloo2 = ctx.bloom_download(L.BLOO2)

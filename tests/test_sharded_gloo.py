@@ -190,3 +190,49 @@ def test_sharded_protocol_matches_single_process(name, world, protocol, tmp_path
     st = np.load(tmp_path / "stats.npy")
     assert list(st) == [cn["nb_processed"], cn["nb_skipped"], cn["nb_jcheck_kmer"], cn["nb_no_juncs"], cn["reads_no_errors"],
                         cn["scan_reads_processed"]]
+
+
+class _CpuOr:
+    """the two backend methods the bitmap exchanges use, on CPU tensors"""
+
+    def fence(self):
+        pass
+
+    def scratch(self, nbytes, tag="gather"):
+        return torch.full((nbytes,), 0xA5, dtype=torch.uint8)       # garbage on purpose: the exchanges must initialise what they read
+
+    def or_tensor(self, dst, src):
+        dst.numpy()[:] |= src.numpy()
+
+
+def _exchange_worker(rank, world, port, nbytes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    maps = [np.random.default_rng(100 + r).integers(0, 256, size=nbytes, dtype=np.uint8) & np.random.default_rng(200 + r).integers(0, 256, size=nbytes, dtype=np.uint8)
+            for r in range(world)]
+    be = _CpuOr()
+    mine = torch.from_numpy(maps[rank].copy())
+    prefix = torch.full((nbytes,), 0x5A, dtype=torch.uint8)
+    sharded.exclusive_prefix_or(be, mine, prefix, rank, world)
+    want = np.zeros(nbytes, dtype=np.uint8)
+    for r in range(rank):
+        want |= maps[r]
+    ok = np.array_equal(prefix.numpy(), want) and np.array_equal(mine.numpy(), maps[rank])      # the input is left alone
+    sharded.or_allreduce(be, mine, rank, world)
+    total = np.zeros(nbytes, dtype=np.uint8)
+    for r in range(world):
+        total |= maps[r]
+    ok = ok and np.array_equal(mine.numpy(), total)
+    with open(os.path.join(out_dir, f"ok_{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nbytes", [(2, 4096), (3, 4096), (3, 64), (4, 16), (3, 1 << 20)])
+def test_bitmap_exchanges_by_slices(world, nbytes, tmp_path):
+    """exclusive prefix-OR and OR-allreduce of the filters' bit arrays as sharded.py runs them: slices collected per rank (grouped
+    send/recv), reduced locally, handed back / gathered -- including slice counts that do not divide the bitmap and ranks whose slice is empty"""
+    mp.spawn(_exchange_worker, args=(world, _free_port(), nbytes, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok_{r}").read_text() == "1" for r in range(world))
