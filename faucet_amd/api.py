@@ -357,6 +357,12 @@ class Context:
         self._c(self.lib.fgpu_diag_load_split(self.h, C.byref(a), C.byref(b)))
         return {"in_mark": int(a.value), "pending": int(b.value)}
 
+    def diag_binned_probes(self, table_bytes: int, n_probes: int, slice_bytes: int = 4 << 20, iters: int = 3) -> dict:
+        """direct random bit probes vs probes binned by filter slice (NS1's query-side blocking), same addresses; rates in probes/s"""
+        v = [C.c_double(0) for _ in range(4)]
+        self._c(self.lib.fgpu_diag_binned_probes(self.h, table_bytes, n_probes, slice_bytes, iters, *[C.byref(x) for x in v]))
+        return dict(zip(("direct_per_s", "binned_per_s", "bin_ms", "probe_ms"), [float(x.value) for x in v]))
+
     def diag_device_attr(self) -> dict:
         v = [C.c_int32(0) for _ in range(4)]
         self._c(self.lib.fgpu_diag_device_attr(self.h, *[C.byref(x) for x in v]))

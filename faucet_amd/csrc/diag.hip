@@ -44,7 +44,138 @@ __global__ void __launch_bounds__(256) k_diag_random(uint32_t* __restrict__ tabl
     if (MODE == 0 && acc == 0x12345678u) sink[0] = acc;   // keeps the loads alive
 }
 
+// ---- NS1 ("LDS-staged per-wave query buckets ... 128 B-coalesced Bloom access"), built and measured -------------------------------------
+// The filter's bit positions are the file format's, so the only blocking available is on the QUERY side: bin the probes by filter slice
+// (one slice = one XCD's 4 MiB L2), then probe slice by slice from workgroups that run on the XCD whose L2 holds the slice.
+//   k_diag_probe_direct   what every kernel of the path does today: address -> one random load -> answer bit (ballot, item order)
+//   k_diag_bin            4096 probes per block: slice histogram in LDS, ONE global reservation per (block, slice), records
+//                         {bit within slice, item} written to the slice's queue in block-contiguous runs
+//   k_diag_probe_binned   blocks b, b+8, b+16 ... (one XCD: workgroups are dealt round-robin over the 8 XCDs) serve the slices
+//                         s = b mod 8, +8, ...: queue records streamed, bits tested in the L2-resident slice, answers as ballot words in
+//                         QUEUE order (what a next, equally binned, level of a probe chain would consume)
+// fgpu_diag_binned_probes times both forms on the same probe addresses; scripts/binned_probe_ab.py adds the rocprofv3 counters.
+constexpr int DIAG_BIN_PER_THREAD = 16;
+constexpr int DIAG_MAX_SLICES = 512;
+
+__global__ void __launch_bounds__(256) k_diag_probe_direct(const uint32_t* __restrict__ table, uint64_t bit_mask, uint64_t n, uint64_t salt,
+                                                           uint64_t* __restrict__ answers) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {   // n is a multiple of 64
+        const uint64_t a = diag_rand(i ^ salt) & bit_mask;
+        const bool hit = (table[a >> 5] >> (a & 31)) & 1u;
+        const uint64_t m = __ballot(hit);
+        if (fd_lane() == 0) answers[i >> 6] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_diag_bin(uint64_t bit_mask, int slice_shift, int n_slices, uint64_t n, uint64_t salt, uint64_t cap,
+                                                  unsigned long long* __restrict__ qcount, uint2* __restrict__ queue) {
+    __shared__ unsigned s_cnt[DIAG_MAX_SLICES], s_base[DIAG_MAX_SLICES];
+    for (int q = threadIdx.x; q < n_slices; q += 256) s_cnt[q] = 0;
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * 256 * DIAG_BIN_PER_THREAD;
+    uint32_t addr[DIAG_BIN_PER_THREAD];
+    unsigned rank[DIAG_BIN_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < DIAG_BIN_PER_THREAD; u++) {
+        const uint64_t i = first + (uint64_t)u * 256 + threadIdx.x;
+        addr[u] = (uint32_t)(diag_rand(i ^ salt) & bit_mask);
+        rank[u] = i < n ? atomicAdd(&s_cnt[addr[u] >> slice_shift], 1u) : 0u;      // LDS: position within this block's run of the slice
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_slices; q += 256) s_base[q] = s_cnt[q] ? (unsigned)atomicAdd(&qcount[q], (unsigned long long)s_cnt[q]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DIAG_BIN_PER_THREAD; u++) {
+        const uint64_t i = first + (uint64_t)u * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t sl = addr[u] >> slice_shift;
+        const uint64_t pos = (uint64_t)s_base[sl] + rank[u];
+        if (pos < cap) queue[(uint64_t)sl * cap + pos] = make_uint2(addr[u], (uint32_t)i);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_diag_probe_binned(const uint32_t* __restrict__ table, int n_slices, uint64_t cap,
+                                                           const unsigned long long* __restrict__ qcount, const uint2* __restrict__ queue,
+                                                           uint64_t* __restrict__ answers) {
+    const unsigned xcd = blockIdx.x & 7u, lane_block = blockIdx.x >> 3, blocks_per_xcd = gridDim.x >> 3;
+    for (int sl = (int)xcd; sl < n_slices; sl += 8) {
+        uint64_t cnt = qcount[sl];
+        if (cnt > cap) cnt = cap;
+        const uint64_t padded = (cnt + 63) & ~63ULL;
+        const uint2* q = queue + (uint64_t)sl * cap;
+        for (uint64_t i = (uint64_t)lane_block * 256 + threadIdx.x; i < padded; i += (uint64_t)blocks_per_xcd * 256) {
+            bool hit = false;
+            if (i < cnt) {
+                const uint2 r = q[i];
+                hit = (table[r.x >> 5] >> (r.x & 31)) & 1u;
+            }
+            const uint64_t m = __ballot(hit);
+            if (fd_lane() == 0) answers[((uint64_t)sl * cap + i) >> 6] = m;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_probes, uint64_t slice_bytes, int iters,
+                                       double* direct_per_s, double* binned_per_s, double* bin_ms, double* probe_ms) {
+    if (!ctx || !direct_per_s || !binned_per_s || !bin_ms || !probe_ms || iters < 1 || table_bytes < (1u << 16) || (table_bytes & (table_bytes - 1)) ||
+        table_bytes > (1ULL << 29) || (slice_bytes & (slice_bytes - 1)) || slice_bytes < 4096 || slice_bytes > table_bytes ||
+        table_bytes / slice_bytes > DIAG_MAX_SLICES || n_probes < (1u << 16))
+        return FGPU_ERR_ARG;
+    n_probes &= ~(uint64_t)(256 * DIAG_BIN_PER_THREAD - 1);
+    const int n_slices = (int)(table_bytes / slice_bytes);
+    int slice_shift = 0;
+    while ((1ULL << slice_shift) < slice_bytes * 8) slice_shift++;
+    const uint64_t cap = ((n_probes / n_slices + n_probes / n_slices / 8 + 65536) + 63) & ~63ULL;   // uniform random addresses: 12 % head room
+    uint32_t* table = nullptr;
+    uint2* queue = nullptr;
+    uint64_t* answers = nullptr;
+    unsigned long long* qcount = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = FGPU_OK;
+    if (hipMalloc(&table, table_bytes) != hipSuccess || hipMalloc(&queue, (uint64_t)n_slices * cap * 8) != hipSuccess ||
+        hipMalloc(&answers, ((uint64_t)n_slices * cap + n_probes) / 8 + 64) != hipSuccess || hipMalloc(&qcount, DIAG_MAX_SLICES * 8) != hipSuccess) {
+        ctx->err = "diag: out of device memory";
+        rc = FGPU_ERR_NOMEM;
+    }
+    if (!rc) {
+        for (auto& e : ev) hipEventCreate(&e);
+        hipMemsetAsync(table, 0x5A, table_bytes, ctx->stream);          // half of the bits set, like a filter at work
+        const unsigned grid = FGPU_GRID_BLOCKS, bin_grid = (unsigned)(n_probes / (256 * DIAG_BIN_PER_THREAD));
+        float direct = 0, bin = 0, probe = 0;
+        for (int i = -1; i < iters; i++) {                               // one untimed round first
+            const uint64_t salt = 0x5851F42D4C957F2DULL * (uint64_t)(i + 2);
+            hipEventRecord(ev[0], ctx->stream);
+            hipLaunchKernelGGL(k_diag_probe_direct, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)table, table_bytes * 8 - 1, n_probes, salt, answers);
+            hipEventRecord(ev[1], ctx->stream);
+            hipMemsetAsync(qcount, 0, DIAG_MAX_SLICES * 8, ctx->stream);
+            hipLaunchKernelGGL(k_diag_bin, dim3(bin_grid), dim3(256), 0, ctx->stream, table_bytes * 8 - 1, slice_shift, n_slices, n_probes, salt, cap, qcount, queue);
+            hipEventRecord(ev[2], ctx->stream);
+            hipLaunchKernelGGL(k_diag_probe_binned, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)table, n_slices, cap, (const unsigned long long*)qcount,
+                               (const uint2*)queue, answers + n_probes / 64);
+            hipEventRecord(ev[3], ctx->stream);
+            if (hipEventSynchronize(ev[3]) != hipSuccess) { rc = FGPU_ERR_HIP; ctx->err = "diag: binned probes failed"; break; }
+            if (i >= 0) {
+                float a = 0, b = 0, c = 0;
+                hipEventElapsedTime(&a, ev[0], ev[1]);
+                hipEventElapsedTime(&b, ev[1], ev[2]);
+                hipEventElapsedTime(&c, ev[2], ev[3]);
+                direct += a; bin += b; probe += c;
+            }
+        }
+        if (!rc) {
+            *direct_per_s = (double)n_probes * iters / (direct * 1e-3);
+            *binned_per_s = (double)n_probes * iters / ((bin + probe) * 1e-3);
+            *bin_ms = bin / iters;
+            *probe_ms = probe / iters;
+        }
+        for (auto& e : ev) hipEventDestroy(e);
+    }
+    hipFree(table); hipFree(queue); hipFree(answers); hipFree(qcount);
+    return rc;
+}
 
 extern "C" int fgpu_diag_stream_copy(fgpu_ctx* ctx, uint64_t bytes, int iters, double* gb_per_s) {
     if (!ctx || !gb_per_s || bytes < 4096 || iters < 1) return FGPU_ERR_ARG;

@@ -283,6 +283,12 @@ int fgpu_diag_stream_copy(fgpu_ctx* ctx, uint64_t bytes, int iters, double* gb_p
 /* n_access independent random 32-bit accesses into a table of table_bytes (power of two) per iteration.
  * mode 0 = load, 1 = atomicMin (the load pass' first-set times), 2 = test-then-atomicOr (Bloom::add). */
 int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_access, int mode, int iters, double* access_per_s);
+/* NS1's query-side blocking, measured: n_probes single-bit probes at pseudo-random positions of a table of table_bytes (power of two, <= 512 MiB),
+ * once directly (one random load each, what the path's kernels do) and once binned by slice of slice_bytes (LDS-staged buckets per 4096 probes,
+ * one queue per slice, slices probed by the workgroups of the XCD whose L2 then holds them).  Rates in probes/s; the binned one covers both of
+ * its kernels, whose mean times come back separately. */
+int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_probes, uint64_t slice_bytes, int iters, double* direct_per_s,
+                            double* binned_per_s, double* bin_ms, double* probe_ms);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */
