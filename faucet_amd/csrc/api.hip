@@ -460,9 +460,12 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_pieces_seen = 0;
     ctx->scan_piece_base = 0;
     ctx->scan_imported = 0;
+    ctx->delta_next = 0;
     ctx->hint_in_table = false;
+    // calibrated upwards window by window; a context that has scanned before starts a quarter below where that scan ended up
+    const uint64_t start_span = std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4);
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
-                                                 : std::min<uint64_t>(1ULL << 18, ctx->max_span);   // calibrated upwards window by window
+                                                 : std::min<uint64_t>(start_span, ctx->max_span);
     ctx->calib_left = 16;
     ctx->calib_f = ctx->calib_p = 0;
     ctx->adapt_followers = 0;
@@ -489,7 +492,8 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
         if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
-        else if (f * 4 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN)) ctx->window_span *= 2;
+        else if (f * 3 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN))
+            ctx->window_span = std::min<uint64_t>(ctx->window_span * 4, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
         else if (f * 16 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;   // thin coverage per window: see FGPU_MAX_SPAN
     }
     ctx->adapt_followers = ctx->counters_host->followers;
@@ -499,7 +503,8 @@ static void adapt_window(fgpu_ctx* ctx) {
 static BatchBufs* acquire_batch(fgpu_ctx* ctx) {
     // FIFO over (at least) two BatchBufs, so that the one handed out was last walked two batches ago
     BatchBufs* b;
-    static const size_t depth = getenv("FGPU_SCAN_BUFFERS") ? (size_t)std::max(2, atoi(getenv("FGPU_SCAN_BUFFERS"))) : 2;
+    // (at most FGPU_DELTA_RING: a batch registers the created-key lists of the FGPU_DELTA_RING - 1 batches before it)
+    static const size_t depth = getenv("FGPU_SCAN_BUFFERS") ? (size_t)std::min(FGPU_DELTA_RING, std::max(2, atoi(getenv("FGPU_SCAN_BUFFERS")))) : 2;
     if (ctx->pool.size() >= depth) { b = ctx->pool.front(); ctx->pool.erase(ctx->pool.begin()); }
     else {
         b = new BatchBufs();
@@ -595,7 +600,9 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
             if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported))) break;
         }
         ctx->cur = b;
+        ctx->refresh_snapshot = true;
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
+        ctx->refresh_snapshot = false;
         ctx->walked_pieces += b->n_pieces;
         if (!rc) note_walked(ctx, b);
     }
@@ -638,6 +645,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     int rc = pull_counters(ctx);
     while (!rc && !ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());   // every walk has finished
     ctx->phase = 0;
+    if (!rc && !ctx->prm.walk_window_span && ctx->scan_windows > 8) ctx->settled_span = ctx->window_span;
     if (rc) return rc;
     const DevCounters& c = *ctx->counters_host;
     fgpu_scan_stats& s = ctx->scan_stats;

@@ -16,12 +16,13 @@
 // every per-position plane / code array carries this many padding words past ceil(T/64): kernels run
 // whole 256-thread blocks and funnel-read one word ahead
 #define FGPU_PADW 8
-// Scheduling windows of the ordered walk, in stream positions.  Up to FGPU_USUAL_SPAN a window grows while fewer than a quarter of its
-// pieces queue behind another piece of their cluster (50x data settles there: 2^25 and 2^26 measured no better on config 2).  Beyond, up
-// to FGPU_MAX_SPAN, only while fewer than 1/16 do: reads of a large genome -- 10 M reads of 160 Mb, the per-rank shape of an 8-GPU run --
-// barely meet inside a window, and there 2^26 takes the walk stage from 28.8 to 25.9 ms per 10 M reads.  The window tables are sized for
-// FGPU_MAX_SPAN (3 GiB).
-#define FGPU_USUAL_SPAN (1ULL << 24)
+// Scheduling windows of the ordered walk, in stream positions.  A window grows (x4, up to FGPU_MAX_SPAN) while fewer than a third of its
+// pieces queue behind another piece of their cluster and is halved above a half.  Since the walk takes its in-map bits from the batch's
+// snapshot planes and registers the keys created since then per window (round 2), a window's fixed costs -- the delta registrations, five
+// launches -- weigh more than the longer clusters of a larger window: config 2 measured 131.3 / 127.0 / 126.0 ms per step at 2^24 / 2^25 /
+// 2^26 positions (16 % / 27 % / 36 % of the pieces queueing; round 1's look-up kernel per window had its optimum at 2^24).  The window
+// tables are sized for FGPU_MAX_SPAN (2 GiB).
+#define FGPU_USUAL_SPAN (1ULL << 26)
 #define FGPU_MAX_SPAN (1ULL << 26)
 
 // A growable device buffer (hipMalloc'd; freed with the context).
@@ -43,6 +44,7 @@ struct BatchBufs {
     DevBuf lk;                     // walk: positions whose k-mer is a registered candidate of the current window
     DevBuf nF, nB, need;           // lazy flags: in-map snapshot planes of the pure stage, positions whose flags get evaluated
     DevBuf kh;                     // uint32 per stream position: hash of the canonical k-mer (positions inside pieces; see jt_h32)
+    DevBuf cr;                     // walk: positions at which this batch's walk created a junction record
     DevBuf ps_prefix;              // exclusive prefix of popcount(ps) per 64-bit word (uint32)
     DevBuf pieces;                 // uint2 {start position, windows} per valid piece, in stream order
     // FGPU_FLAG_RECORD_STOPS: where the walk stopped (junction visits), for scanInputRead's return value
@@ -70,6 +72,14 @@ struct ResidentBatch {
     uint64_t T = 0, n_words = 0;
     uint32_t tb = 0;             // time base of the batch's first-set times (FGPU_LOAD_SHARD_TIMES: position within the pass)
 };
+
+// hashes of the junction keys one batch's walk created (k_delta_collect): what later batches register as the delta of their snapshot
+struct DeltaList {
+    DevBuf list, count;
+};
+// A batch's snapshot planes are made while up to FGPU_SCAN_BUFFERS - 1 earlier batches are still being walked: the lists of that many
+// batches back are registered (the ring holds one more: the list being filled)
+#define FGPU_DELTA_RING 4
 
 struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_scan_take_stops
     uint64_t seq;
@@ -160,6 +170,9 @@ struct fgpu_ctx {
     uint64_t wcap = 0;
     uint64_t* wkeys = nullptr;
     uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
+    DeltaList delta_ring[FGPU_DELTA_RING];
+    bool refresh_snapshot = false;   // the batch about to be walked was prepared ahead of its turn: its snapshot planes are made again first
+    uint64_t delta_next = 0;         // batches walked in this scan (index of the list the next one fills)
     uint32_t wt_epoch = 0;           // epoch of the window table's newest entries (1..255; 0 = table not initialised yet)
     // union-find / cluster scratch (per window)
     uint32_t wmax = 0;               // max pieces per window
@@ -171,6 +184,7 @@ struct fgpu_ctx {
     void* wdesc = nullptr;           // device WinDesc of the window in flight
     uint64_t window_span = 1ULL << 17;   // adaptive: stream positions per scheduling window
     uint64_t max_span = FGPU_MAX_SPAN;   // upper bound of window_span (sizes the window table)
+    uint64_t settled_span = 0;       // window_span at the end of the context's previous scan (0: none yet): where the next one starts from
     uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
     uint64_t scan_imported = 0;      // junction records imported from a previous shard
     bool hint_in_table = false;      // fgpu_scan_import_hint: the table holds a preview, not the state to walk on

@@ -11,8 +11,9 @@
 //      reach, and the middle k-mer where add_fake_junction plants a junction.
 // So two pieces can only interact if a candidate k-mer of one occurs (at any position) on the other.
 // Per scheduling window of W consecutive pieces:
-//   A  k_walk_lookup   every position: look its canonical k-mer up in the junction table (snapshot before the
-//                      window) -> in-map bit planes; register candidate k-mers in a small window table
+//   A  k_walk_register candidate positions (in the map as of the batch's snapshot planes nF/nB, flagged, fake-junction or spacer
+//                      positions) register their k-mer's hash in a small window table; k_walk_delta adds the keys created since
+//                      that snapshot was taken (creation planes of the batches walked since, and of this batch's earlier windows)
 //   B  k_walk_link     every position: probe the window table; a hit unions the piece with the candidate's owner
 //   C  k_walk_cluster  flatten the union-find; list each cluster's members in ascending piece order
 //   D  k_walk          one thread per cluster replays its pieces IN ORDER against the live table; clusters are
@@ -95,6 +96,7 @@ struct Planes {
     const uint64_t* need;
     unsigned long long *sF, *sB;   // junction visits (FGPU_FLAG_RECORD_STOPS), else nullptr
     const uint32_t* kh;            // 32-bit hash of the canonical k-mer of every position inside a piece (k_need_lookup)
+    unsigned long long* cr;        // positions at which this batch's walk created a junction record (either facing): the delta of later windows
 };
 
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
@@ -192,6 +194,7 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 constexpr int W_OWNER_BITS = 24;
 constexpr uint64_t W_OWNER_MASK = (1ULL << W_OWNER_BITS) - 1;
 constexpr uint64_t W_EPOCH_MASK = 0xFFULL << 56;
+constexpr uint32_t W_NO_OWNER = (uint32_t)W_OWNER_MASK;   // a key registered by k_walk_delta: no piece of the window owns it yet
 __device__ __forceinline__ uint32_t wt_filter_bit(uint32_t h32) { return (h32 * 0x85EBCA6Bu) >> (32 - WBITS_LOG2); }
 
 __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, uint32_t h32, uint32_t piece, DevCounters* cnt) {
@@ -209,9 +212,10 @@ __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, 
             v = old;                                            // somebody of this window was faster
         }
         if ((v & W_EPOCH_MASK) == wt.epoch && (uint32_t)(v >> W_OWNER_BITS) == h32) {
+            if (piece == W_NO_OWNER) return;                    // a delta key that is there already
             const unsigned long long prev = atomicMin((unsigned long long*)&wt.keys[s], mine);
             const uint32_t prev_owner = (uint32_t)(prev & W_OWNER_MASK);
-            if (prev_owner != piece) uf_union(parent, piece, prev_owner);
+            if (prev_owner != piece && prev_owner != W_NO_OWNER) uf_union(parent, piece, prev_owner);
             return;
         }
         s = (s + 1) & wt.mask;
@@ -219,14 +223,14 @@ __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, 
     atomicOr(&cnt->error_flags, 2ULL);
 }
 
-__device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint32_t h32) {
+__device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint32_t h32, uint64_t& slot) {
     const uint32_t b = wt_filter_bit(h32);
     if (!((wt.bits[b >> 5] >> (b & 31)) & 1u)) return U_INF;
     uint64_t s = (uint64_t)h32 & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
         const uint64_t w = wt.keys[s];
         if ((w & W_EPOCH_MASK) != wt.epoch) return U_INF;
-        if ((uint32_t)(w >> W_OWNER_BITS) == h32) return (uint32_t)(w & W_OWNER_MASK);
+        if ((uint32_t)(w >> W_OWNER_BITS) == h32) { slot = s; return (uint32_t)(w & W_OWNER_MASK); }
         s = (s + 1) & wt.mask;
     }
     return U_INF;
@@ -267,63 +271,118 @@ __device__ __forceinline__ bool piece_in_window(const Planes& pl, const WinDesc&
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_walk_lookup(Planes pl, FdParams fp, JTable jt, WTable wt, uint32_t* parent,
-                                                     uint64_t lo, uint64_t hi, uint64_t pos_end, DevCounters* cnt, int parity) {
+// In-map bits are NOT looked up per window any more (that was 0.46e9 filter probes and ~5e7 table look-ups per step on the walk's
+// critical queue: k_walk_lookup 12.6 ms alone, 24.8 ms beside the pure stage): the planes nF / nB that the pure stage's k_need_lookup
+// made for the whole batch are the walk's snapshot.  They are STALE by the time a window is walked -- taken while the previous batch was
+// still being walked -- so every key created since then is registered as a candidate as well (k_walk_delta): its positions become lk
+// positions, and at lk positions the walk asks the LIVE table (created_bits).  in-map(K) = K in the snapshot, or K created since =
+// K registered, looked up live by the one cluster that holds every piece K occurs on: exact.
+// ONE launch does all registering of a window; the grid has three parts:
+//   blocks [0, word_blocks)              one thread per 64-position word of the window: the few candidate bits of the word (in the map as of
+//                                        the snapshot, or testForJunction fired) register; a thread per POSITION -- what the look-up kernel
+//                                        of earlier versions was -- spent its time on the dependent loads of 65 k tiny blocks
+//   the next piece_blocks                one thread per piece: add_fake_junction's k-mer (ReadScanner.cpp:94) and, in pieces long enough, the
+//                                        positions the spacer rule can reach (:72)
+//   the last delta_blocks                the delta: keys created since the snapshot planes were made -- lists of the batches walked since
+//                                        (k_delta_collect), and this batch's own creation plane as far as earlier windows' pieces reach
+struct DeltaSrc {
+    const uint32_t* list[FGPU_DELTA_RING - 1];
+    const unsigned long long* count[FGPU_DELTA_RING - 1];
+    const unsigned long long* cr;   // own creation plane, words [0, cr_words)
+    uint64_t cr_words;
+};
+
+__global__ void __launch_bounds__(256) k_walk_register(Planes pl, FdParams fp, WTable wt, uint32_t* parent, uint64_t lo, uint64_t hi,
+                                                       uint64_t pos_end, DevCounters* cnt, unsigned word_blocks, unsigned piece_blocks, DeltaSrc ds) {
     const WinDesc wd = make_window(pl, lo, hi);
-    uint64_t p = (wd.lo & ~63ULL) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool inF = false, inB = false;
-    uint32_t li;
-    uint2 pc;
-    if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL) && piece_in_window(pl, wd, p, li, pc)) {
-        const uint32_t h32 = pl.kh[p];
-        // most k-mers own no junction: one bit of a small (cache-resident) filter answers that without touching the table --
-        // or the k-mer: it is only extracted where the filter says "maybe"
-        const uint64_t hb = jt_filter_bit_h(jt, h32);
-        uint32_t present = 0;
-        if ((jt.filter[hb >> 5] >> (hb & 31)) & 1u) {
-            const uint64_t km = fd_kmer_at(pl.codes, p, fp.k);
-            const uint64_t rc = fd_revcomp(km, fp.k);
-            const uint64_t canon = km < rc ? km : rc;
-            present = jt_present_snapshot(jt, canon);
-            inF = (present >> (km == canon ? 0 : 1)) & 1u;   // forward-facing key = the k-mer itself
-            inB = (present >> (rc == canon ? 0 : 1)) & 1u;   // backward-facing key = its reverse complement
+    if (blockIdx.x < word_blocks) {
+        const uint64_t w = (wd.lo >> 6) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (w * 64 >= pos_end) return;
+        unsigned long long m = pl.pm[w] & (pl.inF[w] | pl.inB[w] | pl.ff[w] | pl.fb[w]);
+        if (w == (wd.lo >> 6)) m &= ~0ULL << (wd.lo & 63);
+        if ((w + 1) * 64 > pos_end) m &= (1ULL << (pos_end & 63)) - 1;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint64_t p = w * 64 + (uint64_t)b;
+            uint32_t li;
+            uint2 pc;
+            if (piece_in_window(pl, wd, p, li, pc)) wt_register(wt, parent, pl.kh[p], li, cnt);
         }
-        uint32_t q = (uint32_t)(p - pc.x);
-        uint32_t len = pc.y + fp.k - 1;
-        bool cand = present != 0;
-        cand |= ((pl.ff[p >> 6] | pl.fb[p >> 6]) >> (p & 63)) & 1ULL;
-        cand |= q == len / 2 - (uint32_t)fp.k / 2;                       // add_fake_junction's k-mer (ReadScanner.cpp:94)
-        cand |= 2 * q + 1 >= (uint32_t)(2 * fp.max_spacer - 1);           // spacer rule can fire here (ReadScanner.cpp:72)
-        if (cand) wt_register(wt, parent, h32, li, cnt);
-    }
-    uint64_t mF = __ballot(inF), mB = __ballot(inB);
-    if (fd_lane() == 0) {
-        pl.inF[p >> 6] = mF;
-        pl.inB[p >> 6] = mB;
+    } else if (blockIdx.x < word_blocks + piece_blocks) {
+        const uint32_t li = (blockIdx.x - word_blocks) * blockDim.x + threadIdx.x;
+        if (li >= wd.n) return;
+        const uint2 pc = pl.pieces[wd.first_piece + li];
+        const uint32_t len = pc.y + (uint32_t)fp.k - 1;
+        wt_register(wt, parent, pl.kh[pc.x + (len / 2 - (uint32_t)fp.k / 2)], li, cnt);
+        for (uint32_t q = (uint32_t)fp.max_spacer - 1; q < pc.y; q++) wt_register(wt, parent, pl.kh[pc.x + q], li, cnt);   // 2q + 1 >= 2 spacer - 1
+    } else {
+        const uint64_t t = (uint64_t)(blockIdx.x - word_blocks - piece_blocks) * blockDim.x + threadIdx.x;
+        const uint64_t stride = (uint64_t)(gridDim.x - word_blocks - piece_blocks) * blockDim.x;
+        for (int r = 0; r < FGPU_DELTA_RING - 1; r++) {
+            if (!ds.list[r]) continue;
+            const uint64_t n = *ds.count[r];
+            for (uint64_t i = t; i < n; i += stride) wt_register(wt, nullptr, ds.list[r][i], W_NO_OWNER, cnt);
+        }
+        for (uint64_t w = t; w < ds.cr_words; w += stride) {
+            unsigned long long m = ds.cr[w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                wt_register(wt, nullptr, pl.kh[w * 64 + (uint64_t)b], W_NO_OWNER, cnt);
+            }
+        }
     }
 }
 
 // ---- B: link every piece to the owners of the candidate k-mers that occur on it ---------------------
 __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTable wt, uint32_t* parent, uint64_t lo, uint64_t hi,
                                                    uint64_t pos_end) {
+    // a fixed grid strides over the window, 1024 positions per block and round: the loads of four positions per thread (hash, then
+    // filter word) are in flight together -- one position per thread left this kernel waiting on two dependent loads per 256-thread block
     const WinDesc wd = make_window(pl, lo, hi);
-    uint64_t p = (wd.lo & ~63ULL) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool hit = false;
-    if (p >= wd.lo && p < pos_end && ((pl.pm[p >> 6] >> (p & 63)) & 1ULL)) {
-        uint32_t owner = wt_owner(wt, pl.kh[p]);
-        if (owner != U_INF) {
-            uint32_t li;
-            uint2 pc;
-            if (piece_in_window(pl, wd, p, li, pc)) {
-                hit = true;
-                if (owner != li) uf_union(parent, li, owner);
+    const uint64_t base0 = wd.lo & ~63ULL;
+    constexpr int U = 4;
+    for (uint64_t base = base0 + (uint64_t)blockIdx.x * (256 * U); base < pos_end; base += (uint64_t)gridDim.x * (256 * U)) {
+        uint64_t p[U];
+        uint32_t h[U], fw[U];
+        bool act[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            p[u] = base + (uint64_t)u * 256 + threadIdx.x;
+            act[u] = p[u] >= wd.lo && p[u] < pos_end && ((pl.pm[p[u] >> 6] >> (p[u] & 63)) & 1ULL);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) h[u] = act[u] ? pl.kh[p[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t b = wt_filter_bit(h[u]);
+            fw[u] = act[u] ? ((wt.bits[b >> 5] >> (b & 31)) & 1u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bool hit = false;
+            if (fw[u]) {
+                uint64_t slot = 0;
+                uint32_t owner = wt_owner(wt, h[u], slot);
+                if (owner != U_INF) {
+                    uint32_t li;
+                    uint2 pc;
+                    if (piece_in_window(pl, wd, p[u], li, pc)) {
+                        hit = true;
+                        if (owner == W_NO_OWNER) {   // a key created since the snapshot: the first piece it occurs on becomes its owner, the others join it
+                            const unsigned long long mine = (unsigned long long)(wt.epoch | ((uint64_t)h[u] << W_OWNER_BITS) | (uint64_t)li);
+                            owner = (uint32_t)(atomicMin((unsigned long long*)&wt.keys[slot], mine) & W_OWNER_MASK);
+                        }
+                        if (owner != li && owner != W_NO_OWNER) uf_union(parent, li, owner);
+                    }
+                }
             }
+            // lk plane: the positions that hold a registered k-mer -- the only ones at which the walk has to ask the live table
+            const uint64_t m = __ballot(hit);
+            if (fd_lane() == 0 && p[u] < ((pos_end + 63) & ~63ULL)) pl.lk[p[u] >> 6] = m;
         }
     }
-    // lk plane: the only positions where a key created DURING this window can sit (a key is only ever created at a
-    // registered candidate), so the walk compares its created-key list at these few positions instead of all of them
-    uint64_t m = __ballot(hit);
-    if (fd_lane() == 0) pl.lk[p >> 6] = m;
 }
 
 // ---- C: clusters -> member lists ---------------------------------------------------------------------
@@ -378,7 +437,6 @@ struct WalkCtx {
     unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
     // oriented keys this thread's cluster has created in the current window: the snapshot planes of phase A cannot
     // know them, every later in-map test of the cluster has to (tandem repeats inside a piece; later pieces of the cluster)
-    static constexpr int NC = 16;
     uint64_t* ckey;     // NC entries, a thread-private array of the kernel (the only part of the state in scratch)
     int nc;
     bool c_overflow;    // more than NC creations: fall back to live table lookups
@@ -620,7 +678,7 @@ __device__ __forceinline__ void rr_link(RecRegs& r, int idx) { rr_set(r, 9, rr_g
 __device__ __forceinline__ void rr_store(const RecRegs& r) { r.addr[0] = r.lo; r.addr[1] = r.hi; }
 
 // find or create the junction keyed by the oriented k-mer `key`; the record comes back in registers
-__device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, RecRegs& out) {
+__device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, uint64_t pos, RecRegs& out) {
     uint64_t rc = fd_revcomp(key, wc.fp.k);
     uint64_t canon = key < rc ? key : rc;
     int orient = key == canon ? 0 : 1;
@@ -640,8 +698,7 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     wc.created_now = false;
     if (!((present >> orient) & 1u)) {   // JunctionMap::createJunction, JunctionMap.cpp:567-570
         wc.created_now = true;
-        if (wc.nc < WalkCtx::NC) wc.ckey[wc.nc++] = key;
-        else wc.c_overflow = true;
+        atomicOr(&wc.pl.cr[pos >> 6], 1ULL << (pos & 63));   // later windows (and the next batch) register this key: their snapshot cannot know it
         out.lo = out.hi = 0;
         wc.jt.stamps[slot * 2 + orient] = stamp;
         atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
@@ -744,7 +801,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         uint64_t key = fwd ? km : fd_revcomp(km, k);
         int real = fwd ? pv_base(v, wc.pl.codes, p0 + q + k) : (pv_base(v, wc.pl.codes, p0 + q - 1) ^ 2);
         RecRegs cur;
-        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, cur)) return;
+        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur)) return;
         if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
         if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
             created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
@@ -789,7 +846,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         uint64_t key = pv_kmer(v, wc.pl.codes, p0 + m, k);
         int real = pv_base(v, wc.pl.codes, p0 + m + k);
         RecRegs rec;
-        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, rec)) return;
+        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, p0 + (uint64_t)m, rec)) return;
         rr_add_cov(rec, real);
         const int tm = 2 * m + 1;
         rr_update(rec, 4, tm - 2 * j);
@@ -807,12 +864,11 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
                                              uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t created_keys[WalkCtx::NC];
     WalkCtx wc;
-    wc.ckey = created_keys;
+    wc.ckey = nullptr;   // no list of created keys: the table itself is asked at the candidate positions (c_overflow)
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.nc = 0; wc.c_overflow = false; wc.created_now = false; wc.dbg = dbg;
+    wc.nc = 0; wc.c_overflow = true; wc.created_now = false; wc.dbg = dbg;
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;
@@ -859,6 +915,36 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
         if (v[4]) atomicAdd(&cnt->n_junctions, v[4]);
         if (v[6]) atomicAdd(&cnt->flags_filled, v[6]);
+    }
+}
+
+// After the last window of a batch: the hashes of the keys its walk created, as a list the following batches register as their delta.
+// (The planes themselves belong to a batch buffer that the pure stage recycles while later walks still run; the lists are the context's.)
+__global__ void __launch_bounds__(256) k_delta_collect(const unsigned long long* __restrict__ cr, const uint32_t* __restrict__ kh, uint64_t n_words,
+                                                       uint32_t* __restrict__ list, unsigned long long* __restrict__ count) {
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned long long s_base;
+    const int wave = (int)(threadIdx.x >> 6);
+    for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < n_words; w0 += (uint64_t)gridDim.x * 256) {   // uniform trip count per block
+        const uint64_t w = w0 + threadIdx.x;
+        unsigned long long m = w < n_words ? cr[w] : 0ULL;
+        unsigned mine = (unsigned)__popcll(m), incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (fd_lane() >= o) incl += t; }
+        if (fd_lane() == 63) s_wave[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = total ? atomicAdd(count, (unsigned long long)total) : 0ULL;     // one reservation per block and round
+        }
+        __syncthreads();
+        unsigned long long at = s_base + (incl - mine);
+        for (int q = 0; q < wave; q++) at += s_wave[q];
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            list[at++] = kh[w * 64 + (uint64_t)b];
+        }
+        __syncthreads();
     }
 }
 
@@ -1251,8 +1337,13 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     BatchBufs& bb = *ctx->cur;
     Planes pl{(const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, (const uint64_t*)bb.ps.p, (const uint32_t*)bb.ps_prefix.p,
               (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p, (const uint64_t*)bb.cf0.p, (const uint64_t*)bb.cf1.p,
-              (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.inF.p, (uint64_t*)bb.inB.p, (const uint2*)bb.pieces.p,
-              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p, nullptr, nullptr, (const uint32_t*)bb.kh.p};
+              (const uint64_t*)bb.cb0.p, (const uint64_t*)bb.cb1.p, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (const uint2*)bb.pieces.p,
+              (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p, nullptr, nullptr, (const uint32_t*)bb.kh.p, nullptr};
+    {   // in-map planes of the walk = the pure stage's snapshot planes nF / nB (see k_walk_register); creation plane of this batch
+        const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
+        if (int rc = fgpu_ensure(ctx, &bb.cr, wb)) return rc;
+        pl.cr = (unsigned long long*)bb.cr.p;
+    }
     if (ctx->record_stops) {
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
         int rc;
@@ -1280,10 +1371,26 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
     ctx->launch_stream = walk_stream;
     if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(walk_stream, bb.pure_done, 0));
+    if (ctx->refresh_snapshot) {
+        // batches that were prepared before their turn (multi-GPU shards; scan_prepare / scan_walk_prepared) carry snapshot planes of a table
+        // that has since been replaced or walked on by an unknown number of batches: made again here, behind the previous batch's walk
+        // (the preview -- need plane and junction tests -- stays what it was: it is checked by the walk, not trusted)
+        FGPU_LAUNCH("walk_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
+                    ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p);
+    }
     if (ctx->record_stops) {
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
         FGPU_HIP(hipMemsetAsync(bb.sF.p, 0, wb, walk_stream));
         FGPU_HIP(hipMemsetAsync(bb.sB.p, 0, wb, walk_stream));
+    }
+    FGPU_HIP(hipMemsetAsync(bb.cr.p, 0, (bb.n_words + FGPU_PADW) * 8, walk_stream));
+    // the list this batch's created keys go to: the oldest of the ring (its readers -- the windows of the batches in between -- are
+    // behind us on this stream)
+    DeltaList& mine_list = ctx->delta_ring[ctx->delta_next % FGPU_DELTA_RING];
+    {
+        int rc;
+        if ((rc = fgpu_ensure(ctx, &mine_list.list, (bb.n_words + FGPU_PADW) * 64 * 4)) || (rc = fgpu_ensure(ctx, &mine_list.count, 64))) return rc;
+        FGPU_HIP(hipMemsetAsync(mine_list.count.p, 0, 8, walk_stream));
     }
     // thousands of tiny launches: by default one event pair around the whole stage
     const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
@@ -1293,7 +1400,6 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         step = span_now;
         const uint64_t hi = std::min<uint64_t>(T, lo + step);
         const uint64_t pos_end = std::min<uint64_t>(T, hi + ext);
-        const unsigned grid = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) & ~63ULL, 256);
         const int parity = (int)(ctx->scan_windows & 1);
         // grids sized for THIS window (a window of w positions holds at most w/(k+1)+2 piece starts): small windows -- high
         // coverage data -- must not pay for the launch of the thousands of empty blocks the largest window would need
@@ -1310,8 +1416,24 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             ctx->wt_epoch = 1;
         }
         const WTable wt = make_wt(ctx, ctx->wt_epoch, parity);   // its presence filter was zeroed by the reset kernel of the window before last
-        FGPU_LAUNCH("walk_lookup", k_walk_lookup, grid, 256, pl, ctx->fd, jt, wt, uf_parent, lo, hi, pos_end, ctx->counters, parity);
-        FGPU_LAUNCH("walk_link", k_walk_link, grid, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end);
+        {
+            DeltaSrc ds;
+            memset(&ds, 0, sizeof(ds));
+            // the delta: keys created since this batch's snapshot planes were made -- by the batches walked since (their lists) and by this
+            // batch's earlier windows (its creation plane up to where their pieces reach)
+            for (int r = 1; r < FGPU_DELTA_RING && (uint64_t)r <= ctx->delta_next; r++) {
+                const DeltaList& dl = ctx->delta_ring[(ctx->delta_next - r) % FGPU_DELTA_RING];
+                ds.list[r - 1] = (const uint32_t*)dl.list.p;
+                ds.count[r - 1] = (const unsigned long long*)dl.count.p;
+            }
+            ds.cr = (const unsigned long long*)bb.cr.p;
+            ds.cr_words = lo ? std::min<uint64_t>(bb.n_words, (lo + ext + 63) / 64 + 1) : 0;
+            const unsigned word_blocks = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) / 64, 256);
+            const unsigned piece_blocks = fgpu_blocks(max_pieces, 256);
+            FGPU_LAUNCH("walk_lookup", k_walk_register, word_blocks + piece_blocks + 64, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, ctx->counters,
+                        word_blocks, piece_blocks, ds);
+        }
+        FGPU_LAUNCH("walk_link", k_walk_link, std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end);
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
@@ -1339,15 +1461,23 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             if (p >= 64) {
                 ctx->calib_f = ctx->fb_host[0];
                 ctx->calib_p = ctx->fb_host[1];
-                if (f * 2 > p && span_now > 4096) span_now /= 2;
-                else if (f * 4 < p && span_now < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN))
+                bool shrunk = false;
+                if (f * 2 > p && span_now > 4096) { span_now /= 2; shrunk = true; }
+                else if (f * 3 < p && span_now < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN))
                     span_now = std::min<uint64_t>(span_now * 4, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
                 else if (f * 16 < p && span_now < ctx->max_span) span_now = std::min<uint64_t>(span_now * 4, ctx->max_span);
                 else ctx->calib_left = 1;          // settled
                 ctx->calib_left--;
+                // waiting for a window keeps the host from feeding the pure stage of the next batch: worth it while windows are small
+                // (a fraction of a millisecond each, and the wrong size hurts most there); from 2^22 positions on the per-batch
+                // controller (adapt_window, no waiting) takes over unless the last look said "too large"
+                if (!shrunk && span_now >= (1ULL << 22)) ctx->calib_left = 0;
             }
         }
     }
+    FGPU_LAUNCH("walk_delta", k_delta_collect, (unsigned)std::min<uint64_t>(fgpu_blocks(bb.n_words, 256), 512), 256, (const unsigned long long*)bb.cr.p,
+                (const uint32_t*)bb.kh.p, bb.n_words, (uint32_t*)mine_list.list.p, (unsigned long long*)mine_list.count.p);
+    ctx->delta_next++;
     ctx->window_span = span_now;
     ctx->prof_suppress = false;
     fgpu_prof_end(ctx, stage_tok);
