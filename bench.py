@@ -458,7 +458,7 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                per_launch = json.load(f).get("bytes_per_launch", {})
+                per_launch = {kk.split("<")[0]: vv for kk, vv in json.load(f).get("bytes_per_launch", {}).items()}
                 traffic = per_launch.get("k_" + name, per_launch.get("k_" + name + "_sm"))   # scan_flags runs as k_scan_flags_sm for j <= 1
         res["device_time_share"] = {n: round(ms / (1e3 * elapsed), 4) for n, (c, ms) in ktimes.items() if ms / (1e3 * elapsed) > 0.01}
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -471,7 +471,7 @@ def main():
         # ---- what the counters say: FETCH_SIZE + WRITE_SIZE of every kernel of a step, from the committed PMC passes
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                pl = json.load(f).get("bytes_per_launch", {})
+                pl = {kk.split("<")[0]: vv for kk, vv in json.load(f).get("bytes_per_launch", {}).items()}
             alias = {"scan_flags": "k_scan_flags_sm", "load_resolve": "k_load_resolve_sm", "carry_update": "k_carry_from_first"}
             tot, missing = 0.0, []
             for n, (c, ms) in ktimes.items():
@@ -481,7 +481,7 @@ def main():
                         missing.append(n)
                     continue
                 tot += b * c / args.steps
-            for n in ("k_walk_lookup", "k_walk_link", "k_walk", "k_walk_cluster", "k_walk_reset_uf"):   # the walk stage is timed as one entry
+            for n in ("k_walk_register", "k_walk_link", "k_walk", "k_walk_cluster", "k_walk_reset_uf"):   # the walk stage is timed as one entry
                 if n in pl and "walk_stage" in ktimes:
                     tot += pl[n] * sst["walk_windows"]
             res["pipeline_measured"] = {"hbm_bytes_per_step": tot, "GBps": tot / (elapsed / args.steps) / 1e9, "frac_of_hbm_peak": tot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
