@@ -492,8 +492,12 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
         if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
-        else if (f * 3 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN))
-            ctx->window_span = std::min<uint64_t>(ctx->window_span * 4, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
+        else if (f * 3 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN)) {
+            // clusters percolate at a sharp threshold (about one genome coverage per window): a whole batch at a size that turns out to be
+            // beyond it costs seconds, so the first windows at the new size are looked at one by one again
+            ctx->window_span = std::min<uint64_t>(ctx->window_span * 2, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
+            ctx->calib_left = std::max(ctx->calib_left, 2);
+        }
         else if (f * 16 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;   // thin coverage per window: see FGPU_MAX_SPAN
     }
     ctx->adapt_followers = ctx->counters_host->followers;

@@ -172,6 +172,8 @@ struct fgpu_ctx {
     uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
     DeltaList delta_ring[FGPU_DELTA_RING];
     bool refresh_snapshot = false;   // the batch about to be walked was prepared ahead of its turn: its snapshot planes are made again first
+    uint64_t delta_hist[FGPU_DELTA_RING] = {0, 0, 0, 0};   // records counted when the walk of each ring batch was issued
+    uint64_t delta_ring_keys = 0, delta_batch_base = 0;   // host-side estimate of the delta (fgpu_stage_scan_walk)
     uint64_t delta_next = 0;         // batches walked in this scan (index of the list the next one fills)
     uint32_t wt_epoch = 0;           // epoch of the window table's newest entries (1..255; 0 = table not initialised yet)
     // union-find / cluster scratch (per window)

@@ -283,13 +283,11 @@ __device__ __forceinline__ bool piece_in_window(const Planes& pl, const WinDesc&
 //                                        of earlier versions was -- spent its time on the dependent loads of 65 k tiny blocks
 //   the next piece_blocks                one thread per piece: add_fake_junction's k-mer (ReadScanner.cpp:94) and, in pieces long enough, the
 //                                        positions the spacer rule can reach (:72)
-//   the last delta_blocks                the delta: keys created since the snapshot planes were made -- lists of the batches walked since
-//                                        (k_delta_collect), and this batch's own creation plane as far as earlier windows' pieces reach
-struct DeltaSrc {
-    const uint32_t* list[FGPU_DELTA_RING - 1];
-    const unsigned long long* count[FGPU_DELTA_RING - 1];
-    const unsigned long long* cr;   // own creation plane, words [0, cr_words)
-    uint64_t cr_words;
+//   the last delta_blocks                the delta: keys created since the snapshot planes were made -- the lists k_delta_collect keeps of
+//                                        the batches walked since, and of this batch's earlier windows
+struct DeltaSrc {   // lists of created-key hashes: the batches walked since the snapshot, and this batch's earlier windows (last entry)
+    const uint32_t* list[FGPU_DELTA_RING];
+    const unsigned long long* count[FGPU_DELTA_RING];
 };
 
 __global__ void __launch_bounds__(256) k_walk_register(Planes pl, FdParams fp, WTable wt, uint32_t* parent, uint64_t lo, uint64_t hi,
@@ -319,18 +317,10 @@ __global__ void __launch_bounds__(256) k_walk_register(Planes pl, FdParams fp, W
     } else {
         const uint64_t t = (uint64_t)(blockIdx.x - word_blocks - piece_blocks) * blockDim.x + threadIdx.x;
         const uint64_t stride = (uint64_t)(gridDim.x - word_blocks - piece_blocks) * blockDim.x;
-        for (int r = 0; r < FGPU_DELTA_RING - 1; r++) {
+        for (int r = 0; r < FGPU_DELTA_RING; r++) {
             if (!ds.list[r]) continue;
             const uint64_t n = *ds.count[r];
             for (uint64_t i = t; i < n; i += stride) wt_register(wt, nullptr, ds.list[r][i], W_NO_OWNER, cnt);
-        }
-        for (uint64_t w = t; w < ds.cr_words; w += stride) {
-            unsigned long long m = ds.cr[w];
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                wt_register(wt, nullptr, pl.kh[w * 64 + (uint64_t)b], W_NO_OWNER, cnt);
-            }
         }
     }
 }
@@ -920,14 +910,17 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
 
 // After the last window of a batch: the hashes of the keys its walk created, as a list the following batches register as their delta.
 // (The planes themselves belong to a batch buffer that the pure stage recycles while later walks still run; the lists are the context's.)
-__global__ void __launch_bounds__(256) k_delta_collect(const unsigned long long* __restrict__ cr, const uint32_t* __restrict__ kh, uint64_t n_words,
+// (run after every window over the words that window's pieces reach; the bits are cleared as they are taken, so a word that two
+// consecutive windows share is collected twice without listing anything twice)
+__global__ void __launch_bounds__(256) k_delta_collect(unsigned long long* __restrict__ cr, const uint32_t* __restrict__ kh, uint64_t w_first, uint64_t n_words,
                                                        uint32_t* __restrict__ list, unsigned long long* __restrict__ count) {
     __shared__ unsigned s_wave[4];
     __shared__ unsigned long long s_base;
     const int wave = (int)(threadIdx.x >> 6);
-    for (uint64_t w0 = (uint64_t)blockIdx.x * 256; w0 < n_words; w0 += (uint64_t)gridDim.x * 256) {   // uniform trip count per block
+    for (uint64_t w0 = w_first + (uint64_t)blockIdx.x * 256; w0 < n_words; w0 += (uint64_t)gridDim.x * 256) {   // uniform trip count per block
         const uint64_t w = w0 + threadIdx.x;
         unsigned long long m = w < n_words ? cr[w] : 0ULL;
+        if (m) cr[w] = 0;
         unsigned mine = (unsigned)__popcll(m), incl = mine;
         for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (fd_lane() >= o) incl += t; }
         if (fd_lane() == 63) s_wave[wave] = incl;
@@ -998,9 +991,9 @@ __global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, const
 // is clear raises error bit 4 (surfaced as FGPU_ERR_STATE), it never silently uses a flag that was not computed.
 __global__ void __launch_bounds__(256) k_need_lookup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm, uint64_t n_words,
                                                      FdParams fp, JTable jt, uint64_t* __restrict__ nF, uint64_t* __restrict__ nB,
-                                                     uint32_t* __restrict__ kh) {
+                                                     uint32_t* __restrict__ kh, uint64_t w_first) {
     const uint64_t total = n_words * 64;
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t p = w_first * 64 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool inF = false, inB = false;
         if ((pm[p >> 6] >> (p & 63)) & 1ULL) {
             uint64_t km = fd_kmer_at(codes, p, fp.k);
@@ -1314,7 +1307,7 @@ int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     JTable jt = make_jt(ctx);
     // also with eager flags: this kernel writes the hash plane the walk stage's kernels work from
     FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
-                bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p);
+                bb.n_words, ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p, (uint64_t)0);
     if (eager) return FGPU_OK;
     FGPU_LAUNCH("need_prewalk", k_need_prewalk, fgpu_grid(bb.n_pieces, 256), 256, (const uint64_t*)bb.codes.p, (const uint2*)bb.pieces.p,
                 bb.n_pieces, ctx->fd, jt, (const uint64_t*)bb.nF.p, (const uint64_t*)bb.nB.p, (unsigned long long*)bb.need.p, need_tight);
@@ -1376,7 +1369,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // that has since been replaced or walked on by an unknown number of batches: made again here, behind the previous batch's walk
         // (the preview -- need plane and junction tests -- stays what it was: it is checked by the walk, not trusted)
         FGPU_LAUNCH("walk_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
-                    ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p);
+                    ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p, (uint64_t)0);
     }
     if (ctx->record_stops) {
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
@@ -1384,6 +1377,14 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_HIP(hipMemsetAsync(bb.sB.p, 0, wb, walk_stream));
     }
     FGPU_HIP(hipMemsetAsync(bb.cr.p, 0, (bb.n_words + FGPU_PADW) * 8, walk_stream));
+    {   // host-side estimate of the delta (see the per-window decision below): records counted when this batch's planes were made, and
+        // how many the batches in the ring added
+        const uint64_t now = ctx->counters_host->n_junctions;
+        ctx->delta_hist[ctx->delta_next % FGPU_DELTA_RING] = now;
+        const uint64_t back = ctx->delta_next >= (uint64_t)(FGPU_DELTA_RING - 1) ? ctx->delta_hist[(ctx->delta_next - (FGPU_DELTA_RING - 1)) % FGPU_DELTA_RING] : 0;
+        ctx->delta_ring_keys = now > back ? now - back : 0;
+        ctx->delta_batch_base = now;
+    }
     // the list this batch's created keys go to: the oldest of the ring (its readers -- the windows of the batches in between -- are
     // behind us on this stream)
     DeltaList& mine_list = ctx->delta_ring[ctx->delta_next % FGPU_DELTA_RING];
@@ -1419,15 +1420,31 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         {
             DeltaSrc ds;
             memset(&ds, 0, sizeof(ds));
-            // the delta: keys created since this batch's snapshot planes were made -- by the batches walked since (their lists) and by this
-            // batch's earlier windows (its creation plane up to where their pieces reach)
-            for (int r = 1; r < FGPU_DELTA_RING && (uint64_t)r <= ctx->delta_next; r++) {
-                const DeltaList& dl = ctx->delta_ring[(ctx->delta_next - r) % FGPU_DELTA_RING];
-                ds.list[r - 1] = (const uint32_t*)dl.list.p;
-                ds.count[r - 1] = (const unsigned long long*)dl.count.p;
+            // The delta of this window: keys created since the batch's snapshot planes were made -- by the batches walked since (their lists)
+            // and by this batch's earlier windows (its own list so far).  Registering it costs one atomic pair per key and WINDOW; where the
+            // windows are small and the delta is not (very high coverage: thousands of windows per batch, a million keys created by the
+            // first of them) it is cheaper to make the snapshot planes of the window's own positions again -- what the look-up kernel of
+            // round 1 did for every window -- and register no delta at all.  The host's estimate of the delta is an upper bound of what it
+            // has seen counted; being wrong only picks the dearer of two exact ways.
+            // (earlier batches: records counted between their walks' issue times; this batch: at most ~3 creations per piece walked so far)
+            const uint64_t delta_est = ctx->delta_ring_keys + (uint64_t)(3.0 * (double)bb.n_pieces * (double)lo / (double)T);
+            const bool refresh_window = !ctx->refresh_snapshot && delta_est > (pos_end - lo) / 4;
+            if (refresh_window) {
+                const uint64_t w_first = lo >> 6, w_last = std::min<uint64_t>(bb.n_words, (pos_end + 63) / 64);
+                FGPU_LAUNCH("walk_lookup", k_need_lookup, fgpu_grid((w_last - w_first) * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, w_last,
+                            ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p, w_first);
+            } else {
+                if (!ctx->refresh_snapshot)      // (a batch whose planes were just made again needs no earlier batch's keys)
+                    for (int r = 1; r < FGPU_DELTA_RING && (uint64_t)r <= ctx->delta_next; r++) {
+                        const DeltaList& dl = ctx->delta_ring[(ctx->delta_next - r) % FGPU_DELTA_RING];
+                        ds.list[r - 1] = (const uint32_t*)dl.list.p;
+                        ds.count[r - 1] = (const unsigned long long*)dl.count.p;
+                    }
+                if (lo) {
+                    ds.list[FGPU_DELTA_RING - 1] = (const uint32_t*)mine_list.list.p;
+                    ds.count[FGPU_DELTA_RING - 1] = (const unsigned long long*)mine_list.count.p;
+                }
             }
-            ds.cr = (const unsigned long long*)bb.cr.p;
-            ds.cr_words = lo ? std::min<uint64_t>(bb.n_words, (lo + ext + 63) / 64 + 1) : 0;
             const unsigned word_blocks = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) / 64, 256);
             const unsigned piece_blocks = fgpu_blocks(max_pieces, 256);
             FGPU_LAUNCH("walk_lookup", k_walk_register, word_blocks + piece_blocks + 64, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, ctx->counters,
@@ -1440,6 +1457,11 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                     (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk);
+        {   // the keys this window created join the batch's list (and leave the plane): the next window's delta
+            const uint64_t w_first = lo >> 6, w_last = std::min<uint64_t>(bb.n_words, (pos_end + 63) / 64);
+            FGPU_LAUNCH("walk_delta", k_delta_collect, (unsigned)std::min<uint64_t>(fgpu_blocks(w_last - w_first, 256), 256), 256, (unsigned long long*)bb.cr.p,
+                        (const uint32_t*)bb.kh.p, w_first, w_last, (uint32_t*)mine_list.list.p, (unsigned long long*)mine_list.count.p);
+        }
         // this window's set is reset on the side stream while the next window (the other set) is looked up and linked
         FGPU_HIP(hipEventRecord(ctx->ev_walked, walk_stream));
         FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_walked, 0));
@@ -1475,8 +1497,6 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             }
         }
     }
-    FGPU_LAUNCH("walk_delta", k_delta_collect, (unsigned)std::min<uint64_t>(fgpu_blocks(bb.n_words, 256), 512), 256, (const unsigned long long*)bb.cr.p,
-                (const uint32_t*)bb.kh.p, bb.n_words, (uint32_t*)mine_list.list.p, (unsigned long long*)mine_list.count.p);
     ctx->delta_next++;
     ctx->window_span = span_now;
     ctx->prof_suppress = false;
