@@ -108,6 +108,7 @@ SIGNATURES = {
     "fgpu_diag_random_access": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_int, _P(_f64)]),
     "fgpu_diag_device_attr": (C.c_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
     "fgpu_diag_load_split": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
+    "fgpu_diag_scan_replays": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_binned_probes": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, _P(_f64), _P(_f64), _P(_f64), _P(_f64)]),
 }
 

@@ -351,6 +351,12 @@ class Context:
         self._c(self.lib.fgpu_diag_stream_copy(self.h, nbytes, iters, C.byref(out)))
         return out.value
 
+    def diag_scan_replays(self) -> int:
+        """how often the library has scanned a pass again by itself because the lazy junction-test preview could not be repaired"""
+        n = C.c_uint64(0)
+        self._c(self.lib.fgpu_diag_scan_replays(self.h, C.byref(n)))
+        return int(n.value)
+
     def diag_load_split(self) -> dict:
         """where the last load pass settled its occurrences: routed to bloo2 by the marking kernel itself / left to the resolution"""
         a, b = C.c_uint64(0), C.c_uint64(0)

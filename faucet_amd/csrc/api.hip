@@ -86,8 +86,12 @@ static int check_errors(fgpu_ctx* ctx) {
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
     // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
     static const bool force_lazy_fail = getenv("FGPU_DEBUG_LAZY_FAIL") && getenv("FGPU_DEBUG_LAZY_FAIL")[0] == '1';
-    const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
+    const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime && !ctx->eager_scan;
     if ((ctx->counters_host->error_flags & 4ULL) || (force_lazy_fail && lazy && ctx->phase == 2)) {
+        if (ctx->journal_on && ctx->phase == 2 && !ctx->in_replay) {
+            ctx->lazy_failed = true;     // every batch of this scan is still in HBM: the next entry point scans them again, eagerly (scan_replay)
+            return FGPU_OK;
+        }
         ctx->err = "lazy-flag check failed: the walk scanned a position whose junction test was not evaluated; "
                    "repeat the scan after fgpu_scan_set_eager(ctx, 1) (or with FGPU_FLAG_EAGER_FLAGS)";
         return FGPU_ERR_STATE;
@@ -112,6 +116,10 @@ static int pull_counters(fgpu_ctx* ctx) {
 }
 
 static bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+
+static void journal_recycle(fgpu_ctx* ctx);
+static int journal_add(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads);
+static int scan_replay(fgpu_ctx* ctx);
 
 extern "C" {
 
@@ -167,6 +175,8 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     if (!ctx->prm.max_batch_bases) ctx->prm.max_batch_bases = 1ULL << 30;
     // load batches kept in HBM for the scan of the same reads: 4 bits per base, at most an eighth of the device memory
     ctx->resident_budget = (p->flags & FGPU_FLAG_NO_RESIDENT) ? 0 : prop.totalGlobalMem / 8;
+    ctx->journal_budget = prop.totalGlobalMem / 8;   // packed reads of a lazy scan kept for a replay (3 bits per base)
+    if (const char* e = getenv("FGPU_JOURNAL_MB")) ctx->journal_budget = (uint64_t)atoll(e) << 20;   // tests: force the "outgrown" path
     ctx->fd.k = p->k;
     ctx->fd.j = p->j;
     ctx->fd.n_hash = p->n_hash;
@@ -243,6 +253,8 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (int q = 0; q < 2; q++) if (ctx->ev_uf_reset[q]) hipEventDestroy(ctx->ev_uf_reset[q]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     for (ResidentBatch* r : ctx->resident) delete r;
+    for (JournalBatch* j : ctx->journal) delete j;
+    for (JournalBatch* j : ctx->journal_pool) delete j;
     for (BatchBufs* b : ctx->all_batches) {
         if (b->pure_done) hipEventDestroy(b->pure_done);
         if (b->walk_done) hipEventDestroy(b->walk_done);
@@ -461,6 +473,12 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_piece_base = 0;
     ctx->scan_imported = 0;
     ctx->delta_next = 0;
+    journal_recycle(ctx);
+    ctx->journal_on = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
+    ctx->eager_scan = ctx->lazy_failed = false;
+    ctx->stops_delivered = 0;
+    ctx->have_import = false;
+    ctx->journal_max_read_len = 0;
     ctx->hint_in_table = false;
     // calibrated upwards window by window; a context that has scanned before starts a quarter below where that scan ended up
     const uint64_t start_span = std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4);
@@ -529,7 +547,7 @@ static void note_walked(fgpu_ctx* ctx, BatchBufs* b) {
 static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
     if (b->stops_pending) {   // the buffers still hold the visit planes of an earlier batch: bring its lists to the host first
         int hrc = fgpu_scan_harvest(ctx, b);
-        if (hrc) return hrc;
+        if (hrc) return hrc;      // (FGPU_INTERNAL_REPLAY: that batch's walk went wrong; the caller replays and comes back)
     }
     b->seq = ctx->scan_batch_seq++;
     ctx->cur = b;
@@ -538,11 +556,143 @@ static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) 
         b->walk_pending = false;
     }
     int rc = fgpu_stage_pack(ctx, reads);
+    if (!rc) rc = journal_add(ctx, b, reads);
     uint64_t n_pieces = 0;
     if (!rc) rc = fgpu_stage_scan_pure(ctx, &n_pieces);   // ends with the batch's only synchronisation (piece count)
+    if (!rc) ctx->journal_max_read_len = std::max<uint64_t>(ctx->journal_max_read_len, ctx->counters_host->max_read_len);
     if (!rc) rc = check_errors(ctx);
     if (!rc) ctx->scan_stats.reads_processed += reads->n_reads;
     if (!rc && b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
+    return rc;
+}
+
+// ---- the scan's journal: lazy junction tests without a caller-visible fall-back ---------------------------------------------------------
+// While a scan evaluates its junction tests lazily the packed form of every batch (codes + bad plane, 3 bits per base; the read offsets when
+// scanInputRead's lists are recorded) stays in HBM, up to an eighth of the device memory.  If the walk meets a preview it cannot repair
+// (never seen on real input, forced by FGPU_DEBUG_LAZY_FAIL=1) the library itself resets the junction map and scans the
+// journal again with every test evaluated: same results, nothing for the caller to do -- ReadScanner::scanReads has no such contract
+// either (src/ReadScanner.cpp:284-359).  A scan that outgrows the journal is first brought to a point where everything walked so far is
+// known to be good, then goes on with eager tests (which cannot fail that way) and without a journal.
+static void journal_recycle(fgpu_ctx* ctx) {
+    for (JournalBatch* j : ctx->journal) ctx->journal_pool.push_back(j);
+    ctx->journal.clear();
+    ctx->journal_bytes = 0;
+}
+
+static int journal_add(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
+    if (!ctx->journal_on || ctx->in_replay) return FGPU_OK;
+    const uint64_t cb = 2 * (b->n_words + FGPU_PADW) * 8, bbytes = (b->n_words + FGPU_PADW) * 8, ob = ctx->record_stops ? (b->n_reads + 1) * 8 : 0;
+    if (ctx->journal_bytes + cb + bbytes + ob > ctx->journal_budget) {
+        // no room: everything walked so far is checked (and scanned again if need be), the rest of the scan is eager
+        int rc = pull_counters(ctx);
+        if (rc) return rc;
+        BatchBufs* const cur = ctx->cur;
+        if (ctx->lazy_failed && (rc = scan_replay(ctx))) return rc;
+        ctx->cur = cur;
+        ctx->journal_on = false;
+        ctx->eager_scan = true;
+        journal_recycle(ctx);
+        return FGPU_OK;
+    }
+    JournalBatch* j;
+    if (!ctx->journal_pool.empty()) { j = ctx->journal_pool.back(); ctx->journal_pool.pop_back(); }
+    else j = new JournalBatch();
+    int rc;
+    if ((rc = fgpu_ensure(ctx, &j->codes, cb)) || (rc = fgpu_ensure(ctx, &j->bad, bbytes)) || (ob && (rc = fgpu_ensure(ctx, &j->offs, ob)))) {
+        ctx->journal_pool.push_back(j);
+        return rc;
+    }
+    if (b->T) {
+        FGPU_HIP(hipMemcpyAsync(j->codes.p, b->codes.p, cb, hipMemcpyDeviceToDevice, ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(j->bad.p, b->bad.p, bbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (ob) FGPU_HIP(hipMemcpyAsync(j->offs.p, b->d_offs, ob, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    j->T = b->T; j->n_words = b->n_words; j->n_reads = b->n_reads; j->seq = b->seq;
+    ctx->journal.push_back(j);
+    ctx->journal_bytes += cb + bbytes + ob;
+    (void)reads;
+    return FGPU_OK;
+}
+
+// Reset the junction map and scan every journalled batch again with all junction tests evaluated.  On return everything the journal holds
+// has been walked; batches that were only prepared are walked as well (their turn has come: this is only reached from a walk or after one).
+static int scan_replay(fgpu_ctx* ctx) {
+    ctx->in_replay = true;
+    ctx->journal_on = false;
+    ctx->eager_scan = true;
+    ctx->lazy_failed = false;
+    int rc = sync_all(ctx);
+    for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
+    ctx->prepared.clear();
+    for (BatchBufs* b : ctx->to_harvest) b->stops_pending = false;
+    ctx->to_harvest.clear();
+    ctx->stop_queue.clear();
+    if (!rc) rc = fgpu_scan_reset(ctx);
+    if (rc) { ctx->in_replay = false; return rc; }
+    FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&ctx->counters->max_read_len, &ctx->journal_max_read_len, 8, hipMemcpyHostToDevice, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t reads_processed = ctx->scan_stats.reads_processed;
+    memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
+    ctx->scan_stats.reads_processed = reads_processed;
+    memset(ctx->counters_host, 0, sizeof(DevCounters));
+    ctx->scan_windows = 0;
+    ctx->scan_pieces_seen = 0;
+    ctx->scan_piece_base = 0;
+    ctx->scan_imported = 0;
+    ctx->delta_next = 0;
+    ctx->hint_in_table = false;
+    ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
+                                                 : std::min<uint64_t>(1ULL << 18, ctx->max_span);
+    ctx->calib_left = 16;
+    ctx->calib_f = ctx->calib_p = 0;
+    ctx->adapt_followers = ctx->adapt_pieces = 0;
+    ctx->walked_pieces = 0;
+    ctx->scan_batch_index = 0;
+    memset(&ctx->carried, 0, sizeof(ctx->carried));
+    if (ctx->have_import) {   // the table the previous shard handed over comes first again
+        if ((rc = fgpu_scan_reserve(ctx, ctx->import_n)) || (rc = fgpu_scan_import_impl(ctx, ctx->import_copy.p, ctx->import_n))) { ctx->in_replay = false; return rc; }
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->scan_imported = ctx->import_n;
+        if (ctx->import_has_carried) {
+            ctx->carried = ctx->import_carried;
+            ctx->scan_piece_base = ctx->import_carried.reads_no_errors;
+        }
+    }
+    for (size_t i = 0; i < ctx->journal.size() && !rc; i++) {
+        JournalBatch* j = ctx->journal[i];
+        BatchBufs* b = acquire_batch(ctx);
+        if (b->stops_pending && (rc = fgpu_scan_harvest(ctx, b))) break;   // lists of the replayed batch these buffers held two batches ago
+        if (b->walk_pending) {
+            FGPU_HIP(hipEventSynchronize(b->walk_done));
+            b->walk_pending = false;
+        }
+        b->seq = j->seq;
+        ctx->cur = b;
+        b->T = j->T; b->n_words = j->n_words; b->n_reads = j->n_reads;
+        b->d_offs = (const uint64_t*)j->offs.p;
+        if (b->T) {
+            const uint64_t cb = 2 * (b->n_words + FGPU_PADW) * 8, bbytes = (b->n_words + FGPU_PADW) * 8;
+            if ((rc = fgpu_ensure(ctx, &b->codes, cb)) || (rc = fgpu_ensure(ctx, &b->bad, bbytes))) break;
+            FGPU_HIP(hipMemcpyAsync(b->codes.p, j->codes.p, cb, hipMemcpyDeviceToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(b->bad.p, j->bad.p, bbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        uint64_t n_pieces = 0;
+        rc = fgpu_stage_scan_pure(ctx, &n_pieces);
+        if (!rc) rc = check_errors(ctx);
+        if (!rc && b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
+        if (!rc) rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported);
+        if (!rc) {
+            adapt_window(ctx);
+            rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
+            ctx->walked_pieces += b->n_pieces;
+            if (!rc) note_walked(ctx, b);
+        }
+        ctx->pool.push_back(b);
+    }
+    ctx->cur = &ctx->bb_default;
+    ctx->in_replay = false;
+    ctx->scan_replays++;
     return rc;
 }
 
@@ -554,8 +704,22 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     int rc = check_reads(ctx, reads);
     if (rc) return rc;
     FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (ctx->lazy_failed && (rc = scan_replay(ctx))) return rc;      // an earlier walk met a preview it could not repair: scan again, eagerly
     BatchBufs* b = acquire_batch(ctx);
     rc = scan_pure_into(ctx, b, reads);          // main stream; overlaps the previous batch's walk on the walk stream
+    if (rc == FGPU_INTERNAL_REPLAY) {            // noticed while the buffers' previous lists were fetched: replay, then this batch from the start
+        ctx->cur = &ctx->bb_default;
+        ctx->pool.insert(ctx->pool.begin(), b);
+        if ((rc = scan_replay(ctx))) return rc;
+        b = acquire_batch(ctx);
+        rc = scan_pure_into(ctx, b, reads);
+    }
+    if (!rc && ctx->lazy_failed) {
+        // noticed at this batch's own synchronisation: the batch is in the journal (prepared lazily); the replay scans it with the others
+        ctx->cur = &ctx->bb_default;
+        ctx->pool.push_back(b);
+        return scan_replay(ctx);
+    }
     // records as of the pure stage's synchronisation (the previous walk may still be adding some): room for this batch's
     if (!rc) rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported);
     if (!rc) {
@@ -585,6 +749,11 @@ int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
     }
     rc = scan_pure_into(ctx, b, reads);
     ctx->cur = &ctx->bb_default;
+    if (rc == FGPU_INTERNAL_REPLAY) {   // (only after walks of this scan: prepare-only scans never get here)
+        ctx->pool.insert(ctx->pool.begin(), b);
+        if ((rc = scan_replay(ctx))) return rc;
+        return fgpu_scan_prepare(ctx, reads);
+    }
     if (rc) { ctx->pool.push_back(b); return rc; }
     ctx->prepared.push_back(b);
     return FGPU_OK;
@@ -596,10 +765,12 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
     if (ctx->hint_in_table) { ctx->err = "the junction table holds a preview (fgpu_scan_import_hint): import the real table before walking"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     int rc = FGPU_OK;
+    if (ctx->lazy_failed) return scan_replay(ctx);      // (walks the prepared batches as well)
     for (size_t i = 0; i < ctx->prepared.size() && !rc; i++) {
         BatchBufs* b = ctx->prepared[i];
         if (i > 0) {   // feedback for the window controller and for the size of the junction table between batches
             if ((rc = pull_counters(ctx))) break;
+            if (ctx->lazy_failed) { ctx->cur = &ctx->bb_default; return scan_replay(ctx); }
             if (!ctx->prm.walk_window_span) adapt_window(ctx);
             if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported))) break;
         }
@@ -628,9 +799,16 @@ int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* 
     if (!ctx->record_stops) { ctx->err = "fgpu_scan_take_stops needs FGPU_FLAG_RECORD_STOPS"; return FGPU_ERR_STATE; }
     *n_out = 0;
     *batch_seq = -1;
+    if (ctx->phase == 2 && ctx->lazy_failed) {
+        if (int rc = scan_replay(ctx)) return rc;
+    }
     if (ctx->stop_queue.empty() && !ctx->to_harvest.empty()) {
         FGPU_HIP(hipSetDevice(ctx->prm.device));
         int rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());
+        if (rc == FGPU_INTERNAL_REPLAY && ctx->phase == 2) {
+            if ((rc = scan_replay(ctx))) return rc;
+            if (!ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());
+        }
         if (rc) return rc;
     }
     if (ctx->stop_queue.empty()) return FGPU_OK;
@@ -639,6 +817,7 @@ int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* 
     *batch_seq = (int64_t)sb.seq;
     if (sb.stops.size() > cap || (sb.stops.size() && !out)) return FGPU_ERR_CAPACITY;
     if (!sb.stops.empty()) memcpy(out, sb.stops.data(), sb.stops.size() * sizeof(fgpu_stop));
+    ctx->stops_delivered = sb.seq + 1;
     ctx->stop_queue.pop_front();
     return FGPU_OK;
 }
@@ -647,8 +826,13 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_end without scan_begin"; return FGPU_ERR_STATE; }
     int rc = pull_counters(ctx);
+    if (!rc && ctx->lazy_failed) {                          // the last walks met a preview they could not repair: scan again before closing
+        rc = scan_replay(ctx);
+        if (!rc) rc = pull_counters(ctx);
+    }
     while (!rc && !ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());   // every walk has finished
     ctx->phase = 0;
+    ctx->journal_on = false;
     if (!rc && !ctx->prm.walk_window_span && ctx->scan_windows > 8) ctx->settled_span = ctx->window_span;
     if (rc) return rc;
     const DevCounters& c = *ctx->counters_host;
@@ -712,6 +896,14 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported + n_entries))) return rc;
     rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
     if (rc) return rc;
+    if (ctx->journal_on) {   // a replay starts from this table again
+        if ((rc = fgpu_ensure(ctx, &ctx->import_copy, n_entries * FGPU_TABLE_ENTRY_BYTES + 16))) return rc;
+        if (n_entries) FGPU_HIP(hipMemcpyAsync(ctx->import_copy.p, dev_buf, n_entries * FGPU_TABLE_ENTRY_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->import_n = n_entries;
+        ctx->have_import = true;
+        ctx->import_has_carried = carried != nullptr;
+        if (carried) ctx->import_carried = *carried;
+    }
     // the import runs on the main stream, the ordered walk on the walk stream behind events recorded BEFORE this call
     // (end of each prepared batch's pure stage): without this wait the walk would start on a half-imported table
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
@@ -786,6 +978,12 @@ static int probe_stage3(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, i
 int fgpu_probe_jcheck(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 0, out); }
 int fgpu_probe_valid_extension(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 1, out); }
 int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 2, out); }
+
+int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays) {
+    if (!ctx || !replays) return FGPU_ERR_ARG;
+    *replays = ctx->scan_replays;
+    return FGPU_OK;
+}
 
 int fgpu_diag_load_split(fgpu_ctx* ctx, uint64_t* in_mark, uint64_t* pending) {
     if (!ctx || !in_mark || !pending) return FGPU_ERR_ARG;

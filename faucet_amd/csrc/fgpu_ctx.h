@@ -81,6 +81,14 @@ struct DeltaList {
 // batches back are registered (the ring holds one more: the list being filled)
 #define FGPU_DELTA_RING 4
 
+// The packed reads of one scanned batch, kept while the scan evaluates its junction tests lazily: should the walk meet a preview it
+// cannot repair the library scans the journal again with every test evaluated -- the caller never has to.
+struct JournalBatch {
+    DevBuf codes, bad, offs;
+    uint64_t T = 0, n_words = 0, n_reads = 0, seq = 0;
+};
+#define FGPU_INTERNAL_REPLAY 1000   // internal status: the lazy-flag check fired, the journal has to be replayed before this call goes on
+
 struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_scan_take_stops
     uint64_t seq;
     std::vector<fgpu_stop> stops;
@@ -212,6 +220,19 @@ struct fgpu_ctx {
     std::vector<BatchBufs*> prepared;     // scan_prepare'd batches waiting for the ordered walk, in file order
     std::vector<BatchBufs*> pool;         // recycled BatchBufs (device buffers kept)
     std::vector<BatchBufs*> all_batches;  // every heap BatchBufs, for destruction
+    std::vector<JournalBatch*> journal, journal_pool;   // batches of the scan in progress / recycled entries
+    uint64_t journal_bytes = 0, journal_budget = 0;
+    bool journal_on = false;              // this scan is lazy and every batch so far is in the journal
+    bool eager_scan = false;              // the rest of this scan evaluates every junction test (after a replay, or beyond the journal's budget)
+    bool lazy_failed = false;             // a synchronising call has seen the lazy-flag check fire: replay at the next entry point
+    bool in_replay = false;
+    uint64_t stops_delivered = 0;         // batches whose lists the caller has taken (a replay does not hand them out again)
+    uint64_t scan_replays = 0;            // replays since the context was made (fgpu_diag_scan_replays)
+    uint64_t journal_max_read_len = 0;
+    DevBuf import_copy;                   // the table handed over by the previous shard, kept for a replay
+    uint64_t import_n = 0;
+    fgpu_scan_stats import_carried = {};
+    bool have_import = false, import_has_carried = false;
     bool record_stops = false;            // FGPU_FLAG_RECORD_STOPS
     bool eager_runtime = false;           // fgpu_scan_set_eager: evaluate testForJunction everywhere in the following scans
     std::vector<BatchBufs*> to_harvest;   // walked batches whose stops are still on the device, in scan order

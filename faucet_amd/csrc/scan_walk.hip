@@ -1298,7 +1298,7 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
 int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
-    const bool eager = (ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime;   // evaluate testForJunction everywhere
+    const bool eager = (ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime || ctx->eager_scan;   // evaluate testForJunction everywhere
     FGPU_HIP(hipMemsetAsync(bb.need.p, eager ? 0xFF : 0, wb, ctx->stream));
     if (!bb.n_pieces) return FGPU_OK;
     if (int rc = fgpu_ensure(ctx, &bb.kh, (bb.n_words + FGPU_PADW) * 64 * 4)) return rc;
@@ -1581,10 +1581,16 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
         FGPU_HIP(hipEventSynchronize(b->walk_done));
         b->walk_pending = false;
     }
+    if (ctx->journal_on && !ctx->in_replay) {   // lists of a walk that went wrong must not leave the library: look before handing out
+        FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->error_flags, &ctx->counters->error_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->counters_host->error_flags & 4ULL) { ctx->lazy_failed = true; ctx->to_harvest.insert(ctx->to_harvest.begin(), b); return FGPU_INTERNAL_REPLAY; }
+    }
+    b->stops_pending = false;
+    if (b->seq < ctx->stops_delivered) return FGPU_OK;   // scanned again by a replay: the caller has this batch's lists already
     ctx->stop_queue.emplace_back();
     StopBatch& sb = ctx->stop_queue.back();
     sb.seq = b->seq;
-    b->stops_pending = false;
     const uint64_t np = b->n_pieces;
     if (!np) return FGPU_OK;
     int rc;

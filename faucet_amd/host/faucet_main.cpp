@@ -12,7 +12,6 @@
 // scanInputRead's per-read lists (fgpu_scan_take_stops) exactly as ReadScanner does it.
 #include <stdint.h>
 #include <stdio.h>
-#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -637,8 +636,7 @@ int main(int argc, char** argv) {
         printf("Weight before read scan: %f \n", w2);
         PairLogic pairs;
         fgpu_scan_stats ss;
-        // One scan of the file.  0 = done, 2 = fatal, -1 = the lazy-flag self-check of the library fired:
-        // the caller switches to eager flags and scans the file again.
+        // One scan of the file.  0 = done, 2 = fatal (-1: a status only library versions before the scan journal could return).
         auto scan_once = [&]() -> int {
             BatchSource src(o, o.read_scan_file);
             if (!src.is_open()) { fprintf(stderr, "cannot open %s\n", o.read_scan_file.c_str()); return 2; }
@@ -699,28 +697,10 @@ int main(int argc, char** argv) {
             }
             return 0;
         };
-        // The fall-back below reads the scan input a second time.  A pipe or a process substitution (how the reference is fed when it
-        // streams, src/stream_data_from_urls_list.sh:12-15) cannot be read twice -- re-opening a FIFO blocks for ever, /dev/fd/N yields an
-        // empty second scan -- so such input is scanned with every junction test evaluated from the start (same results, about 1.5x the
-        // junction-test probes), and a fall-back that is asked for nonetheless fails loudly instead of rescanning.
-        struct stat scan_sb;
-        const bool rereadable = stat(o.read_scan_file.c_str(), &scan_sb) == 0 && S_ISREG(scan_sb.st_mode);
-        if (!rereadable) {
-            fprintf(stderr, "note: %s is not a regular file: it cannot be scanned twice, so every junction test is evaluated up front\n", o.read_scan_file.c_str());
-            CHECK(fgpu_scan_set_eager(ctx, 1));
-        }
-        int src_rc = scan_once();
-        if (src_rc == -1 && !rereadable) {
-            fprintf(stderr, "scan failed and the input is not re-readable: %s\n", fgpu_last_error(ctx));
-            return 2;
-        }
-        if (src_rc == -1) {
-            fprintf(stderr, "\nnote: the preview of the junction walk did not hold for this input; scanning again with every junction test evaluated\n");
-            fgpu_scan_end(ctx, nullptr);                 // closes the failed pass (its status is the failure itself)
-            CHECK(fgpu_scan_set_eager(ctx, 1));
-            src_rc = scan_once();
-            if (src_rc == -1) { fprintf(stderr, "scan failed: %s\n", fgpu_last_error(ctx)); return 2; }
-        }
+        // (a preview of the junction walk that the library cannot repair is absorbed inside the library: it keeps the scan's batches in HBM and
+        // scans them again by itself -- nothing is read twice here, which is what lets both inputs be pipes)
+        const int src_rc = scan_once();
+        if (src_rc == -1) { fprintf(stderr, "scan failed: %s\n", fgpu_last_error(ctx)); return 2; }
         if (src_rc) return src_rc;
         time(&stop);
         printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);

@@ -66,7 +66,7 @@ typedef struct {
 #define FGPU_FLAG_RECORD_STOPS 8 /* keep scanInputRead's return value for every read (fgpu_scan_take_stops) */
 #define FGPU_FLAG_NO_RESIDENT 4 /* do not keep the load batches in HBM for the scan pass (see fgpu_load_batch) */
 #define FGPU_FLAG_EAGER_FLAGS 2 /* evaluate testForJunction at every position instead of only where the walk can stop
-                                 * skipping (same results; the lazy default self-checks and fails with FGPU_ERR_STATE) */
+                                 * skipping (same results; the lazy default checks itself and repairs what it finds, see fgpu_scan_set_eager) */
 
 /* A batch of sequence lines in file order: read i = bases[offsets[i] .. offsets[i+1]).  Any byte
  * may occur; everything except upper-case A C G T splits a read exactly as isValidNuc /
@@ -217,10 +217,13 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx);
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
 /* The scan evaluates testForJunction only where its preview of the walk says the walk can stop (lazy
  * flags); where the walk scans a window outside that preview it evaluates the tests itself, so the results are exact either
- * way.  The one case it cannot absorb is such a late test coming out TRUE (a junction at a k-mer the window's dependency
- * clusters did not know): the scan call (or fgpu_scan_end) then returns FGPU_ERR_STATE instead of a possibly different map --
- * finish with fgpu_scan_end, switch the preview off with fgpu_scan_set_eager(ctx, 1) and scan again (same results as
- * FGPU_FLAG_EAGER_FLAGS, about 1.5x the probes).  fgpu_scan_stats.flags_filled counts the windows evaluated inside the walk. */
+ * way.  The one case the walk cannot absorb on the spot is such a late test coming out TRUE (a junction at a k-mer the window's dependency
+ * clusters did not know).  The library absorbs that too: while a scan is lazy it keeps the packed form of every batch in HBM (3 bits per
+ * base, up to an eighth of the device memory) and, should the case arise, resets the junction map and scans those batches again by itself
+ * with every test evaluated -- the caller sees an ordinary scan and never has to hand its reads over twice (they may come from a pipe).
+ * A scan that outgrows that journal is verified up to there and goes on with eager tests.  fgpu_diag_scan_replays counts the replays;
+ * fgpu_scan_stats.flags_filled counts the windows evaluated inside the walk.  fgpu_scan_set_eager(ctx, 1) switches the preview off for the
+ * following scans altogether (same results as FGPU_FLAG_EAGER_FLAGS, about 1.5x the junction-test probes, no journal). */
 int fgpu_scan_set_eager(fgpu_ctx* ctx, int on);
 /* scanInputRead's lists of one scanned batch, flattened in processing order (reads in file order; inside a read the
  * valid pieces in the order scanInputRead walks them; inside a piece by half-step).  Batches come out in scan order,
@@ -289,6 +292,8 @@ int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_acce
  * its kernels, whose mean times come back separately. */
 int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_probes, uint64_t slice_bytes, int iters, double* direct_per_s,
                             double* binned_per_s, double* bin_ms, double* probe_ms);
+/* How often the library has scanned a pass's batches again by itself (lazy junction tests, see fgpu_scan_batch) since the context was made. */
+int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */

@@ -6,11 +6,9 @@
 // Junction::setCoverage / dist / linked) are checked against the real declarations.  It replaces
 //     load_two_filters(bloo1, bloo2, read_load_file, fastq, mercy)        src/Faucet.cpp:220   (def utils/Bloom.cpp:267)
 //     scanner->scanReads(fastq, paired_ends, no_cleaning)                  src/Faucet.cpp:241-245 (def src/ReadScanner.cpp:284)
-// Every fgpu_* status is checked; the one status a caller has to ACT on is FGPU_ERR_STATE from the scan with "lazy-flag" in
-// fgpu_last_error (faucet_gpu.h, fgpu_scan_set_eager): close the pass, switch the preview off, scan the reads again.  An input that
-// cannot be read twice (a pipe, a process substitution -- src/stream_data_from_urls_list.sh feeds Faucet that way) must therefore be
-// scanned with the preview off from the start.
-#include <sys/stat.h>
+// Every fgpu_* status is checked.  No status asks the caller to read its input again: should the scan's preview of the junction walk not
+// hold (faucet_gpu.h, fgpu_scan_batch) the library scans its own copy of the batches again -- both inputs may be pipes
+// (src/stream_data_from_urls_list.sh feeds Faucet process substitutions).
 
 #include <cstdio>
 #include <cstdlib>
@@ -89,11 +87,6 @@ void gpu_load_two_filters(Bloom* bloo1, Bloom* bloo2, std::string reads_filename
     printf("Reads processed: %llu\nUnambiguous reads: %llu\n", (unsigned long long)st.reads_processed, (unsigned long long)st.unambiguous_reads);
 }
 
-static bool is_regular_file(const std::string& path) {
-    struct stat sb;
-    return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
-}
-
 // one pass over the scan file; FGPU_OK, or the status of the first call that failed
 static int gpu_scan_pass(const std::string& read_scan_file, bool fastq, fgpu_scan_stats* st) {
     int rc = fgpu_scan_begin(g_ctx);
@@ -105,16 +98,8 @@ static int gpu_scan_pass(const std::string& read_scan_file, bool fastq, fgpu_sca
 
 // replaces buildJunctionMapFromReads() (src/Faucet.cpp:240-246) for the --no_cleaning / single-end flow
 void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq) {
-    // The library evaluates testForJunction only where its preview of the walk expects the walk to look, and checks that preview while
-    // walking.  A preview it cannot repair ends the pass with FGPU_ERR_STATE ("lazy-flag ..."): scan again with every test evaluated.
-    // Reads that cannot be read a second time are scanned that way from the start.
-    if (!is_regular_file(read_scan_file)) GPU_CHECK(fgpu_scan_set_eager(g_ctx, 1));
     fgpu_scan_stats st;
-    int rc = gpu_scan_pass(read_scan_file, fastq, &st);
-    if (rc == FGPU_ERR_STATE && strstr(fgpu_last_error(g_ctx), "lazy-flag") && is_regular_file(read_scan_file)) {
-        GPU_CHECK(fgpu_scan_set_eager(g_ctx, 1));
-        rc = gpu_scan_pass(read_scan_file, fastq, &st);
-    }
+    const int rc = gpu_scan_pass(read_scan_file, fastq, &st);
     if (rc != FGPU_OK) gpu_die("junction scan", rc);
 
     uint64_t n = 0;

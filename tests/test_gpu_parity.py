@@ -447,8 +447,8 @@ def test_cli_restarts_from_junction_files_like_the_reference(tmp_path):
 def test_cli_reads_both_passes_from_named_pipes(tmp_path, force_lazy_fail):
     """The reference's streaming scripts (src/stream_data_from_urls_list.sh) feed both passes through pipes: the host must read its
     inputs strictly sequentially, never seek or ask for a size -- and never need them twice: with FGPU_DEBUG_LAZY_FAIL=1 every lazy scan
-    reports the failure that regular files answer by scanning again; on a pipe that second scan would hang or find nothing,
-    so the CLI scans pipes with every junction test evaluated up front and the forced failure cannot occur."""
+    meets the failure that round 1 answered by opening the scan input again (on a pipe: a hang, or an empty second scan -- ADVICE r1);
+    the library now scans its own copy of the batches again, so pipes are scanned lazily like files and nothing is read twice."""
     import os
     import subprocess
     import threading
@@ -473,7 +473,6 @@ def test_cli_reads_both_passes_from_named_pipes(tmp_path, force_lazy_fail):
     r = subprocess.run([exe, "-read_load_file", pipes[0], "-read_scan_file", pipes[1], "-file_prefix", str(tmp_path / "out")] + args,
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stderr
-    assert "not a regular file" in r.stderr
     for t in feeders:
         t.join(timeout=10)
         assert not t.is_alive()
@@ -807,43 +806,57 @@ def test_fuzz_small_inputs_against_the_oracle(seed):
     _scan_equals_oracle(sc, sst, osc)
 
 
-def test_callers_fall_back_to_eager_flags_when_the_lazy_check_fires(tmp_path, monkeypatch):
-    """FGPU_DEBUG_LAZY_FAIL=1 makes the library report the lazy-flag self-check as failed: the CLI and ReadScanner must finish
-    the pass, switch the preview off (fgpu_scan_set_eager) and deliver the same files / records."""
+def test_the_library_absorbs_a_failed_lazy_check(tmp_path, monkeypatch):
+    """FGPU_DEBUG_LAZY_FAIL=1 makes every lazy scan meet the one failure its self-check cannot repair.  The library keeps the packed
+    batches of a lazy scan in HBM and scans them again by itself with every junction test evaluated (fgpu_diag_scan_replays counts it):
+    the callers see an ordinary scan -- same files through the CLI (paired-end lists included: none handed out twice), same records
+    through the Python mirror, streaming and prepared, and also when the journal is too small to hold the scan (FGPU_JOURNAL_MB=0: the
+    scan is checked, then goes on eagerly)."""
     import os
     import subprocess
     c = Case("pe_fastq_k21")
     reads = tmp_path / "reads.fq"
     reads.write_bytes(c.reads_text())
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
-    env = dict(os.environ, FGPU_DEBUG_LAZY_FAIL="1")
-    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
-                        "-batch_reads", "300"] + c.meta["args"], capture_output=True, text=True, env=env)
-    assert r.returncode == 3, r.stderr
-    assert "scanning again with every junction test evaluated" in r.stderr
-    assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
-    assert np.array_equal(np.fromfile(tmp_path / "out.short_pair_filter", dtype=np.uint8), c.pair_filter("short"))
-    assert np.array_equal(np.fromfile(tmp_path / "out.long_pair_filter", dtype=np.uint8), c.pair_filter("long"))
+    for extra in ({}, {"FGPU_JOURNAL_MB": "0"}):
+        env = dict(os.environ, FGPU_DEBUG_LAZY_FAIL="1", **extra)
+        r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out"),
+                            "-batch_reads", "300"] + c.meta["args"], capture_output=True, text=True, env=env)
+        assert r.returncode == 3, r.stderr
+        assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
+        assert np.array_equal(np.fromfile(tmp_path / "out.short_pair_filter", dtype=np.uint8), c.pair_filter("short"))
+        assert np.array_equal(np.fromfile(tmp_path / "out.long_pair_filter", dtype=np.uint8), c.pair_filter("long"))
     # the same through the Python mirror, in a child process (the knob is read once per process)
     code = (
         "import numpy as np\n"
         "from faucet_amd import _lib as L, api\n"
         "from oracle import pyoracle as po\n"
         "from tests.golden_util import Case\n"
-        "c = Case('c1_k21')\n"
+        "from tests.test_gpu_parity import chunks\n"
+        "c = Case('ragged_k31')\n"
         "bases, offs = po.reads_from_lines(c.lines())\n"
         "tai, nh = api.load_filter_shape(c.E, c.S)\n"
-        "ctx = api.Context(c.k, tai, nh)\n"
-        "ctx.bloom_upload(L.BLOO2, c.bloom())\n"
-        "sc = api.ReadScanner(ctx)\n"
-        "st = sc.scanReads([api.ReadBatch(bases, offs)])\n"
-        "keys, recs = sc.junctions()\n"
-        "assert sc.fell_back_to_eager and st['flag_positions'] >= st['piece_positions']\n"
-        "assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())\n"
-        "print('fallback ok')\n")
+        "want = sorted(c.junction_lines())\n"
+        "for mode in ('stream', 'prepared'):\n"
+        "    ctx = api.Context(c.k, tai, nh, walk_window_span=512)\n"
+        "    ctx.bloom_upload(L.BLOO2, c.bloom())\n"
+        "    ctx.scan_begin()\n"
+        "    for b in chunks(bases, offs, 5):\n"
+        "        ctx.scan_batch(b) if mode == 'stream' else ctx.scan_prepare(b)\n"
+        "    if mode == 'prepared':\n"
+        "        ctx.scan_walk_prepared()\n"
+        "    st = ctx.scan_end()\n"
+        "    keys, recs = ctx.junctions()\n"
+        "    assert ctx.diag_scan_replays() == 1, (mode, ctx.diag_scan_replays())\n"
+        "    assert st['reads_processed'] == len(offs) - 1\n"
+        "    assert sorted(api.junction_lines(keys, recs, c.k)) == want, mode\n"
+        "    for key, val in (('nb_processed', c.counters['nb_processed']), ('nb_skipped', c.counters['nb_skipped']), ('nb_jcheck_kmer', c.counters['nb_jcheck_kmer'])):\n"
+        "        assert st[key] == val, (mode, key)\n"
+        "print('absorbed ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGPU_DEBUG_LAZY_FAIL="1")
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
-    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "absorbed ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("n_batches", [1, 5])
