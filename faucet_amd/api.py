@@ -424,18 +424,11 @@ class ReadScanner:
         self.fell_back_to_eager = False
 
     def scanReads(self, batches):                    # src/ReadScanner.cpp:284-359
-        try:
-            return self._scan(batches)
-        except FaucetGpuError as e:                  # the lazy-flag self-check fired: same scan with the flags evaluated everywhere
-            if "lazy-flag" not in str(e):
-                raise
-            try:
-                self.ctx.scan_end()
-            except FaucetGpuError:
-                pass
-            self.ctx.scan_set_eager(True)
-            self.fell_back_to_eager = True
-            return self._scan(batches)
+        replays = self.ctx.diag_scan_replays()
+        st = self._scan(batches)
+        # (the library scanned its journal again because the lazy junction-test preview could not be repaired: DESIGN.md section 4)
+        self.fell_back_to_eager = self.ctx.diag_scan_replays() > replays
+        return st
 
     def _scan(self, batches):
         self.ctx.scan_begin()

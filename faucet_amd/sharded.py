@@ -403,56 +403,24 @@ class GpuShard:
     def scan_prepare(self, batch):
         self.ctx.scan_prepare(batch)
 
-    def _restart_eager(self):
-        from .api import FaucetGpuError
-        try:
-            self.ctx.scan_end()
-        except FaucetGpuError:
-            pass
-        self.ctx.scan_set_eager(True)
-        self.ctx.scan_begin()
-
     def scan_stream(self, batches, after_batch=None):
-        """scan_batch over all batches (after_batch(i) is called behind each); when the lazy-flag self-check fires
-        the pass is closed and repeated with every junction test evaluated -- the table is reset by scan_begin, and what has left this
-        rank so far is at most a preview of the table (an earlier state of the same table in the repeated scan as well)"""
-        from .api import FaucetGpuError
-        try:
-            for i, b in enumerate(batches):
-                self.ctx.scan_batch(b)
-                if after_batch:
-                    after_batch(i)
-            return self.ctx.scan_end()
-        except FaucetGpuError as e:
-            if "lazy-flag" not in str(e):
-                raise
-            self._restart_eager()
-            for i, b in enumerate(batches):
-                self.ctx.scan_batch(b)
-                if after_batch:
-                    after_batch(i)
-            return self.ctx.scan_end()
+        """scan_batch over all batches (after_batch(i) is called behind each), scan_end.  (A preview of the walk that does not hold is the
+        library's business: it scans its journal again by itself; what has left this rank before that is at most a preview of the table,
+        and the repeated scan's table is again a later state of it.)"""
+        for i, b in enumerate(batches):
+            self.ctx.scan_batch(b)
+            if after_batch:
+                after_batch(i)
+        return self.ctx.scan_end()
 
     def import_hint(self, buf, n):
         self.ctx.import_hint(buf.data_ptr(), n)
 
     def walk_shard(self, batches, buf, n, carried):
-        """the handed-over table takes the place of the preview, then the ordered walk of the prepared batches.  Should the walk find
-        the preview wanting in a way it cannot repair the shard is prepared again with every test evaluated."""
-        from .api import FaucetGpuError
-        try:
-            self.import_table(buf, n, carried)
-            self.ctx.scan_walk_prepared()
-            return self.ctx.scan_end()
-        except FaucetGpuError as e:
-            if "lazy-flag" not in str(e):
-                raise
-            self._restart_eager()
-            for b in batches:
-                self.ctx.scan_prepare(b)
-            self.import_table(buf, n, carried)
-            self.ctx.scan_walk_prepared()
-            return self.ctx.scan_end()
+        """the handed-over table takes the place of the preview, then the ordered walk of the prepared batches"""
+        self.import_table(buf, n, carried)
+        self.ctx.scan_walk_prepared()
+        return self.ctx.scan_end()
 
     def scan_walk_prepared(self):
         self.ctx.scan_walk_prepared()
