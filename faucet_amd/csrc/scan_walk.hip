@@ -425,11 +425,6 @@ struct WalkCtx {
     const uint32_t* bloom;   // bloo2, for the junction tests the preview did not order (walk_fill_flags)
     // per-thread accumulators
     unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
-    // oriented keys this thread's cluster has created in the current window: the snapshot planes of phase A cannot
-    // know them, every later in-map test of the cluster has to (tandem repeats inside a piece; later pieces of the cluster)
-    uint64_t* ckey;     // NC entries, a thread-private array of the kernel (the only part of the state in scratch)
-    int nc;
-    bool c_overflow;    // more than NC creations: fall back to live table lookups
     bool created_now;   // set by junction_get
     int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
 };
@@ -493,56 +488,46 @@ __device__ __forceinline__ int pv_base(const PieceView& v, const uint64_t* codes
     return (int)((pv_cw(v, (uint32_t)(rel >> 5)) >> (62 - 2 * (int)(rel & 31))) & 3);
 }
 
-// in-map bits of chunk c that the snapshot cannot know: keys created by this cluster since phase A.
-// Either compared k-mer by k-mer against the short created list (no memory traffic), or, once that list has
-// overflowed, by live table lookups.
-// Out of line and fed by value on purpose: it is the rare path, and it is the only code that indexes the created-key
-// list at run time — keeping it away from WalkCtx lets the rest of the walk state live in registers.
-__device__ __noinline__ uint4 created_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint64_t where,
-                                                const uint64_t* ckey, int nc, bool overflow, JTable jt) {
+// In-map bits that the batch's snapshot planes cannot know (keys created since they were made: by earlier batches' walks still in flight
+// then, by earlier windows, by earlier pieces of this cluster, by the piece itself): the LIVE table is asked, and only at the piece's lk
+// positions -- a key created since the snapshot is a registered candidate of this window (k_walk_register's delta), so its positions are
+// lk positions, and every piece it occurs on is in this thread's cluster: what the look-up sees is what the sequential run has.
+// Out of line and fed by value on purpose: the rare path stays out of the walk's register allocation.
+__device__ __noinline__ uint4 live_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint64_t where, JTable jt) {
     uint64_t mF = 0, mB = 0;
     while (where) {   // only the candidate positions of the chunk
         const uint32_t i = (uint32_t)__builtin_ctzll(where);
         where &= where - 1;
-        uint64_t km = fd_kmer_at(codes, p + i, k);
-        uint64_t rc = fd_revcomp(km, k);
-        if (!overflow) {
-            for (int n = 0; n < nc; n++) {
-                if (ckey[n] == km) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
-                if (ckey[n] == rc) mB |= 1ULL << i;   // backward-facing key = its reverse complement
-            }
-        } else {
-            uint64_t canon = km < rc ? km : rc;
-            uint64_t slot;
-            uint32_t present;
-            if (jt_find_live(jt, canon, slot, present)) {
-                if ((present >> (km == canon ? 0 : 1)) & 1u) mF |= 1ULL << i;
-                if ((present >> (rc == canon ? 0 : 1)) & 1u) mB |= 1ULL << i;
-            }
+        const uint64_t km = fd_kmer_at(codes, p + i, k);
+        const uint64_t rc = fd_revcomp(km, k);
+        const uint64_t canon = km < rc ? km : rc;
+        uint64_t slot;
+        uint32_t present;
+        if (jt_find_live(jt, canon, slot, present)) {
+            if ((present >> (km == canon ? 0 : 1)) & 1u) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
+            if ((present >> (rc == canon ? 0 : 1)) & 1u) mB |= 1ULL << i;   // backward-facing key = its reverse complement
         }
     }
     return make_uint4((uint32_t)mF, (uint32_t)(mF >> 32), (uint32_t)mB, (uint32_t)(mB >> 32));
 }
 
-__device__ __forceinline__ void created_bits(const WalkCtx& wc, const uint64_t* ckey, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+__device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
     if (wc.dbg & 1) { mF = mB = 0; return; }
     const uint32_t base = c * 64;
     const uint64_t where = pv_word(v, v.lk0, v.lk1, wc.pl.lk, c);
     if (!where) { mF = mB = 0; return; }
-    uint4 r = created_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, where, ckey, wc.nc, wc.c_overflow, wc.jt);
+    uint4 r = live_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, where, wc.jt);
     mF = (uint64_t)r.x | ((uint64_t)r.y << 32);
     mB = (uint64_t)r.z | ((uint64_t)r.w << 32);
 }
 
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
-    const uint64_t* ckey = wc.ckey;
     mF = pv_word(v, v.inF0, v.inF1, wc.pl.inF, c);
     mB = pv_word(v, v.inB0, v.inB1, wc.pl.inB, c);
-    if (wc.nc == 0 && !wc.c_overflow) return;
     if (c == 0) { mF |= v.xF0; mB |= v.xB0; return; }
     if (c == 1) { mF |= v.xF1; mB |= v.xB1; return; }
     uint64_t a, b;
-    created_bits(wc, ckey, v, c, a, b);
+    created_bits(wc, v, c, a, b);
     mF |= a;
     mB |= b;
 }
@@ -713,10 +698,8 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
     const int spacer = 2 * wc.fp.max_spacer - 1;
     PieceView v;
     pv_load(v, wc.pl, p0, nwin);
-    if (wc.nc || wc.c_overflow) {                   // an earlier piece of this cluster created keys
-        created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
-        if (nwin > 64) created_bits(wc, wc.ckey, v, 1, v.xF1, v.xB1);
-    }
+    created_bits(wc, v, 0, v.xF0, v.xB0);           // what the snapshot planes cannot know: the live table at the candidate positions
+    if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
     int t = 2 * j + 1;
     int last_pos = 0;                               // lastJuncPos
     bool have_last = false;
@@ -794,8 +777,8 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur)) return;
         if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
         if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
-            created_bits(wc, wc.ckey, v, 0, v.xF0, v.xB0);
-            if (nwin > 64) created_bits(wc, wc.ckey, v, 1, v.xF1, v.xB1);
+            created_bits(wc, v, 0, v.xF0, v.xB0);
+            if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
         }
         const bool same = have_last && cur.addr == last.addr;   // the same junction twice in a row: one register copy
         if (same) cur = last;
@@ -855,10 +838,9 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
                                              uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     WalkCtx wc;
-    wc.ckey = nullptr;   // no list of created keys: the table itself is asked at the candidate positions (c_overflow)
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.nc = 0; wc.c_overflow = true; wc.created_now = false; wc.dbg = dbg;
+    wc.created_now = false; wc.dbg = dbg;
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;

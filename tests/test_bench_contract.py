@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_config2.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_config2.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "k-mers/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -18,6 +18,10 @@ def test_committed_bench_line_has_the_contract_keys():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    # round 2: what the counters say, the PCIe-inclusive rate and the all-cores CPU figure ride in the same line
+    assert d["pipeline_measured"]["GBps"] > 0 and not d["pipeline_measured"]["kernels_without_counters"]
+    assert 0 < d["host_input"]["value"] < d["value"] and c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"]
+    assert r["frac_bloo1_accesses_only"] < r["frac"] and "attribution" in r
     # value is consistent with the step time it was derived from
     assert abs(d["value"] - d["kmers_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
