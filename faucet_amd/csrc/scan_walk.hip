@@ -12,13 +12,14 @@
 // So two pieces can only interact if a candidate k-mer of one occurs (at any position) on the other.
 // Per scheduling window of W consecutive pieces:
 //   A  k_walk_register candidate positions (in the map as of the batch's snapshot planes nF/nB, flagged, fake-junction or spacer
-//                      positions) register their k-mer's hash in a small window table; k_walk_delta adds the keys created since
-//                      that snapshot was taken (creation planes of the batches walked since, and of this batch's earlier windows)
+//                      positions) register their k-mer's hash in a small window table, and so do the keys created since that snapshot
+//                      was taken (lists kept by k_delta_collect: the batches walked since, this batch's earlier windows)
 //   B  k_walk_link     every position: probe the window table; a hit unions the piece with the candidate's owner
 //   C  k_walk_cluster  flatten the union-find; list each cluster's members in ascending piece order
 //   D  k_walk          one thread per cluster replays its pieces IN ORDER against the live table; clusters are
 //                      disjoint in the keys they touch, so they run concurrently without changing any result
-//   E  k_walk_clean    sparse reset of the window table
+//   E  k_delta_collect the keys the window created go to the batch's list; k_walk_reset_uf (side stream) resets the union-find arrays
+//                      and the window table's presence filter of this parity (the table itself needs no cleaning: epoch-tagged entries)
 // Windows run one after another on the stream, so a later window sees everything earlier ones wrote.
 // The result is the reference's map, record for record; creation stamps (global piece number, half-step)
 // give the reference's insertion order back for the dump.
@@ -59,11 +60,10 @@ struct JTable {
 
 // The 32-bit hash of a canonical k-mer that every table of the walk stage works from: h32 = low half of fd_mix(canon).  It is computed
 // ONCE per position and batch (k_need_lookup writes the plane `kh`, 4 bytes per position); the per-window kernels read it back
-// instead of extracting, reverse-complementing and mixing the k-mer again -- those 64-bit multiplies were most of what
-// k_walk_lookup / k_walk_link executed (lookup 11.9 -> 6.x ms, link 7.1 -> 3.x ms per step on config 2).
+// instead of extracting, reverse-complementing and mixing the k-mer again (which, measured, was NOT what bounded them: they wait on
+// dependent loads and on the window table's atomics -- but it is what lets k_walk_register and k_walk_link work without the k-mers).
 __device__ __forceinline__ uint32_t jt_h32(uint64_t canon) { return (uint32_t)fd_mix(canon); }
 // junction-table slot (capacities up to 2^32) and filter bit (a multiplicative scramble: other bits than the slot's low ones decide)
-__device__ __forceinline__ uint64_t jt_home(const JTable& jt, uint32_t h32) { return (uint64_t)h32 & jt.mask; }
 __device__ __forceinline__ uint64_t jt_filter_bit_h(const JTable& jt, uint32_t h32) {
     return (((uint64_t)(h32 * 0x9E3779B1u) << 16) ^ (uint64_t)(h32 >> 7)) & jt.filter_mask;
 }
