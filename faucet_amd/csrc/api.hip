@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <string>
 
+#include <thread>
+
 #include "fgpu_ctx.h"
 
 int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries, uint64_t* d_stamps, uint64_t* n_entries);
@@ -164,6 +166,20 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
 
     fgpu_ctx* ctx = new fgpu_ctx();
     ctx->prm = *p;
+    // Beside the stream and buffer set-up below, a helper thread loads the code objects of the units the first batches use (the runtime
+    // loads a unit at the first use of one of its kernels: 20-25 ms for the large ones) and creates the text stream (a queue: 10 ms).
+    const int device = p->device;
+    std::thread warm([device, ctx] {
+        if (hipSetDevice(device) != hipSuccess) return;
+        fgpu_touch_text();
+        fgpu_touch_pack();
+        fgpu_touch_load();
+        (void)fgpu_text_streams(ctx);
+        fgpu_touch_scan_pure();
+        fgpu_touch_scan_walk();
+        (void)hipGetLastError();
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
     if (!ctx->prm.junction_capacity) {
         // default: one slot per 32 filter bits (2^24 slots for config 2's 2^29-bit filters, 2^27 for 2^32 bits), within 2^22..2^28;
         // at the reference's ~0.1 junctions per read that leaves the table below 10 % load
@@ -226,6 +242,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream);
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) fail("initial memset", e);
     }
+    warm.join();   // (before the context can be destroyed)
     if (rc) {
         fgpu_destroy(ctx);
         return rc;
@@ -237,6 +254,12 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
 void fgpu_destroy(fgpu_ctx* ctx) {
     if (!ctx) return;
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); hipEventDestroy(ctx->copy_after); }
+    if (ctx->tstream) {
+        hipStreamSynchronize(ctx->tstream);
+        hipStreamDestroy(ctx->tstream);
+    }
+    for (int i = 0; i < 2; i++) if (ctx->ev_text_mark[i]) hipEventDestroy(ctx->ev_text_mark[i]);
+    if (ctx->ev_text_done) hipEventDestroy(ctx->ev_text_done);
     if (ctx->wstream) hipStreamSynchronize(ctx->wstream);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }

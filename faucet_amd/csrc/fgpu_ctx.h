@@ -134,6 +134,8 @@ struct DevCounters {
     unsigned long long mark_pending;    // pass 1: occurrences left to k_load_resolve
 };
 
+struct TextSet { DevBuf buf, nl, rank, tmp, rec; };
+
 struct fgpu_ctx {
     fgpu_params prm;
     FdParams fd;
@@ -178,6 +180,7 @@ struct fgpu_ctx {
     uint64_t wcap = 0;
     uint64_t* wkeys = nullptr;
     uint32_t* wbits = nullptr;       // small presence bitmap in front of the window table
+    int wbits_log2 = 24;             // its size in bits (2 MiB: L2-resident; 2^22 was half full with windows of 2^26 positions)
     DeltaList delta_ring[FGPU_DELTA_RING];
     bool refresh_snapshot = false;   // the batch about to be walked was prepared ahead of its turn: its snapshot planes are made again first
     uint64_t delta_hist[FGPU_DELTA_RING] = {0, 0, 0, 0};   // records counted when the walk of each ring batch was issued
@@ -244,7 +247,14 @@ struct fgpu_ctx {
     hipStream_t copy_stream = nullptr;    // fgpu_bloom_download_begin: a device-to-host copy next to the kernels
     hipEvent_t copy_after = nullptr;      // main stream: everything the copy has to wait for
     bool copy_pending = false;
-    DevBuf text_buf, text_nl, text_rank, text_tmp, text_rec;   // fgpu_text_split: the text and the batch that points into it
+    // fgpu_text_split: the text and the batch that points into it, two sets used in turn, on a stream of their own
+    TextSet text[2];
+    uint64_t text_calls = 0;
+    hipStream_t tstream = nullptr;
+    hipEvent_t ev_text_mark[2] = {nullptr, nullptr};   // main stream, at the beginning of each call
+    hipEvent_t ev_text_done = nullptr;                 // text stream, at the end of each call (the main stream waits for it)
+    const uint64_t* split_offsets = nullptr;           // the batch the last call returned: its offsets, read count and number of bases
+    uint64_t split_n = 0, split_total = 0;
     std::vector<DevBuf*> owned;
 
     // profiling
@@ -294,6 +304,12 @@ static inline unsigned fgpu_grid(uint64_t n, unsigned per_block) {
 }
 
 // stage entry points implemented in the .hip files
+int fgpu_text_streams(fgpu_ctx* ctx);
+void fgpu_touch_load();
+void fgpu_touch_pack();
+void fgpu_touch_text();
+void fgpu_touch_scan_pure();
+void fgpu_touch_scan_walk();
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_stage_load(fgpu_ctx* ctx);
 int fgpu_load_sweep(fgpu_ctx* ctx);

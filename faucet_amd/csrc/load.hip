@@ -548,6 +548,13 @@ __global__ void k_probe_contains(const uint32_t* __restrict__ bloom, const uint6
 
 }  // namespace
 
+// fgpu_create touches one kernel of every translation unit from a helper thread: the runtime loads a unit's code object at the first use of
+// one of its kernels (20-25 ms for the large units), which otherwise lands on the first batch of each pass
+void fgpu_touch_load() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)k_popcount);
+}
+
 // Forget the kept batches (their buffers are recycled by the next load pass).  keep_going: a new load pass starts.
 void fgpu_resident_reset(fgpu_ctx* ctx, bool keep_going) {
     ctx->resident_count = 0;

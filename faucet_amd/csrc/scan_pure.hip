@@ -537,6 +537,13 @@ __global__ void __launch_bounds__(256) k_probe_stage3(const uint64_t* __restrict
 
 }  // namespace
 
+// fgpu_create touches one kernel of every translation unit from a helper thread: the runtime loads a unit's code object at the first use of
+// one of its kernels (20-25 ms for the large units), which otherwise lands on the first batch of each pass
+void fgpu_touch_scan_pure() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)k_scan_same);
+}
+
 int fgpu_util_probe_stage3(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int mode, signed char* d_out) {
     FGPU_LAUNCH("probe_stage3", k_probe_stage3, fgpu_blocks(n, 256), 256, d_kmers, n, mode, ctx->fd, (const uint32_t*)ctx->bloo2, d_out);
     return FGPU_OK;

@@ -71,11 +71,11 @@ __device__ __forceinline__ uint64_t jt_filter_bit(const JTable& jt, uint64_t can
 
 struct WTable {
     uint64_t* keys;      // epoch << 56 | h32 << 24 | owner (see wt_register)
-    uint32_t* bits;      // 2^WBITS_LOG2-bit presence filter (cleared by a memset before every window)
+    uint32_t* bits;      // presence filter of 2^(32 - fshift) bits in front of the table (zeroed by k_walk_reset_uf of the window two before)
     uint64_t mask;
     uint64_t epoch;      // number of the window (1..255) << 56: entries of any other epoch count as empty slots
+    uint32_t fshift;     // 32 - log2(bits of the presence filter)
 };
-constexpr int WBITS_LOG2 = 22;   // 4 Mbit = 512 KiB
 
 // scheduling window = all pieces whose first window lies in [lo, hi); filled by k_walk_setup
 struct WinDesc {
@@ -195,7 +195,7 @@ constexpr int W_OWNER_BITS = 24;
 constexpr uint64_t W_OWNER_MASK = (1ULL << W_OWNER_BITS) - 1;
 constexpr uint64_t W_EPOCH_MASK = 0xFFULL << 56;
 constexpr uint32_t W_NO_OWNER = (uint32_t)W_OWNER_MASK;   // a key registered by k_walk_delta: no piece of the window owns it yet
-__device__ __forceinline__ uint32_t wt_filter_bit(uint32_t h32) { return (h32 * 0x85EBCA6Bu) >> (32 - WBITS_LOG2); }
+__device__ __forceinline__ uint32_t wt_filter_bit(const WTable& wt, uint32_t h32) { return (h32 * 0x85EBCA6Bu) >> wt.fshift; }
 
 __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, uint32_t h32, uint32_t piece, DevCounters* cnt) {
     const unsigned long long mine = (unsigned long long)(wt.epoch | ((uint64_t)h32 << W_OWNER_BITS) | (uint64_t)piece);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, 
         if ((v & W_EPOCH_MASK) != wt.epoch) {                   // left by an earlier window: free
             const unsigned long long old = atomicCAS((unsigned long long*)&wt.keys[s], v, mine);
             if (old == v) {
-                const uint32_t b = wt_filter_bit(h32);
+                const uint32_t b = wt_filter_bit(wt, h32);
                 atomicOr(&wt.bits[b >> 5], 1u << (b & 31));
                 return;
             }
@@ -224,7 +224,7 @@ __device__ __forceinline__ void wt_register(const WTable& wt, uint32_t* parent, 
 }
 
 __device__ __forceinline__ uint32_t wt_owner(const WTable& wt, uint32_t h32, uint64_t& slot) {
-    const uint32_t b = wt_filter_bit(h32);
+    const uint32_t b = wt_filter_bit(wt, h32);
     if (!((wt.bits[b >> 5] >> (b & 31)) & 1u)) return U_INF;
     uint64_t s = (uint64_t)h32 & wt.mask;
     for (uint64_t n = 0; n <= wt.mask; n++) {
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
         for (int u = 0; u < U; u++) h[u] = act[u] ? pl.kh[p[u]] : 0u;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t b = wt_filter_bit(h[u]);
+            const uint32_t b = wt_filter_bit(wt, h[u]);
             fw[u] = act[u] ? ((wt.bits[b >> 5] >> (b & 31)) & 1u) : 0u;
         }
 #pragma unroll
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(256) k_delta_collect(unsigned long long* __res
 
 // union-find and list entries of a window's pieces back to "every piece its own cluster": the arrays exist twice and consecutive
 // windows alternate, so this runs on the side stream while the NEXT window is already being looked up and linked
-__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t n, uint4* wbits) {
+__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t n, uint4* wbits, uint32_t wbits_vec) {
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
         parent[a] = a;
         count[a] = 0;
@@ -933,7 +933,7 @@ __global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_
     }
     // ... and the window table's presence filter of this parity (a memset on the walk stream took 47 us per window when the
     // pure stage of the next batch ran beside it: 3.6 ms per step on the critical queue)
-    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < (1u << WBITS_LOG2) / 128; a += gridDim.x * blockDim.x) wbits[a] = make_uint4(0, 0, 0, 0);
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < wbits_vec; a += gridDim.x * blockDim.x) wbits[a] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ void __launch_bounds__(256) k_fill_u64(uint64_t* p, uint64_t n, uint64_t v) {
@@ -1179,10 +1179,17 @@ static uint64_t jfilter_bits(fgpu_ctx* ctx) {
 }
 JTable make_jt(fgpu_ctx* ctx) { return JTable{ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jcap - 1, ctx->jfilter, jfilter_bits(ctx) - 1}; }
 WTable make_wt(fgpu_ctx* ctx, uint64_t epoch, int parity) {
-    return WTable{ctx->wkeys, ctx->wbits + parity * ((1ULL << WBITS_LOG2) / 32), ctx->wcap - 1, epoch << 56};
+    return WTable{ctx->wkeys, ctx->wbits + parity * ((1ULL << ctx->wbits_log2) / 32), ctx->wcap - 1, epoch << 56, (uint32_t)(32 - ctx->wbits_log2)};
 }
 
 }  // namespace
+
+// fgpu_create touches one kernel of every translation unit from a helper thread: the runtime loads a unit's code object at the first use of
+// one of its kernels (20-25 ms for the large units), which otherwise lands on the first batch of each pass
+void fgpu_touch_scan_walk() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)k_iota_u32);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 int fgpu_scan_alloc(fgpu_ctx* ctx) {
@@ -1198,8 +1205,9 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     ctx->wcap = 4 * ctx->max_span;
     ctx->wmax = (uint32_t)(ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2);
     FGPU_HIP(hipMalloc(&ctx->wdesc, 64));
+    if (const char* e = getenv("FGPU_WBITS_LOG2")) ctx->wbits_log2 = std::min(28, std::max(16, atoi(e)));   // measurement aid
     FGPU_HIP(hipMalloc(&ctx->wkeys, ctx->wcap * 8));
-    FGPU_HIP(hipMalloc(&ctx->wbits, 2 * (1ULL << WBITS_LOG2) / 8));   // two filters: consecutive windows alternate
+    FGPU_HIP(hipMalloc(&ctx->wbits, 2 * (1ULL << ctx->wbits_log2) / 8));   // two filters: consecutive windows alternate
     FGPU_HIP(hipMalloc(&ctx->uf_parent, 2 * ctx->wmax * 4));   // two sets each: consecutive windows alternate (k_walk_reset_uf)
     FGPU_HIP(hipMalloc(&ctx->cl_count, 2 * ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_offset, 2 * ctx->wmax * 4));
@@ -1268,7 +1276,7 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
     if (!ctx->wt_epoch) FGPU_HIP(hipMemsetAsync(ctx->wkeys, 0, ctx->wcap * 8, ctx->stream));   // a new table: epoch 0 = no window's entry
-    FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, 2 * (1ULL << WBITS_LOG2) / 8, ctx->stream));        // (a scan that broke off may have left bits behind)
+    FGPU_HIP(hipMemsetAsync(ctx->wbits, 0, 2 * (1ULL << ctx->wbits_log2) / 8, ctx->stream));        // (a scan that broke off may have left bits behind)
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent, (uint64_t)ctx->wmax);
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent + ctx->wmax, (uint64_t)ctx->wmax);
     FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, 2 * ctx->wmax * 4, ctx->stream));
@@ -1448,7 +1456,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_HIP(hipEventRecord(ctx->ev_walked, walk_stream));
         FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_walked, 0));
         ctx->launch_stream = ctx->cstream;
-        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, (uint32_t)max_pieces, (uint4*)wt.bits);
+        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, (uint32_t)max_pieces, (uint4*)wt.bits, (uint32_t)((1u << ctx->wbits_log2) / 128));
         ctx->launch_stream = walk_stream;
         FGPU_HIP(hipEventRecord(ctx->ev_uf_reset[parity], ctx->cstream));
         if (serial_clean) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));

@@ -69,6 +69,25 @@ __global__ void __launch_bounds__(256) k_text_lengths(const uint64_t* __restrict
 
 }  // namespace
 
+// fgpu_create touches one kernel of every translation unit from a helper thread: the runtime loads a unit's code object at the first use of
+// one of its kernels (20-25 ms for the large units), which otherwise lands on the first batch of each pass
+void fgpu_touch_text() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, (const void*)k_text_lengths);
+}
+
+// The split runs on its own stream with two alternating sets of buffers: while the main stream works on the batch cut out of the previous
+// chunk, this chunk is copied to the device and cut, and the host waits for the text stream only.  (On the main stream -- round 1 -- every
+// chunk waited for the batch before it, the device idled during the copy, and a 1.1 GB file took 2.4 times the kernels' time per pass.)
+int fgpu_text_streams(fgpu_ctx* ctx) {
+    if (ctx->tstream) return FGPU_OK;
+    for (int i = 0; i < 2; i++)
+        if (!ctx->ev_text_mark[i]) FGPU_HIP(hipEventCreateWithFlags(&ctx->ev_text_mark[i], hipEventDisableTiming));
+    if (!ctx->ev_text_done) FGPU_HIP(hipEventCreateWithFlags(&ctx->ev_text_done, hipEventDisableTiming));
+    FGPU_HIP(hipStreamCreateWithFlags(&ctx->tstream, hipStreamNonBlocking));   // last: its presence says the events are there
+    return FGPU_OK;
+}
+
 extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
                                fgpu_reads* out, uint64_t* consumed) {
     if (!ctx || !out || !consumed || (nbytes && !text)) return FGPU_ERR_ARG;
@@ -77,64 +96,84 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     memset(out, 0, sizeof(*out));
     out->on_device = 1;
     *consumed = 0;
+    ctx->split_offsets = nullptr;
     if (nbytes == 0) return FGPU_OK;
     int rc;
+    if ((rc = fgpu_text_streams(ctx))) return rc;
+    // Set c & 1 was last read by the batch of call c - 2, which was queued before call c - 1 began: the mark call c - 1 left on the main
+    // stream.  Text that is on the device already was written in main-stream order by the caller: this call's own mark.
+    const uint64_t c = ctx->text_calls++;
+    TextSet& ts = ctx->text[c & 1];
+    FGPU_HIP(hipEventRecord(ctx->ev_text_mark[c & 1], ctx->stream));
+    if (text_on_device) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_text_mark[c & 1], 0));
+    else if (c) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_text_mark[(c - 1) & 1], 0));
+    struct OnStream {   // kernels of this call go to the text stream
+        fgpu_ctx* c;
+        hipStream_t saved;
+        OnStream(fgpu_ctx* ctx) : c(ctx), saved(ctx->launch_stream) { ctx->launch_stream = ctx->tstream; }
+        ~OnStream() { c->launch_stream = saved; }
+    } on_stream(ctx);
+    hipStream_t st = ctx->tstream;
     const unsigned char* d_text;
     if (text_on_device) {
         d_text = (const unsigned char*)text;
     } else {
-        if ((rc = fgpu_ensure(ctx, &ctx->text_buf, nbytes + 64))) return rc;
-        FGPU_HIP(hipMemcpyAsync(ctx->text_buf.p, text, nbytes, hipMemcpyHostToDevice, ctx->stream));
-        d_text = (const unsigned char*)ctx->text_buf.p;
+        if ((rc = fgpu_ensure(ctx, &ts.buf, nbytes + 64))) return rc;
+        FGPU_HIP(hipMemcpyAsync(ts.buf.p, text, nbytes, hipMemcpyHostToDevice, st));
+        d_text = (const unsigned char*)ts.buf.p;
     }
     const uint64_t n_words = (nbytes + 63) / 64;
     const uint32_t P = fastq ? 4u : 2u;
-    if ((rc = fgpu_ensure(ctx, &ctx->text_nl, n_words * 8))) return rc;
-    if ((rc = fgpu_ensure(ctx, &ctx->text_rank, (2 * n_words + 2) * 4))) return rc;
-    uint64_t* nl = (uint64_t*)ctx->text_nl.p;
-    uint32_t* count = (uint32_t*)ctx->text_rank.p;
+    if ((rc = fgpu_ensure(ctx, &ts.nl, n_words * 8))) return rc;
+    if ((rc = fgpu_ensure(ctx, &ts.rank, (2 * n_words + 2) * 4))) return rc;
+    uint64_t* nl = (uint64_t*)ts.nl.p;
+    uint32_t* count = (uint32_t*)ts.rank.p;
     uint32_t* rank = count + n_words + 1;
     FGPU_LAUNCH("text_newlines", k_text_newlines, fgpu_grid(n_words * 64, 256), 256, d_text, nbytes, n_words, nl, count);
     size_t tmp_bytes = 0, tmp2 = 0;
-    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), ctx->stream));
-    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, n_words * 64 / 2 + 2, rocprim::plus<uint64_t>(), ctx->stream));
+    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), st));
+    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, n_words * 64 / 2 + 2, rocprim::plus<uint64_t>(), st));
     if (tmp2 > tmp_bytes) tmp_bytes = tmp2;   // the second scan (at most one record per 2 bytes) reuses the scratch
-    if ((rc = fgpu_ensure(ctx, &ctx->text_tmp, tmp_bytes + 16))) return rc;
-    FGPU_HIP(rocprim::exclusive_scan(ctx->text_tmp.p, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), ctx->stream));
+    if ((rc = fgpu_ensure(ctx, &ts.tmp, tmp_bytes + 16))) return rc;
+    FGPU_HIP(rocprim::exclusive_scan(ts.tmp.p, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), st));
     uint32_t last[2];
     unsigned char last_byte = 0;
-    FGPU_HIP(hipMemcpyAsync(&last[0], count + n_words - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipMemcpyAsync(&last[1], rank + n_words - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipMemcpyAsync(&last_byte, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(&last[0], count + n_words - 1, 4, hipMemcpyDeviceToHost, st));
+    FGPU_HIP(hipMemcpyAsync(&last[1], rank + n_words - 1, 4, hipMemcpyDeviceToHost, st));
+    FGPU_HIP(hipMemcpyAsync(&last_byte, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
+    FGPU_HIP(hipStreamSynchronize(st));
     const uint64_t n_newlines = (uint64_t)last[0] + last[1];
     // lines as getline counts them: every '\n' ends one; at the end of the file a non-empty unterminated tail is one more
     const uint64_t n_lines = n_newlines + ((final_chunk && last_byte != '\n') ? 1 : 0);
     const uint64_t n_rec = final_chunk ? (n_lines + P - 1) / P : n_newlines / P;
     if (n_rec == 0) return FGPU_OK;   // not even one complete record: the caller reads more
     if (n_rec >= 0xFFFFFFFFULL) { ctx->err = "more than 2^32 records in one chunk of text"; return FGPU_ERR_CAPACITY; }
-    if ((rc = fgpu_ensure(ctx, &ctx->text_rec, (4 * n_rec + 4) * 8))) return rc;
-    uint64_t* starts = (uint64_t*)ctx->text_rec.p;
+    if ((rc = fgpu_ensure(ctx, &ts.rec, (4 * n_rec + 4) * 8))) return rc;
+    uint64_t* starts = (uint64_t*)ts.rec.p;
     uint64_t* ends = starts + n_rec;         // becomes the lengths
     uint64_t* offsets = ends + n_rec + 1;    // n_rec + 1 entries
     uint64_t* rec_end = offsets + n_rec + 1;
     FGPU_LAUNCH("text_defaults", k_text_defaults, fgpu_grid(n_rec, 256), 256, starts, ends, n_rec, nbytes);
-    FGPU_HIP(hipMemsetAsync(rec_end, 0, n_rec * 8, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(rec_end, 0, n_rec * 8, st));
     FGPU_LAUNCH("text_records", k_text_records, fgpu_grid(n_words, 256), 256, (const uint64_t*)nl, (const uint32_t*)rank, n_words, P, n_rec,
                 starts, ends, rec_end);
     FGPU_LAUNCH("text_lengths", k_text_lengths, fgpu_grid(n_rec + 1, 256), 256, (const uint64_t*)starts, (const uint64_t*)ends, n_rec, ends);
     size_t need = tmp_bytes;
-    FGPU_HIP(rocprim::exclusive_scan(ctx->text_tmp.p, need, ends, offsets, (uint64_t)0, n_rec + 1, rocprim::plus<uint64_t>(), ctx->stream));
-    uint64_t used = nbytes;
-    if (!final_chunk) {
-        FGPU_HIP(hipMemcpyAsync(&used, rec_end + n_rec - 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    FGPU_HIP(rocprim::exclusive_scan(ts.tmp.p, need, ends, offsets, (uint64_t)0, n_rec + 1, rocprim::plus<uint64_t>(), st));
+    uint64_t used = nbytes, total = 0;
+    if (!final_chunk) FGPU_HIP(hipMemcpyAsync(&used, rec_end + n_rec - 1, 8, hipMemcpyDeviceToHost, st));
+    FGPU_HIP(hipMemcpyAsync(&total, offsets + n_rec, 8, hipMemcpyDeviceToHost, st));   // saves the batch call its own look at the offsets
+    FGPU_HIP(hipEventRecord(ctx->ev_text_done, st));
+    FGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_text_done, 0));
+    FGPU_HIP(hipStreamSynchronize(st));
     *consumed = used;
     out->bases = (const char*)d_text;
     out->offsets = offsets;
     out->starts = starts;
     out->n_reads = n_rec;
+    ctx->split_offsets = offsets;
+    ctx->split_n = n_rec;
+    ctx->split_total = total;
     return FGPU_OK;
 }
 

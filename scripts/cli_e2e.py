@@ -63,4 +63,7 @@ for name, extra in (("host getline, 1 M reads per call", ["-batch_reads", "10000
     sig = (digest(pref + ".bloom"), digest(pref + ".junctions"))
     sigs.append(sig)
     print(f"{name:42s} {dt:7.2f} s  {70 * n / dt / 1e6:8.1f} M k-mers/s file to files   bloom {sig[0]} junctions {sig[1]}")
+    for line in r.stderr.splitlines():          # FGPU_CLI_TIMES=1: the CLI's own phase clock
+        if line.startswith("[cli]"):
+            print("    " + line)
 assert len(set(sigs)) == 1, "the runs disagree"

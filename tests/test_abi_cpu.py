@@ -106,3 +106,21 @@ def test_integration_binding_compiles_against_the_reference_headers():
                         "-I", os.path.join(ref, "utils"), "-I", os.path.join(root, "include"), os.path.join(root, "integration", "faucet_binding.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_replayed_dump_order_equals_the_containers(tmp_path):
+    """faucet_amd/host/junction_order.h: the CLI writes `.junctions` in the iteration order of the reference's std::unordered_map
+    (utils/JunctionMap.h:61, writeToFile utils/JunctionMap.cpp:579-596) without building the container; the replay is checked here against a
+    real container through many rehashes, on crowded small key spaces, and must refuse repeated keys (tests/host/junction_order_check.cpp)."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "junction_order_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++11", "-I", os.path.join(root, "faucet_amd", "host"),
+                        os.path.join(root, "tests", "host", "junction_order_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
