@@ -102,6 +102,9 @@ SIGNATURES = {
     "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),
     "fgpu_probe_valid_extension": (C.c_int, [_vp, _vp, _u64, _vp]),
     "fgpu_probe_bloom_junction": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "fgpu_stage3_set_junctions": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "fgpu_stage3_find_neighbors": (C.c_int, [_vp, _vp, _vp, _u64, _i32, _vp, _P(_u64), _vp, _u64]),
+    "fgpu_stage3_contig_words": (_u64, [_i32, _i32]),
     "fgpu_kernel_times": (C.c_int, [_vp, _P(KernelTime), C.c_int]),
     "fgpu_kernel_times_reset": (C.c_int, [_vp]),
     "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),

@@ -97,6 +97,8 @@ class ReadBatch:
 
 STOP_DTYPE = np.dtype([("ext", "<u8"), ("read", "<u4"), ("info", "<u4")])
 JUNC_DTYPE = np.dtype([("cov", np.uint8, 4), ("dist", np.uint8, 5), ("linked", np.uint8, 5)])
+NEIGHBOR_DTYPE = np.dtype([("kmer", "<u8"), ("dist", "<i4"), ("len", "<i4"), ("node", "i1"), ("rindex", "i1"), ("abort", "i1"), ("reserved", "i1"),
+                           ("reserved2", "<i4")])   # fgpu_neighbor
 
 
 class HostBuffer:
@@ -336,6 +338,32 @@ class Context:
 
     def probe_bloom_junction(self, kmers):           # JunctionMap::isBloomJunction, batched
         return self._probe_stage3(self.lib.fgpu_probe_bloom_junction, kmers)
+
+    def stage3_set_junctions(self, keys, recs):
+        """the junction map Stage 3's walks look into (keys as JunctionMap keys them; records as junctions() returns them)"""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        recs = np.ascontiguousarray(recs, dtype=JUNC_DTYPE)
+        assert len(keys) == len(recs)
+        self._c(self.lib.fgpu_stage3_set_junctions(self.h, keys.ctypes.data, recs.ctypes.data, len(keys)))
+
+    def stage3_find_neighbors(self, start_kmers, indices, max_read_length: int, contigs: bool = False):
+        """JunctionMap::findNeighbor for every (start k-mer, extension index) pair, whole walks on the device; returns (NEIGHBOR_DTYPE array,
+        number of getValidJExtension evaluations) and, with contigs=True, the list of contig strings (BfSearchResult::contig) as third item"""
+        start_kmers = np.ascontiguousarray(start_kmers, dtype=np.uint64)
+        indices = np.ascontiguousarray(indices, dtype=np.int8)
+        assert len(start_kmers) == len(indices)
+        n = len(start_kmers)
+        out = np.zeros(n, dtype=NEIGHBOR_DTYPE)
+        probes = C.c_uint64(0)
+        stride = int(self.lib.fgpu_stage3_contig_words(self.k, int(max_read_length))) if contigs else 0
+        text = np.zeros(max(n * stride, 1), dtype=np.uint64)
+        self._c(self.lib.fgpu_stage3_find_neighbors(self.h, start_kmers.ctypes.data, indices.ctypes.data, n, int(max_read_length), out.ctypes.data,
+                                                    C.byref(probes), text.ctypes.data if contigs else None, stride))
+        if not contigs:
+            return out, int(probes.value)
+        codes = (text.reshape(n, stride)[:, :, None] >> (2 * np.arange(32, dtype=np.uint64))[None, None, :]) & np.uint64(3)
+        chars = np.frombuffer(b"ACTG", dtype=np.uint8)[codes.reshape(n, stride * 32).astype(np.int64)]
+        return out, int(probes.value), [chars[i, :int(out["len"][i])].tobytes().decode() for i in range(n)]
 
     def kernel_times(self) -> dict:
         arr = (L.KernelTime * 64)()

@@ -243,6 +243,9 @@ struct fgpu_ctx {
     uint64_t scan_batch_seq = 0;
     uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;
+    DevBuf s3_keys, s3_dist, s3_in;       // Stage 3's junction map on the device (stage3.hip): k-mer -> five distances
+    uint64_t s3_mask = 0, s3_count = 0;
+    bool s3_ready = false;
     DevBuf dl_entries, dl_stamps, dl_stamps_sorted, dl_idx, dl_idx_sorted, dl_keys, dl_recs, dl_tmp;   // junction download scratch
     hipStream_t copy_stream = nullptr;    // fgpu_bloom_download_begin: a device-to-host copy next to the kernels
     hipEvent_t copy_after = nullptr;      // main stream: everything the copy has to wait for

@@ -270,6 +270,37 @@ int fgpu_probe_jcheck(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int
 int fgpu_probe_valid_extension(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out);
 int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out);
 
+/* ---- Stage 3's walks, whole ------------------------------------------------------
+ * JunctionMap::findNeighbor(Junction junc, kmer_type startKmer, int index) (utils/JunctionMap.cpp:231-412) for n (junction, extension)
+ * pairs at once, one device lane per walk: every getValidJExtension, every DoubleKmer step and every junctionMap.find of the walk happens
+ * on the device, against bloo2 as it stands (after a load, or fgpu_bloom_upload) and against the junction map handed over by
+ * fgpu_stage3_set_junctions (k-mers as JunctionMap keys them, i.e. as fgpu_scan_download_junctions / a .junctions file give them; only the
+ * five distances of a record are read, as in the reference).  The map stays on the device until it is set again.
+ * Result per walk = the reference's return value: the BaseNode* it would build -- `node` 1: a junction was reached (`kmer` its key, `rindex`
+ * the index it was entered through, 4 = backward), 0: a sink (`rindex` as the reference sets it) -- with the distance and the contig
+ * length the reference reports through its pointer arguments.  `abort` 1 marks the calls in which the reference trips one of its asserts
+ * (dist <= maxDist, validExtension >= 0) instead of returning; 2 = startKmer is not in the map or index is not 0..4.
+ * n_probes (may be NULL): getValidJExtension evaluations made, each up to 4 x (Bloom::oldContains + JChecker::jcheck).
+ * contigs_out (may be NULL): BfSearchResult::contig of every walk, the sequence getContig (utils/JunctionMap.cpp:133-227) appends to its
+ * contig string: walk w's string is `len` bases in contigs_out[w * contig_stride_words ..], 2 bits per base in the reference's code
+ * (A 0, C 1, T 2, G 3), 32 bases per word, the first base in the lowest bits; contig_stride_words >= fgpu_stage3_contig_words(k,
+ * max_read_length). */
+typedef struct {
+    uint64_t kmer;
+    int32_t  dist;
+    int32_t  len;
+    int8_t   node;
+    int8_t   rindex;
+    int8_t   abort;
+    int8_t   reserved;
+    int32_t  reserved2;
+} fgpu_neighbor;
+int fgpu_stage3_set_junctions(fgpu_ctx* ctx, const uint64_t* keys_host, const fgpu_junction* recs_host, uint64_t n);
+int fgpu_stage3_find_neighbors(fgpu_ctx* ctx, const uint64_t* start_kmers_host, const int8_t* indices_host, uint64_t n,
+                               int32_t max_read_length, fgpu_neighbor* out, uint64_t* n_probes, uint64_t* contigs_out,
+                               uint64_t contig_stride_words);
+uint64_t fgpu_stage3_contig_words(int32_t k, int32_t max_read_length);
+
 /* ---- profiling --------------------------------------------------------------------------------- */
 typedef struct {
     char     name[48];

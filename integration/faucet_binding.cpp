@@ -121,3 +121,42 @@ void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq) 
     printf("Number of skipped kmers: %llu \n", (unsigned long long)st.nb_skipped);
     printf("Reads without errors: %llu\n", (unsigned long long)st.reads_no_errors);
 }
+
+// ---- Stage 3: JunctionMap::findNeighbor for many (junction, extension) pairs in one device call ------------------------------------------
+// getContig (utils/JunctionMap.cpp:133-227) calls findNeighbor(junc, kmer, index) once per contig segment, each call a chain of dependent
+// Bloom probes (getValidJExtension, :474-490).  The calls that start from the junctions of the map as it stands are independent of each
+// other, so a patched buildBranchingPaths / buildLinearRegions can ask for all of them at once and look the answers up while it builds the
+// graph; the results are the BfSearchResult values the reference's function returns (k-mer, isNode, index, distance, contig string).
+// `max_read_length` is the JunctionMap constructor's third argument (a private member there).  Calls in which the reference would trip one
+// of its asserts come back with kmer == -1, the value of a default-constructed BfSearchResult.
+void gpu_set_junction_map(JunctionMap* junctionMap) {
+    std::vector<uint64_t> keys;
+    std::vector<fgpu_junction> recs;
+    for (auto it = junctionMap->junctionMap.begin(); it != junctionMap->junctionMap.end(); ++it) {
+        fgpu_junction r;
+        memset(&r, 0, sizeof(r));
+        for (int e = 0; e < 4; e++) r.cov[e] = it->second.getCoverage(e);
+        for (int e = 0; e < 5; e++) { r.dist[e] = it->second.dist[e]; r.linked[e] = it->second.linked[e] ? 1 : 0; }
+        keys.push_back((uint64_t)it->first);
+        recs.push_back(r);
+    }
+    GPU_CHECK(fgpu_stage3_set_junctions(g_ctx, keys.data(), recs.data(), keys.size()));
+}
+
+std::vector<BfSearchResult> gpu_find_neighbors(const std::vector<kmer_type>& start_kmers, const std::vector<int>& indices, int max_read_length) {
+    const size_t n = start_kmers.size();
+    std::vector<uint64_t> starts(start_kmers.begin(), start_kmers.end());
+    std::vector<int8_t> idx(indices.begin(), indices.end());
+    std::vector<fgpu_neighbor> out(n ? n : 1);
+    const uint64_t stride = fgpu_stage3_contig_words(sizeKmer, max_read_length);
+    std::vector<uint64_t> text((n ? n : 1) * stride);
+    GPU_CHECK(fgpu_stage3_find_neighbors(g_ctx, starts.data(), idx.data(), n, max_read_length, out.data(), NULL, text.data(), stride));
+    std::vector<BfSearchResult> results(n);
+    for (size_t w = 0; w < n; w++) {
+        if (out[w].abort) continue;                      // the reference asserts here; the caller sees an unset result
+        std::string contig((size_t)out[w].len, 'A');
+        for (int b = 0; b < out[w].len; b++) contig[(size_t)b] = "ACTG"[(text[w * stride + (size_t)b / 32] >> (2 * (b % 32))) & 3];
+        results[w] = BfSearchResult((kmer_type)out[w].kmer, out[w].node != 0, out[w].rindex, out[w].dist, contig);
+    }
+    return results;
+}

@@ -98,7 +98,7 @@ static int stage3_kat(int argc, char** argv) {
 /* ref_kat neighbors <bloom file> <bloom size request> <n_hash> <k> <j> <junctions file> <max read length>: the reference's own
  * JunctionMap::findNeighbor (utils/JunctionMap.cpp:231-412) from every junction of a reloaded map along every extension a contig would be
  * built on, on the STATIC map (buildContigGraph removes junctions as it goes; the walk itself is what is pinned here).  One JSON line per
- * call: start k-mer, index, then the result's k-mer, isNode, index, distance and contig length.  The reference's asserts stay armed: a call
+ * call: start k-mer, index, then the result's k-mer, isNode, index, distance, contig length and the contig string itself.  The reference's asserts stay armed: a call
  * that trips one (a filter false positive off the real sequence) is reported as "abort" instead of ending the harness. */
 #include <csetjmp>
 #include <csignal>
@@ -132,8 +132,8 @@ static int neighbors_kat(int argc, char** argv) {
                 continue;
             }
             BfSearchResult r = jm.findNeighbor(junc, key, i);
-            printf("{\"kat\":\"neighbor\",\"start\":\"%llx\",\"index\":%d,\"kmer\":\"%llx\",\"node\":%d,\"rindex\":%d,\"dist\":%d,\"len\":%d}\n",
-                   (unsigned long long)key, i, (unsigned long long)r.kmer, r.isNode ? 1 : 0, r.index, r.distance, (int)r.contig.size());
+            printf("{\"kat\":\"neighbor\",\"start\":\"%llx\",\"index\":%d,\"kmer\":\"%llx\",\"node\":%d,\"rindex\":%d,\"dist\":%d,\"len\":%d,\"contig\":\"%s\"}\n",
+                   (unsigned long long)key, i, (unsigned long long)r.kmer, r.isNode ? 1 : 0, r.index, r.distance, (int)r.contig.size(), r.contig.c_str());
         }
     }
     fclose(devnull);
