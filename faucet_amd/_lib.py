@@ -45,7 +45,7 @@ class LoadStats(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("reads_processed", "unambiguous_reads", "reads_no_errors", "nb_jcheck_kmer", "nb_no_juncs",
                                           "nb_processed", "nb_skipped", "n_junctions", "kmers", "walk_windows", "walk_followers",
-                                          "walk_max_cluster", "flag_positions", "piece_positions", "valid_reused", "flags_filled")]
+                                          "walk_max_cluster", "flag_positions", "piece_positions", "valid_reused", "flags_filled", "walk_parallel")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -97,6 +97,8 @@ SIGNATURES = {
     "fgpu_scan_export_table": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
     "fgpu_scan_import_table": (C.c_int, [_vp, _vp, _u64, _P(ScanStats)]),
     "fgpu_scan_import_hint": (C.c_int, [_vp, _vp, _u64]),
+    "fgpu_scan_short_pairs": (C.c_int, [_vp, _u64, _i32, _i32]),
+    "fgpu_scan_short_pairs_download": (C.c_int, [_vp, _vp, _u64]),
     "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
     "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -110,6 +112,7 @@ SIGNATURES = {
     "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),
     "fgpu_diag_random_access": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_int, _P(_f64)]),
     "fgpu_diag_device_attr": (C.c_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
+    "fgpu_diag_walk_probe": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_load_split": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
     "fgpu_diag_scan_replays": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_binned_probes": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, _P(_f64), _P(_f64), _P(_f64), _P(_f64)]),
@@ -139,7 +142,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fgpu_abi_version() != 1:
+    if lib.fgpu_abi_version() != 2:
         raise RuntimeError("libfaucet_gpu.so ABI version mismatch")
     _lib = lib
     return lib

@@ -339,6 +339,20 @@ class Context:
     def probe_bloom_junction(self, kmers):           # JunctionMap::isBloomJunction, batched
         return self._probe_stage3(self.lib.fgpu_probe_bloom_junction, kmers)
 
+    def diag_walk_probe(self):
+        out = (C.c_uint64 * 4)()
+        self._c(self.lib.fgpu_diag_walk_probe(self.h, out))
+        return [int(v) for v in out]
+
+    def scan_short_pairs(self, tai: int, n_hash: int, lists_to_host: bool = True):
+        """keep the short pair filter (scan_forward's addPair rules) on the device from the next scan on; tai = 0 switches it off"""
+        self._c(self.lib.fgpu_scan_short_pairs(self.h, int(tai), int(n_hash), 1 if lists_to_host else 0))
+
+    def scan_short_pairs_download(self, tai: int):
+        out = np.zeros(tai // 8, dtype=np.uint8)
+        self._c(self.lib.fgpu_scan_short_pairs_download(self.h, out.ctypes.data, len(out)))
+        return out
+
     def stage3_set_junctions(self, keys, recs):
         """the junction map Stage 3's walks look into (keys as JunctionMap keys them; records as junctions() returns them)"""
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

@@ -264,8 +264,8 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
-    void* ptrs[] = {ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
-                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_members, ctx->counters,
+    void* ptrs[] = {ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
+                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->cl_members, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
@@ -500,6 +500,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->journal_on = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
     ctx->eager_scan = ctx->lazy_failed = false;
     ctx->stops_delivered = 0;
+    if (ctx->short_pf) FGPU_HIP(hipMemsetAsync(ctx->short_pf, 0, ctx->short_pf_tai / 8, ctx->stream));   // a scan starts with empty pair filters
     ctx->have_import = false;
     ctx->journal_max_read_len = 0;
     ctx->hint_in_table = false;
@@ -817,6 +818,39 @@ int fgpu_scan_set_eager(fgpu_ctx* ctx, int on) {
     return FGPU_OK;
 }
 
+// ---- the short pair filter on the device ---------------------------------------------------------------------------------
+int fgpu_scan_short_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t lists_to_host) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "fgpu_scan_short_pairs while a pass is open"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (ctx->short_pf) {
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(hipFree(ctx->short_pf));
+        ctx->short_pf = nullptr;
+        ctx->short_pf_tai = 0;
+    }
+    if (!tai) return FGPU_OK;
+    if (!ctx->record_stops) { ctx->err = "fgpu_scan_short_pairs needs FGPU_FLAG_RECORD_STOPS"; return FGPU_ERR_STATE; }
+    if (!is_pow2(tai) || tai < 128 || n_hash < 1 || n_hash > 32) { ctx->err = "fgpu_scan_short_pairs: tai must be a power of two >= 128, n_hash 1..32"; return FGPU_ERR_ARG; }
+    FGPU_HIP(hipMalloc(&ctx->short_pf, tai / 8));
+    FGPU_HIP(hipMemsetAsync(ctx->short_pf, 0, tai / 8, ctx->stream));
+    ctx->short_pf_tai = tai;
+    ctx->short_pf_hashes = n_hash;
+    ctx->short_pf_lists_to_host = lists_to_host != 0;
+    return FGPU_OK;
+}
+
+int fgpu_scan_short_pairs_download(fgpu_ctx* ctx, uint8_t* out, uint64_t n_bytes) {
+    if (!ctx || !out) return FGPU_ERR_ARG;
+    if (!ctx->short_pf) { ctx->err = "fgpu_scan_short_pairs_download without fgpu_scan_short_pairs"; return FGPU_ERR_STATE; }
+    if (ctx->phase != 0) { ctx->err = "fgpu_scan_short_pairs_download while a pass is open"; return FGPU_ERR_STATE; }
+    if (n_bytes != ctx->short_pf_tai / 8) { ctx->err = "fgpu_scan_short_pairs_download: the filter has tai / 8 bytes"; return FGPU_ERR_ARG; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    FGPU_HIP(hipMemcpyAsync(out, ctx->short_pf, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
 int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* n_out, int64_t* batch_seq) {
     if (!ctx || !n_out || !batch_seq) return FGPU_ERR_ARG;
     if (!ctx->record_stops) { ctx->err = "fgpu_scan_take_stops needs FGPU_FLAG_RECORD_STOPS"; return FGPU_ERR_STATE; }
@@ -876,6 +910,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     s.piece_positions = c.piece_positions;
     s.valid_reused = c.valid_reused;
     s.flags_filled = c.flags_filled;
+    s.walk_parallel = c.walk_parallel;
     memset(&ctx->carried, 0, sizeof(ctx->carried));
     if (stats) *stats = s;
     return FGPU_OK;
@@ -1005,6 +1040,12 @@ int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_
 int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays) {
     if (!ctx || !replays) return FGPU_ERR_ARG;
     *replays = ctx->scan_replays;
+    return FGPU_OK;
+}
+
+int fgpu_diag_walk_probe(fgpu_ctx* ctx, uint64_t out[4]) {   // after fgpu_scan_end: probed pieces by outcome (k_walk_par)
+    if (!ctx || !out) return FGPU_ERR_ARG;
+    for (int i = 0; i < 4; i++) out[i] = ctx->counters_host->par_probe[i];
     return FGPU_OK;
 }
 

@@ -132,6 +132,8 @@ struct DevCounters {
     unsigned long long walked_pieces;   // pieces of the windows walked so far (feedback for the window-span controller)
     unsigned long long mark_hits;       // pass 1: occurrences k_load_mark itself routed to bloo2 (all bits already in the carry)
     unsigned long long mark_pending;    // pass 1: occurrences left to k_load_resolve
+    unsigned long long walk_parallel;   // pieces of large clusters walked out of order (k_walk_par)
+    unsigned long long par_probe[4];    // probed pieces by outcome: order-free, would create, would raise a distance, untested positions
 };
 
 struct TextSet { DevBuf buf, nl, rank, tmp, rec; };
@@ -193,6 +195,9 @@ struct fgpu_ctx {
     uint32_t* cl_count = nullptr;
     uint32_t* cl_offset = nullptr;
     uint32_t* cl_fill = nullptr;
+    uint32_t* cl_fail = nullptr;       // per root: the cluster cannot be walked out of order (k_walk_par), two sets like cl_count
+    uint32_t walk_heavy = 0;           // clusters of at least this many pieces are tried out of order; 0 = never, the default: measured, it
+                                       // does not pay; FGPU_WALK_HEAVY sets it
     uint32_t* cl_members = nullptr;
     void* wdesc = nullptr;           // device WinDesc of the window in flight
     uint64_t window_span = 1ULL << 17;   // adaptive: stream positions per scheduling window
@@ -229,6 +234,11 @@ struct fgpu_ctx {
     bool eager_scan = false;              // the rest of this scan evaluates every junction test (after a replay, or beyond the journal's budget)
     bool lazy_failed = false;             // a synchronising call has seen the lazy-flag check fire: replay at the next entry point
     bool in_replay = false;
+    // the short pair filter on the device (fgpu_scan_short_pairs): scan_forward's addPair rules applied to every piece's list as it is harvested
+    uint32_t* short_pf = nullptr;
+    uint64_t short_pf_tai = 0;
+    int short_pf_hashes = 0;
+    bool short_pf_lists_to_host = true;
     uint64_t stops_delivered = 0;         // batches whose lists the caller has taken (a replay does not hand them out again)
     uint64_t scan_replays = 0;            // replays since the context was made (fgpu_diag_scan_replays)
     uint64_t journal_max_read_len = 0;

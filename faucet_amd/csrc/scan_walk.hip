@@ -426,8 +426,15 @@ struct WalkCtx {
     // per-thread accumulators
     unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
     bool created_now;   // set by junction_get
+    int fail;           // WALK_PROBE: why this piece cannot be walked out of order (see k_walk_par): 1 would create, 2 would raise a distance, 3 untested positions
     int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
 };
+
+// How a piece is walked.  WALK_SEQ: in its cluster's order by the cluster's one thread, reading and writing the junction table (the
+// reference's semantics as they stand).  WALK_PROBE / WALK_COMMIT: the two halves of the out-of-order walk of a large cluster, one thread
+// per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
+// COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
+enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2 };
 
 __device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
     uint32_t base = c * 64;
@@ -572,11 +579,13 @@ __device__ __noinline__ uint32_t walk_fill_flags(const uint64_t* __restrict__ co
 }
 
 // every half-step in [t0, t1) is about to be scanned: evaluate the junction tests the preview left out; true if there were any
+template <int MODE>
 __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, int t1) {
     if (t1 <= t0) return false;
     uint32_t qa = (uint32_t)(t0 >> 1), qb = (uint32_t)((t1 - 1) >> 1) + 1;
     if (qb > v.nwin) qb = v.nwin;
     if (pv_popc(v, v.nd0, v.nd1, wc.pl.need, qa, qb) == qb - qa) return false;   // the usual case: the preview covered the stretch
+    if (MODE != WALK_SEQ) { wc.fail = 3; return false; }                          // left to the cluster's ordered walk
     bool any = false;
     while (qa < qb) {
         const uint32_t c = qa >> 6;
@@ -691,7 +700,41 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     return true;
 }
 
+
+// the record of an EXISTING junction, read-only (WALK_PROBE / WALK_COMMIT); false = the key is not in the map (a walk would create it)
+__device__ __forceinline__ bool junction_find(const WalkCtx& wc, uint64_t key, RecRegs& out) {
+    const uint64_t rc = fd_revcomp(key, wc.fp.k);
+    const uint64_t canon = key < rc ? key : rc;
+    const int orient = key == canon ? 0 : 1;
+    uint64_t slot;
+    uint32_t present;
+    if (!jt_find_live(wc.jt, canon, slot, present) || !((present >> orient) & 1u)) return false;
+    out.addr = (uint64_t*)(wc.jt.recs + (slot * 2 + orient) * 16);
+    out.lo = out.addr[0];
+    out.hi = out.addr[1];
+    return true;
+}
+__device__ __forceinline__ bool rr_raises(const RecRegs& r, int idx, int length) { return rr_get(r, idx) < ((uint32_t)length & 0xFF); }
+// Junction::addCoverage / the link flags on a record other threads update at the same time (WALK_COMMIT): saturating +1 on one byte,
+// OR of one bit; `seen` is this thread's earlier plain read of the record and only saves atomics that cannot change anything
+__device__ __forceinline__ void rec_add_cov_atomic(const RecRegs& seen, int nuc) {
+    if (rr_get(seen, 5 + nuc) == 255) return;
+    unsigned long long* w = (unsigned long long*)(seen.addr + (nuc < 3 ? 0 : 1));
+    const int sh = nuc < 3 ? 8 * (5 + nuc) : 0;
+    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (((old >> sh) & 0xFF) != 255) {
+        const unsigned long long was = atomicCAS(w, old, old + (1ULL << sh));
+        if (was == old) break;
+        old = was;
+    }
+}
+__device__ __forceinline__ void rec_link_atomic(const RecRegs& seen, int idx) {
+    if ((rr_get(seen, 9) >> idx) & 1u) return;
+    atomicOr((unsigned long long*)(seen.addr + 1), 1ULL << (8 + idx));
+}
+
 // scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}
+template <int MODE>
 __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t piece_seq) {
     const int k = wc.fp.k, j = wc.fp.j;
     const int tmax = 2 * (int)nwin - 2 - 2 * j;     // last half-step with distToEnd > 2j
@@ -744,7 +787,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
             }
             tn = t_ev < t_sp ? t_ev : t_sp;
             if (tn > tmax) {   // runs off the end of the piece: everything up to tmax is scanned
-                if (fill_missing(wc, v, t, tmax + 1)) continue;
+                if (fill_missing<MODE>(wc, v, t, tmax + 1)) continue;
                 break;
             }
             q = (uint32_t)(tn >> 1);
@@ -758,9 +801,10 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
             }
             by_spacer = !in_map && (tn - last_pos >= spacer);
-            if (fill_missing(wc, v, t, (in_map || by_spacer) ? tn : tn + 1)) continue;
+            if (fill_missing<MODE>(wc, v, t, (in_map || by_spacer) ? tn : tn + 1)) continue;
             break;
         }
+        if (MODE != WALK_SEQ && wc.fail) return;
         if (tn > tmax) {   // ran off the end of the piece
             wc.nb_processed += (unsigned long long)(tmax - t + 1);
             wc.nb_jcheck += jcheck_sum(wc, v, t, tmax + 1);
@@ -774,33 +818,56 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         uint64_t key = fwd ? km : fd_revcomp(km, k);
         int real = fwd ? pv_base(v, wc.pl.codes, p0 + q + k) : (pv_base(v, wc.pl.codes, p0 + q - 1) ^ 2);
         RecRegs cur;
-        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur)) return;
-        if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
-        if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
-            created_bits(wc, v, 0, v.xF0, v.xB0);
-            if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
-        }
-        const bool same = have_last && cur.addr == last.addr;   // the same junction twice in a row: one register copy
-        if (same) cur = last;
-        last_pos = tn;
-        rr_add_cov(cur, real);
         const int ext_fwd = fwd ? real : 4;          // getExtensionIndex(FORWARD)
         const int ext_bwd = fwd ? 4 : real;          // getExtensionIndex(BACKWARD)
-        if (have_last) {                             // directLinkJunctions, JunctionMap.cpp:551-561
-            const int d = tn - last_t;
-            if (same) {
-                rr_update(cur, last_ext_fwd, d);
-                rr_link(cur, last_ext_fwd);
-            } else {
-                rr_update(last, last_ext_fwd, d);
-                rr_link(last, last_ext_fwd);
-                rr_store(last);
+        if (MODE == WALK_SEQ) {
+            if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur)) return;
+            if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
+            if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
+                created_bits(wc, v, 0, v.xF0, v.xB0);
+                if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
             }
-            rr_update(cur, ext_bwd, d);
-            rr_link(cur, ext_bwd);
+            const bool same = have_last && cur.addr == last.addr;   // the same junction twice in a row: one register copy
+            if (same) cur = last;
+            last_pos = tn;
+            rr_add_cov(cur, real);
+            if (have_last) {                             // directLinkJunctions, JunctionMap.cpp:551-561
+                const int d = tn - last_t;
+                if (same) {
+                    rr_update(cur, last_ext_fwd, d);
+                    rr_link(cur, last_ext_fwd);
+                } else {
+                    rr_update(last, last_ext_fwd, d);
+                    rr_link(last, last_ext_fwd);
+                    rr_store(last);
+                }
+                rr_update(cur, ext_bwd, d);
+                rr_link(cur, ext_bwd);
+            } else {
+                have_last = true;
+                rr_update(cur, ext_bwd, tn - 2 * j);
+            }
         } else {
-            have_last = true;
-            rr_update(cur, ext_bwd, tn - 2 * j);
+            // Out of order: the junction must exist already, and no distance may be raised (a later piece's skips read them) -- then the
+            // only things this visit changes are a coverage count and two link flags, which no walk reads.
+            if (!junction_find(wc, key, cur)) { wc.fail = 1; return; }
+            if (MODE == WALK_COMMIT) {
+                if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));
+                rec_add_cov_atomic(cur, real);
+            }
+            last_pos = tn;
+            if (have_last) {
+                const int d = tn - last_t;
+                if (MODE == WALK_PROBE) {
+                    if (rr_raises(last, last_ext_fwd, d) || rr_raises(cur, ext_bwd, d)) { wc.fail = 2; return; }
+                } else {
+                    rec_link_atomic(last, last_ext_fwd);
+                    rec_link_atomic(cur, ext_bwd);
+                }
+            } else {
+                have_last = true;
+                if (MODE == WALK_PROBE && rr_raises(cur, ext_bwd, tn - 2 * j)) { wc.fail = 2; return; }
+            }
         }
         last = cur;
         last_t = tn;
@@ -819,15 +886,28 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         uint64_t key = pv_kmer(v, wc.pl.codes, p0 + m, k);
         int real = pv_base(v, wc.pl.codes, p0 + m + k);
         RecRegs rec;
-        if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, p0 + (uint64_t)m, rec)) return;
-        rr_add_cov(rec, real);
         const int tm = 2 * m + 1;
-        rr_update(rec, 4, tm - 2 * j);
-        rr_update(rec, real, (2 * (int)nwin - 1 - tm) - 2 * j);
-        rr_store(rec);
+        if (MODE == WALK_SEQ) {
+            if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, p0 + (uint64_t)m, rec)) return;
+            rr_add_cov(rec, real);
+            rr_update(rec, 4, tm - 2 * j);
+            rr_update(rec, real, (2 * (int)nwin - 1 - tm) - 2 * j);
+            rr_store(rec);
+        } else {
+            if (!junction_find(wc, key, rec)) { wc.fail = 1; return; }
+            if (MODE == WALK_PROBE) {
+                if (rr_raises(rec, 4, tm - 2 * j) || rr_raises(rec, real, (2 * (int)nwin - 1 - tm) - 2 * j)) wc.fail = 2;
+            } else {
+                rec_add_cov_atomic(rec, real);
+            }
+        }
     } else {            // ReadScanner.cpp:202-206
-        rr_update(last, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j);
-        rr_store(last);
+        if (MODE == WALK_SEQ) {
+            rr_update(last, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j);
+            rr_store(last);
+        } else if (MODE == WALK_PROBE && rr_raises(last, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j)) {
+            wc.fail = 2;
+        }
     }
 }
 
@@ -835,12 +915,13 @@ constexpr uint32_t LOCAL_MEMBERS = 16;
 __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root,
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
-                                             uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg) {
+                                             uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg,
+                                             const uint32_t* __restrict__ par_fail, uint32_t heavy) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.created_now = false; wc.dbg = dbg;
+    wc.created_now = false; wc.fail = 0; wc.dbg = dbg;
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;
@@ -849,7 +930,9 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     const uint32_t my_root = root[ii], my_count = count[ii], my_head = head[ii];
     const uint2 my_piece = pl.pieces[first_piece + ii];
 
-    if (i < n && my_root == i) {
+    // a large cluster whose pieces k_walk_par found to be order-free is walked there, one thread per piece
+    const bool walked_out_of_order = heavy && my_count + 1 >= heavy && !par_fail[ii];
+    if (i < n && my_root == i && !walked_out_of_order) {
         const uint32_t nm = (dbg & 2) ? 0 : my_count;
         uint32_t local_mem[LOCAL_MEMBERS];
         uint32_t* mem = local_mem;
@@ -870,7 +953,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         for (uint32_t a = 0; a <= nm; a++) {
             const uint32_t m = a == 0 ? i : mem[a - 1];
             const uint2 pc = a == 0 ? my_piece : pl.pieces[first_piece + m];
-            walk_piece(wc, pc.x, pc.y, piece_seq_base + first_piece + m);
+            walk_piece<WALK_SEQ>(wc, pc.x, pc.y, piece_seq_base + first_piece + m);
         }
     }
     // wave-level reduction of the counters
@@ -887,6 +970,59 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
         if (v[4]) atomicAdd(&cnt->n_junctions, v[4]);
         if (v[6]) atomicAdd(&cnt->flags_filled, v[6]);
+    }
+}
+
+// The out-of-order walk of large clusters.  A cluster is the set of pieces of a window that share a junction k-mer; its one thread walks
+// them in file order because a piece may create junctions and raise distances that later pieces' skips depend on.  Where a repeat of the
+// genome is covered a thousand times the cluster holds hundreds of pieces per window, each with a junction at every position, and that one
+// thread decides how long the window takes (a 6 Mb genome with twenty copies of a 400-base repeat: 29 ms per window, 1.9 s of a 2 s scan).
+// But in such a cluster nearly every piece changes nothing another piece can see: its junctions exist and their distances -- maxima over
+// all earlier reads -- are not raised.  What is left of scan_forward then is a coverage count and two link flags per visit
+// (Junction::addCoverage saturating at 255, linked[] = true: JunctionMap.cpp:551-561), and those commute.  So, for clusters of at least
+// `heavy` pieces, one thread per PIECE:
+//   PROBE  (before k_walk)  walk read-only; par_fail[root] is set if any piece of the cluster would create a junction, raise a distance,
+//          or needs junction tests the preview left out.  If nobody sets it, no distance and no key of the cluster changes during this
+//          window, so every piece reads exactly what it would read in file order: the paths found here are the sequential paths.
+//   k_walk walks the clusters that failed (and all small ones) in order, as before.
+//   COMMIT (after k_walk)   the pieces of the clusters that passed walk the same path again and apply coverage and links with atomics,
+//          mark their visits for scanInputRead's lists and add their counters.
+// Keys are exclusive to a cluster (that is what makes it a cluster), so the three kernels never touch each other's records.
+template <int MODE>
+__global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
+                                                 uint32_t* par_fail, const WinDesc* __restrict__ wdp, const uint32_t* __restrict__ bloom, DevCounters* cnt,
+                                                 uint32_t heavy) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    WalkCtx wc;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
+    wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
+    wc.created_now = false; wc.fail = 0; wc.dbg = 0;
+    const WinDesc wd = *wdp;
+    unsigned long long walked = 0;
+    if (i < wd.n) {
+        const uint32_t r = root[i];
+        if (count[r] + 1 >= heavy && (MODE == WALK_PROBE || !par_fail[r])) {
+            const uint2 pc = pl.pieces[wd.first_piece + i];
+            walk_piece<MODE>(wc, pc.x, pc.y, 0);
+            if (MODE == WALK_PROBE) {
+                if (wc.fail) par_fail[r] = 1u;
+                atomicAdd(&cnt->par_probe[wc.fail], 1ULL);
+            } else {
+                walked = 1;
+            }
+        }
+    }
+    if (MODE == WALK_COMMIT) {
+        unsigned long long v[5] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, walked};
+        for (int c = 0; c < 5; c++)
+            for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_down(v[c], o, 64);
+        if (fd_lane() == 0) {
+            if (v[0]) atomicAdd(&cnt->nb_processed, v[0]);
+            if (v[1]) atomicAdd(&cnt->nb_skipped, v[1]);
+            if (v[2]) atomicAdd(&cnt->nb_jcheck, v[2]);
+            if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
+            if (v[4]) atomicAdd(&cnt->walk_parallel, v[4]);
+        }
     }
 }
 
@@ -925,11 +1061,13 @@ __global__ void __launch_bounds__(256) k_delta_collect(unsigned long long* __res
 
 // union-find and list entries of a window's pieces back to "every piece its own cluster": the arrays exist twice and consecutive
 // windows alternate, so this runs on the side stream while the NEXT window is already being looked up and linked
-__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t n, uint4* wbits, uint32_t wbits_vec) {
+__global__ void __launch_bounds__(256) k_walk_reset_uf(uint32_t* parent, uint32_t* count, uint32_t* head, uint32_t* par_fail, uint32_t n, uint4* wbits,
+                                                       uint32_t wbits_vec) {
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) {
         parent[a] = a;
         count[a] = 0;
         head[a] = U_INF;
+        par_fail[a] = 0;
     }
     // ... and the window table's presence filter of this parity (a memset on the walk stream took 47 us per window when the
     // pure stage of the next batch ran beside it: 3.6 ms per step on the critical queue)
@@ -1212,6 +1350,8 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->cl_count, 2 * ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_offset, 2 * ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_fill, ctx->wmax * 4));
+    FGPU_HIP(hipMalloc(&ctx->cl_fail, 2 * ctx->wmax * 4));
+    if (const char* e = getenv("FGPU_WALK_HEAVY")) ctx->walk_heavy = (uint32_t)std::max(0, atoi(e));   // clusters of at least this many pieces are tried out of order; 0 = never
     FGPU_HIP(hipMalloc(&ctx->cl_members, ctx->wmax * 4 * 2));
     return FGPU_OK;
 }
@@ -1281,6 +1421,7 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_LAUNCH("iota", k_iota_u32, 64, 256, ctx->uf_parent + ctx->wmax, (uint64_t)ctx->wmax);
     FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, 2 * ctx->wmax * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->cl_offset, 0xFF, 2 * ctx->wmax * 4, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->cl_fail, 0, 2 * ctx->wmax * 4, ctx->stream));
     return FGPU_OK;
 }
 
@@ -1400,6 +1541,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         uint32_t* const uf_parent = ctx->uf_parent + parity * (uint64_t)ctx->wmax;     // this window's set of the union-find / list arrays
         uint32_t* const cl_count = ctx->cl_count + parity * (uint64_t)ctx->wmax;
         uint32_t* const cl_offset = ctx->cl_offset + parity * (uint64_t)ctx->wmax;
+        uint32_t* const cl_fail = ctx->cl_fail + parity * (uint64_t)ctx->wmax;
         FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));        // reset since the window before last used it
         // the window table of this window: entries carry the window's epoch, everything older counts as empty (wiped every 255 windows)
         if (++ctx->wt_epoch > 255) {
@@ -1444,9 +1586,16 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
+        const uint32_t heavy = dbg_walk ? 0u : ctx->walk_heavy;
+        if (heavy)
+            FGPU_LAUNCH("walk_probe", k_walk_par<WALK_PROBE>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
+                        (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);
         FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                     (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
-                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk);
+                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy);
+        if (heavy)
+            FGPU_LAUNCH("walk_commit", k_walk_par<WALK_COMMIT>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
+                        (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);
         {   // the keys this window created join the batch's list (and leave the plane): the next window's delta
             const uint64_t w_first = lo >> 6, w_last = std::min<uint64_t>(bb.n_words, (pos_end + 63) / 64);
             FGPU_LAUNCH("walk_delta", k_delta_collect, (unsigned)std::min<uint64_t>(fgpu_blocks(w_last - w_first, 256), 256), 256, (unsigned long long*)bb.cr.p,
@@ -1456,7 +1605,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_HIP(hipEventRecord(ctx->ev_walked, walk_stream));
         FGPU_HIP(hipStreamWaitEvent(ctx->cstream, ctx->ev_walked, 0));
         ctx->launch_stream = ctx->cstream;
-        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, (uint32_t)max_pieces, (uint4*)wt.bits, (uint32_t)((1u << ctx->wbits_log2) / 128));
+        FGPU_LAUNCH("walk_clean", k_walk_reset_uf, std::min(256u, fgpu_blocks(max_pieces, 256)), 256, uf_parent, cl_count, cl_offset, cl_fail, (uint32_t)max_pieces, (uint4*)wt.bits, (uint32_t)((1u << ctx->wbits_log2) / 128));
         ctx->launch_stream = walk_stream;
         FGPU_HIP(hipEventRecord(ctx->ev_uf_reset[parity], ctx->cstream));
         if (serial_clean) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_uf_reset[parity], 0));
@@ -1560,6 +1709,52 @@ __global__ void __launch_bounds__(256) k_stop_fill(const uint2* __restrict__ pie
         o[0] = e;
     }
 }
+
+// Bloom::addPair(JuncPair) (utils/Bloom.cpp:127-139): the two canonical k-mers, the smaller under seed 0 and the larger under seed 1
+struct PairFilterDev {
+    uint32_t* bits;
+    uint64_t mask;
+    int n_hash;
+};
+__device__ __forceinline__ void pf_add_pair(const PairFilterDev& pf, uint64_t k1, uint64_t k2, int k) {
+    const uint64_t e1 = fd_canon(k1, k), e2 = fd_canon(k2, k);
+    uint64_t h0 = fd_old_hash(e1 < e2 ? e1 : e2, FD_SEED0) & pf.mask;
+    const uint64_t h1 = fd_old_hash(e1 < e2 ? e2 : e1, FD_SEED1) & pf.mask;
+    for (int i = 0; i < pf.n_hash; i++) {
+        atomicOr(&pf.bits[h0 >> 5], 1u << (h0 & 31));
+        h0 = (h0 + h1) & pf.mask;
+    }
+}
+
+// What scan_forward does with its result list when cleaning is on (src/ReadScanner.cpp:208-225), one thread per valid piece: a list of two
+// is paired by facing (an outward-facing pair by first backward / last forward junction, two junctions facing the same way as they stand),
+// a longer list pairs every element with the next but one.  Adding is order-free, so the device's order is as good as the file's.
+__global__ void __launch_bounds__(256) k_short_pairs(const fgpu_stop* __restrict__ stops, const uint32_t* __restrict__ count,
+                                                     const uint32_t* __restrict__ offset, uint64_t n_pieces, PairFilterDev pf, int k) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const uint32_t n = count[i];
+    const fgpu_stop* s = stops + offset[i];
+    if (n == 2) {
+        bool have_first_back = false, have_last_fwd = false;
+        uint32_t rev_pos = 0, for_pos = 0;
+        uint64_t first_back = 0, last_fwd = 0;
+        for (int t = 0; t < 2; t++) {
+            const uint32_t info = s[t].info, pos = info & FGPU_STOP_POS_MASK;
+            if (info & FGPU_STOP_FAKE) continue;
+            if (!(info & FGPU_STOP_FORWARD)) {
+                if (!have_first_back) { have_first_back = true; first_back = s[t].ext; rev_pos = pos; }
+            } else {
+                if (!have_last_fwd) { have_last_fwd = true; for_pos = pos; }
+                last_fwd = s[t].ext;
+            }
+        }
+        if (have_first_back && have_last_fwd && !(rev_pos > for_pos)) pf_add_pair(pf, first_back, last_fwd, k);
+        if (have_first_back != have_last_fwd) pf_add_pair(pf, s[0].ext, s[1].ext, k);
+    } else if (n > 2) {
+        for (uint32_t t = 0; t + 2 < n; t++) pf_add_pair(pf, s[t].ext, s[t + 2].ext, k);
+    }
+}
 }  // namespace
 
 // Bring the stops of a walked batch to the host queue (waits for that batch's walk only).
@@ -1578,9 +1773,13 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
     }
     b->stops_pending = false;
     if (b->seq < ctx->stops_delivered) return FGPU_OK;   // scanned again by a replay: the caller has this batch's lists already
-    ctx->stop_queue.emplace_back();
-    StopBatch& sb = ctx->stop_queue.back();
-    sb.seq = b->seq;
+    const bool to_host = !ctx->short_pf || ctx->short_pf_lists_to_host;
+    if (to_host) {
+        ctx->stop_queue.emplace_back();
+        ctx->stop_queue.back().seq = b->seq;
+    } else {
+        ctx->stops_delivered = b->seq + 1;                // nobody takes them: the lists end in the device's pair filter
+    }
     const uint64_t np = b->n_pieces;
     if (!np) return FGPU_OK;
     int rc;
@@ -1603,9 +1802,15 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
     hipLaunchKernelGGL(k_stop_fill, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const uint2*)b->pieces.p, np,
                        (const unsigned long long*)b->sF.p, (const unsigned long long*)b->sB.p, (const uint32_t*)offset,
                        (const uint32_t*)b->piece_read.p, (const uint64_t*)b->codes.p, ctx->fd, (fgpu_stop*)b->stop_out.p);
-    sb.stops.resize(total);
-    FGPU_HIP(hipMemcpyAsync(sb.stops.data(), b->stop_out.p, total * sizeof(fgpu_stop), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->short_pf)
+        hipLaunchKernelGGL(k_short_pairs, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const fgpu_stop*)b->stop_out.p, (const uint32_t*)count,
+                           (const uint32_t*)offset, np, PairFilterDev{ctx->short_pf, ctx->short_pf_tai - 1, ctx->short_pf_hashes}, ctx->fd.k);
+    if (to_host) {
+        StopBatch& sb = ctx->stop_queue.back();
+        sb.stops.resize(total);
+        FGPU_HIP(hipMemcpyAsync(sb.stops.data(), b->stop_out.p, total * sizeof(fgpu_stop), hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return FGPU_OK;
 }
 

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <fstream>
 #include <mutex>
 #include <new>
@@ -359,9 +360,10 @@ const char kDecode[4] = {'A', 'C', 'T', 'G'};   // utils/Kmer.cpp:21
 
 // ---- the pair filters (host side, as in the reference) ---------------------------------------------------------
 uint64_t revcomp(uint64_t x, int k) {   // utils/Kmer.cpp:238-252: complement every 2-bit code (x ^ 2), reverse their order
-    uint64_t r = 0;
-    for (int i = 0; i < k; i++) { r = (r << 2) | ((x & 3) ^ 2); x >>= 2; }
-    return r;
+    x ^= 0xAAAAAAAAAAAAAAAAULL;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    return __builtin_bswap64(x) >> (64 - 2 * k);
 }
 uint64_t canonical(uint64_t x, int k) { const uint64_t r = revcomp(x, k); return x < r ? x : r; }   // utils/Kmer.cpp:531-533
 
@@ -392,22 +394,20 @@ struct PairFilter {   // a Bloom used through addPair / containsPair only (utils
         printf("Number of hash functions: %d \n", n_hash);
         bits.assign(tai / 8, 0);
     }
-    void hashes(uint64_t k1, uint64_t k2, int k, uint64_t& h0, uint64_t& h1) const {
-        const uint64_t e1 = canonical(k1, k), e2 = canonical(k2, k);
-        h0 = old_hash(std::min(e1, e2), kSeed0) & (tai - 1);
-        h1 = old_hash(std::max(e1, e2), kSeed1) & (tai - 1);
-    }
-    void add_pair(uint64_t k1, uint64_t k2, int k) {
-        uint64_t h0, h1;
-        hashes(k1, k2, k, h0, h1);
+    // e1, e2: the canonical forms of the two k-mers of a JuncPair
+    void add_canon(uint64_t e1, uint64_t e2) {
+        uint64_t h0 = old_hash(std::min(e1, e2), kSeed0) & (tai - 1);
+        const uint64_t h1 = old_hash(std::max(e1, e2), kSeed1) & (tai - 1);
         for (int i = 0; i < n_hash; i++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & (tai - 1); }
     }
-    bool contains_pair(uint64_t k1, uint64_t k2, int k) const {
-        uint64_t h0, h1;
-        hashes(k1, k2, k, h0, h1);
-        for (int i = 0; i < n_hash; i++) { if (!(bits[h0 >> 3] & (1u << (h0 & 7)))) return false; h0 = (h0 + h1) & (tai - 1); }
+    bool contains_canon(uint64_t e1, uint64_t e2) const {
+        uint64_t h0 = old_hash(std::min(e1, e2), kSeed0) & (tai - 1);
+        if (!(bits[h0 >> 3] & (1u << (h0 & 7)))) return false;      // most pairs are new: one hash, one probe
+        const uint64_t h1 = old_hash(std::max(e1, e2), kSeed1) & (tai - 1);
+        for (int i = 1; i < n_hash; i++) { h0 = (h0 + h1) & (tai - 1); if (!(bits[h0 >> 3] & (1u << (h0 & 7)))) return false; }
         return true;
     }
+    void add_pair(uint64_t k1, uint64_t k2, int k) { add_canon(canonical(k1, k), canonical(k2, k)); }
     float weight() const {   // Bloom::weight, utils/Bloom.cpp:191-203
         long w = 0;
         for (uint8_t b : bits) w += __builtin_popcount(b);
@@ -430,7 +430,7 @@ struct PairLogic {
     PairFilter* short_pf = nullptr;
     PairFilter* long_pf = nullptr;
     bool first_end = true;
-    std::list<uint64_t> back1, back2;
+    std::vector<uint64_t> back1, back2;   // the two ends' lists, as canonical k-mers (all a JuncPair is hashed by)
     int empty_count = 0, not_empty_count = 0;
 
     void piece(const fgpu_stop* s, size_t n) {   // one scan_forward call
@@ -456,16 +456,17 @@ struct PairLogic {
         }
     }
     void read(const fgpu_stop* s, size_t n) {   // one iteration of the loop in scanReads
-        std::list<uint64_t>& back = first_end ? back1 : back2;
+        std::vector<uint64_t>& back = first_end ? back1 : back2;
         back.clear();
         size_t a = 0;
-        while (a < n) {
+        while (short_pf && !no_cleaning && a < n) {
             size_t b = a + 1;
             while (b < n && !(s[b].info & FGPU_STOP_FIRST)) b++;
             piece(s + a, b - a);
-            for (size_t i = a; i < b; i++) back.push_back(s[i].ext);
             a = b;
         }
+        if (paired_ends)
+            for (size_t i = 0; i < n; i++) back.push_back(canonical(s[i].ext, k));
         if (paired_ends && !first_end) {
             if (!back1.empty() && !back2.empty()) {
                 not_empty_count++;
@@ -473,8 +474,8 @@ struct PairLogic {
                     bool paired = false;
                     if (!no_cleaning) {
                         for (uint64_t pair2 : back2)
-                            if (long_pf->contains_pair(pair1, pair2, k)) { paired = true; break; }
-                        if (!paired) long_pf->add_pair(pair1, back2.front(), k);
+                            if (long_pf->contains_canon(pair1, pair2)) { paired = true; break; }
+                        if (!paired) long_pf->add_canon(pair1, back2.front());
                     }
                 }
             } else {
@@ -483,12 +484,12 @@ struct PairLogic {
         }
         first_end = !first_end;
     }
-    void batch(const std::vector<fgpu_stop>& stops, uint64_t n_reads) {   // reads of a batch, in file order
+    void batch(const fgpu_stop* stops, size_t n_stops, uint64_t n_reads) {   // reads of a batch, in file order
         size_t a = 0;
         for (uint64_t r = 0; r < n_reads; r++) {
             size_t b = a;
-            while (b < stops.size() && stops[b].read == r) b++;
-            read(stops.data() + a, b - a);
+            while (b < n_stops && stops[b].read == r) b++;
+            read(stops + a, b - a);
             a = b;
         }
     }
@@ -604,7 +605,7 @@ int load_pair_filter(PairFilter& pf, const std::string& path) {   // Bloom::load
 // FGPU_CLI_TIMES=1: phase clock on stderr (measurement aid; stdout stays what the reference prints)
 struct PhaseClock {
     bool on = getenv("FGPU_CLI_TIMES") != nullptr;
-    double batch_ms = 0;
+    double batch_ms = 0, take_ms = 0, pairs_ms = 0, scan_ms = 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
     void mark(const char* what) {
         if (!on) return;
@@ -653,8 +654,12 @@ int main(int argc, char** argv) {
     prm.max_spacer_dist = o.max_spacer_dist;
     prm.n_hash = n_hash;
     prm.tai = tai;
-    const bool want_lists = !o.no_cleaning || o.paired_ends;   // scanInputRead's lists feed the pair filters and the pair counts
-    if (want_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
+    // scanInputRead's lists feed the pair filters and the pair counts: the short filter's adds are order-free and happen on the device
+    // (fgpu_scan_short_pairs); the lists come to the host only for the paired-end loop (long filter: check-then-insert in file order)
+    const bool record_lists = !o.no_cleaning || o.paired_ends;
+    const bool device_short_pairs = !o.no_cleaning;
+    const bool want_lists = o.paired_ends;
+    if (record_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
     if (o.mercy) prm.flags |= FGPU_FLAG_MERCY;
     {
         std::thread pin;   // (joined before anything else can fail or read)
@@ -768,40 +773,94 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "%s failed (%d): %s\n", what, rc, msg.c_str());
                 return 2;
             };
-            int rc = fgpu_scan_begin(ctx);
+            int rc = device_short_pairs ? fgpu_scan_short_pairs(ctx, short_pf.tai, short_pf.n_hash, want_lists ? 1 : 0) : FGPU_OK;
+            if (rc != FGPU_OK) return failed("fgpu_scan_short_pairs", rc);
+            rc = fgpu_scan_begin(ctx);
             if (rc != FGPU_OK) return failed("fgpu_scan_begin", rc);
             uint64_t scanned = 0;
             pairs = PairLogic();
             pairs.k = o.k;
             pairs.paired_ends = o.paired_ends;
             pairs.no_cleaning = o.no_cleaning;
-            pairs.short_pf = &short_pf;
+            pairs.short_pf = device_short_pairs ? nullptr : &short_pf;   // (nullptr: the device keeps that filter)
             pairs.long_pf = o.paired_ends ? &long_pf : nullptr;
             std::fill(short_pf.bits.begin(), short_pf.bits.end(), 0);
             std::fill(long_pf.bits.begin(), long_pf.bits.end(), 0);
             std::vector<uint64_t> batch_n_reads;
-            std::vector<fgpu_stop> stops;
+            // The lists are applied to the long pair filter by a worker thread, in batch order, while this thread goes on feeding the device
+            // (the rules are sequential -- check, then insert -- but they need nothing from the scan except the lists).
+            struct ListWorker {
+                PairLogic& pairs;
+                double& busy_ms;
+                std::mutex m;
+                std::condition_variable cv;
+                std::deque<std::pair<std::vector<fgpu_stop>, uint64_t> > q;
+                bool closing = false;
+                std::thread t;
+                ListWorker(PairLogic& p, double& ms) : pairs(p), busy_ms(ms), t([this] { run(); }) {}
+                void run() {
+                    for (;;) {
+                        std::pair<std::vector<fgpu_stop>, uint64_t> item;
+                        {
+                            std::unique_lock<std::mutex> g(m);
+                            cv.wait(g, [&] { return closing || !q.empty(); });
+                            if (q.empty()) return;
+                            item = std::move(q.front());
+                        }
+                        const auto t0 = std::chrono::steady_clock::now();
+                        pairs.batch(item.first.data(), item.first.size(), item.second);
+                        busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                        {
+                            std::lock_guard<std::mutex> g(m);
+                            q.pop_front();                    // only now: `finish` waits for an empty queue
+                        }
+                        cv.notify_all();
+                    }
+                }
+                void put(std::vector<fgpu_stop>&& stops, uint64_t n_reads) {
+                    std::unique_lock<std::mutex> g(m);
+                    cv.wait(g, [&] { return q.size() < 3; });     // at most three batches of lists in flight
+                    q.emplace_back(std::move(stops), n_reads);
+                    cv.notify_all();
+                }
+                void finish() {
+                    if (!t.joinable()) return;
+                    {
+                        std::unique_lock<std::mutex> g(m);
+                        cv.wait(g, [&] { return q.empty(); });
+                        closing = true;
+                    }
+                    cv.notify_all();
+                    t.join();
+                }
+                ~ListWorker() { finish(); }
+            } worker(pairs, clk.pairs_ms);
             // lists of the oldest batch whose walk is done (the newest one keeps walking while the next batch is prepared)
             auto take = [&](bool& got) -> int {
                 got = false;
                 uint64_t n = 0;
                 int64_t seq = -1;
-                int trc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
+                const auto t_take = std::chrono::steady_clock::now();
+                std::vector<fgpu_stop> stops;
+                int trc = fgpu_scan_take_stops(ctx, nullptr, 0, &n, &seq);
                 if (trc == FGPU_ERR_CAPACITY) {
                     stops.resize(n);
                     trc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
                 }
+                clk.take_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_take).count();
                 if (trc != FGPU_OK) return failed("fgpu_scan_take_stops", trc);
                 if (seq < 0) return 0;
                 got = true;
-                std::vector<fgpu_stop> view(stops.begin(), stops.begin() + n);
-                pairs.batch(view, batch_n_reads[(size_t)seq]);
+                stops.resize(n);
+                worker.put(std::move(stops), batch_n_reads[(size_t)seq]);
                 return 0;
             };
             fgpu_reads r;
             for (int more; (more = src.next(ctx, &r)) != 0;) {
                 if (more < 0) return failed("fgpu_text_split", -more);
+                const auto t_scan = std::chrono::steady_clock::now();
                 if ((rc = fgpu_scan_batch(ctx, &r)) != FGPU_OK) return failed("fgpu_scan_batch", rc);
+                clk.scan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count();
                 batch_n_reads.push_back(r.n_reads);
                 if (want_lists && batch_n_reads.size() > 1) {
                     bool got;
@@ -812,11 +871,14 @@ int main(int argc, char** argv) {
                 fflush(stdout);
             }
             if ((rc = fgpu_scan_end(ctx, &ss)) != FGPU_OK) return failed("fgpu_scan_end", rc);
+            if (device_short_pairs && (rc = fgpu_scan_short_pairs_download(ctx, short_pf.bits.data(), short_pf.bits.size())) != FGPU_OK)
+                return failed("fgpu_scan_short_pairs_download", rc);
             if (want_lists) {
                 bool got = true;
                 while (got)
                     if (int trc = take(got)) return trc;
             }
+            worker.finish();
             return 0;
         };
         // (a preview of the junction walk that the library cannot repair is absorbed inside the library: it keeps the scan's batches in HBM and
@@ -825,6 +887,8 @@ int main(int argc, char** argv) {
         if (src_rc == -1) { fprintf(stderr, "scan failed: %s\n", fgpu_last_error(ctx)); return 2; }
         if (src_rc) return src_rc;
         time(&stop);
+        if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_take_stops, %.2f ms applying the lists to the pair filters (worker thread)\n",
+                            clk.scan_ms, clk.take_ms, clk.pairs_ms);
         clk.mark("pass 2 (read + scan)");
         printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);
         printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FGPU_ABI_VERSION 1
+#define FGPU_ABI_VERSION 2
 
 enum {
     FGPU_OK = 0,
@@ -109,6 +109,7 @@ typedef struct {
     uint64_t piece_positions;    /* window positions inside valid pieces */
     uint64_t valid_reused;       /* getValidReads answers taken from the load pass' resident planes (no filter probe) */
     uint64_t flags_filled;       /* windows whose testForJunction the walk evaluated itself because the preview had left them out */
+    uint64_t walk_parallel;      /* pieces of large clusters that were walked out of order (they changed nothing a later piece could see) */
 } fgpu_scan_stats;
 
 /* One element of the list ReadScanner::scanInputRead returns for a read (src/ReadScanner.cpp:260-282): the real-extension
@@ -225,6 +226,17 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
  * fgpu_scan_stats.flags_filled counts the windows evaluated inside the walk.  fgpu_scan_set_eager(ctx, 1) switches the preview off for the
  * following scans altogether (same results as FGPU_FLAG_EAGER_FLAGS, about 1.5x the junction-test probes, no journal). */
 int fgpu_scan_set_eager(fgpu_ctx* ctx, int on);
+/* The short pair filter on the device.  With cleaning on, scan_forward feeds every piece's result list to
+ * short_pair_filter->addPair (src/ReadScanner.cpp:208-225; Bloom::addPair utils/Bloom.cpp:127-139): adds only, so their order is free.
+ * After fgpu_scan_short_pairs(tai, n_hash) -- the filter create_bloom_filter_optimal would make, src/Faucet.cpp:266-283 -- every scan keeps
+ * that filter in HBM and applies the rules to each batch's lists as they are harvested; fgpu_scan_short_pairs_download (after
+ * fgpu_scan_end) returns its tai / 8 bytes, the content of the reference's .short_pair_filter.  lists_to_host = 0: the lists are not
+ * brought to the host at all (single-end runs: nothing else reads them; fgpu_scan_take_stops then reports no batches); != 0: they are
+ * still handed out (paired ends: the long pair filter is check-then-insert in file order and stays with the caller).
+ * Needs FGPU_FLAG_RECORD_STOPS; tai = 0 switches it off again.  Only between passes. */
+int fgpu_scan_short_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t lists_to_host);
+int fgpu_scan_short_pairs_download(fgpu_ctx* ctx, uint8_t* out, uint64_t n_bytes);
+
 /* scanInputRead's lists of one scanned batch, flattened in processing order (reads in file order; inside a read the
  * valid pieces in the order scanInputRead walks them; inside a piece by half-step).  Batches come out in scan order,
  * one per call: *batch_seq = number of the batch within the scan, or -1 (and *n_out = 0) when none is left.  The
@@ -324,6 +336,9 @@ int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_acce
 int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_probes, uint64_t slice_bytes, int iters, double* direct_per_s,
                             double* binned_per_s, double* bin_ms, double* probe_ms);
 /* How often the library has scanned a pass's batches again by itself (lazy junction tests, see fgpu_scan_batch) since the context was made. */
+/* after fgpu_scan_end: pieces of large clusters probed for the out-of-order walk, by outcome: [0] order-free, [1] would create a junction,
+ * [2] would raise a distance, [3] crosses positions whose junction tests the preview left out */
+int fgpu_diag_walk_probe(fgpu_ctx* ctx, uint64_t out[4]);
 int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the

@@ -53,4 +53,7 @@ for name, extra in (("host getline 333333 reads per call", ["-batch_reads", "333
     sigs.append(sig)
     counts = [ln for ln in p.stdout.splitlines() if "Empty count" in ln]
     print(f"{name:36s} {dt:6.2f} s  {sig}  {counts[-1] if counts else ''}", flush=True)
+    for line in p.stderr.splitlines():          # FGPU_CLI_TIMES=1: the CLI's own phase clock
+        if line.startswith("[cli]"):
+            print("    " + line)
 print("PASS" if len(set(sigs)) == 1 else "FAIL")

@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_sizes():
     assert C.sizeof(L.Params) == 64 and C.sizeof(L.Reads) == 40
-    assert C.sizeof(L.LoadStats) == 32 and C.sizeof(L.ScanStats) == 128
-    assert api.JUNC_DTYPE.itemsize == 14 and C.sizeof(L.KernelTime) == 64
+    assert C.sizeof(L.LoadStats) == 32 and C.sizeof(L.ScanStats) == 136
+    assert api.JUNC_DTYPE.itemsize == 14 and C.sizeof(L.KernelTime) == 64 and api.NEIGHBOR_DTYPE.itemsize == 24
 
 
 @pytest.mark.parametrize("d", kat("sizing"), ids=lambda d: f"E{d['E']}_S{d['S']}_fp{d['fp']:.2f}")

@@ -117,6 +117,22 @@ def test_scan_matches_reference_junctions(name, n_batches, span):
     _scan_and_compare(c, bases, offs, n_batches, span)
 
 
+@pytest.mark.parametrize("name", ["c1_k21", "twohash_k31_L150", "j2_spacer20_k15"])
+def test_out_of_order_walk_of_clusters_gives_the_same_result(name, monkeypatch):
+    """FGPU_WALK_HEAVY=2: every cluster of two or more pieces is first probed read-only, one thread per piece; clusters in which no piece would
+    create a junction or raise a distance are then walked out of order (coverage counts and link flags by atomics), the others in order as
+    always.  Off by default (it does not pay) -- the results must not depend on it."""
+    monkeypatch.setenv("FGPU_WALK_HEAVY", "2")
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    for n_batches, span in ((1, 0), (3, 4096), (1, 256)):
+        _scan_and_compare(c, bases, offs, n_batches, span)
+    # and on 40x random reads with planted repeats, where most pieces of the later windows meet only junctions that exist
+    bases, offs = _random_case(20000, 110, 25, 50000, 0.012, 7, 0.002, 4)
+    sst = _check_against_oracle(bases, offs, 25, 1_000_000, 200_000, 1, walk_window_span=1 << 14)
+    assert sst["walk_parallel"] > 1000
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_scan_eager_flags_mode_gives_the_same_result(name):
     c = Case(name)
@@ -191,6 +207,7 @@ def test_random_inputs_vs_oracle(n_reads, L_, k, G, err, E, S, j, n_rate, repeat
     assert np.array_equal(keys, okeys)
     assert np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
     assert np.array_equal(recs["linked"], orecs["linked"])
+    return sst
 
 
 def _scan_equals_oracle(sc, sst, osc):
@@ -532,6 +549,37 @@ def test_scan_input_read_lists_match_the_oracle(n_batches, n_rate, capacity):
     assert seqs == list(range(len(parts)))
     assert got == want
     _scan_equals_oracle(ctx, sst, osc)
+
+
+@pytest.mark.parametrize("lists_to_host", [True, False])
+def test_short_pair_filter_on_the_device_equals_the_oracles(lists_to_host):
+    """fgpu_scan_short_pairs: scan_forward's addPair rules (src/ReadScanner.cpp:208-225) applied on the device to every piece's list; the filter
+    that comes back equals the one the oracle's scan builds with cleaning on.  Without lists to the host nothing is handed out.  (A scan that
+    replays itself repeats some adds, which are idempotent: the paired-end CLI test with FGPU_DEBUG_LAZY_FAIL covers that.)"""
+    k, E, S = 25, 1_000_000, 200_000
+    bases, offs = _random_case(12000, 110, k, 30000, 0.012, 99, 0.003, 3)
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, _ = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    _, ptai, pnh = api.size_optimal(E // 20, np.float32(0.01))      # the short filter of src/Faucet.cpp:266-283
+    short = po.Bloom(ptai, pnh)
+    osc = po.Scanner(k, 1, 100, b2, short_pf=short)
+    osc.scan_reads(bases, offs, paired_ends=False, no_cleaning=False)
+    ctx = api.Context(k, tai, nh, record_stops=True)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    ctx.scan_short_pairs(ptai, pnh, lists_to_host)
+    for attempt in range(2):                 # the second scan starts from an empty filter again
+        ctx.scan_begin()
+        for part in chunks(bases, offs, 5):
+            ctx.scan_batch(part)
+        ctx.scan_end()
+        taken = 0
+        while ctx.take_stops() is not None:
+            taken += 1
+        assert taken == (5 if lists_to_host else 0)
+        got = ctx.scan_short_pairs_download(ptai)
+        assert got.any() and np.array_equal(got, short.bits())
+    with pytest.raises(api.FaucetGpuError):
+        api.Context(k, tai, nh).scan_short_pairs(ptai, pnh)              # needs FGPU_FLAG_RECORD_STOPS
 
 
 def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
