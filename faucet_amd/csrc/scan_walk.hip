@@ -521,7 +521,9 @@ __device__ __noinline__ uint4 live_bits_impl(const uint64_t* __restrict__ codes,
 __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
     if (wc.dbg & 1) { mF = mB = 0; return; }
     const uint32_t base = c * 64;
-    const uint64_t where = pv_word(v, v.lk0, v.lk1, wc.pl.lk, c);
+    // (junctions are never removed during a scan: where the snapshot already has both facings there is nothing the live table could add --
+    // inside a repeat at high coverage that is nearly every position, and the look-ups of a piece were a quarter of its walk)
+    const uint64_t where = pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) & ~(pv_word(v, v.inF0, v.inF1, wc.pl.inF, c) & pv_word(v, v.inB0, v.inB1, wc.pl.inB, c));
     if (!where) { mF = mB = 0; return; }
     uint4 r = live_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, where, wc.jt);
     mF = (uint64_t)r.x | ((uint64_t)r.y << 32);
