@@ -26,9 +26,7 @@
 #include <deque>
 #include <fstream>
 #include <mutex>
-#include <new>
 #include <thread>
-#include <list>
 #include <string>
 #include <unordered_map>
 #include <vector>
