@@ -86,6 +86,8 @@ static int check_errors(fgpu_ctx* ctx) {
     // device-side error flags (table overflow) are surfaced at the synchronising calls
     if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
+    if (ctx->counters_host->error_flags & 8ULL) { ctx->err = "key-ordered walk: a k-mer's turn never came (internal error)"; return FGPU_ERR_STATE; }
+    if (ctx->counters_host->error_flags & 16ULL) { ctx->err = "key-ordered walk: a junction at a k-mer nobody registered (internal error)"; return FGPU_ERR_STATE; }
     // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
     static const bool force_lazy_fail = getenv("FGPU_DEBUG_LAZY_FAIL") && getenv("FGPU_DEBUG_LAZY_FAIL")[0] == '1';
     const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime && !ctx->eager_scan;
@@ -265,7 +267,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
     void* ptrs[] = {ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
-                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->cl_members, ctx->counters,
+                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);

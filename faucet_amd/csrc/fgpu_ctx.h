@@ -195,6 +195,11 @@ struct fgpu_ctx {
     uint32_t* cl_count = nullptr;
     uint32_t* cl_offset = nullptr;
     uint32_t* cl_fill = nullptr;
+    uint32_t* ko_hk = nullptr;         // key-ordered walk (KoTables, scan_walk.hip): k-mer table, occurrence arrays, per-piece arrays
+    uint32_t* ko_occ = nullptr;
+    uint32_t* ko_piece = nullptr;
+    uint32_t ko_hk_cap = 0, ko_occ_cap = 0;
+    uint32_t walk_ko = 0;              // clusters of at least this many pieces are walked in k-mer order instead of piece order (0 = never); FGPU_WALK_KO
     uint32_t* cl_fail = nullptr;       // per root: the cluster cannot be walked out of order (k_walk_par), two sets like cl_count
     uint32_t walk_heavy = 0;           // clusters of at least this many pieces are tried out of order; 0 = never, the default: measured, it
                                        // does not pay; FGPU_WALK_HEAVY sets it

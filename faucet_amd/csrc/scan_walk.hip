@@ -426,6 +426,7 @@ struct WalkCtx {
     // per-thread accumulators
     unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
     bool created_now;   // set by junction_get
+    struct KoState* ko; // WALK_KO: the piece's turn bookkeeping
     int fail;           // WALK_PROBE: why this piece cannot be walked out of order (see k_walk_par): 1 would create, 2 would raise a distance, 3 untested positions
     int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
 };
@@ -434,7 +435,50 @@ struct WalkCtx {
 // reference's semantics as they stand).  WALK_PROBE / WALK_COMMIT: the two halves of the out-of-order walk of a large cluster, one thread
 // per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
 // COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
-enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2 };
+enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3 };
+
+// ---- the key-ordered walk of large clusters (k_walk_ko) ------------------------------------------------------------------------------------
+// A cluster's pieces are walked in file order because of what they read and write in the junction map -- and they read and write it one
+// k-mer at a time.  Ordering the ACCESSES per k-mer instead of the pieces per cluster keeps every read and write where the sequential run
+// has it and lets the pieces of a cluster overlap: piece i+1 follows piece i through the k-mers they share, a few positions behind, instead
+// of starting when piece i has ended.  Every occurrence of a registered k-mer (an lk position) on a piece of a large cluster gets a rank
+// among the occurrences of that k-mer, by (piece, position); a k-mer has a turn counter; a piece may look its k-mer up (and visit, create,
+// update) when the counter equals its occurrence's rank, and sets it to rank + 1 when it has passed the position and stored what it changed.
+// Positions the walk skips are passed just the same (their turn is taken and given back), so the counter of a k-mer advances in piece order
+// whatever the pieces do there.  A piece waits only for pieces before it, which are running or done (pieces are handed out in file order from
+// a ticket counter): no cycle.  One piece per wave (lane 0), so a waiting piece never holds back a lane it waits for.
+struct KoTables {
+    uint32_t* hk_key;     // heavy-key table: 32-bit hash of the canonical k-mer (the window table's notion of a key), KO_EMPTY = free
+    uint32_t* hk_head;    // head of the k-mer's occurrence list (k_ko_prepare), U_INF = none
+    uint32_t* hk_turn;    // the turn counter
+    uint32_t hk_mask;
+    uint32_t* occ_entry;  // per occurrence: its k-mer's table entry
+    uint32_t* occ_rank;   // per occurrence: its rank among the k-mer's occurrences
+    uint32_t* occ_next;   // list link
+    uint64_t* occ_id;     // piece << 32 | position: the order of the occurrences of a k-mer
+    uint32_t occ_cap;
+    uint32_t* piece_base; // per piece of the window: first occurrence number (its lk positions in ascending order follow)
+    uint32_t* state;      // [0] occurrences reserved, [1] bit 0: a table overflowed (every cluster is walked in order), [2] ticket of k_walk_ko
+    uint32_t* bad;        // per root: the cluster holds a piece the key-ordered walk does not take (more than 128 windows)
+};
+constexpr uint32_t KO_EMPTY = 0xFFFFFFFFu;
+constexpr unsigned long long KO_WAIT_LIMIT_TICKS = 30ULL * 100000000ULL;   // 30 s at one turn counter: give up loudly (error bit 8), never hang
+
+struct KoHold {   // a k-mer whose turn this piece holds: entry, rank of its first occurrence here, occurrences merged into the hold
+    uint32_t e, r, n;
+};
+struct KoState {
+    KoTables kt;
+    uint32_t base;          // first occurrence number of this piece
+    uint32_t done;          // every lk position below `done` has been accounted for (passed or held)
+    uint32_t mid;           // the position add_fake_junction would use
+    KoHold last, cur, fake; // held: the last junction's k-mer (until its record is stored), the position under the cursor, the fake candidate
+    uint32_t cur_q;         // the position under the cursor
+    int cur_in;             // which hold carries the cursor's k-mer: 0 cur, 1 last, 2 fake (the same k-mer twice on one piece shares a hold)
+    uint64_t lk0, lk1;      // the piece's lk positions
+    uint64_t aF0, aF1, aB0, aB1;   // positions looked up and found absent (per facing): not events after all
+};
+
 
 __device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
     uint32_t base = c * 64;
@@ -530,7 +574,14 @@ __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView&
     mB = (uint64_t)r.z | ((uint64_t)r.w << 32);
 }
 
+template <int MODE>
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+    if (MODE == WALK_KO) {   // what the map holds is asked when the k-mer's turn has come: until then every registered position may be in it
+        const KoState& ko = *wc.ko;
+        mF = c == 0 ? (ko.lk0 & ~ko.aF0) : c == 1 ? (ko.lk1 & ~ko.aF1) : 0ULL;
+        mB = c == 0 ? (ko.lk0 & ~ko.aB0) : c == 1 ? (ko.lk1 & ~ko.aB1) : 0ULL;
+        return;
+    }
     mF = pv_word(v, v.inF0, v.inF1, wc.pl.inF, c);
     mB = pv_word(v, v.inB0, v.inB1, wc.pl.inB, c);
     if (c == 0) { mF |= v.xF0; mB |= v.xB0; return; }
@@ -587,7 +638,7 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
     uint32_t qa = (uint32_t)(t0 >> 1), qb = (uint32_t)((t1 - 1) >> 1) + 1;
     if (qb > v.nwin) qb = v.nwin;
     if (pv_popc(v, v.nd0, v.nd1, wc.pl.need, qa, qb) == qb - qa) return false;   // the usual case: the preview covered the stretch
-    if (MODE != WALK_SEQ) { wc.fail = 3; return false; }                          // left to the cluster's ordered walk
+    if (MODE == WALK_PROBE || MODE == WALK_COMMIT) { wc.fail = 3; return false; }   // left to the cluster's ordered walk
     bool any = false;
     while (qa < qb) {
         const uint32_t c = qa >> 6;
@@ -662,20 +713,34 @@ __device__ __forceinline__ void rr_add_cov(RecRegs& r, int nuc) {               
 }
 __device__ __forceinline__ void rr_link(RecRegs& r, int idx) { rr_set(r, 9, rr_get(r, 9) | (1u << idx)); }
 __device__ __forceinline__ void rr_store(const RecRegs& r) { r.addr[0] = r.lo; r.addr[1] = r.hi; }
+// the key-ordered walk hands records from thread to thread inside one launch: 8-byte agent-scope accesses on both sides
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int MODE> __device__ __forceinline__ void rr_store_m(const RecRegs& r) {
+    if (MODE == WALK_KO) { st_agent(&r.addr[0], r.lo); st_agent(&r.addr[1], r.hi); }
+    else rr_store(r);
+}
 
 // find or create the junction keyed by the oriented k-mer `key`; the record comes back in registers
-__device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, uint64_t pos, RecRegs& out) {
+template <int MODE>
+__device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t stamp, uint64_t pos, RecRegs& out, uint64_t known_slot = ~0ULL) {
     uint64_t rc = fd_revcomp(key, wc.fp.k);
     uint64_t canon = key < rc ? key : rc;
     int orient = key == canon ? 0 : 1;
     uint64_t slot;
     uint32_t present;
+    if (MODE == WALK_KO && known_slot != ~0ULL) {   // the key-ordered walk has just found this junction in the map: no second probe
+        out.addr = (uint64_t*)(wc.jt.recs + (known_slot * 2 + orient) * 16);
+        out.lo = ld_agent(&out.addr[0]);
+        out.hi = ld_agent(&out.addr[1]);
+        wc.created_now = false;
+        return true;
+    }
     // the key word and the record of the home slot are requested together: at the table's low load factor the key is
     // almost always in its home slot, so an event costs one memory round trip instead of two
     const uint64_t home = fd_mix(canon) & wc.jt.mask;
     const uint64_t* spec = (const uint64_t*)(wc.jt.recs + (home * 2 + orient) * 16);
     const uint64_t w_first = ld_agent(&wc.jt.keys[home]);
-    const uint64_t spec_lo = spec[0], spec_hi = spec[1];
+    const uint64_t spec_lo = MODE == WALK_KO ? ld_agent(&spec[0]) : spec[0], spec_hi = MODE == WALK_KO ? ld_agent(&spec[1]) : spec[1];
     if (!jt_find_or_claim(wc.jt, canon, home, w_first, slot, present, wc.cnt)) {
         atomicOr(&wc.cnt->error_flags, 1ULL);
         return false;
@@ -696,8 +761,8 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
         out.lo = spec_lo;
         out.hi = spec_hi;
     } else {
-        out.lo = out.addr[0];
-        out.hi = out.addr[1];
+        out.lo = MODE == WALK_KO ? ld_agent(&out.addr[0]) : out.addr[0];
+        out.hi = MODE == WALK_KO ? ld_agent(&out.addr[1]) : out.addr[1];
     }
     return true;
 }
@@ -735,6 +800,107 @@ __device__ __forceinline__ void rec_link_atomic(const RecRegs& seen, int idx) {
     atomicOr((unsigned long long*)(seen.addr + 1), 1ULL << (8 + idx));
 }
 
+
+// ---- turn taking of the key-ordered walk (see KoTables) ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ko_ordinal(const KoState& ko, uint32_t q) {   // lk positions of the piece below q (q < 128)
+    if (q < 64) return (uint32_t)__popcll(ko.lk0 & ((1ULL << q) - 1));
+    return (uint32_t)__popcll(ko.lk0) + (uint32_t)__popcll(ko.lk1 & ((1ULL << (q - 64)) - 1));
+}
+__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { return ((q < 64 ? ko.lk0 >> q : ko.lk1 >> (q - 64)) & 1ULL) != 0; }
+__device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounters* cnt) {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    while (ld_agent(turn) != r) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095u) == 0) {   // a turn that never comes is a bug, not a state to wait in: say so once and let every piece run out
+            if (ld_agent((const uint64_t*)&cnt->error_flags) & 8ULL) break;
+            const unsigned long long now = wall_clock64();          // constant 100 MHz
+            if (!t0) t0 = now;
+            else if (now - t0 > KO_WAIT_LIMIT_TICKS) { atomicOr(&cnt->error_flags, 8ULL); break; }
+        }
+    }
+    // no cache invalidate: everything one piece hands to the next (turn counters, key words, records) is read with agent-scope loads
+}
+// the k-mer's turn goes to its next occurrence; whatever this piece stored is visible before the counter moves
+__device__ __forceinline__ void ko_give(const KoState& ko, KoHold& h) {
+    // records are stored with agent-scope (write-through) stores and key words change by atomics: waiting for them to complete is the whole
+    // release -- an agent-scope release fence would also write the L2 back, which this hand-over does not need and pays for dearly
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&ko.kt.hk_turn[h.e], h.r + h.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h.n = 0;
+}
+// the cursor leaves its position without having visited it
+__device__ __forceinline__ void ko_leave_cursor(KoState& ko, bool have_last) {
+    if (!ko.cur.n) return;
+    if (ko.cur_q == ko.mid && !have_last && !ko.fake.n) { ko.fake = ko.cur; ko.cur.n = 0; }   // add_fake_junction may come back to it
+    else ko_give(ko, ko.cur);
+}
+// account for the lk position q: take its turn; keep it (cursor) or pass it on
+__device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_cursor, bool have_last) {
+    KoState& ko = *wc.ko;
+    ko_leave_cursor(ko, have_last);
+    const uint32_t node = ko.base + ko_ordinal(ko, q);
+    const uint32_t e = ko.kt.occ_entry[node], r = ko.kt.occ_rank[node];
+    if (as_cursor) ko.cur_q = q;
+    if (ko.last.n && e == ko.last.e) { ko.last.n++; if (as_cursor) ko.cur_in = 1; return; }     // this piece holds the k-mer already
+    if (ko.fake.n && e == ko.fake.e) { ko.fake.n++; if (as_cursor) ko.cur_in = 2; return; }
+    ko_wait(&ko.kt.hk_turn[e], r, wc.cnt);
+    KoHold h;
+    h.e = e; h.r = r; h.n = 1;
+    if (as_cursor) { ko.cur = h; ko.cur_in = 0; }
+    else if (q == ko.mid && !have_last && !ko.fake.n) ko.fake = h;
+    else ko_give(ko, h);
+}
+// every lk position below q_to has been passed
+__device__ __forceinline__ void ko_pass(WalkCtx& wc, uint32_t q_to, bool have_last) {
+    KoState& ko = *wc.ko;
+    while (ko.done < q_to) {
+        if (ko.done >= 128) { ko.done = q_to; break; }
+        const uint64_t w = ko.done < 64 ? ko.lk0 >> ko.done : ko.lk1 >> (ko.done - 64);
+        if (!w) {                                   // no lk position in the rest of this word
+            const uint32_t next = ko.done < 64 ? 64u : 128u;
+            ko.done = next < q_to ? next : q_to;
+            continue;
+        }
+        const uint32_t q = ko.done + (uint32_t)__builtin_ctzll(w);
+        if (q >= q_to) { ko.done = q_to; break; }
+        ko_account(wc, q, false, have_last);
+        ko.done = q + 1;
+    }
+}
+// the walk is about to look at (or stop at) position q
+__device__ __forceinline__ void ko_cursor(WalkCtx& wc, uint32_t q, bool have_last) {
+    KoState& ko = *wc.ko;
+    if (q < ko.done) return;                       // second half-step of the same position: its k-mer is still held
+    ko_pass(wc, q, have_last);
+    if (ko_is_lk(ko, q)) ko_account(wc, q, true, have_last);
+    else { ko_leave_cursor(ko, have_last); atomicOr(&wc.cnt->error_flags, 16ULL); }   // a stop at a k-mer nobody registered: cannot happen
+    ko.done = q + 1;
+}
+// the junction under the cursor has been visited and becomes the piece's last junction; the previous one's record has been stored
+__device__ __forceinline__ void ko_visited(WalkCtx& wc) {
+    KoState& ko = *wc.ko;
+    if (ko.cur_in == 0) {
+        if (ko.last.n) ko_give(ko, ko.last);
+        ko.last = ko.cur;
+        ko.cur.n = 0;
+    } else if (ko.cur_in == 2) {
+        if (ko.last.n) ko_give(ko, ko.last);
+        ko.last = ko.fake;
+        ko.fake.n = 0;
+    }
+    ko.cur_in = 1;
+    if (ko.fake.n) ko_give(ko, ko.fake);           // a junction was found: there will be no fake one
+}
+// end of the piece (also after an error): everything is passed, every turn given back
+__device__ __forceinline__ void ko_finish(WalkCtx& wc, uint32_t nwin) {
+    KoState& ko = *wc.ko;
+    ko_pass(wc, nwin < 128 ? nwin : 128, true);
+    if (ko.cur.n) ko_give(ko, ko.cur);
+    if (ko.last.n) ko_give(ko, ko.last);
+    if (ko.fake.n) ko_give(ko, ko.fake);
+}
+
 // scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}
 template <int MODE>
 __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nwin, uint64_t piece_seq) {
@@ -743,8 +909,10 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
     const int spacer = 2 * wc.fp.max_spacer - 1;
     PieceView v;
     pv_load(v, wc.pl, p0, nwin);
-    created_bits(wc, v, 0, v.xF0, v.xB0);           // what the snapshot planes cannot know: the live table at the candidate positions
-    if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
+    if (MODE != WALK_KO) {
+        created_bits(wc, v, 0, v.xF0, v.xB0);       // what the snapshot planes cannot know: the live table at the candidate positions
+        if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
+    }
     int t = 2 * j + 1;
     int last_pos = 0;                               // lastJuncPos
     bool have_last = false;
@@ -760,6 +928,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         int tn;
         uint32_t q = 0;
         bool fwd = false, in_map = false, by_spacer = false;
+        uint64_t ko_slot = ~0ULL;
         for (;;) {   // repeated when junction tests had to be evaluated on the spot (fill_missing)
             int t_ev = 0x7fffffff;
             bool ev_in_map = false;
@@ -768,7 +937,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 const int t_stop = tmax < t_sp ? tmax : t_sp;
                 for (uint32_t c = q0 >> 6; c * 64 < nwin && 2 * (int)(c * 64) <= t_stop; c++) {
                     uint64_t mF, mB;
-                    in_map_words(wc, v, c, mF, mB);
+                    in_map_words<MODE>(wc, v, c, mF, mB);
                     uint64_t eF = mF | pv_word(v, v.fF0, v.fF1, wc.pl.ff, c);
                     uint64_t eB = mB | pv_word(v, v.fB0, v.fB1, wc.pl.fb, c);
                     if (c == (q0 >> 6)) {               // nothing before q0; at q0 the backward half-step is behind us if t is odd
@@ -799,14 +968,32 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 in_map = ev_in_map;
             } else {           // stopped by the spacer rule before any event: the position itself may still be in the map
                 uint64_t mF, mB;
-                in_map_words(wc, v, q >> 6, mF, mB);
+                in_map_words<MODE>(wc, v, q >> 6, mF, mB);
                 in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
+            }
+            if (MODE == WALK_KO) {   // the k-mer's turn first; then the map is asked, and says what a piece walked in file order would see
+                ko_cursor(wc, q, have_last);
+                const bool potential = in_map;
+                const uint64_t kmq = pv_kmer(v, wc.pl.codes, p0 + q, k);
+                const uint64_t rcq = fd_revcomp(kmq, k);
+                const uint64_t canon = kmq < rcq ? kmq : rcq;
+                uint64_t slot;
+                uint32_t present;
+                in_map = jt_find_live(wc.jt, canon, slot, present) && ((present >> ((fwd ? kmq : rcq) == canon ? 0 : 1)) & 1u);
+                ko_slot = in_map ? slot : ~0ULL;
+                if (potential && !in_map) {                 // registered, but not in the map (yet): not an event; look again from here
+                    KoState& ko = *wc.ko;
+                    const uint64_t bm = 1ULL << (q & 63);
+                    if (fwd) { if (q < 64) ko.aF0 |= bm; else ko.aF1 |= bm; }
+                    else { if (q < 64) ko.aB0 |= bm; else ko.aB1 |= bm; }
+                    continue;
+                }
             }
             by_spacer = !in_map && (tn - last_pos >= spacer);
             if (fill_missing<MODE>(wc, v, t, (in_map || by_spacer) ? tn : tn + 1)) continue;
             break;
         }
-        if (MODE != WALK_SEQ && wc.fail) return;
+        if ((MODE == WALK_PROBE || MODE == WALK_COMMIT) && wc.fail) return;
         if (tn > tmax) {   // ran off the end of the piece
             wc.nb_processed += (unsigned long long)(tmax - t + 1);
             wc.nb_jcheck += jcheck_sum(wc, v, t, tmax + 1);
@@ -822,10 +1009,10 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         RecRegs cur;
         const int ext_fwd = fwd ? real : 4;          // getExtensionIndex(FORWARD)
         const int ext_bwd = fwd ? 4 : real;          // getExtensionIndex(BACKWARD)
-        if (MODE == WALK_SEQ) {
-            if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur)) return;
+        if (MODE == WALK_SEQ || MODE == WALK_KO) {
+            if (!junction_get<MODE>(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur, ko_slot)) return;
             if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
-            if (wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
+            if (MODE == WALK_SEQ && wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
                 created_bits(wc, v, 0, v.xF0, v.xB0);
                 if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
             }
@@ -841,7 +1028,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 } else {
                     rr_update(last, last_ext_fwd, d);
                     rr_link(last, last_ext_fwd);
-                    rr_store(last);
+                    rr_store_m<MODE>(last);
                 }
                 rr_update(cur, ext_bwd, d);
                 rr_link(cur, ext_bwd);
@@ -879,6 +1066,11 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         t = tn + d;
         wc.nb_processed += 1;
         wc.nb_skipped += (unsigned long long)(d - 1);
+        if (MODE == WALK_KO) {   // the previous junction's record is stored: its k-mer goes on; so do the positions the skip jumps over
+            ko_visited(wc);
+            const uint32_t q_next = (uint32_t)(t >> 1);
+            ko_pass(wc, q_next < nwin ? q_next : nwin, true);
+        }
     }
 
     if (!have_last) {   // add_fake_junction (ReadScanner.cpp:92-104)
@@ -889,12 +1081,16 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         int real = pv_base(v, wc.pl.codes, p0 + m + k);
         RecRegs rec;
         const int tm = 2 * m + 1;
-        if (MODE == WALK_SEQ) {
-            if (!junction_get(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, p0 + (uint64_t)m, rec)) return;
+        if (MODE == WALK_SEQ || MODE == WALK_KO) {
+            if (MODE == WALK_KO) {   // the middle k-mer's turn was kept when the cursor passed it (ko.fake), or is taken now
+                ko_leave_cursor(*wc.ko, false);
+                ko_pass(wc, (uint32_t)m + 1, false);
+            }
+            if (!junction_get<MODE>(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, p0 + (uint64_t)m, rec)) return;
             rr_add_cov(rec, real);
             rr_update(rec, 4, tm - 2 * j);
             rr_update(rec, real, (2 * (int)nwin - 1 - tm) - 2 * j);
-            rr_store(rec);
+            rr_store_m<MODE>(rec);
         } else {
             if (!junction_find(wc, key, rec)) { wc.fail = 1; return; }
             if (MODE == WALK_PROBE) {
@@ -904,9 +1100,9 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
             }
         }
     } else {            // ReadScanner.cpp:202-206
-        if (MODE == WALK_SEQ) {
+        if (MODE == WALK_SEQ || MODE == WALK_KO) {
             rr_update(last, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j);
-            rr_store(last);
+            rr_store_m<MODE>(last);
         } else if (MODE == WALK_PROBE && rr_raises(last, last_ext_fwd, (2 * (int)nwin - 1 - last_t) - 2 * j)) {
             wc.fail = 2;
         }
@@ -918,12 +1114,13 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
                                              const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
                                              uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg,
-                                             const uint32_t* __restrict__ par_fail, uint32_t heavy) {
+                                             const uint32_t* __restrict__ par_fail, uint32_t heavy, const uint32_t* __restrict__ ko_bad,
+                                             const uint32_t* __restrict__ ko_state, uint32_t ko_heavy) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.created_now = false; wc.fail = 0; wc.dbg = dbg;
+    wc.created_now = false; wc.fail = 0; wc.dbg = dbg; wc.ko = nullptr;
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;
@@ -933,7 +1130,8 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     const uint2 my_piece = pl.pieces[first_piece + ii];
 
     // a large cluster whose pieces k_walk_par found to be order-free is walked there, one thread per piece
-    const bool walked_out_of_order = heavy && my_count + 1 >= heavy && !par_fail[ii];
+    const bool walked_out_of_order = (heavy && my_count + 1 >= heavy && !par_fail[ii]) ||
+                                     (ko_heavy && my_count + 1 >= ko_heavy && !ko_bad[ii] && !(ko_state[1] & 1u));   // k_walk_ko has them
     if (i < n && my_root == i && !walked_out_of_order) {
         const uint32_t nm = (dbg & 2) ? 0 : my_count;
         uint32_t local_mem[LOCAL_MEMBERS];
@@ -998,7 +1196,7 @@ __global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable 
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.created_now = false; wc.fail = 0; wc.dbg = 0;
+    wc.created_now = false; wc.fail = 0; wc.dbg = 0; wc.ko = nullptr;
     const WinDesc wd = *wdp;
     unsigned long long walked = 0;
     if (i < wd.n) {
@@ -1025,6 +1223,126 @@ __global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable 
             if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
             if (v[4]) atomicAdd(&cnt->walk_parallel, v[4]);
         }
+    }
+}
+
+// ---- key-ordered walk: preparation and the walk itself (see KoTables) ----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ko_reset(KoTables kt, uint32_t n_pieces) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t a = i; a <= kt.hk_mask; a += stride) { kt.hk_key[a] = KO_EMPTY; kt.hk_head[a] = U_INF; kt.hk_turn[a] = 0; }
+    for (uint32_t a = i; a < n_pieces; a += stride) kt.bad[a] = 0;
+    if (i < 4) kt.state[i] = 0;
+}
+
+// one thread per piece of the window: the pieces of large clusters list their lk positions as occurrences of their k-mers
+__global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
+                                                    const WinDesc* __restrict__ wdp, KoTables kt, uint32_t heavy) {
+    const WinDesc wd = *wdp;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= wd.n) return;
+    const uint32_t r = root[i];
+    if (count[r] + 1 < heavy) return;
+    const uint2 pc = pl.pieces[wd.first_piece + i];
+    if (pc.y > 128) { kt.bad[r] = 1u; return; }                       // the turn bookkeeping keeps a piece's positions in two words
+    const uint64_t lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0), lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
+    const uint32_t n = (uint32_t)__popcll(lk0) + (uint32_t)__popcll(lk1);
+    const uint32_t base = atomicAdd(&kt.state[0], n);
+    if (base + n > kt.occ_cap) { atomicOr(&kt.state[1], 1u); return; }
+    kt.piece_base[i] = base;
+    uint32_t node = base;
+    for (int half = 0; half < 2; half++) {
+        uint64_t w = half ? lk1 : lk0;
+        while (w) {
+            const uint32_t q = (uint32_t)(64 * half) + (uint32_t)__builtin_ctzll(w);
+            w &= w - 1;
+            uint32_t h = pl.kh[pc.x + q];
+            if (h == KO_EMPTY) h = KO_EMPTY - 1;
+            uint32_t s = (h * 0x9E3779B1u) & kt.hk_mask, e = U_INF;
+            for (uint32_t probe = 0; probe < 4096; probe++) {
+                const uint32_t old = atomicCAS(&kt.hk_key[s], KO_EMPTY, h);
+                if (old == KO_EMPTY || old == h) { e = s; break; }
+                s = (s + 1) & kt.hk_mask;
+            }
+            if (e == U_INF) { atomicOr(&kt.state[1], 1u); return; }
+            kt.occ_entry[node] = e;
+            kt.occ_id[node] = ((uint64_t)i << 32) | q;
+            kt.occ_next[node] = atomicExch(&kt.hk_head[e], node);
+            node++;
+        }
+    }
+}
+
+// rank of every occurrence among the occurrences of its k-mer, by (piece, position)
+__global__ void __launch_bounds__(256) k_ko_rank(KoTables kt) {
+    if (kt.state[1] & 1u) return;
+    const uint32_t n = kt.state[0];
+    for (uint32_t node = blockIdx.x * blockDim.x + threadIdx.x; node < n; node += gridDim.x * blockDim.x) {
+        const uint64_t mine = kt.occ_id[node];
+        uint32_t r = 0;
+        for (uint32_t m = kt.hk_head[kt.occ_entry[node]]; m != U_INF; m = kt.occ_next[m]) r += kt.occ_id[m] < mine ? 1u : 0u;
+        kt.occ_rank[node] = r;
+    }
+}
+
+// The walk: waves draw chunks of 64 consecutive pieces from a ticket counter (whoever holds a ticket is running, and every piece a wave can
+// wait for belongs to the same or an earlier ticket); lane 0 walks the chunk's pieces of large clusters one after the other.
+__global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
+                                                const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt,
+                                                KoTables kt, uint32_t heavy) {
+    const WinDesc wd = *wdp;
+    if (kt.state[1] & 1u) return;                                      // a table overflowed: k_walk takes every cluster
+    WalkCtx wc;
+    KoState ko;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
+    wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
+    wc.created_now = false; wc.fail = 0; wc.dbg = 0; wc.ko = &ko;
+    ko.kt = kt;
+    unsigned long long walked = 0;
+    for (;;) {
+        uint32_t chunk = 0;
+        if (fd_lane() == 0) chunk = atomicAdd(&kt.state[2], 1u);
+        chunk = (uint32_t)__shfl((int)chunk, 0, 64);
+        if ((uint64_t)chunk * 64 >= wd.n) break;
+        const uint32_t i = chunk * 64 + (uint32_t)fd_lane();
+        bool mine = false;
+        if (i < wd.n) {
+            const uint32_t r = root[i];
+            mine = count[r] + 1 >= heavy && !kt.bad[r];
+            if (mine && r == i) {                         // the statistics k_walk keeps per cluster
+                atomicAdd(&cnt->followers, (unsigned long long)count[r]);
+                atomicMax(&cnt->max_cluster, (unsigned long long)count[r] + 1);
+            }
+        }
+        uint64_t todo = __ballot(mine);
+        if (fd_lane() == 0) {
+            while (todo) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t li = chunk * 64 + b;
+                const uint2 pc = pl.pieces[wd.first_piece + li];
+                ko.base = kt.piece_base[li];
+                ko.done = 0;
+                ko.mid = (pc.y + (uint32_t)fp.k - 1) / 2 - (uint32_t)fp.k / 2;
+                ko.last.n = ko.cur.n = ko.fake.n = 0;
+                ko.cur_q = 0;
+                ko.cur_in = 0;
+                ko.lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0);
+                ko.lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
+                ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
+                walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
+                ko_finish(wc, pc.y);
+                walked++;
+            }
+        }
+    }
+    if (fd_lane() == 0) {
+        if (wc.nb_processed) atomicAdd(&cnt->nb_processed, wc.nb_processed);
+        if (wc.nb_skipped) atomicAdd(&cnt->nb_skipped, wc.nb_skipped);
+        if (wc.nb_jcheck) atomicAdd(&cnt->nb_jcheck, wc.nb_jcheck);
+        if (wc.nb_no_juncs) atomicAdd(&cnt->nb_no_juncs, wc.nb_no_juncs);
+        if (wc.n_created) atomicAdd(&cnt->n_junctions, wc.n_created);
+        if (wc.n_filled) atomicAdd(&cnt->flags_filled, wc.n_filled);
+        if (walked) atomicAdd(&cnt->walk_parallel, walked);
     }
 }
 
@@ -1353,6 +1671,13 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->cl_offset, 2 * ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_fill, ctx->wmax * 4));
     FGPU_HIP(hipMalloc(&ctx->cl_fail, 2 * ctx->wmax * 4));
+    // the key-ordered walk's tables (KoTables): 2^20 k-mers and 2^22 occurrences of large clusters per window, else the window is walked by cluster
+    if (const char* e = getenv("FGPU_WALK_KO")) ctx->walk_ko = (uint32_t)std::max(0, atoi(e));
+    ctx->ko_hk_cap = 1u << 20;
+    ctx->ko_occ_cap = 1u << 22;
+    FGPU_HIP(hipMalloc(&ctx->ko_hk, (size_t)ctx->ko_hk_cap * 4 * 3));
+    FGPU_HIP(hipMalloc(&ctx->ko_occ, (size_t)ctx->ko_occ_cap * (4 * 3 + 8)));
+    FGPU_HIP(hipMalloc(&ctx->ko_piece, (size_t)ctx->wmax * 4 * 2 + 64));
     if (const char* e = getenv("FGPU_WALK_HEAVY")) ctx->walk_heavy = (uint32_t)std::max(0, atoi(e));   // clusters of at least this many pieces are tried out of order; 0 = never
     FGPU_HIP(hipMalloc(&ctx->cl_members, ctx->wmax * 4 * 2));
     return FGPU_OK;
@@ -1540,6 +1865,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const uint64_t max_pieces = std::min<uint64_t>((hi - lo) / (uint64_t)(ctx->fd.k + 1) + 2, ctx->wmax);
         const unsigned walk_grid_w = fgpu_blocks(max_pieces, 64);
         const unsigned cluster_grid = std::min(256u, fgpu_blocks(max_pieces, 256));
+        const unsigned piece_blocks_ko = fgpu_blocks(max_pieces, 256);
         uint32_t* const uf_parent = ctx->uf_parent + parity * (uint64_t)ctx->wmax;     // this window's set of the union-find / list arrays
         uint32_t* const cl_count = ctx->cl_count + parity * (uint64_t)ctx->wmax;
         uint32_t* const cl_offset = ctx->cl_offset + parity * (uint64_t)ctx->wmax;
@@ -1588,13 +1914,37 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
-        const uint32_t heavy = dbg_walk ? 0u : ctx->walk_heavy;
+        const uint32_t ko_heavy = dbg_walk ? 0u : ctx->walk_ko;
+        const uint32_t heavy = (dbg_walk || ko_heavy) ? 0u : ctx->walk_heavy;   // (one way of taking large clusters out of k_walk at a time)
+        KoTables kt;
+        kt.hk_key = ctx->ko_hk;
+        kt.hk_head = ctx->ko_hk + ctx->ko_hk_cap;
+        kt.hk_turn = ctx->ko_hk + 2 * (size_t)ctx->ko_hk_cap;
+        kt.hk_mask = ctx->ko_hk_cap - 1;
+        kt.occ_id = (uint64_t*)ctx->ko_occ;
+        kt.occ_entry = (uint32_t*)(kt.occ_id + ctx->ko_occ_cap);
+        kt.occ_rank = kt.occ_entry + ctx->ko_occ_cap;
+        kt.occ_next = kt.occ_rank + ctx->ko_occ_cap;
+        kt.occ_cap = ctx->ko_occ_cap;
+        kt.state = ctx->ko_piece;                 // 16 words in front of the per-piece arrays
+        kt.piece_base = ctx->ko_piece + 16;
+        kt.bad = kt.piece_base + ctx->wmax;
+        if (ko_heavy) {
+            FGPU_LAUNCH("walk_ko_prepare", k_ko_reset, 256, 256, kt, (uint32_t)max_pieces);
+            FGPU_LAUNCH("walk_ko_prepare", k_ko_prepare, piece_blocks_ko, 256, pl, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
+                        (const WinDesc*)ctx->wdesc, kt, ko_heavy);
+            FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt);
+        }
         if (heavy)
             FGPU_LAUNCH("walk_probe", k_walk_par<WALK_PROBE>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
                         (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);
         FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                     (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
-                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy);
+                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
+                    (const uint32_t*)kt.state, ko_heavy);
+        if (ko_heavy)
+            FGPU_LAUNCH("walk_ko", k_walk_ko, 512, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
+                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy);
         if (heavy)
             FGPU_LAUNCH("walk_commit", k_walk_par<WALK_COMMIT>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
                         (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);

@@ -207,7 +207,6 @@ def test_random_inputs_vs_oracle(n_reads, L_, k, G, err, E, S, j, n_rate, repeat
     assert np.array_equal(keys, okeys)
     assert np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
     assert np.array_equal(recs["linked"], orecs["linked"])
-    return sst
 
 
 def _scan_equals_oracle(sc, sst, osc):
