@@ -1227,21 +1227,28 @@ __global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable 
 }
 
 // ---- key-ordered walk: preparation and the walk itself (see KoTables) ----------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ko_reset(KoTables kt, uint32_t n_pieces) {
+__global__ void __launch_bounds__(256) k_ko_reset(KoTables kt, uint32_t n_pieces, uint32_t parity) {
+    // the tables are only touched by windows that hold a large cluster (state[4 + parity of that window]): most windows find them clean
+    const bool dirty = kt.state[4 + (parity ^ 1u)] != 0;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (uint32_t a = i; a <= kt.hk_mask; a += stride) { kt.hk_key[a] = KO_EMPTY; kt.hk_head[a] = U_INF; kt.hk_turn[a] = 0; }
-    for (uint32_t a = i; a < n_pieces; a += stride) kt.bad[a] = 0;
+    if (dirty) {
+        for (uint32_t a = i; a <= kt.hk_mask; a += stride) { kt.hk_key[a] = KO_EMPTY; kt.hk_head[a] = U_INF; kt.hk_turn[a] = 0; }
+        for (uint32_t a = i; a < n_pieces; a += stride) kt.bad[a] = 0;
+    }
     if (i < 4) kt.state[i] = 0;
+    if (i == 4) kt.state[4 + parity] = 0;
 }
 
 // one thread per piece of the window: the pieces of large clusters list their lk positions as occurrences of their k-mers
 __global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
-                                                    const WinDesc* __restrict__ wdp, KoTables kt, uint32_t heavy) {
+                                                    const WinDesc* __restrict__ wdp, KoTables kt, uint32_t heavy, uint32_t parity) {
     const WinDesc wd = *wdp;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= wd.n) return;
     const uint32_t r = root[i];
     if (count[r] + 1 < heavy) return;
+    kt.state[4 + parity] = 1u;                                        // the tables are in use: the next window resets them
+    atomicAdd(&kt.state[3], 1u);
     const uint2 pc = pl.pieces[wd.first_piece + i];
     if (pc.y > 128) { kt.bad[r] = 1u; return; }                       // the turn bookkeeping keeps a piece's positions in two words
     const uint64_t lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0), lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
@@ -1288,7 +1295,7 @@ __global__ void __launch_bounds__(256) k_ko_rank(KoTables kt) {
 // wait for belongs to the same or an earlier ticket); lane 0 walks the chunk's pieces of large clusters one after the other.
 __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
                                                 const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt,
-                                                KoTables kt, uint32_t heavy) {
+                                                KoTables kt, uint32_t heavy, uint32_t KO_TICKET) {
     const WinDesc wd = *wdp;
     if (kt.state[1] & 1u) return;                                      // a table overflowed: k_walk takes every cluster
     WalkCtx wc;
@@ -1298,40 +1305,46 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     wc.created_now = false; wc.fail = 0; wc.dbg = 0; wc.ko = &ko;
     ko.kt = kt;
     unsigned long long walked = 0;
+    if (kt.state[3] == 0) return;                                      // no large cluster in this window (the usual case)
+    // KO_TICKET pieces per ticket (a multiple of 64): a same-address atomic per 64 pieces cost 0.2 ms per window
     for (;;) {
-        uint32_t chunk = 0;
-        if (fd_lane() == 0) chunk = atomicAdd(&kt.state[2], 1u);
-        chunk = (uint32_t)__shfl((int)chunk, 0, 64);
-        if ((uint64_t)chunk * 64 >= wd.n) break;
-        const uint32_t i = chunk * 64 + (uint32_t)fd_lane();
-        bool mine = false;
-        if (i < wd.n) {
-            const uint32_t r = root[i];
-            mine = count[r] + 1 >= heavy && !kt.bad[r];
-            if (mine && r == i) {                         // the statistics k_walk keeps per cluster
-                atomicAdd(&cnt->followers, (unsigned long long)count[r]);
-                atomicMax(&cnt->max_cluster, (unsigned long long)count[r] + 1);
+        uint32_t ticket = 0;
+        if (fd_lane() == 0) ticket = atomicAdd(&kt.state[2], 1u);
+        ticket = (uint32_t)__shfl((int)ticket, 0, 64);
+        if ((uint64_t)ticket * KO_TICKET >= wd.n) break;
+        for (uint32_t sub = 0; sub < KO_TICKET / 64; sub++) {
+            const uint32_t first = ticket * KO_TICKET + sub * 64;
+            if (first >= wd.n) break;
+            const uint32_t i = first + (uint32_t)fd_lane();
+            bool mine = false;
+            if (i < wd.n) {
+                const uint32_t r = root[i];
+                mine = count[r] + 1 >= heavy && !kt.bad[r];
+                if (mine && r == i) {                     // the statistics k_walk keeps per cluster
+                    atomicAdd(&cnt->followers, (unsigned long long)count[r]);
+                    atomicMax(&cnt->max_cluster, (unsigned long long)count[r] + 1);
+                }
             }
-        }
-        uint64_t todo = __ballot(mine);
-        if (fd_lane() == 0) {
-            while (todo) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint32_t li = chunk * 64 + b;
-                const uint2 pc = pl.pieces[wd.first_piece + li];
-                ko.base = kt.piece_base[li];
-                ko.done = 0;
-                ko.mid = (pc.y + (uint32_t)fp.k - 1) / 2 - (uint32_t)fp.k / 2;
-                ko.last.n = ko.cur.n = ko.fake.n = 0;
-                ko.cur_q = 0;
-                ko.cur_in = 0;
-                ko.lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0);
-                ko.lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
-                ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
-                walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
-                ko_finish(wc, pc.y);
-                walked++;
+            uint64_t todo = __ballot(mine);
+            if (fd_lane() == 0) {
+                while (todo) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t li = first + b;
+                    const uint2 pc = pl.pieces[wd.first_piece + li];
+                    ko.base = kt.piece_base[li];
+                    ko.done = 0;
+                    ko.mid = (pc.y + (uint32_t)fp.k - 1) / 2 - (uint32_t)fp.k / 2;
+                    ko.last.n = ko.cur.n = ko.fake.n = 0;
+                    ko.cur_q = 0;
+                    ko.cur_in = 0;
+                    ko.lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0);
+                    ko.lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
+                    ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
+                    walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
+                    ko_finish(wc, pc.y);
+                    walked++;
+                }
             }
         }
     }
@@ -1673,6 +1686,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     FGPU_HIP(hipMalloc(&ctx->cl_fail, 2 * ctx->wmax * 4));
     // the key-ordered walk's tables (KoTables): 2^20 k-mers and 2^22 occurrences of large clusters per window, else the window is walked by cluster
     if (const char* e = getenv("FGPU_WALK_KO")) ctx->walk_ko = (uint32_t)std::max(0, atoi(e));
+    ctx->walk_ko_always = getenv("FGPU_WALK_KO_ALWAYS") != nullptr;
     ctx->ko_hk_cap = 1u << 20;
     ctx->ko_occ_cap = 1u << 22;
     FGPU_HIP(hipMalloc(&ctx->ko_hk, (size_t)ctx->ko_hk_cap * 4 * 3));
@@ -1749,6 +1763,9 @@ int fgpu_scan_reset(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemsetAsync(ctx->cl_count, 0, 2 * ctx->wmax * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->cl_offset, 0xFF, 2 * ctx->wmax * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->cl_fail, 0, 2 * ctx->wmax * 4, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(ctx->ko_hk, 0xFF, (size_t)ctx->ko_hk_cap * 4 * 2, ctx->stream));        // keys free, lists empty,
+    FGPU_HIP(hipMemsetAsync(ctx->ko_hk + 2 * (size_t)ctx->ko_hk_cap, 0, (size_t)ctx->ko_hk_cap * 4, ctx->stream));   // turns at zero,
+    FGPU_HIP(hipMemsetAsync(ctx->ko_piece, 0, (size_t)ctx->wmax * 4 * 2 + 64, ctx->stream));        // flags and per-piece arrays clean
     return FGPU_OK;
 }
 
@@ -1914,7 +1931,12 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
-        const uint32_t ko_heavy = dbg_walk ? 0u : ctx->walk_ko;
+        // The key-ordered walk costs four small launches per window whether or not the window holds a large cluster, so it is switched on by
+        // what the scan has shown so far: the largest cluster among the windows whose counters the host has seen (every batch's pure stage
+        // brings them along).  Data without such clusters never pays; data with them walks its first batch by cluster.  Either way the
+        // results are the same.  FGPU_WALK_KO_ALWAYS=1: from the first window (tests).
+        const uint32_t ko_heavy = (dbg_walk || !ctx->walk_ko || !(ctx->walk_ko_always || ctx->counters_host->max_cluster >= ctx->walk_ko)) ? 0u : ctx->walk_ko;
+        static const uint32_t ko_ticket = getenv("FGPU_KO_TICKET") ? (uint32_t)std::max(64, atoi(getenv("FGPU_KO_TICKET")) / 64 * 64) : 64u;
         const uint32_t heavy = (dbg_walk || ko_heavy) ? 0u : ctx->walk_heavy;   // (one way of taking large clusters out of k_walk at a time)
         KoTables kt;
         kt.hk_key = ctx->ko_hk;
@@ -1930,9 +1952,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         kt.piece_base = ctx->ko_piece + 16;
         kt.bad = kt.piece_base + ctx->wmax;
         if (ko_heavy) {
-            FGPU_LAUNCH("walk_ko_prepare", k_ko_reset, 256, 256, kt, (uint32_t)max_pieces);
+            FGPU_LAUNCH("walk_ko_prepare", k_ko_reset, 256, 256, kt, (uint32_t)ctx->wmax, (uint32_t)parity);
             FGPU_LAUNCH("walk_ko_prepare", k_ko_prepare, piece_blocks_ko, 256, pl, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
-                        (const WinDesc*)ctx->wdesc, kt, ko_heavy);
+                        (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity);
             FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt);
         }
         if (heavy)
@@ -1944,7 +1966,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     (const uint32_t*)kt.state, ko_heavy);
         if (ko_heavy)
             FGPU_LAUNCH("walk_ko", k_walk_ko, 512, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
-                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy);
+                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket);
         if (heavy)
             FGPU_LAUNCH("walk_commit", k_walk_par<WALK_COMMIT>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
                         (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);

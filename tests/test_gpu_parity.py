@@ -133,6 +133,29 @@ def test_out_of_order_walk_of_clusters_gives_the_same_result(name, monkeypatch):
     assert sst["walk_parallel"] > 1000
 
 
+@pytest.mark.parametrize("name", ["c1_k21", "ragged_k31", "j2_spacer20_k15"])
+def test_key_ordered_walk_of_clusters_gives_the_same_result(name, monkeypatch):
+    """FGPU_WALK_KO=2 with FGPU_WALK_KO_ALWAYS: every cluster of two or more pieces is walked by k_walk_ko -- one piece per wave, accesses ordered
+    per junction k-mer by turn counters instead of pieces per cluster.  By default it takes clusters of 64 pieces and more,
+    from the moment a scan has shown one; the results must not depend on who walks what.  (The whole GPU suite passes with these two settings;
+    here: three goldens, tandem repeats -- the same k-mer several times on a piece -- and 40x random reads with a fake junction per read end.)"""
+    monkeypatch.setenv("FGPU_WALK_KO", "2")
+    monkeypatch.setenv("FGPU_WALK_KO_ALWAYS", "1")
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    for n_batches, span in ((1, 0), (3, 4096), (1, 256)):
+        _scan_and_compare(c, bases, offs, n_batches, span)
+    bases, offs = _random_case(20000, 110, 25, 50000, 0.012, 7, 0.002, 4)
+    sst = _check_against_oracle(bases, offs, 25, 1_000_000, 200_000, 1, walk_window_span=1 << 14)
+    assert sst["walk_parallel"] > 2000
+    rng = np.random.default_rng(53)
+    unit = synth._ACGT[rng.integers(0, 4, size=53)]
+    genome = np.tile(unit, 20000 // 53 + 2)[:20000].copy()
+    r = synth.make_reads(genome, 3000, 120, 0.004, 54)
+    bases, offs = po.reads_from_matrix(r)
+    assert _check_against_oracle(bases, offs, 21, 500_000, 100_000, 1, scan_chunks=3)["walk_parallel"] > 1000
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_scan_eager_flags_mode_gives_the_same_result(name):
     c = Case(name)
