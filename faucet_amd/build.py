@@ -21,7 +21,7 @@ HIP_SOURCES = ["api.hip", "pack.hip", "load.hip", "scan_pure.hip", "scan_walk.hi
 CPP_SOURCES = ["sizing.cpp"]
 HEADERS = ["fgpu_ctx.h", "fgpu_device.h", "fgpu_flags.h", os.path.join(ROOT, "include", "faucet_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("FGPU_EXTRA_CXXFLAGS", "").split()
 
 
 def _newer(target, deps):

@@ -810,6 +810,15 @@ __device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { return
 __device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounters* cnt) {
     unsigned spins = 0;
     unsigned long long t0 = 0;
+#ifdef FGPU_KO_TIMING
+    const unsigned long long tw = wall_clock64();
+    if (ld_agent(turn) != r) {
+        while (ld_agent(turn) != r) __builtin_amdgcn_s_sleep(1);
+        atomicAdd(&cnt->par_probe[1], wall_clock64() - tw);
+        atomicAdd(&cnt->par_probe[3], 1ULL);
+    }
+    return;
+#endif
     while (ld_agent(turn) != r) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 4095u) == 0) {   // a turn that never comes is a bug, not a state to wait in: say so once and let every piece run out
@@ -1341,9 +1350,16 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
                     ko.lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0);
                     ko.lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
                     ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
+#ifdef FGPU_KO_TIMING
+                    const unsigned long long tp = wall_clock64();
+#endif
                     walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
                     ko_finish(wc, pc.y);
                     walked++;
+#ifdef FGPU_KO_TIMING
+                    atomicAdd(&cnt->par_probe[0], wall_clock64() - tp);
+                    atomicAdd(&cnt->par_probe[2], 1ULL);
+#endif
                 }
             }
         }
