@@ -18,6 +18,10 @@
 //   C  k_walk_cluster  flatten the union-find; list each cluster's members in ascending piece order
 //   D  k_walk          one thread per cluster replays its pieces IN ORDER against the live table; clusters are
 //                      disjoint in the keys they touch, so they run concurrently without changing any result
+//   D' k_walk_ko       clusters of 64 pieces and more (repeats at high coverage), once a scan has shown one: one piece per wave, the
+//                      ACCESSES ordered per junction k-mer by turn counters (k_ko_prepare, k_ko_rank), so the pieces of a cluster
+//                      overlap; k_walk leaves those clusters alone.  (k_walk_par, off: the out-of-order walk of clusters whose
+//                      pieces change nothing another piece reads -- exact, measured, does not pay.)
 //   E  k_delta_collect the keys the window created go to the batch's list; k_walk_reset_uf (side stream) resets the union-find arrays
 //                      and the window table's presence filter of this parity (the table itself needs no cleaning: epoch-tagged entries)
 // Windows run one after another on the stream, so a later window sees everything earlier ones wrote.

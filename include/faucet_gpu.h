@@ -109,7 +109,8 @@ typedef struct {
     uint64_t piece_positions;    /* window positions inside valid pieces */
     uint64_t valid_reused;       /* getValidReads answers taken from the load pass' resident planes (no filter probe) */
     uint64_t flags_filled;       /* windows whose testForJunction the walk evaluated itself because the preview had left them out */
-    uint64_t walk_parallel;      /* pieces of large clusters that were walked out of order (they changed nothing a later piece could see) */
+    uint64_t walk_parallel;      /* pieces of large clusters walked apart from their cluster's thread: in the order of their junction k-mers'
+                                  * turns (k_walk_ko, the default for clusters of 64 pieces and more) or out of order (FGPU_WALK_HEAVY) */
 } fgpu_scan_stats;
 
 /* One element of the list ReadScanner::scanInputRead returns for a read (src/ReadScanner.cpp:260-282): the real-extension
