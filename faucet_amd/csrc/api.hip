@@ -1048,6 +1048,11 @@ int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays) {
 int fgpu_diag_walk_probe(fgpu_ctx* ctx, uint64_t out[4]) {   // after fgpu_scan_end: probed pieces by outcome (k_walk_par)
     if (!ctx || !out) return FGPU_ERR_ARG;
     for (int i = 0; i < 4; i++) out[i] = ctx->counters_host->par_probe[i];
+    if (getenv("FGPU_KO_TIMING_PRINT")) {
+        fprintf(stderr, "[fgpu] k_walk_ko ticks (10 ns):");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", ctx->counters_host->ko_time[i]);
+        fprintf(stderr, "\n");
+    }
     return FGPU_OK;
 }
 

@@ -134,6 +134,7 @@ struct DevCounters {
     unsigned long long mark_pending;    // pass 1: occurrences left to k_load_resolve
     unsigned long long walk_parallel;   // pieces of large clusters walked out of order (k_walk_par)
     unsigned long long par_probe[4];    // probed pieces by outcome: order-free, would create, would raise a distance, untested positions
+    unsigned long long ko_time[8];      // -DFGPU_KO_TIMING: ticks (10 ns) of k_walk_ko by part, see scripts/pe_profile.py
 };
 
 struct TextSet { DevBuf buf, nl, rank, tmp, rec; };

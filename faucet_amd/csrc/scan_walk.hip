@@ -440,6 +440,13 @@ struct WalkCtx {
 // per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
 // COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
 enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3 };
+#ifdef FGPU_KO_TIMING
+#define KO_T0() const unsigned long long ko_t0__ = wall_clock64()
+#define KO_T1(cnt, i) atomicAdd(&(cnt)->ko_time[i], wall_clock64() - ko_t0__)
+#else
+#define KO_T0() do {} while (0)
+#define KO_T1(cnt, i) do {} while (0)
+#endif
 
 // ---- the key-ordered walk of large clusters (k_walk_ko) ------------------------------------------------------------------------------------
 // A cluster's pieces are walked in file order because of what they read and write in the junction map -- and they read and write it one
@@ -473,6 +480,7 @@ struct KoHold {   // a k-mer whose turn this piece holds: entry, rank of its fir
 };
 struct KoState {
     KoTables kt;
+    DevCounters* cnt;       // (timing build)
     uint32_t base;          // first occurrence number of this piece
     uint32_t done;          // every lk position below `done` has been accounted for (passed or held)
     uint32_t mid;           // the position add_fake_junction would use
@@ -733,10 +741,13 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     uint64_t slot;
     uint32_t present;
     if (MODE == WALK_KO && known_slot != ~0ULL) {   // the key-ordered walk has just found this junction in the map: no second probe
+        KO_T0();
         out.addr = (uint64_t*)(wc.jt.recs + (known_slot * 2 + orient) * 16);
         out.lo = ld_agent(&out.addr[0]);
         out.hi = ld_agent(&out.addr[1]);
         wc.created_now = false;
+        if (out.lo == 0xFFFFFFFFFFFFFFF1ULL) return false;
+        KO_T1(wc.cnt, 3);
         return true;
     }
     // the key word and the record of the home slot are requested together: at the table's low load factor the key is
@@ -834,12 +845,17 @@ __device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounte
     }
     // no cache invalidate: everything one piece hands to the next (turn counters, key words, records) is read with agent-scope loads
 }
+__device__ __forceinline__ DevCounters* ko_cnt(const KoState& ko) { return ko.cnt; }
 // the k-mer's turn goes to its next occurrence; whatever this piece stored is visible before the counter moves
 __device__ __forceinline__ void ko_give(const KoState& ko, KoHold& h) {
     // records are stored with agent-scope (write-through) stores and key words change by atomics: waiting for them to complete is the whole
     // release -- an agent-scope release fence would also write the L2 back, which this hand-over does not need and pays for dearly
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __hip_atomic_store(&ko.kt.hk_turn[h.e], h.r + h.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        KO_T0();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&ko.kt.hk_turn[h.e], h.r + h.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        KO_T1(ko_cnt(ko), 1);
+    }
     h.n = 0;
 }
 // the cursor leaves its position without having visited it
@@ -852,9 +868,12 @@ __device__ __forceinline__ void ko_leave_cursor(KoState& ko, bool have_last) {
 __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_cursor, bool have_last) {
     KoState& ko = *wc.ko;
     ko_leave_cursor(ko, have_last);
+    KO_T0();
     const uint32_t node = ko.base + ko_ordinal(ko, q);
     const uint32_t e = ko.kt.occ_entry[node], r = ko.kt.occ_rank[node];
     if (as_cursor) ko.cur_q = q;
+    if (e == 0xFFFFFFF0u) return;                   // (keeps the loads in front of the clock)
+    KO_T1(wc.cnt, 0);
     if (ko.last.n && e == ko.last.e) { ko.last.n++; if (as_cursor) ko.cur_in = 1; return; }     // this piece holds the k-mer already
     if (ko.fake.n && e == ko.fake.e) { ko.fake.n++; if (as_cursor) ko.cur_in = 2; return; }
     ko_wait(&ko.kt.hk_turn[e], r, wc.cnt);
@@ -992,7 +1011,12 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 const uint64_t canon = kmq < rcq ? kmq : rcq;
                 uint64_t slot;
                 uint32_t present;
-                in_map = jt_find_live(wc.jt, canon, slot, present) && ((present >> ((fwd ? kmq : rcq) == canon ? 0 : 1)) & 1u);
+                {
+                    KO_T0();
+                    in_map = jt_find_live(wc.jt, canon, slot, present) && ((present >> ((fwd ? kmq : rcq) == canon ? 0 : 1)) & 1u);
+                    if (slot == 0xFFFFFFFFFFFFFFF0ULL) return;
+                    KO_T1(wc.cnt, 2);
+                }
                 ko_slot = in_map ? slot : ~0ULL;
                 if (potential && !in_map) {                 // registered, but not in the map (yet): not an event; look again from here
                     KoState& ko = *wc.ko;
@@ -1317,6 +1341,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
     wc.created_now = false; wc.fail = 0; wc.dbg = 0; wc.ko = &ko;
     ko.kt = kt;
+    ko.cnt = cnt;
     unsigned long long walked = 0;
     if (kt.state[3] == 0) return;                                      // no large cluster in this window (the usual case)
     // KO_TICKET pieces per ticket (a multiple of 64): a same-address atomic per 64 pieces cost 0.2 ms per window

@@ -12,7 +12,7 @@ n, G = (int(x) for x in sys.argv[1:3])
 tai, nh = api.load_filter_shape(10 * n, 2 * n)
 reads = bench.make_reads(bench.make_genome(G, 100, dev), n, 100, 0.01, 5000, dev)
 batches = bench.device_batches(reads, 1_000_000)
-ctx = api.Context(31, tai, nh, profile=True)
+ctx = api.Context(31, tai, nh, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
 for rep in range(2):
     ctx.kernel_times_reset()
     ctx.load_begin()
