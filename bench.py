@@ -18,6 +18,7 @@ junction records in creation order.  Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -280,6 +281,49 @@ def reference_bit_counts(k, read_len, err, coverage, bits_per_kmer_ratio, seed=7
 
 
 # ---------------------------------------------------------------------------------------------- main
+def cli_leg(reads, args, kmers, want_junctions):
+    """writes the reads as FASTA (fixed-width headers), runs faucet_amd/faucet on it twice, reports the faster run"""
+    import re
+    import shutil
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "faucet_amd", "faucet")
+    host = reads.cpu().numpy()
+    n, L_ = host.shape
+    d = tempfile.mkdtemp(prefix="faucet_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rec = np.empty((n, 10 + L_ + 1), dtype=np.uint8)
+        rec[:, 0] = ord(">")
+        idx = np.arange(n, dtype=np.int64)
+        for dgt in range(8):
+            rec[:, 8 - dgt] = ord("0") + (idx // 10 ** dgt) % 10
+        rec[:, 9] = ord("\n")
+        rec[:, 10:10 + L_] = host
+        rec[:, 10 + L_] = ord("\n")
+        path = os.path.join(d, "reads.fa")
+        rec.tofile(path)
+        size = os.path.getsize(path)
+        del rec
+        cmd = [exe, "-read_load_file", path, "-read_scan_file", path, "-size_kmer", str(args.k), "-max_read_length", str(L_),
+               "-estimated_kmers", str(args.estimated_kmers), "-singletons", str(args.singletons), "--no_cleaning",
+               "-file_prefix", os.path.join(d, "out")]
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("faucet exited with %d: %s" % (r.returncode, r.stderr[-300:]))
+            best = dt if best is None else min(best, dt)
+        m = re.search(r"Distinct junctions: (\d+)", r.stdout)
+        return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "input_bytes": size,
+                "output_bytes": os.path.getsize(os.path.join(d, "out.bloom")) + os.path.getsize(os.path.join(d, "out.junctions")),
+                "junctions_equal_the_steps": bool(m) and int(m.group(1)) == int(want_junctions),
+                "note": "wall time of the whole `faucet` process (runtime start-up, both passes reading the FASTA file from page cache or tmpfs, "
+                        ".bloom and .junctions written), best of two runs"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -559,6 +603,14 @@ def main():
         dt = (time.perf_counter() - t0) / n_h
         res["host_input"] = {"value": kmers_local / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt, "steps": n_h,
                              "note": "reads handed over as pageable host buffers: both passes copy them to the device inside the timed region"}
+    # ---- file to files ("from the first byte of input consumed"): the `faucet` command line on the same reads as a FASTA file,
+    # both passes reading it, `.bloom` and `.junctions` written.  Wall time of the whole process -- runtime start-up, context, output files
+    # included -- beside `value`, never as `value`; the junction count must be the step's.
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+        try:
+            res["cli_file_to_files"] = cli_leg(reads, args, kmers_local, res["outputs"]["junctions"])
+        except Exception as e:   # noqa: BLE001  (a missing /tmp or binary must not cost the bench line)
+            res["cli_file_to_files"] = {"error": repr(e)[:300]}
     emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

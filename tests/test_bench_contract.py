@@ -21,6 +21,8 @@ def test_committed_bench_line_has_the_contract_keys():
     # round 2: what the counters say, the PCIe-inclusive rate and the all-cores CPU figure ride in the same line
     assert d["pipeline_measured"]["GBps"] > 0 and not d["pipeline_measured"]["kernels_without_counters"]
     assert 0 < d["host_input"]["value"] < d["value"] and c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"]
+    f = d["cli_file_to_files"]      # the command line on the same reads as a file: slower than the resident step, same junctions
+    assert 0 < f["value"] < d["host_input"]["value"] and f["junctions_equal_the_steps"] and f["input_bytes"] > 10 ** 9
     assert r["frac_bloo1_accesses_only"] < r["frac"] and "attribution" in r
     # value is consistent with the step time it was derived from
     assert abs(d["value"] - d["kmers_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
