@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21", "mercy_k21", "nomercy_k21"]
+CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21", "mercy_k21", "nomercy_k21", "se_cleaning_k21"]
 
 
 def _gz(path):

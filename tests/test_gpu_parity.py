@@ -651,6 +651,29 @@ def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_p
     assert "Weight of short pair filter: 0.000000" in r.stdout
 
 
+@pytest.mark.parametrize("how", [["-batch_reads", "400"], [], ["-chunk_mb", "1"]])
+def test_cli_single_end_run_with_cleaning_writes_the_reference_short_pair_filter(how, tmp_path):
+    """Single-end reads, cleaning on (neither --no_cleaning nor --paired_ends): the reference writes `.bloom`, `.junctions` and
+    `.short_pair_filter` before its contig-graph stage (golden se_cleaning_k21, tests/golden/make_cleaning_golden.py).  Here the short pair
+    filter is filled on the device and no list reaches the host (fgpu_scan_short_pairs with lists_to_host = 0); exit code 3 as for every run
+    that would go on to the contig graph."""
+    import os
+    import subprocess
+    c = Case("se_cleaning_k21")
+    reads = tmp_path / "reads.fa"
+    reads.write_bytes(c.reads_text())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(tmp_path / "out")]
+                       + how + c.meta["args"], capture_output=True, text=True)
+    assert r.returncode == 3, r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "out.bloom", dtype=np.uint8), c.bloom())
+    assert (tmp_path / "out.junctions").read_text().split("\n")[:-1] == c.junction_lines()
+    short = c.pair_filter("short")
+    assert short.any() and np.array_equal(np.fromfile(tmp_path / "out.short_pair_filter", dtype=np.uint8), short)
+    assert not (tmp_path / "out.long_pair_filter").exists()
+    assert f"Distinct junctions: {c.counters['distinct_junctions']} " in r.stdout
+
+
 @pytest.mark.parametrize("log_tai,nh", [(33, 3), (32, 2)])
 def test_config4_sized_filters_index_past_32_bits(log_tai, nh):
     """BASELINE config 4's filter shape (2^33 bits = 1 GiB per filter, 32 GiB of first-set times): bit positions, the
