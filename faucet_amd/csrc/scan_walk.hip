@@ -473,7 +473,7 @@ struct KoTables {
     uint32_t* bad;        // per root: the cluster holds a piece the key-ordered walk does not take (more than 128 windows)
 };
 constexpr uint32_t KO_EMPTY = 0xFFFFFFFFu;
-constexpr unsigned long long KO_WAIT_LIMIT_TICKS = 30ULL * 100000000ULL;   // 30 s at one turn counter: give up loudly (error bit 8), never hang
+constexpr unsigned long long KO_WAIT_LIMIT_TICKS = 60ULL * 100000000ULL;   // 60 s at one turn counter: give up loudly (error bit 8), never hang
 
 struct KoHold {   // a k-mer whose turn this piece holds: entry, rank of its first occurrence here, occurrences merged into the hold
     uint32_t e, r, n;
