@@ -1344,6 +1344,11 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     ko.cnt = cnt;
     unsigned long long walked = 0;
     if (kt.state[3] == 0) return;                                      // no large cluster in this window (the usual case)
+#ifdef FGPU_KO_ONE_XCD
+    // experiment: only the waves that landed on XCD 0 take tickets (the grid is eight times as large), so that every hand-over stays
+    // inside one XCD; the accesses keep their agent scope, only their latency is looked at
+    if ((__builtin_amdgcn_s_getreg(6164) & 15) != 0) return;           // hwreg(HW_REG_XCC_ID, 0, 4)
+#endif
     // KO_TICKET pieces per ticket (a multiple of 64): a same-address atomic per 64 pieces cost 0.2 ms per window
     for (;;) {
         uint32_t ticket = 0;
@@ -1928,6 +1933,11 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const unsigned walk_grid_w = fgpu_blocks(max_pieces, 64);
         const unsigned cluster_grid = std::min(256u, fgpu_blocks(max_pieces, 256));
         const unsigned piece_blocks_ko = fgpu_blocks(max_pieces, 256);
+#ifdef FGPU_KO_ONE_XCD
+        const unsigned ko_grid = 4096;
+#else
+        const unsigned ko_grid = 512;
+#endif
         uint32_t* const uf_parent = ctx->uf_parent + parity * (uint64_t)ctx->wmax;     // this window's set of the union-find / list arrays
         uint32_t* const cl_count = ctx->cl_count + parity * (uint64_t)ctx->wmax;
         uint32_t* const cl_offset = ctx->cl_offset + parity * (uint64_t)ctx->wmax;
@@ -2010,7 +2020,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
                     (const uint32_t*)kt.state, ko_heavy);
         if (ko_heavy)
-            FGPU_LAUNCH("walk_ko", k_walk_ko, 512, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
+            FGPU_LAUNCH("walk_ko", k_walk_ko, ko_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
                         seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket);
         if (heavy)
             FGPU_LAUNCH("walk_commit", k_walk_par<WALK_COMMIT>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
