@@ -421,33 +421,6 @@ struct PieceView {
     uint64_t cw0, cw1, cw2, cw3, cw4, cw5;   // 192 bases of 2-bit codes: a whole <= 160-base piece, k-mers come out of registers
 };
 
-struct WalkCtx {
-    Planes pl;
-    FdParams fp;
-    JTable jt;
-    DevCounters* cnt;
-    const uint32_t* bloom;   // bloo2, for the junction tests the preview did not order (walk_fill_flags)
-    // per-thread accumulators
-    unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
-    bool created_now;   // set by junction_get
-    struct KoState* ko; // WALK_KO: the piece's turn bookkeeping
-    int fail;           // WALK_PROBE: why this piece cannot be walked out of order (see k_walk_par): 1 would create, 2 would raise a distance, 3 untested positions
-    int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
-};
-
-// How a piece is walked.  WALK_SEQ: in its cluster's order by the cluster's one thread, reading and writing the junction table (the
-// reference's semantics as they stand).  WALK_PROBE / WALK_COMMIT: the two halves of the out-of-order walk of a large cluster, one thread
-// per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
-// COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
-enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3 };
-#ifdef FGPU_KO_TIMING
-#define KO_T0() const unsigned long long ko_t0__ = wall_clock64()
-#define KO_T1(cnt, i) atomicAdd(&(cnt)->ko_time[i], wall_clock64() - ko_t0__)
-#else
-#define KO_T0() do {} while (0)
-#define KO_T1(cnt, i) do {} while (0)
-#endif
-
 // ---- the key-ordered walk of large clusters (k_walk_ko) ------------------------------------------------------------------------------------
 // A cluster's pieces are walked in file order because of what they read and write in the junction map -- and they read and write it one
 // k-mer at a time.  Ordering the ACCESSES per k-mer instead of the pieces per cluster keeps every read and write where the sequential run
@@ -490,6 +463,33 @@ struct KoState {
     uint64_t lk0, lk1;      // the piece's lk positions
     uint64_t aF0, aF1, aB0, aB1;   // positions looked up and found absent (per facing): not events after all
 };
+
+struct WalkCtx {
+    Planes pl;
+    FdParams fp;
+    JTable jt;
+    DevCounters* cnt;
+    const uint32_t* bloom;   // bloo2, for the junction tests the preview did not order (walk_fill_flags)
+    // per-thread accumulators
+    unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
+    bool created_now;   // set by junction_get
+    KoState ko;         // WALK_KO: the piece's turn bookkeeping (by value: through a pointer it lived in scratch memory)
+    int fail;           // WALK_PROBE: why this piece cannot be walked out of order (see k_walk_par): 1 would create, 2 would raise a distance, 3 untested positions
+    int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
+};
+
+// How a piece is walked.  WALK_SEQ: in its cluster's order by the cluster's one thread, reading and writing the junction table (the
+// reference's semantics as they stand).  WALK_PROBE / WALK_COMMIT: the two halves of the out-of-order walk of a large cluster, one thread
+// per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
+// COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
+enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3 };
+#ifdef FGPU_KO_TIMING
+#define KO_T0() const unsigned long long ko_t0__ = wall_clock64()
+#define KO_T1(cnt, i) atomicAdd(&(cnt)->ko_time[i], wall_clock64() - ko_t0__)
+#else
+#define KO_T0() do {} while (0)
+#define KO_T1(cnt, i) do {} while (0)
+#endif
 
 
 __device__ __forceinline__ uint64_t chunk_mask(uint32_t nwin, uint32_t c) {
@@ -589,7 +589,7 @@ __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView&
 template <int MODE>
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
     if (MODE == WALK_KO) {   // what the map holds is asked when the k-mer's turn has come: until then every registered position may be in it
-        const KoState& ko = *wc.ko;
+        const KoState& ko = wc.ko;
         mF = c == 0 ? (ko.lk0 & ~ko.aF0) : c == 1 ? (ko.lk1 & ~ko.aF1) : 0ULL;
         mB = c == 0 ? (ko.lk0 & ~ko.aB0) : c == 1 ? (ko.lk1 & ~ko.aB1) : 0ULL;
         return;
@@ -866,7 +866,7 @@ __device__ __forceinline__ void ko_leave_cursor(KoState& ko, bool have_last) {
 }
 // account for the lk position q: take its turn; keep it (cursor) or pass it on
 __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_cursor, bool have_last) {
-    KoState& ko = *wc.ko;
+    KoState& ko = wc.ko;
     ko_leave_cursor(ko, have_last);
     KO_T0();
     const uint32_t node = ko.base + ko_ordinal(ko, q);
@@ -885,7 +885,7 @@ __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_curs
 }
 // every lk position below q_to has been passed
 __device__ __forceinline__ void ko_pass(WalkCtx& wc, uint32_t q_to, bool have_last) {
-    KoState& ko = *wc.ko;
+    KoState& ko = wc.ko;
     while (ko.done < q_to) {
         if (ko.done >= 128) { ko.done = q_to; break; }
         const uint64_t w = ko.done < 64 ? ko.lk0 >> ko.done : ko.lk1 >> (ko.done - 64);
@@ -902,7 +902,7 @@ __device__ __forceinline__ void ko_pass(WalkCtx& wc, uint32_t q_to, bool have_la
 }
 // the walk is about to look at (or stop at) position q
 __device__ __forceinline__ void ko_cursor(WalkCtx& wc, uint32_t q, bool have_last) {
-    KoState& ko = *wc.ko;
+    KoState& ko = wc.ko;
     if (q < ko.done) return;                       // second half-step of the same position: its k-mer is still held
     ko_pass(wc, q, have_last);
     if (ko_is_lk(ko, q)) ko_account(wc, q, true, have_last);
@@ -911,7 +911,7 @@ __device__ __forceinline__ void ko_cursor(WalkCtx& wc, uint32_t q, bool have_las
 }
 // the junction under the cursor has been visited and becomes the piece's last junction; the previous one's record has been stored
 __device__ __forceinline__ void ko_visited(WalkCtx& wc) {
-    KoState& ko = *wc.ko;
+    KoState& ko = wc.ko;
     if (ko.cur_in == 0) {
         if (ko.last.n) ko_give(ko, ko.last);
         ko.last = ko.cur;
@@ -926,7 +926,7 @@ __device__ __forceinline__ void ko_visited(WalkCtx& wc) {
 }
 // end of the piece (also after an error): everything is passed, every turn given back
 __device__ __forceinline__ void ko_finish(WalkCtx& wc, uint32_t nwin) {
-    KoState& ko = *wc.ko;
+    KoState& ko = wc.ko;
     ko_pass(wc, nwin < 128 ? nwin : 128, true);
     if (ko.cur.n) ko_give(ko, ko.cur);
     if (ko.last.n) ko_give(ko, ko.last);
@@ -1019,7 +1019,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 }
                 ko_slot = in_map ? slot : ~0ULL;
                 if (potential && !in_map) {                 // registered, but not in the map (yet): not an event; look again from here
-                    KoState& ko = *wc.ko;
+                    KoState& ko = wc.ko;
                     const uint64_t bm = 1ULL << (q & 63);
                     if (fwd) { if (q < 64) ko.aF0 |= bm; else ko.aF1 |= bm; }
                     else { if (q < 64) ko.aB0 |= bm; else ko.aB1 |= bm; }
@@ -1120,7 +1120,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         const int tm = 2 * m + 1;
         if (MODE == WALK_SEQ || MODE == WALK_KO) {
             if (MODE == WALK_KO) {   // the middle k-mer's turn was kept when the cursor passed it (ko.fake), or is taken now
-                ko_leave_cursor(*wc.ko, false);
+                ko_leave_cursor(wc.ko, false);
                 ko_pass(wc, (uint32_t)m + 1, false);
             }
             if (!junction_get<MODE>(wc, key, (piece_seq << STAMP_SHIFT) | STAMP_FAKE, p0 + (uint64_t)m, rec)) return;
@@ -1157,7 +1157,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.created_now = false; wc.fail = 0; wc.dbg = dbg; wc.ko = nullptr;
+    wc.created_now = false; wc.fail = 0; wc.dbg = dbg; 
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
     unsigned long long n_follow = 0, biggest = 0;
@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable 
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.created_now = false; wc.fail = 0; wc.dbg = 0; wc.ko = nullptr;
+    wc.created_now = false; wc.fail = 0; wc.dbg = 0; 
     const WinDesc wd = *wdp;
     unsigned long long walked = 0;
     if (i < wd.n) {
@@ -1336,10 +1336,10 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     const WinDesc wd = *wdp;
     if (kt.state[1] & 1u) return;                                      // a table overflowed: k_walk takes every cluster
     WalkCtx wc;
-    KoState ko;
+    KoState& ko = wc.ko;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-    wc.created_now = false; wc.fail = 0; wc.dbg = 0; wc.ko = &ko;
+    wc.created_now = false; wc.fail = 0; wc.dbg = 0;
     ko.kt = kt;
     ko.cnt = cnt;
     unsigned long long walked = 0;
