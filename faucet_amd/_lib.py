@@ -17,6 +17,7 @@ FLAG_EAGER_FLAGS = 2
 FLAG_NO_RESIDENT = 4
 FLAG_RECORD_STOPS = 8
 FLAG_MERCY = 16
+FLAG_KEY_ORDER_FROM_START = 32
 STOP_POS_MASK, STOP_FORWARD, STOP_FIRST, STOP_FAKE = 0x0FFFFFFF, 1 << 28, 1 << 29, 1 << 30
 TABLE_ENTRY_BYTES = 32
 

@@ -131,11 +131,12 @@ class Context:
     """One fgpu_ctx: one MI355X, one pair of load filters, one junction map."""
 
     def __init__(self, k, tai, n_hash, j=1, max_spacer_dist=100, device=0, profile=False, junction_capacity=0,
-                 max_batch_bases=0, stream=None, walk_window_span=0, eager_flags=False, keep_resident=True, record_stops=False, mercy=False):
+                 max_batch_bases=0, stream=None, walk_window_span=0, eager_flags=False, keep_resident=True, record_stops=False, mercy=False,
+                 key_order_from_start=False):
         self.lib = L.load()
         flags = ((L.FLAG_PROFILE if profile else 0) | (L.FLAG_EAGER_FLAGS if eager_flags else 0)
                  | (0 if keep_resident else L.FLAG_NO_RESIDENT) | (L.FLAG_RECORD_STOPS if record_stops else 0)
-                 | (L.FLAG_MERCY if mercy else 0))
+                 | (L.FLAG_MERCY if mercy else 0) | (L.FLAG_KEY_ORDER_FROM_START if key_order_from_start else 0))
         p = L.Params(k, j, max_spacer_dist, n_hash, tai, device, flags, junction_capacity,
                      max_batch_bases, stream, walk_window_span)
         h = C.c_void_p()

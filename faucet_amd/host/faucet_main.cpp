@@ -658,6 +658,7 @@ int main(int argc, char** argv) {
     const bool device_short_pairs = !o.no_cleaning;
     const bool want_lists = o.paired_ends;
     if (record_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
+    prm.flags |= FGPU_FLAG_KEY_ORDER_FROM_START;   // real genomes have repeats: a few launches per window against a first batch walked by cluster
     if (o.mercy) prm.flags |= FGPU_FLAG_MERCY;
     {
         std::thread pin;   // (joined before anything else can fail or read)
