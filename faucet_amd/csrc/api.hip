@@ -261,6 +261,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
         hipStreamDestroy(ctx->tstream);
     }
     for (int i = 0; i < 2; i++) if (ctx->ev_text_mark[i]) hipEventDestroy(ctx->ev_text_mark[i]);
+    for (int i = 0; i < 2; i++) if (ctx->ev_stage_free[i]) hipEventDestroy(ctx->ev_stage_free[i]);
     if (ctx->ev_text_done) hipEventDestroy(ctx->ev_text_done);
     if (ctx->wstream) hipStreamSynchronize(ctx->wstream);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
@@ -359,8 +360,7 @@ int fgpu_load_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if ((rc = fgpu_stage_load(ctx))) return rc;
     if (ctx->cur->T) ctx->pass_batches++;
     ctx->load_stats.reads_processed += reads->n_reads;
-    if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));   // caller may reuse its host buffers
-    return FGPU_OK;
+    return fgpu_host_batch_done(ctx, reads);   // (the host buffers were free again when the copy had run: fgpu_stage_pack)
 }
 
 int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
@@ -371,8 +371,7 @@ int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     if ((rc = fgpu_stage_pack(ctx, reads))) return rc;
     if ((rc = fgpu_stage_presence(ctx))) return rc;
-    if (!reads->on_device) FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    return FGPU_OK;
+    return fgpu_host_batch_done(ctx, reads);
 }
 
 int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
@@ -589,6 +588,7 @@ static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) 
     if (!rc) rc = check_errors(ctx);
     if (!rc) ctx->scan_stats.reads_processed += reads->n_reads;
     if (!rc && b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
+    if (!rc) rc = fgpu_host_batch_done(ctx, reads);
     return rc;
 }
 

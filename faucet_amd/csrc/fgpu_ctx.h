@@ -33,7 +33,6 @@ struct DevBuf {
 
 // Everything one batch of reads turns into on the device ("data layout in HBM").
 struct BatchBufs {
-    DevBuf in_bases, in_offsets;   // staging when the caller hands over host pointers
     DevBuf codes, bad;             // normalized stream: 2-bit codes, bad-position mask
     DevBuf readflag;               // 1 byte per read: has interior non-ACGT characters
     DevBuf pending;                // pass 1: occurrences that need the first-set-time test
@@ -273,6 +272,11 @@ struct fgpu_ctx {
     hipStream_t tstream = nullptr;
     hipEvent_t ev_text_mark[2] = {nullptr, nullptr};   // main stream, at the beginning of each call
     hipEvent_t ev_text_done = nullptr;                 // text stream, at the end of each call (the main stream waits for it)
+    DevBuf host_stage[4];                              // host batches: {bases, offsets} x 2 staging sets (pack.hip)
+    hipEvent_t ev_stage_free[2] = {nullptr, nullptr};   // main stream: the call that used the set has been queued completely
+    bool host_stage_used[2] = {false, false};
+    uint64_t host_turn = 0;
+    int host_set = -1;                                 // set of the batch being packed by the current call
     const uint64_t* split_offsets = nullptr;           // the batch the last call returned: its offsets, read count and number of bases
     uint64_t split_n = 0, split_total = 0;
     std::vector<DevBuf*> owned;
@@ -331,6 +335,7 @@ void fgpu_touch_text();
 void fgpu_touch_scan_pure();
 void fgpu_touch_scan_walk();
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads);
+int fgpu_host_batch_done(fgpu_ctx* ctx, const fgpu_reads* reads);
 int fgpu_stage_load(fgpu_ctx* ctx);
 int fgpu_load_sweep(fgpu_ctx* ctx);
 int fgpu_stage_fixup(fgpu_ctx* ctx, const uint32_t* prefix);

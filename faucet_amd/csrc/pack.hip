@@ -220,6 +220,16 @@ void fgpu_touch_pack() {
     (void)hipFuncGetAttributes(&attr, (const void*)k_pack_fix);
 }
 
+// end of an API call that packed a host batch: everything that reads its staging set has been queued on the main stream
+int fgpu_host_batch_done(fgpu_ctx* ctx, const fgpu_reads* reads) {
+    if (reads->on_device || ctx->host_set < 0) return FGPU_OK;
+    if (!ctx->ev_stage_free[ctx->host_set]) FGPU_HIP(hipEventCreateWithFlags(&ctx->ev_stage_free[ctx->host_set], hipEventDisableTiming));
+    FGPU_HIP(hipEventRecord(ctx->ev_stage_free[ctx->host_set], ctx->stream));
+    ctx->host_stage_used[ctx->host_set] = true;
+    ctx->host_set = -1;
+    return FGPU_OK;
+}
+
 int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     BatchBufs& bb = *ctx->cur;
     const uint64_t n = reads->n_reads;
@@ -243,16 +253,33 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
         d_offs = reads->offsets;
     } else {
         total = reads->offsets[n] - reads->offsets[0];
-        int rc = fgpu_ensure(ctx, &bb.in_bases, total + 16);
+        // Host buffers go through one of two staging sets on the text stream: the copy of this batch runs beside the kernels of the batch
+        // before it, and the host waits for the copy only (so the caller may reuse its buffers) -- on the main stream the device idled
+        // during every copy and the host waited for every batch.  A set is written again only after the call that used it has run
+        // (ev_stage_free, recorded by fgpu_host_batch_done at the end of that call).
+        int rc = fgpu_text_streams(ctx);
         if (rc) return rc;
-        rc = fgpu_ensure(ctx, &bb.in_offsets, (n + 1) * 8);
-        if (rc) return rc;
+        if (ctx->host_set >= 0) {   // the call that packed the previous host batch failed half-way: nothing is known about its set
+            FGPU_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->host_stage_used[0] = ctx->host_stage_used[1] = false;
+            ctx->host_set = -1;
+        }
+        const int b = (int)(ctx->host_turn++ & 1);
+        ctx->host_set = b;
+        DevBuf& sb = ctx->host_stage[2 * b];
+        DevBuf& so = ctx->host_stage[2 * b + 1];
+        if ((rc = fgpu_ensure(ctx, &sb, total + 16))) return rc;
+        if ((rc = fgpu_ensure(ctx, &so, (n + 1) * 8))) return rc;
+        if (ctx->host_stage_used[b]) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_stage_free[b], 0));
         // bases are copied from offsets[0] on, so the device copy is addressed with the same offsets
         // shifted by offsets[0]: keep the original offsets and bias the base pointer instead.
-        FGPU_HIP(hipMemcpyAsync(bb.in_bases.p, reads->bases + reads->offsets[0], total, hipMemcpyHostToDevice, ctx->stream));
-        FGPU_HIP(hipMemcpyAsync(bb.in_offsets.p, reads->offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        d_bases = (const unsigned char*)bb.in_bases.p - reads->offsets[0];
-        d_offs = (const uint64_t*)bb.in_offsets.p;
+        FGPU_HIP(hipMemcpyAsync(sb.p, reads->bases + reads->offsets[0], total, hipMemcpyHostToDevice, ctx->tstream));
+        FGPU_HIP(hipMemcpyAsync(so.p, reads->offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->tstream));
+        FGPU_HIP(hipEventRecord(ctx->ev_text_done, ctx->tstream));
+        FGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_text_done, 0));
+        FGPU_HIP(hipStreamSynchronize(ctx->tstream));
+        d_bases = (const unsigned char*)sb.p - reads->offsets[0];
+        d_offs = (const uint64_t*)so.p;
     }
     const uint64_t T = total + n;
     uint64_t maxb = ctx->prm.max_batch_bases;

@@ -237,12 +237,17 @@ def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "scripts", "two_rank_check.py"), str(per_rank)],
-                       capture_output=True, text=True, cwd=root, timeout=900)
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(root, "scripts", "two_rank_check.py"), str(per_rank)],
+                           capture_output=True, text=True, cwd=root, timeout=900)
+        if "RESULT" in r.stdout:          # the comparison was reached: its verdict stands, whatever it is
+            break
+        # the launcher did not get as far as the comparison (rendezvous: the port picked above was taken in between, a rank did not come up):
+        # that is the harness, not the product -- once more with another port
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "RESULT PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
