@@ -418,7 +418,6 @@ struct PieceView {
     uint64_t lk0, lk1;             // positions holding a registered candidate k-mer (where created keys can sit)
     uint64_t nd0, nd1;             // positions whose flags the pure stage evaluated (need plane)
     uint64_t cbase;                // stream position of the first base held in cw0 (multiple of 32)
-    uint64_t cw0, cw1, cw2, cw3, cw4, cw5;   // 192 bases of 2-bit codes: a whole <= 160-base piece, k-mers come out of registers
 };
 
 // ---- the key-ordered walk of large clusters (k_walk_ko) ------------------------------------------------------------------------------------
@@ -511,6 +510,15 @@ __device__ __forceinline__ uint64_t pv_word(const PieceView& v, uint64_t r0, uin
     return ((lo >> o) | ((hi << 1) << (63 - o))) & chunk_mask(v.nwin, c);
 }
 
+// The 192 bases of 2-bit codes around a piece (a whole <= 160-base piece) live in LDS, one column of six words per lane: a k-mer comes out
+// of two LDS reads at a computed row.  (As six register members picked by a chain of selects the compiler turned every pick into a 48-byte
+// array in SCRATCH memory -- three stores and an indexed load through the vector memory path per k-mer, on the path of every junction visit.)
+// The walk kernels run blocks of one wave.
+__device__ __forceinline__ uint64_t* pv_codes() {
+    __shared__ uint64_t s_codes[6 * 64];
+    return s_codes + (threadIdx.x & 63);
+}
+
 __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t p0, uint32_t nwin) {
     v.p0 = p0;
     v.nwin = nwin;
@@ -530,11 +538,13 @@ __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t
     v.nd0 = fd_bits_at(pl.need, p0) & m0;   v.nd1 = fd_bits_at(pl.need, p1) & m1;
     v.cbase = p0 & ~31ULL;
     const uint64_t* cw = pl.codes + (v.cbase >> 5);   // padded: reading 6 words from any piece start stays inside the buffer
-    v.cw0 = cw[0]; v.cw1 = cw[1]; v.cw2 = cw[2]; v.cw3 = cw[3]; v.cw4 = cw[4]; v.cw5 = cw[5];
+    uint64_t* l = pv_codes();
+    l[0 * 64] = cw[0]; l[1 * 64] = cw[1]; l[2 * 64] = cw[2]; l[3 * 64] = cw[3]; l[4 * 64] = cw[4]; l[5 * 64] = cw[5];
 }
 
 __device__ __forceinline__ uint64_t pv_cw(const PieceView& v, uint32_t w) {
-    return w == 0 ? v.cw0 : w == 1 ? v.cw1 : w == 2 ? v.cw2 : w == 3 ? v.cw3 : w == 4 ? v.cw4 : v.cw5;
+    (void)v;
+    return pv_codes()[w * 64];
 }
 // k-mer / base at stream position p: from the register copy when it covers p, else from memory
 __device__ __forceinline__ uint64_t pv_kmer(const PieceView& v, const uint64_t* codes, uint64_t p, int k) {
