@@ -1747,6 +1747,8 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     // the key-ordered walk's tables (KoTables): 2^20 k-mers and 2^22 occurrences of large clusters per window, else the window is walked by cluster
     if (const char* e = getenv("FGPU_WALK_KO")) ctx->walk_ko = (uint32_t)std::max(0, atoi(e));
     ctx->walk_ko_always = getenv("FGPU_WALK_KO_ALWAYS") != nullptr || (ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) != 0;
+    // a caller that expects repeats also gets the lower bar: with small batches a window holds only a few dozen pieces of a repeat's cluster
+    if ((ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) && !getenv("FGPU_WALK_KO")) ctx->walk_ko = 32;
     ctx->ko_hk_cap = 1u << 20;
     ctx->ko_occ_cap = 1u << 22;
     FGPU_HIP(hipMalloc(&ctx->ko_hk, (size_t)ctx->ko_hk_cap * 4 * 3));

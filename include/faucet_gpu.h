@@ -66,8 +66,9 @@ typedef struct {
 #define FGPU_FLAG_RECORD_STOPS 8 /* keep scanInputRead's return value for every read (fgpu_scan_take_stops) */
 #define FGPU_FLAG_NO_RESIDENT 4 /* do not keep the load batches in HBM for the scan pass (see fgpu_load_batch) */
 #define FGPU_FLAG_KEY_ORDER_FROM_START 32 /* large clusters are walked in the order of their junction k-mers' turns from a scan's first window on,
-                                 * not only once the scan has shown such a cluster: four small launches more per
-                                 * window, nothing else; same results.  For callers that expect repeats at high coverage. */
+                                 * not only once the scan has shown such a cluster, and "large" means 32 pieces instead of 64 (DESIGN.md
+                                 * section 4): four small launches more per window; same results.  For callers that expect repeats at
+                                 * high coverage. */
 #define FGPU_FLAG_EAGER_FLAGS 2 /* evaluate testForJunction at every position instead of only where the walk can stop
                                  * skipping (same results; the lazy default checks itself and repairs what it finds, see fgpu_scan_set_eager) */
 
