@@ -154,6 +154,10 @@ def test_key_ordered_walk_of_clusters_gives_the_same_result(name, monkeypatch):
     r = synth.make_reads(genome, 3000, 120, 0.004, 54)
     bases, offs = po.reads_from_matrix(r)
     assert _check_against_oracle(bases, offs, 21, 500_000, 100_000, 1, scan_chunks=3)["walk_parallel"] > 1000
+    # and as a caller asks for it (what the CLI does): the flag instead of the environment, clusters of 32 pieces and more
+    monkeypatch.delenv("FGPU_WALK_KO")
+    monkeypatch.delenv("FGPU_WALK_KO_ALWAYS")
+    assert _check_against_oracle(bases, offs, 21, 500_000, 100_000, 1, scan_chunks=3, key_order_from_start=True)["walk_parallel"] > 100
 
 
 @pytest.mark.parametrize("name", CASES)
