@@ -21,6 +21,7 @@ from faucet_amd import api, sharded  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: do not let gloo look the host name up to find an interface (it may not resolve)
 dist.init_process_group("gloo")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)

@@ -237,13 +237,19 @@ def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo")      # one node: gloo must not look the host name up to find an interface
+    r = None
     for attempt in range(2):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-                            "--master-port", str(port), os.path.join(root, "scripts", "two_rank_check.py"), str(per_rank)],
-                           capture_output=True, text=True, cwd=root, timeout=900)
+        try:
+            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                                "--master-port", str(port), os.path.join(root, "scripts", "two_rank_check.py"), str(per_rank)],
+                               capture_output=True, text=True, cwd=root, timeout=240, env=env)
+        except subprocess.TimeoutExpired as e:           # (a run takes ten seconds) the rendezvous never came up
+            r = subprocess.CompletedProcess(e.cmd, 124, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""),
+                                            "timed out after 240 s")
         if "RESULT" in r.stdout:          # the comparison was reached: its verdict stands, whatever it is
             break
         # the launcher did not get as far as the comparison (rendezvous: the port picked above was taken in between, a rank did not come up):

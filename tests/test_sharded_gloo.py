@@ -153,6 +153,7 @@ def _worker(rank, world, port, name, out_dir, protocol):
     os.environ["FAUCET_SHARD_PROTOCOL"] = protocol
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: no host-name look-up for the interface
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = Case(name)
     bases, offs = po.reads_from_lines(c.lines())
@@ -208,6 +209,7 @@ class _CpuOr:
 def _exchange_worker(rank, world, port, nbytes, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: no host-name look-up for the interface
     dist.init_process_group("gloo", rank=rank, world_size=world)
     maps = [np.random.default_rng(100 + r).integers(0, 256, size=nbytes, dtype=np.uint8) & np.random.default_rng(200 + r).integers(0, 256, size=nbytes, dtype=np.uint8)
             for r in range(world)]
