@@ -125,6 +125,7 @@ def or_allreduce(backend, bitmap, rank: int, world: int):
     # reduce-scatter: slice q of this rank's bitmap goes to rank q; slice `rank` of everybody else's comes here
     _exchange([(bitmap[sl[q][0]:sl[q][1]], q) for q in others if sl[q][1] > sl[q][0]],
               [(stage[i * mine:(i + 1) * mine], q) for i, q in enumerate(others)] if mine else [])
+    backend.fence()      # what has just landed in `stage` (a copy torch queued) is read by the library's OR kernel next
     for i in range(len(others) if mine else 0):
         backend.or_tensor(bitmap[lo:hi], stage[i * mine:(i + 1) * mine])
     backend.fence()
@@ -195,6 +196,7 @@ def load_sharded_presence(backend, batches, rank: int, world: int):
     prefix = backend.scratch(b1.numel(), tag="prefix")
     exclusive_prefix_or(backend, b1, prefix, rank, world)
     b1.copy_(prefix)
+    backend.fence()      # the carried-in filter is in place before the library's load kernels read it
     stats = backend.load(batches, keep_carry=True)
     or_allreduce(backend, backend.bloom_tensor(L.BLOO2), rank, world)
     backend.fence()
