@@ -96,11 +96,16 @@ static int gpu_scan_pass(const std::string& read_scan_file, bool fastq, fgpu_sca
     return rc != FGPU_OK ? rc : end_rc;
 }
 
-// replaces buildJunctionMapFromReads() (src/Faucet.cpp:240-246) for the --no_cleaning / single-end flow
-void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq) {
+// replaces buildJunctionMapFromReads() (src/Faucet.cpp:240-246) for single-end input.  With cleaning on (short_pair_filter != NULL, the
+// Bloom made at src/Faucet.cpp:266-283) scan_forward's addPair calls (src/ReadScanner.cpp:208-225) happen on the device and the filter's
+// bytes come back at the end; g_ctx must then have been created with FGPU_FLAG_RECORD_STOPS.  (Paired ends: the long pair filter is
+// check-then-insert in file order and stays host code fed by fgpu_scan_take_stops, as faucet_amd/host/faucet_main.cpp does it.)
+void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, Bloom* short_pair_filter = NULL) {
     fgpu_scan_stats st;
+    if (short_pair_filter) GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 0));
     const int rc = gpu_scan_pass(read_scan_file, fastq, &st);
     if (rc != FGPU_OK) gpu_die("junction scan", rc);
+    if (short_pair_filter) GPU_CHECK(fgpu_scan_short_pairs_download(g_ctx, short_pair_filter->blooma, short_pair_filter->tai / 8));
 
     uint64_t n = 0;
     GPU_CHECK(fgpu_scan_junction_count(g_ctx, &n));
