@@ -44,9 +44,11 @@ public:
     }
 
 private:
-    static constexpr uint32_t kNil = 0xFFFFFFFFu;    // no node
-    static constexpr uint32_t kHead = 0xFFFFFFFEu;   // the list's before-begin sentinel in the role of a bucket's "before" node
-    DumpOrder(const uint64_t* keys, size_t n) : keys_(keys), next_(n, kNil), bucket_(1, kNil) {}
+    enum : uint32_t {              // (enumerators, not static members: C++11 wants a definition for a static member that is bound to a reference)
+        kNil = 0xFFFFFFFFu,        // no node
+        kHead = 0xFFFFFFFEu        // the list's before-begin sentinel in the role of a bucket's "before" node
+    };
+    DumpOrder(const uint64_t* keys, size_t n) : keys_(keys), next_(n, (uint32_t)kNil), bucket_(1, (uint32_t)kNil) {}
     uint32_t& link_of(uint32_t before) { return before == kHead ? head_ : next_[before]; }
     void insert(uint32_t i) {
         const std::pair<bool, size_t> grow = policy_._M_need_rehash(bucket_.size(), count_, 1);
@@ -65,7 +67,7 @@ private:
         count_++;
     }
     void rehash(size_t n_buckets) {
-        std::vector<uint32_t> fresh(n_buckets, kNil);
+        std::vector<uint32_t> fresh(n_buckets, (uint32_t)kNil);
         uint32_t p = head_;
         head_ = kNil;
         size_t first_bucket = 0;

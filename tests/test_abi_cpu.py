@@ -119,8 +119,10 @@ def test_replayed_dump_order_equals_the_containers(tmp_path):
         pytest.skip("no g++")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "junction_order_check")
-    r = subprocess.run(["g++", "-O2", "-std=c++11", "-I", os.path.join(root, "faucet_amd", "host"),
-                        os.path.join(root, "tests", "host", "junction_order_check.cpp"), "-o", exe], capture_output=True, text=True)
+    # (-O1 with the address and undefined-behaviour sanitizers: host code only, no GPU involved)
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I",
+                        os.path.join(root, "faucet_amd", "host"), os.path.join(root, "tests", "host", "junction_order_check.cpp"), "-o", exe],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
