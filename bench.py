@@ -603,6 +603,28 @@ def main():
         dt = (time.perf_counter() - t0) / n_h
         res["host_input"] = {"value": kmers_local / dt, "unit": "k-mers/s", "ms_per_step": 1e3 * dt, "steps": n_h,
                              "note": "reads handed over as pageable host buffers: both passes copy them to the device inside the timed region"}
+    # ---- Stage 3's walks on the step's own result: JunctionMap::findNeighbor from every junction along every covered
+    # extension, whole walks on the device, host to host.  Beside `value`, never part of it.
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+        try:
+            starts, idx = [], []
+            for i in range(5):
+                m = (recs["dist"][:, i] > 0) & ((recs["cov"][:, i] > 0) if i < 4 else True)
+                starts.append(np.asarray(keys)[m])
+                idx.append(np.full(int(m.sum()), i, dtype=np.int8))
+            starts, idx = np.concatenate(starts), np.concatenate(idx)
+            t0 = time.perf_counter()
+            ctx.stage3_set_junctions(np.asarray(keys), np.asarray(recs))
+            t1 = time.perf_counter()
+            nb, probes = ctx.stage3_find_neighbors(starts, idx, L_)
+            t2 = time.perf_counter()
+            res["stage3_find_neighbors"] = {"walks": int(len(starts)), "probes": int(probes), "seconds": t2 - t1, "set_map_seconds": t1 - t0,
+                                            "value": probes / (t2 - t1), "unit": "getValidJExtension/s",
+                                            "reached_a_junction": int((nb["node"] == 1).sum()), "asserts_tripped": int((nb["abort"] == 1).sum()),
+                                            "note": "JunctionMap::findNeighbor for every (junction, covered extension) of the step's junction map in one "
+                                                    "call, host arrays in, host arrays out"}
+        except Exception as e:   # noqa: BLE001
+            res["stage3_find_neighbors"] = {"error": repr(e)[:300]}
     # ---- file to files ("from the first byte of input consumed"): the `faucet` command line on the same reads as a FASTA file,
     # both passes reading it, `.bloom` and `.junctions` written.  Wall time of the whole process -- runtime start-up, context, output files
     # included -- beside `value`, never as `value`; the junction count must be the step's.

@@ -23,6 +23,8 @@ def test_committed_bench_line_has_the_contract_keys():
     assert 0 < d["host_input"]["value"] < d["value"] and c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"]
     f = d["cli_file_to_files"]      # the command line on the same reads as a file: slower than the resident step, same junctions
     assert 0 < f["value"] < d["host_input"]["value"] and f["junctions_equal_the_steps"] and f["input_bytes"] > 10 ** 9
+    s3 = d["stage3_find_neighbors"]   # findNeighbor from every junction of the step's own map, whole walks on the device
+    assert s3["walks"] > d["outputs"]["junctions"] and s3["probes"] > s3["walks"] and s3["asserts_tripped"] == 0 and s3["value"] > 1e8
     assert r["frac_bloo1_accesses_only"] < r["frac"] and "attribution" in r
     # value is consistent with the step time it was derived from
     assert abs(d["value"] - d["kmers_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
