@@ -447,6 +447,16 @@ struct KoTables {
 constexpr uint32_t KO_EMPTY = 0xFFFFFFFFu;
 constexpr unsigned long long KO_WAIT_LIMIT_TICKS = 60ULL * 100000000ULL;   // 60 s at one turn counter: give up loudly (error bit 8), never hang
 
+// A piece's lk positions and the positions looked up and found absent (per facing: not events after all), 64 windows per word, in LDS: the
+// one walking lane of the block indexes them by chunk at run time (registers picked by an index end up in scratch memory, see pv_codes).
+constexpr uint32_t KO_CHUNKS = 8;              // pieces of up to 512 windows; longer ones keep their cluster with k_walk
+__device__ __forceinline__ uint64_t* ko_masks() {
+    __shared__ uint64_t s_ko[3 * KO_CHUNKS];
+    return s_ko;
+}
+__device__ __forceinline__ uint64_t& ko_lk(uint32_t c) { return ko_masks()[c]; }
+__device__ __forceinline__ uint64_t& ko_absent(bool fwd, uint32_t c) { return ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]; }
+
 struct KoHold {   // a k-mer whose turn this piece holds: entry, rank of its first occurrence here, occurrences merged into the hold
     uint32_t e, r, n;
 };
@@ -459,8 +469,6 @@ struct KoState {
     KoHold last, cur, fake; // held: the last junction's k-mer (until its record is stored), the position under the cursor, the fake candidate
     uint32_t cur_q;         // the position under the cursor
     int cur_in;             // which hold carries the cursor's k-mer: 0 cur, 1 last, 2 fake (the same k-mer twice on one piece shares a hold)
-    uint64_t lk0, lk1;      // the piece's lk positions
-    uint64_t aF0, aF1, aB0, aB1;   // positions looked up and found absent (per facing): not events after all
 };
 
 struct WalkCtx {
@@ -599,9 +607,8 @@ __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView&
 template <int MODE>
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
     if (MODE == WALK_KO) {   // what the map holds is asked when the k-mer's turn has come: until then every registered position may be in it
-        const KoState& ko = wc.ko;
-        mF = c == 0 ? (ko.lk0 & ~ko.aF0) : c == 1 ? (ko.lk1 & ~ko.aF1) : 0ULL;
-        mB = c == 0 ? (ko.lk0 & ~ko.aB0) : c == 1 ? (ko.lk1 & ~ko.aB1) : 0ULL;
+        mF = c < KO_CHUNKS ? (ko_lk(c) & ~ko_absent(true, c)) : 0ULL;
+        mB = c < KO_CHUNKS ? (ko_lk(c) & ~ko_absent(false, c)) : 0ULL;
         return;
     }
     mF = pv_word(v, v.inF0, v.inF1, wc.pl.inF, c);
@@ -827,11 +834,13 @@ __device__ __forceinline__ void rec_link_atomic(const RecRegs& seen, int idx) {
 
 
 // ---- turn taking of the key-ordered walk (see KoTables) ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ko_ordinal(const KoState& ko, uint32_t q) {   // lk positions of the piece below q (q < 128)
-    if (q < 64) return (uint32_t)__popcll(ko.lk0 & ((1ULL << q) - 1));
-    return (uint32_t)__popcll(ko.lk0) + (uint32_t)__popcll(ko.lk1 & ((1ULL << (q - 64)) - 1));
+__device__ __forceinline__ uint32_t ko_ordinal(const KoState& ko, uint32_t q) {   // lk positions of the piece below q
+    (void)ko;
+    uint32_t n = 0;
+    for (uint32_t c = 0; c < (q >> 6); c++) n += (uint32_t)__popcll(ko_lk(c));
+    return n + (uint32_t)__popcll(ko_lk(q >> 6) & ((1ULL << (q & 63)) - 1));
 }
-__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { return ((q < 64 ? ko.lk0 >> q : ko.lk1 >> (q - 64)) & 1ULL) != 0; }
+__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { (void)ko; return ((ko_lk(q >> 6) >> (q & 63)) & 1ULL) != 0; }
 __device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounters* cnt) {
     unsigned spins = 0;
     unsigned long long t0 = 0;
@@ -897,10 +906,10 @@ __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_curs
 __device__ __forceinline__ void ko_pass(WalkCtx& wc, uint32_t q_to, bool have_last) {
     KoState& ko = wc.ko;
     while (ko.done < q_to) {
-        if (ko.done >= 128) { ko.done = q_to; break; }
-        const uint64_t w = ko.done < 64 ? ko.lk0 >> ko.done : ko.lk1 >> (ko.done - 64);
+        if (ko.done >= 64 * KO_CHUNKS) { ko.done = q_to; break; }
+        const uint64_t w = ko_lk(ko.done >> 6) >> (ko.done & 63);
         if (!w) {                                   // no lk position in the rest of this word
-            const uint32_t next = ko.done < 64 ? 64u : 128u;
+            const uint32_t next = ((ko.done >> 6) + 1) * 64;
             ko.done = next < q_to ? next : q_to;
             continue;
         }
@@ -937,7 +946,7 @@ __device__ __forceinline__ void ko_visited(WalkCtx& wc) {
 // end of the piece (also after an error): everything is passed, every turn given back
 __device__ __forceinline__ void ko_finish(WalkCtx& wc, uint32_t nwin) {
     KoState& ko = wc.ko;
-    ko_pass(wc, nwin < 128 ? nwin : 128, true);
+    ko_pass(wc, nwin < 64 * KO_CHUNKS ? nwin : 64 * KO_CHUNKS, true);
     if (ko.cur.n) ko_give(ko, ko.cur);
     if (ko.last.n) ko_give(ko, ko.last);
     if (ko.fake.n) ko_give(ko, ko.fake);
@@ -1029,10 +1038,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 }
                 ko_slot = in_map ? slot : ~0ULL;
                 if (potential && !in_map) {                 // registered, but not in the map (yet): not an event; look again from here
-                    KoState& ko = wc.ko;
-                    const uint64_t bm = 1ULL << (q & 63);
-                    if (fwd) { if (q < 64) ko.aF0 |= bm; else ko.aF1 |= bm; }
-                    else { if (q < 64) ko.aB0 |= bm; else ko.aB1 |= bm; }
+                    ko_absent(fwd, q >> 6) |= 1ULL << (q & 63);
                     continue;
                 }
             }
@@ -1297,17 +1303,17 @@ __global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* _
     kt.state[4 + parity] = 1u;                                        // the tables are in use: the next window resets them
     atomicAdd(&kt.state[3], 1u);
     const uint2 pc = pl.pieces[wd.first_piece + i];
-    if (pc.y > 128) { kt.bad[r] = 1u; return; }                       // the turn bookkeeping keeps a piece's positions in two words
-    const uint64_t lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0), lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
-    const uint32_t n = (uint32_t)__popcll(lk0) + (uint32_t)__popcll(lk1);
+    if (pc.y > 64 * KO_CHUNKS) { kt.bad[r] = 1u; return; }           // the turn bookkeeping keeps KO_CHUNKS words of positions per piece
+    uint32_t n = 0;
+    for (uint32_t c = 0; c < KO_CHUNKS && c * 64 < pc.y; c++) n += (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x + 64 * c) & chunk_mask(pc.y, c));
     const uint32_t base = atomicAdd(&kt.state[0], n);
     if (base + n > kt.occ_cap) { atomicOr(&kt.state[1], 1u); return; }
     kt.piece_base[i] = base;
     uint32_t node = base;
-    for (int half = 0; half < 2; half++) {
-        uint64_t w = half ? lk1 : lk0;
+    for (uint32_t c = 0; c < KO_CHUNKS && c * 64 < pc.y; c++) {
+        uint64_t w = fd_bits_at(pl.lk, pc.x + 64 * c) & chunk_mask(pc.y, c);
         while (w) {
-            const uint32_t q = (uint32_t)(64 * half) + (uint32_t)__builtin_ctzll(w);
+            const uint32_t q = 64 * c + (uint32_t)__builtin_ctzll(w);
             w &= w - 1;
             uint32_t h = pl.kh[pc.x + q];
             if (h == KO_EMPTY) h = KO_EMPTY - 1;
@@ -1391,9 +1397,11 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
                     ko.last.n = ko.cur.n = ko.fake.n = 0;
                     ko.cur_q = 0;
                     ko.cur_in = 0;
-                    ko.lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0);
-                    ko.lk1 = fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1);
-                    ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
+                    for (uint32_t c = 0; c < KO_CHUNKS; c++) {
+                        ko_lk(c) = c * 64 < pc.y ? fd_bits_at(pl.lk, pc.x + 64 * c) & chunk_mask(pc.y, c) : 0ULL;
+                        ko_absent(true, c) = 0;
+                        ko_absent(false, c) = 0;
+                    }
 #ifdef FGPU_KO_TIMING
                     const unsigned long long tp = wall_clock64();
 #endif

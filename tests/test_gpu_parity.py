@@ -154,6 +154,11 @@ def test_key_ordered_walk_of_clusters_gives_the_same_result(name, monkeypatch):
     r = synth.make_reads(genome, 3000, 120, 0.004, 54)
     bases, offs = po.reads_from_matrix(r)
     assert _check_against_oracle(bases, offs, 21, 500_000, 100_000, 1, scan_chunks=3)["walk_parallel"] > 1000
+    # reads of 300 bases: pieces of up to 270 windows (the turn bookkeeping holds 512), and of 2000 bases (their clusters stay with k_walk)
+    long_bases, long_offs = _random_case(4000, 300, 27, 30000, 0.01, 11, 0.001, 3)
+    assert _check_against_oracle(long_bases, long_offs, 27, 1_000_000, 200_000, 1)["walk_parallel"] > 1000
+    long_bases, long_offs = _random_case(300, 2000, 31, 20000, 0.004, 12, 0.0, 2)
+    _check_against_oracle(long_bases, long_offs, 31, 500_000, 100_000, 1)
     # and as a caller asks for it (what the CLI does): the flag instead of the environment, clusters of 32 pieces and more
     monkeypatch.delenv("FGPU_WALK_KO")
     monkeypatch.delenv("FGPU_WALK_KO_ALWAYS")
