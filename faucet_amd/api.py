@@ -144,7 +144,8 @@ class Context:
         self.h = h
         self.k, self.tai, self.n_hash, self.j = k, tai, n_hash, j
         self.mercy = bool(mercy)
-        self.on_torch_stream = False     # set by callers that create the context on torch's current stream (sharded.GpuShard)
+        self.stream = int(stream) if stream else None    # the caller's stream the library runs on (None: a stream of its own)
+        self.device = int(device)
 
     def close(self):
         if getattr(self, "h", None):

@@ -613,6 +613,9 @@ static int journal_add(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
         int rc = pull_counters(ctx);
         if (rc) return rc;
         BatchBufs* const cur = ctx->cur;
+        // the batch being packed has already been folded into the device's longest-read maximum (fgpu_stage_pack) and is not in the journal:
+        // the replay restores that maximum from journal_max_read_len, so it has to know this batch's reads too
+        ctx->journal_max_read_len = std::max<uint64_t>(ctx->journal_max_read_len, ctx->counters_host->max_read_len);
         if (ctx->lazy_failed && (rc = scan_replay(ctx))) return rc;
         ctx->cur = cur;
         ctx->journal_on = false;
@@ -669,7 +672,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->delta_next = 0;
     ctx->hint_in_table = false;
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
-                                                 : std::min<uint64_t>(1ULL << 18, ctx->max_span);
+                                                 : std::min<uint64_t>(std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4), ctx->max_span);
     ctx->calib_left = 16;
     ctx->calib_f = ctx->calib_p = 0;
     ctx->adapt_followers = ctx->adapt_pieces = 0;

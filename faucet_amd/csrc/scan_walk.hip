@@ -783,7 +783,8 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
         wc.created_now = true;
         atomicOr(&wc.pl.cr[pos >> 6], 1ULL << (pos & 63));   // later windows (and the next batch) register this key: their snapshot cannot know it
         out.lo = out.hi = 0;
-        wc.jt.stamps[slot * 2 + orient] = stamp;
+        if (MODE == WALK_KO) st_agent(&wc.jt.stamps[slot * 2 + orient], stamp);
+        else wc.jt.stamps[slot * 2 + orient] = stamp;
         atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
         // presence filter in front of the table (phase A of later windows tests it before probing)
         const uint64_t hb = jt_filter_bit(wc.jt, canon);
@@ -867,11 +868,14 @@ __device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounte
 __device__ __forceinline__ DevCounters* ko_cnt(const KoState& ko) { return ko.cnt; }
 // the k-mer's turn goes to its next occurrence; whatever this piece stored is visible before the counter moves
 __device__ __forceinline__ void ko_give(const KoState& ko, KoHold& h) {
-    // records are stored with agent-scope (write-through) stores and key words change by atomics: waiting for them to complete is the whole
-    // release -- an agent-scope release fence would also write the L2 back, which this hand-over does not need and pays for dearly
+    // records and stamps are stored with agent-scope (write-through, sc1) stores and key words / planes change by device-scope atomics, so the
+    // release is: wait until every one of them has been acknowledged (gfx950 counts stores and atomics in vmcnt), then move the counter.  A
+    // workgroup-scope fence alone emits NO wait on this target (the turn store followed the record stores with nothing in between: ADVICE r2);
+    // an agent-scope release fence would add a write-back of the whole L2 (buffer_wbl2), which nothing here needs: no plain store is shared.
     {
         KO_T0();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // compiler barrier: no store may sink below the counter's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(&ko.kt.hk_turn[h.e], h.r + h.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         KO_T1(ko_cnt(ko), 1);
     }

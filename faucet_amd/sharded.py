@@ -31,30 +31,74 @@ _STAT_NAMES = [n for n, _ in L.ScanStats._fields_]
 HEADER_WORDS = 1 + len(_STAT_NAMES)          # [entries in the table, carried scan counters...]
 
 
-# RCCL moves device tensors directly.  With the gloo backend (CPU tests; two ranks sharing one GPU when no multi-GPU box is
+# RCCL moves device tensors directly.  With the gloo backend (CPU tests; several ranks sharing one GPU when no multi-GPU box is
 # at hand) device tensors are staged through host memory: same protocol, same library calls, another transport.
 def _staged(t):
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
+class _Staging:
+    """The host hop of the gloo transport, ordered the way ProcessGroupNCCL orders a collective: a transport stream of its own that
+    waits (by event) for torch's CURRENT stream as of the call, and that the current stream waits for (by event) once data has landed.
+    Page-locked bounce buffers, non-blocking copies; the host waits for exactly one thing -- the copy whose bytes gloo is about to send.
+    Nothing here synchronises the device or the library's stream, so a library stream that is NOT the one the exchange is ordered with
+    shows up as wrong bits in the multi-process tests, as it would under RCCL (`t.cpu()` used to hide that)."""
+
+    def __init__(self):
+        self._streams = {}
+
+    def _stream(self, device):
+        st = self._streams.get(device)
+        if st is None:
+            st = self._streams[device] = torch.cuda.Stream(device)
+        return st
+
+    def out(self, t):
+        """device tensor -> page-locked host tensor, complete when this returns"""
+        cur, st = torch.cuda.current_stream(t.device), self._stream(t.device)
+        st.wait_stream(cur)
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        with torch.cuda.stream(st):
+            h.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        ev.synchronize()
+        return h
+
+    @staticmethod
+    def landing(t):
+        return torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+
+    def into(self, t, h):
+        """page-locked host tensor -> device tensor; later work on the current stream is ordered behind the copy, the host does not wait"""
+        cur, st = torch.cuda.current_stream(t.device), self._stream(t.device)
+        st.wait_stream(cur)                  # whatever still reads or writes `t` on the current stream comes first
+        with torch.cuda.stream(st):
+            t.copy_(h, non_blocking=True)
+        cur.wait_stream(st)
+
+
+_staging = _Staging()
+
+
 def _all_gather(out, t):
     if _staged(t):
-        h = torch.empty(out.numel(), dtype=out.dtype)
-        dist.all_gather_into_tensor(h, t.cpu())
-        out.copy_(h)
+        h = _staging.landing(out)
+        dist.all_gather_into_tensor(h, _staging.out(t))
+        _staging.into(out, h)
     else:
         dist.all_gather_into_tensor(out, t)
 
 
 def _send(t, dst):
-    dist.send(t.cpu() if _staged(t) else t, dst=dst)
+    dist.send(_staging.out(t) if _staged(t) else t, dst=dst)
 
 
 def _recv(t, src):
     if _staged(t):
-        h = torch.empty(t.shape, dtype=t.dtype)
+        h = _staging.landing(t)
         dist.recv(h, src=src)
-        t.copy_(h)
+        _staging.into(t, h)
     else:
         dist.recv(t, src=src)
 
@@ -97,10 +141,10 @@ def _exchange(sends, recvs):
         return
     ops, landing = [], []
     for t, dst in sends:
-        ops.append(dist.P2POp(dist.isend, t.cpu() if _staged(t) else t, dst))
+        ops.append(dist.P2POp(dist.isend, _staging.out(t) if _staged(t) else t, dst))
     for t, src in recvs:
         if _staged(t):
-            h = torch.empty(t.shape, dtype=t.dtype)
+            h = _staging.landing(t)
             landing.append((t, h))
             ops.append(dist.P2POp(dist.irecv, h, src))
         else:
@@ -108,7 +152,7 @@ def _exchange(sends, recvs):
     for w in dist.batch_isend_irecv(ops):
         w.wait()
     for t, h in landing:
-        t.copy_(h)
+        _staging.into(t, h)
 
 
 def or_allreduce(backend, bitmap, rank: int, world: int):
@@ -215,10 +259,10 @@ def _n_reads(b):
 
 def _bcast(t, src, rank):
     if _staged(t):
-        h = t.cpu() if rank == src else torch.empty(t.shape, dtype=t.dtype)
+        h = _staging.out(t) if rank == src else _staging.landing(t)
         dist.broadcast(h, src=src)
         if rank != src:
-            t.copy_(h)
+            _staging.into(t, h)
     else:
         dist.broadcast(t, src=src)
 
@@ -233,13 +277,13 @@ class _HintReceiver:
 
     def _post(self, t):
         if _staged(t):
-            h = torch.empty(t.shape, dtype=t.dtype)
+            h = _staging.landing(t)
             return dist.broadcast(h, src=0, async_op=True), h
         return dist.broadcast(t, src=0, async_op=True), None
 
     def _landed(self, t):
         if self.host is not None:
-            t.copy_(self.host)
+            _staging.into(t, self.host)
 
     def _advance(self):
         if self.stage == 0:
@@ -330,6 +374,115 @@ def scan_sharded(backend, batches, rank: int, world: int):
     return stats, rank == world - 1
 
 
+def _or_by_slices(backend, dst, src, world: int):
+    """dst |= src, one slice of the N-rank layout after the other with the backend's OR kernel: the reduction step of the exchanges above"""
+    for lo, hi in _slices(dst.numel(), world):
+        if hi > lo:
+            backend.or_tensor(dst[lo:hi], src[lo:hi])
+
+
+def run_in_turn(make_backend, shards, protocol: str = "presence", after_load=None, after_scan=None):
+    """The N-rank pipeline of this module executed by ONE process, one rank after the other -- for workloads whose N contexts do not fit one
+    device together (BASELINE config 4: 8 shards x 32 GiB of first-set times) and for boxes without N GPUs.  Every rank runs the very
+    backend calls it runs under load_sharded_* / scan_sharded, in a context of its own that is closed before the next one is made; what the
+    ranks exchange travels as device tensors of this process, and the two reductions are the same slice-wise ORs (`_slices`, the backend's
+    OR kernel).  Possible because every dependency of the protocol points from lower to higher ranks (the exclusive prefix-OR, the walk's
+    hand-over) except the final OR of bloo2, which every scan needs: all loads come first, then all scans.
+
+        make_backend()   -> a backend with GpuShard's methods (and close())
+        shards           -> the ranks' batch lists, in file order
+        protocol         -> "presence" | "fixup" (pass 1)
+        after_load(r, stats, bloo1, bloo2): bloo1 / bloo2 = the SEQUENTIAL run's filters after shard r (tensors; valid during the call)
+        after_scan(r, stats, backend):      backend.junctions() = the sequential run's map after shard r
+
+    Returns (load stats per rank, scan stats of the last rank, the last rank's backend, still open)."""
+    world = len(shards)
+    close = lambda b: getattr(b, "close", lambda: None)()     # noqa: E731
+    load_stats = []
+    running = acc2 = None            # OR of the lower ranks' bloo1 bits (= the exclusive prefix of the next rank) / of the ranks' bloo2 so far
+    if protocol == "presence":
+        pres = []
+        for r in range(world):
+            b = make_backend()
+            b.clear_filters()
+            for batch in shards[r]:
+                b.presence(batch)
+            b.fence()
+            pres.append(b.bloom_tensor(L.BLOO1).clone())
+            close(b)
+    for r in range(world):
+        b = make_backend()
+        b.clear_filters()
+        b1 = b.bloom_tensor(L.BLOO1)
+        if running is None:
+            running, acc2 = torch.zeros_like(b1), torch.zeros_like(b1)
+        if protocol == "presence":
+            b1.copy_(running)            # carried-in bloo1 of rank r = exclusive prefix-OR of the presence bitmaps
+            b.fence()
+            stats = b.load(shards[r], keep_carry=True)
+            b.fence()
+            _or_by_slices(b, running, pres[r], world)
+            pres[r] = None
+            seq1 = b.bloom_tensor(L.BLOO1)                       # carried-in bits + this shard's = the sequential bloo1 after shard r
+        elif protocol == "fixup":
+            stats = b.load(shards[r], keep_carry=False, shard_times=True)
+            b.fence()
+            if r > 0:
+                stats = b.load_fixup(running)
+                b.fence()
+            _or_by_slices(b, running, b.bloom_tensor(L.BLOO1), world)
+            seq1 = running
+        else:
+            raise ValueError(protocol)
+        _or_by_slices(b, acc2, b.bloom_tensor(L.BLOO2), world)
+        b.fence()
+        load_stats.append(stats)
+        if after_load:
+            after_load(r, stats, seq1, acc2)
+        close(b)
+    del running
+    hint = [None, 0]
+    table, n_table, stats = None, 0, None
+    last = None
+    for r in range(world):
+        b = make_backend()
+        b.clear_filters()
+        b.bloom_tensor(L.BLOO2).copy_(acc2)      # what the OR-allreduce leaves on every rank
+        b.fence()
+        b.scan_begin()
+        if r == 0:
+            total, done, marks = sum(_n_reads(x) for x in shards[0]), 0, []
+            for x in shards[0]:
+                done += _n_reads(x)
+                marks.append(done >= HINT_AFTER * total)
+            hint_index = marks.index(True) if True in marks else len(shards[0]) - 1
+
+            def show(i, b=b):
+                if hint[0] is None and i >= hint_index:
+                    n, buf = b.export_table(tag="table_hint_out")
+                    b.fence()
+                    hint[0], hint[1] = buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n
+
+            stats = b.scan_stream(shards[0], after_batch=show)
+            show(len(shards[0]))
+        else:
+            b.import_hint(hint[0], hint[1])
+            for batch in shards[r]:
+                b.scan_prepare(batch)
+            carried = {n: int(stats[n]) for n in _STAT_NAMES}
+            stats = b.walk_shard(shards[r], table, n_table, carried)
+        if after_scan:
+            after_scan(r, stats, b)
+        if r < world - 1:
+            n_table, buf = b.export_table()
+            b.fence()
+            table = buf[:max(n_table, 1) * L.TABLE_ENTRY_BYTES].clone()
+            close(b)
+        else:
+            last = b
+    return load_stats, stats, last
+
+
 class _DevView:
     """zero-copy torch view of device memory owned by libfaucet_gpu (through __cuda_array_interface__)"""
 
@@ -346,13 +499,27 @@ class GpuShard:
     def __init__(self, ctx, device, stream_ordered=None):
         self.ctx, self.device = ctx, device
         self._scratch = {}
-        self.stream_ordered = bool(getattr(ctx, "on_torch_stream", False)) if stream_ordered is None else stream_ordered
+        self._forced = stream_ordered          # tests may force the fenced path; None = look at the streams themselves
+
+    @property
+    def stream_ordered(self) -> bool:
+        """True iff the library's kernels and torch's copies / collectives are ordered by ONE stream: the context was created on a
+        caller's stream and that stream is torch's current stream on this device right now.  Derived from the handles at every use
+        (a hand-set attribute said nothing about the stream the collectives really run on)."""
+        if self._forced is not None:
+            return bool(self._forced)
+        s = getattr(self.ctx, "stream", None)
+        return s is not None and s == torch.cuda.current_stream(self.device).cuda_stream
 
     def fence(self):
         if self.stream_ordered:
             return
         self.ctx.synchronize()
         torch.cuda.synchronize(self.device)
+
+    def close(self):
+        self._scratch = {}
+        self.ctx.close()
 
     def scratch(self, nbytes, tag="gather"):
         t = self._scratch.get(tag)

@@ -89,20 +89,22 @@ def _comp_table(device):
     return comp
 
 
-def make_reads(genome: torch.Tensor, n_reads: int, read_len: int, err: float, seed: int, device, chunk: int = 1_000_000) -> torch.Tensor:
-    """(n_reads, read_len) uint8 ASCII"""
+def make_reads(genome: torch.Tensor, n_reads: int, read_len: int, err: float, seed: int, device, chunk: int = 1_000_000,
+               first_row: int = 0) -> torch.Tensor:
+    """(n_reads, read_len) uint8 ASCII: rows first_row .. first_row + n_reads of the read set (a row is a pure function of
+    (seed, row number), so a set can be made in slices — 200 M reads never have to exist in one place)"""
     G = genome.numel()
     comp = _comp_table(device)
     out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
     ar = torch.arange(read_len, dtype=torch.int64, device=device)
     for lo in range(0, n_reads, chunk):
         n = min(chunk, n_reads - lo)
-        rid = torch.arange(lo, lo + n, dtype=torch.int64, device=device)
+        rid = torch.arange(first_row + lo, first_row + lo + n, dtype=torch.int64, device=device)
         u = mix(seed, rid)
         starts = (u & _M63) % (G - read_len + 1)
         r = genome[starts[:, None] + ar[None, :]]
         if err > 0:
-            r = _substitute(r, seed + 1, lo, err, device)
+            r = _substitute(r, seed + 1, first_row + lo, err, device)
         rc = (_lsr(mix(seed + 2, rid), 63) == 1)
         r = torch.where(rc[:, None], comp[r.long()].flip(1), r)
         out[lo:lo + n] = r

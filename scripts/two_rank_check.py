@@ -23,6 +23,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: do not let gloo look the host name up to find an interface (it may not resolve)
 dist.init_process_group("gloo")
+dist.barrier()
+print(f"INIT OK rank {rank}", flush=True)      # from here on a stall is the product's, not the rendezvous' (tests/test_gpu_fullsize.py tells them apart)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 k, Lr = 31, 100
@@ -34,7 +36,6 @@ if os.environ.get("FAUCET_TORCH_STREAM", "0") == "1":      # the library on torc
     ts = torch.cuda.Stream(dev)
     torch.cuda.set_stream(ts)
     ctx = api.Context(k, tai, nh, device=0, stream=ts.cuda_stream)
-    ctx.on_torch_stream = True
 else:
     ctx = api.Context(k, tai, nh, device=0)
 shard = sharded.GpuShard(ctx, dev)

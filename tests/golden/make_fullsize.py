@@ -8,6 +8,7 @@ Run in the build container (hours of one CPU core in total; every case is indepe
     python tests/golden/make_fullsize.py config3        # 2.5 M pairs x 100 bp interleaved FASTQ, --paired_ends --fastq   reference binary, ~6 min
     python tests/golden/make_fullsize.py config5        # 50 M x 150 bp, 5 % errors, S/E = 0.5 -> 2 hashes   oracle, ~1.5 h
     python tests/golden/make_fullsize.py config2_cli    # config 2 as a FASTA file through the reference binary (.bloom / .junctions bytes)
+    python tests/golden/make_fullsize.py config4        # 200 M x 100 bp, E = 1e9 / S = 2e8, 2^33-bit filters; streamed in slices   oracle, hours
 
 The reads come from faucet_amd/synth_det.py (bit-identical on CPU and GPU); tests/test_gpu_fullsize.py regenerates them in HBM,
 runs the device path and compares digests.  Stored: parameters, digest of the reads themselves (so that a generator mismatch is
@@ -43,6 +44,11 @@ CASES = {
                     read_seed=3000, k=31, E=100_000_000, S=20_000_000),
 }
 CASES["config2_cli"] = dict(CASES["config2"])
+# BASELINE config 4 at its real size: 200 M x 100 bp of a 400 Mb genome, E = 1e9 / S = 2e8 -> 2^33-bit filters, 3 hashes.  Streamed: the
+# reads are made `slice` rows at a time and handed to the oracle cumulatively (its filters and junction map carry over between calls),
+# so 20 GB of reads never exist at once; checkpoint digests at every 1/8 of the reads = the shard boundaries of the 8-rank layout.
+CASES["config4"] = dict(genome=400_000_000, genome_seed=4, reads=200_000_000, read_len=100, err=0.01, read_seed=4000, k=31,
+                        E=1_000_000_000, S=200_000_000, slice=5_000_000, shards=8)
 
 
 def sha(a) -> str:
@@ -109,6 +115,66 @@ def oracle_case(name):
     merge(name, entry)
 
 
+def oracle_case_streamed(name, limit_reads=None):
+    """like oracle_case for a read set that is made and consumed in slices (config 4: 1.4e10 k-mers, hours of one core)"""
+    c = dict(CASES[name])
+    if limit_reads:                      # a cut-down rehearsal of the same procedure (not merged into the fixture file)
+        c["reads"] = limit_reads
+    g = sd.make_genome(c["genome"], c["genome_seed"], "cpu")
+    tai, nh, p1, bits = po.sizing_from_cli(c["E"], c["S"])
+    n, sl, shards = c["reads"], c["slice"], c["shards"]
+    bounds = sorted({(n * (r + 1)) // shards for r in range(shards)})
+    entry = {"params": c, "tai": tai, "n_hash": nh, "made_by": "oracle/liboracle.so (pinned on the reference, tests/test_oracle_vs_golden.py), reads streamed in slices"}
+
+    def slices():
+        lo = 0
+        while lo < n:
+            hi = min(n, lo + sl, min(b for b in bounds if b > lo))
+            yield lo, hi, sd.make_reads(g, hi - lo, c["read_len"], c["err"], c["read_seed"], "cpu", first_row=lo).numpy()
+            lo = hi
+
+    t0 = time.time()
+    b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
+    h = hashlib.sha256()
+    kmers = to2 = 0
+    ck = []
+    for lo, hi, reads in slices():
+        h.update(np.ascontiguousarray(reads).tobytes())
+        bases, offs = po.reads_from_matrix(reads)
+        lst = po.load_two_filters(b1, b2, bases, offs, c["k"])
+        kmers += int(lst.kmers)
+        to2 += int(lst.to_bloo2)
+        if hi in bounds:
+            ck.append({"reads": hi, "kmers": kmers, "to_bloo2": to2, "bloo1_sha256": sha(b1.bits()), "bloo2_sha256": sha(b2.bits())})
+            print("CHECKPOINT load", json.dumps(ck[-1]), flush=True)
+        print(f"{name}: load {hi} reads, {time.time() - t0:.0f} s", flush=True)
+    entry.update(reads_sha256=h.hexdigest(), kmers=kmers, to_bloo2=to2, bloo1_sha256=ck[-1]["bloo1_sha256"], bloo2_sha256=ck[-1]["bloo2_sha256"],
+                 load_checkpoints=ck, load_seconds=round(time.time() - t0))
+    del b1
+    t0 = time.time()
+    sc = po.Scanner(c["k"], 1, 100, b2)
+    ck = []
+    names = ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors", "unambiguous_reads", "reads_processed")
+    for lo, hi, reads in slices():
+        bases, offs = po.reads_from_matrix(reads)
+        sc.scan_reads(bases, offs)
+        if hi in bounds:
+            keys, recs = sc.junctions("creation")
+            st = sc.stats()
+            ck.append({"reads": hi, "keys_sha256": sha(keys), "recs_sha256": sha(recs), "counters": {k: int(st[k]) for k in names}})
+            print("CHECKPOINT scan", json.dumps(ck[-1]), flush=True)
+        print(f"{name}: scan {hi} reads, {time.time() - t0:.0f} s", flush=True)
+    keys, recs = sc.junctions("creation")
+    st = sc.stats()
+    entry.update(keys_sha256=sha(keys), recs_sha256=sha(recs), dist_sha256=sha(recs["dist"]), cov_sha256=sha(recs["cov"]),
+                 linked_sha256=sha(recs["linked"]), scan_seconds=round(time.time() - t0), scan_checkpoints=ck,
+                 counters={k: int(st[k]) for k in names})
+    if limit_reads:
+        print(json.dumps(entry)[:2000])
+    else:
+        merge(name, entry)
+
+
 def reference_cli_case(name):
     """the reads as a file through the compiled reference itself; stopped once the hot path's files are written (its contig-graph
     stage is not part of the path and needs minutes to hours on these sizes)"""
@@ -163,5 +229,7 @@ if __name__ == "__main__":
     for name in sys.argv[1:]:
         if name in ("config3", "config2_cli"):
             reference_cli_case(name)
+        elif name.startswith("config4"):                 # "config4" or the rehearsal "config4:<reads>"
+            oracle_case_streamed("config4", int(name.split(":")[1]) if ":" in name else None)
         else:
             oracle_case(name)

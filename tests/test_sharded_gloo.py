@@ -238,3 +238,45 @@ def test_bitmap_exchanges_by_slices(world, nbytes, tmp_path):
     send/recv), reduced locally, handed back / gathered -- including slice counts that do not divide the bitmap and ranks whose slice is empty"""
     mp.spawn(_exchange_worker, args=(world, _free_port(), nbytes, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok_{r}").read_text() == "1" for r in range(world))
+
+
+@pytest.mark.parametrize("protocol", ["presence", "fixup"])
+@pytest.mark.parametrize("name,world", [("c1_k21", 3), ("ragged_k31", 2), ("j2_spacer20_k15", 4)])
+def test_ranks_in_turn_in_one_process_match_the_sequential_run(name, world, protocol):
+    """sharded.run_in_turn (how tests/test_gpu_fullsize.py runs BASELINE config 4's eight shards on one GPU): after every rank the filters
+    and the junction map are the SEQUENTIAL run's after that shard -- checked here against the oracle run over the same prefix of the reads"""
+    c = Case(name)
+    bases, offs = po.reads_from_lines(c.lines())
+    n = len(offs) - 1
+    cuts = np.linspace(0, n, world + 1).astype(int)
+    shards = []
+    for r in range(world):
+        lo, hi = cuts[r], cuts[r + 1]
+        shards.append([(bases, offs[lo:(lo + hi) // 2 + 1].copy()), (bases, offs[(lo + hi) // 2:hi + 1].copy())])
+    tai, nh, _, _ = po.sizing_from_cli(c.E, c.S)
+    s1, s2 = po.Bloom(tai, nh), po.Bloom(tai, nh)                    # the sequential run, advanced shard by shard
+    seen = {"load": 0, "scan": 0}
+
+    def after_load(r, stats, bloo1, bloo2):
+        po.load_two_filters(s1, s2, bases, offs[cuts[r]:cuts[r + 1] + 1].copy(), c.k)
+        assert np.array_equal(bloo1.numpy(), s1.bits()) and np.array_equal(bloo2.numpy(), s2.bits()), f"filters after shard {r}"
+        seen["load"] += 1
+
+    seq = {}
+
+    def after_scan(r, stats, backend):
+        if "sc" not in seq:
+            seq["sc"] = po.Scanner(c.k, c.j, c.spacer, s2)           # s2 is final by now: all loads come before the first scan
+        seq["sc"].scan_reads(bases, offs[cuts[r]:cuts[r + 1] + 1].copy())
+        keys, recs = backend.junctions()
+        okeys, orecs = seq["sc"].junctions("creation")
+        assert np.array_equal(keys, okeys) and np.array_equal(recs, orecs), f"junction map after shard {r}"
+        ost = seq["sc"].stats()
+        for key in ("nb_processed", "nb_skipped", "nb_jcheck_kmer", "nb_no_juncs", "reads_no_errors", "reads_processed"):
+            assert stats[key] == ost[key], (r, key)
+        seen["scan"] += 1
+
+    lst, st, last = sharded.run_in_turn(lambda: OracleShard(c.k, tai, nh, c.j, c.spacer, protocol), shards, protocol, after_load, after_scan)
+    assert seen == {"load": world, "scan": world}
+    assert np.array_equal(s2.bits(), c.bloom())
+    assert sorted(po.junction_lines(*last.junctions(), c.k)) == sorted(c.junction_lines())
