@@ -195,6 +195,9 @@ struct fo_scanner {
     bool first_end = true;
     std::list<uint64_t> back1, back2;
     uint64_t bit_tests_valid = 0;   /* bit tests spent inside getValidReads (the rest of bloom->n_tests is junction probing) */
+    /* optional log, one entry per element of scanInputRead's list: ReadKmer::pos inside the valid piece | facing FORWARD << 28 | first
+     * element of its scan_forward call << 29 | add_fake_junction's element << 30 (the layout of fgpu_stop::info, include/faucet_gpu.h) */
+    std::vector<uint32_t>* visit_log = nullptr;
 
     Junction* find(uint64_t key) {
         auto it = map.find(key);
@@ -276,6 +279,7 @@ struct fo_scanner {
             Junction* junc = find(c.key());
             last_junc_pos = c.t();
             if (!junc) junc = create(c.key());
+            if (visit_log) visit_log->push_back(static_cast<uint32_t>(c.pos) | (c.forward_facing ? 1u << 28 : 0u) | (result.empty() ? 1u << 29 : 0u));
             result.push_back(c.real_ext());
 
             if (!c.forward_facing) {                                                 /* :147-157 */
@@ -310,6 +314,7 @@ struct fo_scanner {
 
         if (!have_last) {                                                            /* :195-200 */
             st.nb_no_juncs++;
+            if (visit_log) visit_log->push_back(static_cast<uint32_t>(len / 2 - k / 2) | (1u << 28) | (1u << 29) | (1u << 30));
             result.push_back(add_fake_junction(s, len));
         } else {                                                                     /* :202-206 */
             find(last_key)->update(last_k.ext_index(true), last_k.dist_to_end() - 2 * j);
@@ -688,6 +693,19 @@ void fo_scan_reads(fo_scanner* s, const char* bases, const uint64_t* offsets, ui
     for (uint64_t r = 0; r < n; r++)
         s->scan_record(bases + offsets[r], offsets[r + 1] - offsets[r], paired_ends != 0, no_cleaning != 0);
 }
+uint64_t fo_scan_input_read_ex(fo_scanner* s, const char* line, uint64_t len, int no_cleaning, uint64_t* ext_out, uint32_t* info_out, uint64_t cap) {
+    std::vector<uint32_t> log;
+    s->visit_log = &log;
+    std::list<uint64_t> r = s->scan_input_read(line, len, no_cleaning != 0);
+    s->visit_log = nullptr;
+    uint64_t n = 0;
+    for (uint64_t e : r) {
+        if (n < cap) { ext_out[n] = e; info_out[n] = log[n]; }
+        n++;
+    }
+    return n;
+}
+
 uint64_t fo_scan_input_read(fo_scanner* s, const char* line, uint64_t len, int no_cleaning, uint64_t* ext_out, uint64_t cap) {
     std::list<uint64_t> r = s->scan_input_read(line, len, no_cleaning != 0);
     uint64_t i = 0;

@@ -128,6 +128,10 @@ void fo_scan_reads(fo_scanner*, const char* bases, const uint64_t* offsets, uint
  * copies up to cap of them into ext_out. */
 uint64_t fo_scan_input_read(fo_scanner*, const char* line, uint64_t len, int no_cleaning,
                             uint64_t* ext_out, uint64_t cap);
+/* the same, with what the callers of that list need to know about every visit (the layout of fgpu_stop::info in include/faucet_gpu.h:
+ * ReadKmer::pos inside the valid piece, bit 28 facing FORWARD, bit 29 first element of its scan_forward call, bit 30 the fake junction's) */
+uint64_t fo_scan_input_read_ex(fo_scanner*, const char* line, uint64_t len, int no_cleaning,
+                               uint64_t* ext_out, uint32_t* info_out, uint64_t cap);
 void     fo_scan_get_stats(const fo_scanner*, fo_scan_stats*);
 /* Junction map contents.  order = 0: iteration order of the std::unordered_map (= dump order of
  * JunctionMap::writeToFile, JunctionMap.cpp:588-593); order = 1: creation order. */

@@ -1,0 +1,49 @@
+"""The reference's OWN contig-graph stage on top of the GPU passes: oracle/_ref/faucet_ref_gpu is the compiled reference (unmodified
+objects, built where /root/reference is mounted by `make -C oracle ref_gpu`) with integration/faucet_binding.cpp linked in and its two
+call sites of the hot path rerouted to it (integration/wrap_shim.cpp) -- load_two_filters and ReadScanner::scanReads run on
+libfaucet_gpu.so, everything else (sizing, Bloom::dump, JunctionMap::writeToFile, the pair filters, buildContigGraph, cleaning, the contig
+files) is the reference as compiled.  The binary travels to the GPU box like the other built files under oracle/_ref; the expected files
+are the PURE reference's, by digest (tests/golden/binding_stage3.json, made by tests/golden/make_binding_golden.py)."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.golden_util import Case
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "faucet_ref_gpu")
+with open(os.path.join(ROOT, "tests", "golden", "binding_stage3.json")) as _f:
+    WANT = json.load(_f)
+
+
+def normalised(path):
+    data = open(path, "rb").read()
+    if not path.endswith(".fastg"):          # the reference names graph nodes by heap address
+        return data
+    seen = {}
+    return re.sub(rb"0x[0-9a-f]+", lambda m: seen.setdefault(m.group(0), b"n%d" % len(seen)), data)
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/faucet_ref_gpu was not built (it needs the reference tree: make -C oracle ref_gpu)")
+@pytest.mark.parametrize("case", sorted(WANT))
+def test_reference_stage3_runs_on_the_gpu_passes_and_ends_like_the_pure_reference(case, tmp_path):
+    c = Case(case)
+    inp = str(tmp_path / ("reads.fq" if c.fastq else "reads.fa"))
+    with open(inp, "wb") as f:
+        f.write(c.reads_text())
+    r = subprocess.run([EXE, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", str(tmp_path / "out")] + c.meta["args"],
+                       capture_output=True, text=True, timeout=600)
+    want = WANT[case]
+    assert r.returncode == want["exit"], (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    got = {f: hashlib.sha256(normalised(str(tmp_path / f))).hexdigest() for f in sorted(os.listdir(tmp_path)) if f.startswith("out.")}
+    assert sorted(got) == sorted(want["files"]), (sorted(got), sorted(want["files"]))
+    for f, d in want["files"].items():       # .bloom / .junctions / pair filters AND the contig files the reference's Stage 3 writes
+        assert got[f] == d, f
+    for line in want["summary"]:
+        assert line in r.stdout.splitlines(), line

@@ -1,0 +1,86 @@
+"""The HOST side of the product under sanitizers (CPU build only: GPU AddressSanitizer is not available on the pool).
+
+faucet_amd/host/faucet_main.cpp -- four positioned-read threads, a read-ahead thread, the pair-filter worker, four formatting threads -- is
+built with -fsanitize=thread and with -fsanitize=address,undefined against tests/stub/faucet_gpu_stub.cpp, a TEST-ONLY stand-in that answers the
+C ABI of include/faucet_gpu.h on the CPU through the oracle (the product has no CPU path; nothing outside tests/ builds or links the stub).
+What is checked: the sanitizers stay silent on a paired-end FASTQ run with cleaning and on a FIFO input, and -- because the stub's answers
+are the oracle's -- the files the CLI writes are the compiled reference's goldens byte for byte, which pins the CLI's own host logic
+(device-shaped record splitting aside: chunking, list handling, long pair filter, dump order, formatting)."""
+import gzip
+import os
+import shutil
+import subprocess
+import threading
+
+import pytest
+
+from tests.golden_util import Case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = [os.path.join(ROOT, "faucet_amd", "host", "faucet_main.cpp"), os.path.join(ROOT, "tests", "stub", "faucet_gpu_stub.cpp"),
+           os.path.join(ROOT, "oracle", "faucet_oracle.cpp"), os.path.join(ROOT, "faucet_amd", "csrc", "sizing.cpp")]
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+
+
+@pytest.fixture(scope="module", params=["thread", "address,undefined"])
+def cli(request, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("san") / ("faucet_" + request.param.replace(",", "_")))
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + request.param, "-I", os.path.join(ROOT, "include"),
+                        *SOURCES, "-o", exe, "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe, request.param
+
+
+def _env():
+    return dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=66", UBSAN_OPTIONS="halt_on_error=1 print_stacktrace=1")
+
+
+def _check(r, want_rc):
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == want_rc, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("extra", [[], ["-chunk_mb", "1"], ["-batch_reads", "333"]], ids=["chunks_64MB", "chunks_1MB", "host_getline"])
+def test_paired_end_fastq_with_cleaning_is_clean_and_equals_the_reference(cli, extra, tmp_path):
+    exe, _ = cli
+    c = Case("pe_fastq_k21")
+    inp = str(tmp_path / "reads.fq")
+    with open(inp, "wb") as f:
+        f.write(c.reads_text())
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + c.meta["args"] + extra,
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    _check(r, 3)                                  # the contig graph is not built: the CLI's documented exit code after the scan's files
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        with open(prefix + "." + ext, "rb") as f, gzip.open(os.path.join(c.dir, f"out.{ext}.gz"), "rb") as g:
+            assert f.read() == g.read(), ext
+    assert f"Empty count: {c.counters['empty_count']}, not empty count: {c.counters['not_empty_count']}" in r.stdout
+
+
+def test_fifo_input_is_clean_and_equals_the_reference(cli, tmp_path):
+    """both passes read a named pipe (the reference is fed process substitutions, src/stream_data_from_urls_list.sh)"""
+    exe, _ = cli
+    c = Case("c1_k21")
+    text = c.reads_text()
+    fifos = [str(tmp_path / "load.fifo"), str(tmp_path / "scan.fifo")]
+    for p in fifos:
+        os.mkfifo(p)
+
+    def feed(p):
+        with open(p, "wb") as f:
+            f.write(text)
+
+    th = [threading.Thread(target=feed, args=(p,)) for p in fifos]
+    for t in th:
+        t.start()
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, "-read_load_file", fifos[0], "-read_scan_file", fifos[1], "-file_prefix", prefix] + c.meta["args"],
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    for t in th:
+        t.join()
+    _check(r, 0 if c.no_cleaning else 3)
+    with open(prefix + ".bloom", "rb") as f:
+        assert f.read() == c.bloom().tobytes()
+    with open(prefix + ".junctions") as f:
+        assert f.read().split("\n")[:-1] == c.junction_lines()
