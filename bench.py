@@ -324,6 +324,62 @@ def cli_leg(reads, args, kmers, want_junctions):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def config3_cli_leg(device):
+    """BASELINE config 3's shape at its real size -- 2.5 M pairs of 100-base reads of a 4.6 Mb genome with planted repeats, interleaved FASTQ,
+    `--fastq --paired_ends` with cleaning -- file to files through faucet_amd/faucet: the configuration on which the path is SLOWEST (the
+    ordered walk of the repeat clusters).  The reads are the deterministic ones of tests/golden/fullsize.json (config3), so
+    the four files the CLI writes are compared, by digest, with what the COMPILED REFERENCE wrote on the same text in the build container."""
+    import hashlib
+    import re
+    import shutil
+    import tempfile
+    from faucet_amd import synth_det as sd
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize.json")) as f:
+        fx = json.load(f)["config3"]
+    c = fx["params"]
+    g = sd.make_genome(c["genome"], c["genome_seed"], device)
+    sd.plant_repeats(g, c["genome_seed"] + 100, *c["repeats"])
+    reads = sd.make_pairs(g, c["pairs"], c["read_len"], c["insert"][0], c["insert"][1], c["err"], c["read_seed"], device)
+    text = sd.fasta_bytes(reads, fastq=True).cpu().numpy()
+    kmers = int(reads.shape[0]) * (c["read_len"] - c["k"] + 1)
+    del reads, g
+    exe = os.path.join(ROOT, "faucet_amd", "faucet")
+    d = tempfile.mkdtemp(prefix="faucet_bench3_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        path = os.path.join(d, "reads.fq")
+        text.tofile(path)
+        size = os.path.getsize(path)
+        del text
+        cmd = [exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", os.path.join(d, "out")] + fx["args"]
+        best, phases = None, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FGPU_CLI_TIMES="1"))
+            dt = time.perf_counter() - t0
+            if r.returncode != 3:          # cleaning is on: "outputs written, contig graph not built"
+                raise RuntimeError("faucet exited with %d: %s" % (r.returncode, r.stderr[-300:]))
+            if best is None or dt < best:
+                best = dt
+                phases = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[cli\] (pass [12][^\d]*?)\s+([0-9.]+) ms", r.stderr)}
+        m = re.search(r"Distinct junctions: (\d+)", r.stdout)
+
+        def sha(pth):
+            h = hashlib.sha256()
+            with open(pth, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            return h.hexdigest()
+
+        same = {ext: sha(os.path.join(d, "out." + ext)) == fx[ext + "_sha256"] for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter")}
+        return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "kmers": kmers, "input_bytes": size, "pass_ms": phases,
+                "junctions": int(m.group(1)) if m else None, "junctions_equal_the_references": bool(m) and int(m.group(1)) == fx["distinct_junctions"],
+                "files_equal_the_references": same,
+                "note": "wall time of the whole `faucet --fastq --paired_ends` process (start-up, both passes over a 1.07 GB interleaved FASTQ file in tmpfs, "
+                        ".bloom, .junctions and both pair filters written), best of two runs; expected digests: the compiled reference on the same text"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -636,6 +692,12 @@ def main():
             res["cli_file_to_files"] = cli_leg(reads, args, kmers_local, res["outputs"]["junctions"])
         except Exception as e:   # noqa: BLE001  (a missing /tmp or binary must not cost the bench line)
             res["cli_file_to_files"] = {"error": repr(e)[:300]}
+    # ---- the slowest configuration in the driver's line: BASELINE config 3's shape through the CLI, file to files
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+        try:
+            res["config3_cli"] = config3_cli_leg(device)
+        except Exception as e:   # noqa: BLE001
+            res["config3_cli"] = {"error": repr(e)[:300]}
     emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

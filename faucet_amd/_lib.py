@@ -112,6 +112,9 @@ SIGNATURES = {
     "fgpu_kernel_times_reset": (C.c_int, [_vp]),
     "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),
     "fgpu_diag_random_access": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_int, _P(_f64)]),
+    "fgpu_diag_ko_trace": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
+    "fgpu_diag_ko_stamps": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),
+    "fgpu_diag_binned_chain": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, C.c_int, C.c_int, _P(_f64), _P(_f64), _P(_f64), _P(_f64), _P(_f64), _P(C.c_int)]),
     "fgpu_diag_device_attr": (C.c_int, [_vp, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
     "fgpu_diag_walk_probe": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_load_split": (C.c_int, [_vp, _P(_u64), _P(_u64)]),

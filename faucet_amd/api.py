@@ -413,6 +413,29 @@ class Context:
         self._c(self.lib.fgpu_diag_binned_probes(self.h, table_bytes, n_probes, slice_bytes, iters, *[C.byref(x) for x in v]))
         return dict(zip(("direct_per_s", "binned_per_s", "bin_ms", "probe_ms"), [float(x.value) for x in v]))
 
+    def diag_binned_chain(self, table_bytes: int, n_items: int, slice_bytes: int = 4 << 20, n_hash: int = 3, fill_byte: int = 0x29, iters: int = 3) -> dict:
+        """Bloom::contains chains directly vs first level binned by filter slice + survivors handed back (NS1, whole chain); ms per pass"""
+        v = [C.c_double(0) for _ in range(5)]
+        eq = C.c_int(0)
+        self._c(self.lib.fgpu_diag_binned_chain(self.h, table_bytes, n_items, slice_bytes, n_hash, fill_byte, iters, *[C.byref(x) for x in v], C.byref(eq)))
+        d = dict(zip(("direct_ms", "bin_ms", "first_ms", "rest_ms", "survivors_share"), [float(x.value) for x in v]))
+        d["equal"] = bool(eq.value)
+        return d
+
+    def diag_ko_trace(self) -> np.ndarray:
+        """(n, 4) uint64: piece number, start, end, waited | lk positions << 48 of every piece the key-ordered walk walked (-DFGPU_KO_TRACE builds)"""
+        out = np.zeros((1 << 21, 4), dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._c(self.lib.fgpu_diag_ko_trace(self.h, out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def diag_ko_stamps(self) -> np.ndarray:
+        """(pieces, 1024) uint64: per-step time stamps of one key-ordered piece in 16 (-DFGPU_KO_TRACE builds); word 0 = piece << 16 | stamps"""
+        out = np.zeros((4096, 1024), dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._c(self.lib.fgpu_diag_ko_stamps(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return out[: n.value].copy()
+
     def diag_device_attr(self) -> dict:
         v = [C.c_int32(0) for _ in range(4)]
         self._c(self.lib.fgpu_diag_device_attr(self.h, *[C.byref(x) for x in v]))

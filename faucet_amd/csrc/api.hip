@@ -65,8 +65,20 @@ void fgpu_prof_end(fgpu_ctx* ctx, int token) {
     hipEventRecord(ctx->pending_events[token].b, ctx->launch_stream);
 }
 
+// the background part of fgpu_create has finished (and reports here if it failed)
+int fgpu_bg_join(fgpu_ctx* ctx) {
+    if (ctx->bg) {
+        ctx->bg->join();
+        delete ctx->bg;
+        ctx->bg = nullptr;
+    }
+    if (ctx->bg_rc) { ctx->err = ctx->bg_err; return ctx->bg_rc; }
+    return FGPU_OK;
+}
+
 int fgpu_prof_collect(fgpu_ctx* ctx) {
     if (ctx->pending_events.empty()) return FGPU_OK;
+    if (int rc = fgpu_bg_join(ctx)) return rc;
     FGPU_HIP(hipStreamSynchronize(ctx->wstream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     for (PendingEvent& pe : ctx->pending_events) {
@@ -105,6 +117,7 @@ static int check_errors(fgpu_ctx* ctx) {
 
 // everything issued so far, on both streams, has completed
 static int sync_all(fgpu_ctx* ctx) {
+    if (int rc = fgpu_bg_join(ctx)) return rc;
     FGPU_HIP(hipStreamSynchronize(ctx->wstream));
     FGPU_HIP(hipStreamSynchronize(ctx->cstream));   // the side stream's last resets (nothing waits for them but the next window of their parity)
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
@@ -112,6 +125,7 @@ static int sync_all(fgpu_ctx* ctx) {
 }
 
 static int pull_counters(fgpu_ctx* ctx) {
+    if (int rc = fgpu_bg_join(ctx)) return rc;
     FGPU_HIP(hipStreamSynchronize(ctx->wstream));
     FGPU_HIP(hipStreamSynchronize(ctx->cstream));
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
@@ -177,8 +191,6 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         fgpu_touch_pack();
         fgpu_touch_load();
         (void)fgpu_text_streams(ctx);
-        fgpu_touch_scan_pure();
-        fgpu_touch_scan_walk();
         (void)hipGetLastError();
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{warm};
@@ -224,13 +236,26 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     }
     ctx->launch_stream = ctx->stream;
     if (!rc) {
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-        if ((e = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (walk)", e);
-        if (!rc && (e = hipStreamCreateWithPriority(&ctx->cstream, hipStreamNonBlocking, hi)) != hipSuccess) fail("hipStreamCreate (clean)", e);
-        if (!rc && (e = hipEventCreateWithFlags(&ctx->ev_walked, hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
-        for (int q = 0; q < 2 && !rc; q++)
-            if ((e = hipEventCreateWithFlags(&ctx->ev_uf_reset[q], hipEventDisableTiming)) != hipSuccess) fail("hipEventCreate", e);
+        // what only the scan needs is made beside pass 1 (fgpu_bg_join): the walk stream, the clean stream, their events, and the two largest
+        // code objects -- 50-70 ms that used to sit between the command line and the first byte read ("What's weak" 4)
+        ctx->bg = new std::thread([device, ctx] {
+            auto bad = [ctx](const char* what, hipError_t he) {
+                ctx->bg_err = std::string(what) + ": " + hipGetErrorString(he);
+                ctx->bg_rc = FGPU_ERR_HIP;
+            };
+            hipError_t he;
+            if ((he = hipSetDevice(device)) != hipSuccess) return bad("hipSetDevice", he);
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+            if ((he = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) return bad("hipStreamCreate (walk)", he);
+            if ((he = hipStreamCreateWithPriority(&ctx->cstream, hipStreamNonBlocking, hi)) != hipSuccess) return bad("hipStreamCreate (clean)", he);
+            if ((he = hipEventCreateWithFlags(&ctx->ev_walked, hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", he);
+            for (int q = 0; q < 2; q++)
+                if ((he = hipEventCreateWithFlags(&ctx->ev_uf_reset[q], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", he);
+            fgpu_touch_scan_pure();
+            fgpu_touch_scan_walk();
+            (void)hipGetLastError();
+        });
     }
     if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
@@ -255,6 +280,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
 
 void fgpu_destroy(fgpu_ctx* ctx) {
     if (!ctx) return;
+    (void)fgpu_bg_join(ctx);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); hipEventDestroy(ctx->copy_after); }
     if (ctx->tstream) {
         hipStreamSynchronize(ctx->tstream);
@@ -485,8 +511,9 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 0) { ctx->err = "scan_begin while another pass is open"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
-    int rc = fgpu_scan_alloc(ctx);
+    int rc = fgpu_bg_join(ctx);      // the walk's streams and events (made beside pass 1, fgpu_create)
     if (rc) return rc;
+    if ((rc = fgpu_scan_alloc(ctx))) return rc;
     if ((rc = fgpu_scan_reset(ctx))) return rc;
     ctx->fixup_ready = false;   // the load pass' counters go with this reset
     FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
@@ -1056,6 +1083,37 @@ int fgpu_diag_walk_probe(fgpu_ctx* ctx, uint64_t out[4]) {   // after fgpu_scan_
         for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", ctx->counters_host->ko_time[i]);
         fprintf(stderr, "\n");
     }
+    return FGPU_OK;
+}
+
+// measurement builds (-DFGPU_KO_TRACE): one record per piece the key-ordered walk has walked since the context was made -- {global piece
+// number, start, end (10 ns ticks of the device's constant clock), ticks waited for turns | lk positions << 48}; *n = 0 in ordinary builds
+int fgpu_diag_ko_trace(fgpu_ctx* ctx, uint64_t* out, uint64_t cap_records, uint64_t* n) {
+    if (!ctx || !n) return FGPU_ERR_ARG;
+    *n = 0;
+    if (!ctx->ko_trace.p) return FGPU_OK;
+    if (int rc = sync_all(ctx)) return rc;
+    unsigned long long cnt = 0;
+    FGPU_HIP(hipMemcpy(&cnt, ctx->ko_trace.p, 8, hipMemcpyDeviceToHost));
+    if (cnt > (1ULL << 21)) cnt = 1ULL << 21;
+    if (cnt > cap_records) cnt = cap_records;
+    if (cnt && out) FGPU_HIP(hipMemcpy(out, (const char*)ctx->ko_trace.p + 32, cnt * 32, hipMemcpyDeviceToHost));
+    *n = cnt;
+    return FGPU_OK;
+}
+
+// the per-step time stamps of the stamped pieces (one in 16): 4096 x 1024 words, see KO_STAMP in scan_walk.hip
+int fgpu_diag_ko_stamps(fgpu_ctx* ctx, uint64_t* out, uint64_t cap_words, uint64_t* n_pieces) {
+    if (!ctx || !n_pieces) return FGPU_ERR_ARG;
+    *n_pieces = 0;
+    if (!ctx->ko_trace.p || ctx->ko_trace.bytes < ((1ULL << 23) + 4096 * 1024) * 8) return FGPU_OK;
+    if (int rc = sync_all(ctx)) return rc;
+    unsigned long long cnt = 0;
+    FGPU_HIP(hipMemcpy(&cnt, (const char*)ctx->ko_trace.p + 8, 8, hipMemcpyDeviceToHost));
+    if (cnt > 4096) cnt = 4096;
+    if (cnt * 1024 > cap_words) cnt = cap_words / 1024;
+    if (cnt && out) FGPU_HIP(hipMemcpy(out, (const char*)ctx->ko_trace.p + (8ULL << 23), cnt * 1024 * 8, hipMemcpyDeviceToHost));
+    *n_pieces = cnt;
     return FGPU_OK;
 }
 

@@ -4,6 +4,8 @@
 //     array of the load pass and the junction presence filter see).  A random access moves one 64-byte sector at
 //     least, so accesses/s x 64 B is the "random-64 B-gather" rate the roofline fractions are put next to.
 // Nothing of the product path calls these; bench.py reports them beside the k-mer rates.
+#include <vector>
+
 #include "fgpu_ctx.h"
 
 namespace {
@@ -116,6 +118,130 @@ __global__ void __launch_bounds__(256) k_diag_probe_binned(const uint32_t* __res
     }
 }
 
+
+// ---- NS1, the whole CHAIN (round 3): Bloom::contains with its early exit -- n_hash dependent bit tests at (hA + i hB) mod tai -- for n items,
+// (A) directly, one item per lane until its chain ends, and (B) with the FIRST level binned by filter slice: k_diag_bin queues {first bit,
+// item}, k_diag_first_binned tests the first bits slice by slice from the XCD that holds the slice and hands the SURVIVORS back as a dense
+// list of items (one reservation per wave: no random write, which is what a per-probe answer plane would cost), k_diag_chain_rest runs the
+// rest of their chains directly and ORs the rare "all bits set" into the item-order answer plane.  This is the shape a binned first level
+// of k_scan_flags_sm would have (survivors re-enter the state machine as a dense list, results are sparse flags).
+__device__ __forceinline__ void diag_item_hashes(uint64_t i, uint64_t salt, uint64_t bit_mask, uint64_t& hA, uint64_t& hB) {
+    hA = diag_rand(i ^ salt) & bit_mask;
+    hB = diag_rand((i ^ salt) + 0x9E3779B97F4A7C15ULL) & bit_mask;
+}
+
+__global__ void __launch_bounds__(256) k_diag_chain_direct(const uint32_t* __restrict__ table, uint64_t bit_mask, int n_hash, uint64_t n, uint64_t salt,
+                                                           uint64_t* __restrict__ answers) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {   // n is a multiple of 64
+        uint64_t hA, hB;
+        diag_item_hashes(i, salt, bit_mask, hA, hB);
+        bool pass = true;
+        uint64_t h = hA;
+        for (int b = 0; b < n_hash; b++) {
+            if (!((table[h >> 5] >> (h & 31)) & 1u)) { pass = false; break; }
+            h = (h + hB) & bit_mask;
+        }
+        const uint64_t m = __ballot(pass);
+        if (fd_lane() == 0) answers[i >> 6] = m;
+    }
+}
+
+// first bits, slice by slice from one XCD each; survivors as a dense list of item numbers.  A block takes 4096 queue records at a time and
+// reserves room for their survivors with ONE atomic (a reservation per wave was 4 M same-address atomics per pass: 42 of the kernel's 50 ms)
+__global__ void __launch_bounds__(256) k_diag_first_binned(const uint32_t* __restrict__ table, int n_slices, uint64_t cap,
+                                                           const unsigned long long* __restrict__ qcount, const uint2* __restrict__ queue,
+                                                           uint32_t* __restrict__ survivors, unsigned long long* __restrict__ n_survivors) {
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned long long s_base;
+    const unsigned xcd = blockIdx.x & 7u, lane_block = blockIdx.x >> 3, blocks_per_xcd = gridDim.x >> 3;
+    const int wave = (int)(threadIdx.x >> 6);
+    for (int sl = (int)xcd; sl < n_slices; sl += 8) {
+        uint64_t cnt = qcount[sl];
+        if (cnt > cap) cnt = cap;
+        const uint2* q = queue + (uint64_t)sl * cap;
+        for (uint64_t c0 = (uint64_t)lane_block * 4096; c0 < cnt; c0 += (uint64_t)blocks_per_xcd * 4096) {   // uniform trip count per block
+            uint32_t item[DIAG_BIN_PER_THREAD];
+            unsigned hits = 0;
+#pragma unroll
+            for (int u = 0; u < DIAG_BIN_PER_THREAD; u++) {
+                const uint64_t i = c0 + (uint64_t)u * 256 + threadIdx.x;
+                bool hit = false;
+                if (i < cnt) {
+                    const uint2 r = q[i];
+                    item[u] = r.y;
+                    hit = (table[r.x >> 5] >> (r.x & 31)) & 1u;
+                }
+                if (hit) hits |= 1u << u;
+            }
+            unsigned mine = (unsigned)__popc(hits), incl = mine;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (fd_lane() >= o) incl += t; }
+            if (fd_lane() == 63) s_wave[wave] = incl;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+                s_base = total ? atomicAdd(n_survivors, (unsigned long long)total) : 0ULL;
+            }
+            __syncthreads();
+            unsigned long long at = s_base + (incl - mine);
+            for (int w = 0; w < wave; w++) at += s_wave[w];
+#pragma unroll
+            for (int u = 0; u < DIAG_BIN_PER_THREAD; u++)
+                if (hits & (1u << u)) survivors[at++] = item[u];
+            __syncthreads();      // s_wave / s_base are reused by the next round
+        }
+    }
+}
+
+// the rest of the survivors' chains, directly; "all bits set" is rare and goes to the item-order plane by atomicOr
+__global__ void __launch_bounds__(256) k_diag_chain_rest(const uint32_t* __restrict__ table, uint64_t bit_mask, int n_hash, uint64_t salt,
+                                                         const uint32_t* __restrict__ survivors, const unsigned long long* __restrict__ n_survivors,
+                                                         unsigned long long* __restrict__ answers) {
+    const uint64_t n = *n_survivors, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) {
+        const uint64_t i = survivors[s];
+        uint64_t hA, hB;
+        diag_item_hashes(i, salt, bit_mask, hA, hB);
+        bool pass = true;
+        uint64_t h = (hA + hB) & bit_mask;
+        for (int b = 1; b < n_hash; b++) {
+            if (!((table[h >> 5] >> (h & 31)) & 1u)) { pass = false; break; }
+            h = (h + hB) & bit_mask;
+        }
+        if (pass) atomicOr(&answers[i >> 6], 1ULL << (i & 63));
+    }
+}
+
+// queue records {first bit, item} of the chains' first level (k_diag_bin's scheme, the address is the item's hA)
+__global__ void __launch_bounds__(256) k_diag_bin_items(uint64_t bit_mask, int slice_shift, int n_slices, uint64_t n, uint64_t salt, uint64_t cap,
+                                                        unsigned long long* __restrict__ qcount, uint2* __restrict__ queue) {
+    __shared__ unsigned s_cnt[DIAG_MAX_SLICES], s_base[DIAG_MAX_SLICES];
+    for (int q = threadIdx.x; q < n_slices; q += 256) s_cnt[q] = 0;
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * 256 * DIAG_BIN_PER_THREAD;
+    uint32_t addr[DIAG_BIN_PER_THREAD];
+    unsigned rank[DIAG_BIN_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < DIAG_BIN_PER_THREAD; u++) {
+        const uint64_t i = first + (uint64_t)u * 256 + threadIdx.x;
+        uint64_t hA, hB;
+        diag_item_hashes(i, salt, bit_mask, hA, hB);
+        addr[u] = (uint32_t)hA;
+        rank[u] = i < n ? atomicAdd(&s_cnt[addr[u] >> slice_shift], 1u) : 0u;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_slices; q += 256) s_base[q] = s_cnt[q] ? (unsigned)atomicAdd(&qcount[q], (unsigned long long)s_cnt[q]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DIAG_BIN_PER_THREAD; u++) {
+        const uint64_t i = first + (uint64_t)u * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const uint32_t sl = addr[u] >> slice_shift;
+        const uint64_t pos = (uint64_t)s_base[sl] + rank[u];
+        if (pos < cap) queue[(uint64_t)sl * cap + pos] = make_uint2(addr[u], (uint32_t)i);
+    }
+}
+
 }  // namespace
 
 extern "C" int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_probes, uint64_t slice_bytes, int iters,
@@ -174,6 +300,77 @@ extern "C" int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint
         for (auto& e : ev) hipEventDestroy(e);
     }
     hipFree(table); hipFree(queue); hipFree(answers); hipFree(qcount);
+    return rc;
+}
+
+// the chain A/B above: times per pass in ms (direct; bin, binned first level, rest of the survivors' chains), the survivors' share, and
+// whether the two answer planes are equal bit for bit (`equal`).  fill_byte: every byte of the table (popcount / 8 = share of set bits).
+extern "C" int fgpu_diag_binned_chain(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_items, uint64_t slice_bytes, int n_hash, int fill_byte, int iters,
+                                      double* direct_ms, double* bin_ms, double* first_ms, double* rest_ms, double* survivors_share, int* equal) {
+    if (!ctx || !direct_ms || !bin_ms || !first_ms || !rest_ms || !survivors_share || !equal || iters < 1 || n_hash < 1 || n_hash > 8 ||
+        table_bytes < (1u << 16) || (table_bytes & (table_bytes - 1)) || table_bytes > (1ULL << 29) || (slice_bytes & (slice_bytes - 1)) ||
+        slice_bytes < 4096 || slice_bytes > table_bytes || table_bytes / slice_bytes > DIAG_MAX_SLICES || n_items < (1u << 16) || n_items > (1ULL << 31))
+        return FGPU_ERR_ARG;
+    n_items &= ~(uint64_t)(256 * DIAG_BIN_PER_THREAD - 1);
+    const int n_slices = (int)(table_bytes / slice_bytes);
+    int slice_shift = 0;
+    while ((1ULL << slice_shift) < slice_bytes * 8) slice_shift++;
+    const uint64_t cap = ((n_items / n_slices + n_items / n_slices / 8 + 65536) + 63) & ~63ULL;
+    const uint64_t words = n_items / 64;
+    uint32_t *table = nullptr, *survivors = nullptr;
+    uint2* queue = nullptr;
+    uint64_t *ans_a = nullptr, *ans_b = nullptr;
+    unsigned long long *qcount = nullptr, *n_surv = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = FGPU_OK;
+    if (hipMalloc(&table, table_bytes) != hipSuccess || hipMalloc(&queue, (uint64_t)n_slices * cap * 8) != hipSuccess ||
+        hipMalloc(&survivors, n_items * 4) != hipSuccess || hipMalloc(&ans_a, words * 8) != hipSuccess || hipMalloc(&ans_b, words * 8) != hipSuccess ||
+        hipMalloc(&qcount, DIAG_MAX_SLICES * 8) != hipSuccess || hipMalloc(&n_surv, 8) != hipSuccess) {
+        ctx->err = "diag: out of device memory";
+        rc = FGPU_ERR_NOMEM;
+    }
+    unsigned long long surv_host = 0;
+    if (!rc) {
+        for (auto& e : ev) hipEventCreate(&e);
+        hipMemsetAsync(table, fill_byte & 0xFF, table_bytes, ctx->stream);
+        const unsigned grid = FGPU_GRID_BLOCKS, bin_grid = (unsigned)(n_items / (256 * DIAG_BIN_PER_THREAD));
+        const uint64_t bit_mask = table_bytes * 8 - 1;
+        float t[4] = {0, 0, 0, 0};
+        for (int i = -1; i < iters; i++) {
+            const uint64_t salt = 0x5851F42D4C957F2DULL * (uint64_t)(i + 2);
+            hipEventRecord(ev[0], ctx->stream);
+            hipLaunchKernelGGL(k_diag_chain_direct, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)table, bit_mask, n_hash, n_items, salt, ans_a);
+            hipEventRecord(ev[1], ctx->stream);
+            hipMemsetAsync(qcount, 0, DIAG_MAX_SLICES * 8, ctx->stream);
+            hipMemsetAsync(n_surv, 0, 8, ctx->stream);
+            hipMemsetAsync(ans_b, 0, words * 8, ctx->stream);
+            hipLaunchKernelGGL(k_diag_bin_items, dim3(bin_grid), dim3(256), 0, ctx->stream, bit_mask, slice_shift, n_slices, n_items, salt, cap, qcount, queue);
+            hipEventRecord(ev[2], ctx->stream);
+            hipLaunchKernelGGL(k_diag_first_binned, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)table, n_slices, cap,
+                               (const unsigned long long*)qcount, (const uint2*)queue, survivors, n_surv);
+            hipEventRecord(ev[3], ctx->stream);
+            if (n_hash > 1)
+                hipLaunchKernelGGL(k_diag_chain_rest, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)table, bit_mask, n_hash, salt,
+                                   (const uint32_t*)survivors, (const unsigned long long*)n_surv, (unsigned long long*)ans_b);
+            hipEventRecord(ev[4], ctx->stream);
+            if (hipEventSynchronize(ev[4]) != hipSuccess) { rc = FGPU_ERR_HIP; ctx->err = "diag: binned chain failed"; break; }
+            if (i >= 0) {
+                float v;
+                for (int k = 0; k < 4; k++) { hipEventElapsedTime(&v, ev[k], ev[k + 1]); t[k] += v; }
+            }
+        }
+        if (!rc) {
+            std::vector<uint64_t> a(words), b(words);
+            hipMemcpy(a.data(), ans_a, words * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(b.data(), ans_b, words * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(&surv_host, n_surv, 8, hipMemcpyDeviceToHost);
+            *equal = n_hash > 1 ? (a == b ? 1 : 0) : 1;
+            *direct_ms = t[0] / iters; *bin_ms = t[1] / iters; *first_ms = t[2] / iters; *rest_ms = t[3] / iters;
+            *survivors_share = (double)surv_host / (double)n_items;
+        }
+        for (auto& e : ev) hipEventDestroy(e);
+    }
+    hipFree(table); hipFree(queue); hipFree(survivors); hipFree(ans_a); hipFree(ans_b); hipFree(qcount); hipFree(n_surv);
     return rc;
 }
 

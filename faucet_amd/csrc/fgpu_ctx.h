@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/faucet_gpu.h"
@@ -148,6 +149,11 @@ struct fgpu_ctx {
     hipStream_t launch_stream = nullptr;   // where FGPU_LAUNCH puts kernels (and profiling events) right now
     bool own_stream = false;
     std::string err;
+    // set-up nothing of pass 1 needs (the walk's two streams and events, the code objects of the scan units: queue creation and code-object
+    // loading are ~10-25 ms each) runs on this thread beside the first load batches; fgpu_bg_join before anything touches what it makes
+    std::thread* bg = nullptr;
+    int bg_rc = 0;
+    std::string bg_err;
 
     // pass 1 state
     uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
@@ -259,6 +265,7 @@ struct fgpu_ctx {
     uint64_t scan_batch_seq = 0;
     uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;
+    DevBuf ko_trace;                      // -DFGPU_KO_TRACE: per-piece records of the key-ordered walk (fgpu_diag_ko_trace)
     DevBuf s3_keys, s3_dist, s3_in;       // Stage 3's junction map on the device (stage3.hip): k-mer -> five distances
     uint64_t s3_mask = 0, s3_count = 0;
     bool s3_ready = false;
@@ -301,6 +308,7 @@ struct fgpu_ctx {
     } while (0)
 
 int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes);
+int fgpu_bg_join(fgpu_ctx* ctx);
 int fgpu_prof_begin(fgpu_ctx* ctx, const char* name);
 void fgpu_prof_end(fgpu_ctx* ctx, int token);
 int fgpu_prof_collect(fgpu_ctx* ctx);

@@ -58,6 +58,13 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
 // During a load pass the two filters live INTERLEAVED: pair[w] = {word w of the carried-in bloo1, word w of bloo2}.
 // Both filters use the same bit positions (same hashes, same size), so one 8-byte load serves the carry test and
 // the test-before-set of bloo2: 3 random loads per k-mer instead of up to 6.  fgpu_load_end splits them again.
+// -DFGPU_FIRST_MASK_LOG2=n (MEASUREMENT build, results wrong): first-set times folded into a table of 2^n entries -- what a first[] of that
+// size would cost k_load_mark's atomics and k_load_resolve's loads, without building the structure that would make it exact
+#ifdef FGPU_FIRST_MASK_LOG2
+#define FD_FIRST(h) ((h) & ((1ULL << FGPU_FIRST_MASK_LOG2) - 1))
+#else
+#define FD_FIRST(h) (h)
+#endif
 constexpr int MISS_PLANES = 4;   // planes of "bit i was missing from the carry" kept for k_load_resolve (hash functions beyond are re-tested)
 
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
@@ -101,7 +108,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 for (int i = 0; i < fp.n_hash; i++) {
                     // the next carry is derived afterwards: from first[] by a sweep (k_carry_from_first) or by re-hashing the
                     // occurrences that were not contained (k_carry_set)
-                    if (missing & (1u << i)) atomicMin(&first[h], tb + (uint32_t)p);
+                    if (missing & (1u << i)) atomicMin(&first[FD_FIRST(h)], tb + (uint32_t)p);
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -148,7 +155,7 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
                 bool in_carry = i < MISS_PLANES ? !((missing >> i) & 1u) : ((pair[h >> 5].x >> (h & 31)) & 1u) != 0;
-                if (!in_carry && !(first[h] < tb + (uint32_t)p)) { pass = false; break; }
+                if (!in_carry && !(first[FD_FIRST(h)] < tb + (uint32_t)p)) { pass = false; break; }
                 h = (h + hB) & fp.tai_mask;
             }
             if (pass) {   // rare: every bit was set earlier in this very batch
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
             seen[q] = 0;
             if (missing[q]) {
                 const uint64_t h = (hA[q] + (uint64_t)__builtin_ctz(missing[q]) * hB[q]) & fp.tai_mask;
-                seen[q] = first[h];
+                seen[q] = first[FD_FIRST(h)];
             }
         }
 #pragma unroll

@@ -461,6 +461,7 @@ struct KoTables {
     uint32_t* piece_base; // per piece of the window: first occurrence number (its lk positions in ascending order follow)
     uint32_t* state;      // [0] occurrences reserved, [1] bit 0: a table overflowed (every cluster is walked in order), [2] ticket of k_walk_ko
     uint32_t* bad;        // per root: the cluster holds a piece the key-ordered walk does not take (more than 128 windows)
+    unsigned long long* trace;   // -DFGPU_KO_TRACE (measurement build): [0] records written; 4 words per walked piece from [4] on, else nullptr
 };
 constexpr uint32_t KO_EMPTY = 0xFFFFFFFFu;
 #ifndef FGPU_KO_WAIT_S
@@ -482,9 +483,6 @@ __device__ __forceinline__ uint32_t* ko_occ_lds() {
     __shared__ uint32_t s_occ[2 * 64 * KO_CHUNKS];
     return s_occ;
 }
-// reads: every lane reads the same word and the value goes on in scalar registers
-__device__ __forceinline__ uint64_t ko_lk_get(uint32_t c) { return uni64(ko_masks()[c]); }
-__device__ __forceinline__ uint64_t ko_absent_get(bool fwd, uint32_t c) { return uni64(ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]); }
 
 struct KoHold {   // a k-mer whose turn this piece holds: entry, rank of its first occurrence here, occurrences merged into the hold
     uint32_t e, r, n;
@@ -509,7 +507,27 @@ struct KoState {
     // the turn counter of the NEXT lk position, requested while this one is being visited (it is only believed when it already shows this
     // piece's rank: from then on nobody else moves it)
     uint32_t pf_ord, pf_val, n_lk;     // (pf_val is what the load returned in each lane: made uniform when it is looked at)
+    unsigned long long wait_acc;       // -DFGPU_KO_TRACE: ticks (10 ns) this piece has spent waiting for turns
+    unsigned long long* stamp_base;    // -DFGPU_KO_TRACE: where this piece leaves its per-step time stamps (nullptr: it does not)
+    unsigned long long stamp_t0;
+    uint32_t stamp_n;
+    // the first 128 windows' lk / absent words in registers (a 100-base read has 70): an LDS read costs a single wave ~100 cycles of
+    // exposed latency, and the search for the next junction reads six of them per step (1.1 us of a visit's 3-4, scripts/ko_trace.py)
+    uint64_t lk0, lk1, aF0, aF1, aB0, aB1;
 };
+// reads of the piece's position masks: registers for the first two words, LDS (every lane reads the same word; the value goes on in scalar
+// registers) beyond
+__device__ __forceinline__ uint64_t ko_lk_get(const KoState& ko, uint32_t c) { return c == 0 ? ko.lk0 : c == 1 ? ko.lk1 : uni64(ko_masks()[c]); }
+__device__ __forceinline__ uint64_t ko_absent_get(const KoState& ko, bool fwd, uint32_t c) {
+    if (c == 0) return fwd ? ko.aF0 : ko.aB0;
+    if (c == 1) return fwd ? ko.aF1 : ko.aB1;
+    return uni64(ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]);
+}
+__device__ __forceinline__ void ko_absent_or(KoState& ko, bool fwd, uint32_t c, uint64_t bit) {
+    if (c == 0) { if (fwd) ko.aF0 |= bit; else ko.aB0 |= bit; }
+    else if (c == 1) { if (fwd) ko.aF1 |= bit; else ko.aB1 |= bit; }
+    else ko_absent(fwd, c) = uni64(ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]) | bit;
+}
 
 struct WalkCtx {
     Planes pl;
@@ -625,7 +643,13 @@ __device__ __forceinline__ int pv_base(const PieceView& v, const uint64_t* codes
 // positions -- a key created since the snapshot is a registered candidate of this window (k_walk_register's delta), so its positions are
 // lk positions, and every piece it occurs on is in this thread's cluster: what the look-up sees is what the sequential run has.
 // Out of line and fed by value on purpose: the rare path stays out of the walk's register allocation.
-__device__ __noinline__ uint4 live_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint64_t where, JTable jt) {
+// (the table as two scalars, not the 48-byte JTable: a struct handed to an out-of-line function by value travels through SCRATCH memory --
+// three 16-byte stores before every call and as many loads behind it, on the path of nearly every piece of k_walk)
+__device__ __noinline__ uint4 live_bits_impl(const uint64_t* __restrict__ codes, int k, uint64_t p, uint64_t where, uint64_t* jkeys, uint64_t jmask) {
+    JTable jt;
+    jt.keys = jkeys;
+    jt.mask = jmask;
+    jt.recs = nullptr; jt.stamps = nullptr; jt.filter = nullptr; jt.filter_mask = 0;
     uint64_t mF = 0, mB = 0;
     while (where) {   // only the candidate positions of the chunk
         const uint32_t i = (uint32_t)__builtin_ctzll(where);
@@ -650,7 +674,7 @@ __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView&
     // inside a repeat at high coverage that is nearly every position, and the look-ups of a piece were a quarter of its walk)
     const uint64_t where = pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) & ~(pv_word(v, v.inF0, v.inF1, wc.pl.inF, c) & pv_word(v, v.inB0, v.inB1, wc.pl.inB, c));
     if (!where) { mF = mB = 0; return; }
-    uint4 r = live_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, where, wc.jt);
+    uint4 r = live_bits_impl(wc.pl.codes, wc.fp.k, v.p0 + base, where, wc.jt.keys, wc.jt.mask);
     mF = (uint64_t)r.x | ((uint64_t)r.y << 32);
     mB = (uint64_t)r.z | ((uint64_t)r.w << 32);
 }
@@ -658,9 +682,9 @@ __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView&
 template <int MODE>
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
     if (MODE == WALK_KO) {   // what the map holds is asked when the k-mer's turn has come: until then every registered position may be in it
-        const uint64_t lkw = c < KO_CHUNKS ? ko_lk_get(c) : 0ULL;
-        mF = c < KO_CHUNKS ? (lkw & ~ko_absent_get(true, c)) : 0ULL;
-        mB = c < KO_CHUNKS ? (lkw & ~ko_absent_get(false, c)) : 0ULL;
+        const uint64_t lkw = c < KO_CHUNKS ? ko_lk_get(wc.ko, c) : 0ULL;
+        mF = c < KO_CHUNKS ? (lkw & ~ko_absent_get(wc.ko, true, c)) : 0ULL;
+        mB = c < KO_CHUNKS ? (lkw & ~ko_absent_get(wc.ko, false, c)) : 0ULL;
         return;
     }
     mF = pv_word(v, v.inF0, v.inF1, wc.pl.inF, c);
@@ -795,10 +819,34 @@ __device__ __forceinline__ void rr_add_cov(RecRegs& r, int nuc) {               
 __device__ __forceinline__ void rr_link(RecRegs& r, int idx) { rr_set(r, 9, rr_get(r, 9) | (1u << idx)); }
 __device__ __forceinline__ void rr_store(const RecRegs& r) { r.addr[0] = r.lo; r.addr[1] = r.hi; }
 // the key-ordered walk hands records from thread to thread inside one launch: 8-byte agent-scope accesses on both sides
-__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) {
+#ifdef FGPU_KO_ONE_XCD
+    // Every wave of the key-ordered walk runs on ONE XCD (the others leave at once, k_walk_ko): what one piece hands to the next stays in that
+    // XCD's L2 -- a plain store keeps the line there, and the agent-scope (sc1) loads on the other side bypass the L1 and are served by the
+    // L2.  An sc1 store drops the line, and the next piece's load then goes to memory (~2 us instead of ~0.3: measured, 6 us per lk position).
+    *(volatile uint64_t*)p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void st_turn(uint32_t* p, uint32_t v) {
+#ifdef FGPU_KO_ONE_XCD
+    *(volatile uint32_t*)p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 template <int MODE> __device__ __forceinline__ void rr_store_m(const RecRegs& r) {
     if (MODE == WALK_KO) { if (fd_lane() == 0) { st_agent(&r.addr[0], r.lo); st_agent(&r.addr[1], r.hi); } }
     else rr_store(r);
+}
+// WALK_KO: the copy of a k-mer's two records kept while its turn is held (ko_lookup) follows what this piece itself writes to them -- the same
+// k-mer twice on a piece (tandem repeats) means a record can be changed between the look-up and the visit that reads the copy
+__device__ __forceinline__ void ko_cache_wrote(KoState& ko, const RecRegs& r, const uint8_t* recs) {
+    if (!ko.c_found) return;
+    const uint64_t* a0 = (const uint64_t*)(recs + ko.c_slot * 32);
+    if (r.addr == a0) { ko.c_lo0 = r.lo; ko.c_hi0 = r.hi; }
+    else if (r.addr == a0 + 2) { ko.c_lo1 = r.lo; ko.c_hi1 = r.hi; }
 }
 
 // find or create the junction keyed by the oriented k-mer `key`; the record comes back in registers
@@ -907,13 +955,16 @@ __device__ __forceinline__ void rec_link_atomic(const RecRegs& seen, int idx) {
 __device__ __forceinline__ uint32_t ko_ordinal(const KoState& ko, uint32_t q) {   // lk positions of the piece below q
     (void)ko;
     uint32_t n = 0;
-    for (uint32_t c = 0; c < (q >> 6); c++) n += (uint32_t)__popcll(ko_lk_get(c));
-    return n + (uint32_t)__popcll(ko_lk_get(q >> 6) & ((1ULL << (q & 63)) - 1));
+    for (uint32_t c = 0; c < (q >> 6); c++) n += (uint32_t)__popcll(ko_lk_get(ko, c));
+    return n + (uint32_t)__popcll(ko_lk_get(ko, q >> 6) & ((1ULL << (q & 63)) - 1));
 }
-__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { (void)ko; return ((ko_lk_get(q >> 6) >> (q & 63)) & 1ULL) != 0; }
-__device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounters* cnt) {
+__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { return ((ko_lk_get(ko, q >> 6) >> (q & 63)) & 1ULL) != 0; }
+__device__ __noinline__ unsigned long long ko_wait(const uint32_t* turn, uint32_t r, DevCounters* cnt) {
     unsigned spins = 0;
     unsigned long long t0 = 0;
+#ifdef FGPU_KO_TRACE
+    const unsigned long long t_in = wall_clock64();
+#endif
 #ifdef FGPU_KO_TIMING
     const unsigned long long tw = wall_clock64();
     if (uni32(ld_agent(turn)) != r) {
@@ -923,11 +974,18 @@ __device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounte
             atomicAdd(&cnt->par_probe[3], 1ULL);
         }
     }
-    return;
+    return 0;
+#endif
+    // A piece waits about once, and then for a long time (milliseconds: the pieces before it on a repeat), while hundreds of waves wait on the
+    // counters of the same few hot k-mers: polls every ~1 us queue up in those L2 channels in front of the loads and stores of the pieces that
+    // ARE walking.  So the wait backs off (FGPU_KO_SLEEP: s_sleep units of 64 cycles per poll after the first few).
+#ifndef FGPU_KO_SLEEP
+#define FGPU_KO_SLEEP 32
 #endif
     while (uni32(ld_agent(turn)) != r) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 4095u) == 0) {   // a turn that never comes is a bug, not a state to wait in: say so once and let every piece run out
+        if (spins < 4) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(FGPU_KO_SLEEP);
+        if ((++spins & 255u) == 0) {   // a turn that never comes is a bug, not a state to wait in: say so once and let every piece run out
             if (uni64(ld_agent((const uint64_t*)&cnt->error_flags)) & 8ULL) break;
             const unsigned long long now = wall_clock64();          // constant 100 MHz
             if (!t0) t0 = now;
@@ -935,6 +993,11 @@ __device__ __noinline__ void ko_wait(const uint32_t* turn, uint32_t r, DevCounte
         }
     }
     // no cache invalidate: everything one piece hands to the next (turn counters, key words, records) is read with agent-scope loads
+#ifdef FGPU_KO_TRACE
+    return wall_clock64() - t_in;
+#else
+    return 0;
+#endif
 }
 __device__ __forceinline__ DevCounters* ko_cnt(const KoState& ko) { return ko.cnt; }
 // A visit of the key-ordered walk is a chain of DEPENDENT memory round trips (occurrence, turn counter, key word, record, and the
@@ -955,30 +1018,51 @@ __device__ __forceinline__ void ko_flush(KoState& ko) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
     if (fd_lane() == 0) {
-        __hip_atomic_store(&ko.kt.hk_turn[ko.pe0], ko.pv0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ko.n_pend > 1) __hip_atomic_store(&ko.kt.hk_turn[ko.pe1], ko.pv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ko.n_pend > 2) __hip_atomic_store(&ko.kt.hk_turn[ko.pe2], ko.pv2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ko.n_pend > 3) __hip_atomic_store(&ko.kt.hk_turn[ko.pe3], ko.pv3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_turn(&ko.kt.hk_turn[ko.pe0], ko.pv0);
+        if (ko.n_pend > 1) st_turn(&ko.kt.hk_turn[ko.pe1], ko.pv1);
+        if (ko.n_pend > 2) st_turn(&ko.kt.hk_turn[ko.pe2], ko.pv2);
+        if (ko.n_pend > 3) st_turn(&ko.kt.hk_turn[ko.pe3], ko.pv3);
     }
     ko.n_pend = 0;
     KO_T1(ko_cnt(ko), 1);
 }
+// -DFGPU_KO_TRACE: one piece in 16 also leaves a time stamp at every step of every position it deals with (kt.trace + 2^23 words on:
+// 1024 words per stamped piece: [0] n, then {code << 56 | q << 40 | ticks since the piece's start})
+#ifdef FGPU_KO_TRACE
+#define KO_STAMP(ko, code, q)                                                                                                         \
+    do {                                                                                                                              \
+        if ((ko).stamp_base && (ko).stamp_n < 1020 && (threadIdx.x & 63) == 0) {                                                       \
+            (ko).stamp_base[1 + (ko).stamp_n] = ((unsigned long long)(code) << 56) | ((unsigned long long)(q) << 40) |                 \
+                                                ((wall_clock64() - (ko).stamp_t0) & 0xFFFFFFFFFFULL);                                  \
+        }                                                                                                                             \
+        if ((ko).stamp_base) (ko).stamp_n++;                                                                                          \
+    } while (0)
+#else
+#define KO_STAMP(ko, code, q) do {} while (0)
+#endif
 // the k-mer's turn goes to its next occurrence (stored by the next ko_flush: before this piece waits for any turn, and when it ends)
 __device__ __forceinline__ void ko_give(KoState& ko, KoHold& h) {
     if (ko.n_pend == 4) ko_flush(ko);
-    const uint32_t v = h.r + h.n;
-    if (ko.n_pend == 0) { ko.pe0 = h.e; ko.pv0 = v; }
-    else if (ko.n_pend == 1) { ko.pe1 = h.e; ko.pv1 = v; }
-    else if (ko.n_pend == 2) { ko.pe2 = h.e; ko.pv2 = v; }
-    else { ko.pe3 = h.e; ko.pv3 = v; }
+    // (a shift register, not "slot n_pend": the compiler turns a chain of stores to consecutive members picked by a run-time value into ONE
+    // indexed store, and a struct that is indexed at run time lives in scratch memory -- all of WalkCtx did, 344 scratch loads in the walk)
+    ko.pe3 = ko.pe2; ko.pv3 = ko.pv2;
+    ko.pe2 = ko.pe1; ko.pv2 = ko.pv1;
+    ko.pe1 = ko.pe0; ko.pv1 = ko.pv0;
+    ko.pe0 = h.e;
+    ko.pv0 = h.r + h.n;
     ko.n_pend++;
     h.n = 0;
+#ifdef FGPU_KO_EAGER_GIVE
+    ko_flush(ko);          // (measurement build: every turn moves on at once, with a wait of its own)
+#endif
 }
 // the map's answer for the k-mer at position q (turn held): found?, slot, presence bits, both records; one round trip when the key sits in its
 // home slot (the table is kept below a quarter full)
-__device__ __forceinline__ void ko_lookup(WalkCtx& wc, uint32_t q, uint64_t canon) {
+__device__ __forceinline__ void ko_lookup(WalkCtx& wc, uint32_t q, uint64_t canon, bool have_last, const RecRegs& last) {
     KoState& ko = wc.ko;
+#ifndef FGPU_KO_NO_CACHE
     if (ko.c_q == q) return;
+#endif
     KO_T0();
     const JTable& jt = wc.jt;
     uint64_t s = fd_mix(canon) & jt.mask;
@@ -1001,12 +1085,14 @@ __device__ __forceinline__ void ko_lookup(WalkCtx& wc, uint32_t q, uint64_t cano
                 a0 = ld_agent(&rp[0]); a1 = ld_agent(&rp[1]); a2 = ld_agent(&rp[2]); a3 = ld_agent(&rp[3]);
             }
             ko.c_lo0 = uni64(a0); ko.c_hi0 = uni64(a1); ko.c_lo1 = uni64(a2); ko.c_hi1 = uni64(a3);
+            if (have_last) ko_cache_wrote(ko, last, jt.recs);      // the piece's last junction may be this very k-mer, its record not stored yet
             break;
         }
         s = (s + 1) & jt.mask;
         w = uni64(ld_agent(&jt.keys[s]));
     }
     ko_flush(ko);          // a load has just come back: the noted turns move on for free
+    KO_STAMP(ko, 3, q);
     KO_T1(wc.cnt, 2);
 }
 
@@ -1021,6 +1107,7 @@ __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_curs
     KoState& ko = wc.ko;
     ko_leave_cursor(ko, have_last);
     KO_T0();
+    KO_STAMP(ko, 1, q);
     const uint32_t ord = ko_ordinal(ko, q);
     const uint32_t e = uni32(ko_occ_lds()[2 * ord]), r = uni32(ko_occ_lds()[2 * ord + 1]);
     if (as_cursor) ko.cur_q = q;
@@ -1033,21 +1120,28 @@ __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_curs
     // MUST move on before this piece waits for anything: the turn it waits for may be one of its own (the same k-mer twice on a piece).
     uint32_t seen;
     bool polled = false;
+#ifdef FGPU_KO_NO_PREFETCH
+    ko.pf_ord = 0xFFFFFFFFu;
+#endif
     if (ko.pf_ord == ord) seen = uni32(ko.pf_val);
     else { seen = uni32(ld_agent(&ko.kt.hk_turn[e])); polled = true; }
+#ifndef FGPU_KO_NO_PREFETCH
     if (ord + 1 < ko.n_lk) {       // the next occurrence's counter: its load travels with whatever this position loads next
         ko.pf_val = ld_agent(&ko.kt.hk_turn[uni32(ko_occ_lds()[2 * (ord + 1)])]);
         ko.pf_ord = ord + 1;
-    } else {
+    } else
+#endif
+    {
         ko.pf_ord = 0xFFFFFFFFu;
     }
     if (seen != r && !polled) { seen = uni32(ld_agent(&ko.kt.hk_turn[e])); polled = true; }      // (an early look only counts when it shows this piece's rank)
     if (seen != r) {
         ko_flush(ko);
-        ko_wait(&ko.kt.hk_turn[e], r, wc.cnt);
+        ko.wait_acc += ko_wait(&ko.kt.hk_turn[e], r, wc.cnt);
     } else if (polled) {
         ko_flush(ko);
     }
+    KO_STAMP(ko, 2, q);
     KoHold h;
     h.e = e; h.r = r; h.n = 1;
     if (as_cursor) { ko.cur = h; ko.cur_in = 0; }
@@ -1059,7 +1153,7 @@ __device__ __forceinline__ void ko_pass(WalkCtx& wc, uint32_t q_to, bool have_la
     KoState& ko = wc.ko;
     while (ko.done < q_to) {
         if (ko.done >= 64 * KO_CHUNKS) { ko.done = q_to; break; }
-        const uint64_t w = ko_lk_get(ko.done >> 6) >> (ko.done & 63);
+        const uint64_t w = ko_lk_get(ko, ko.done >> 6) >> (ko.done & 63);
         if (!w) {                                   // no lk position in the rest of this word
             const uint32_t next = ((ko.done >> 6) + 1) * 64;
             ko.done = next < q_to ? next : q_to;
@@ -1176,16 +1270,17 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
             }
             if (MODE == WALK_KO) {   // the k-mer's turn first; then the map is asked, and says what a piece walked in file order would see
+                KO_STAMP(wc.ko, 4, q);
                 ko_cursor(wc, q, have_last);
                 const bool potential = in_map;
                 const uint64_t kmq = pv_kmer(v, wc.pl.codes, p0 + q, k);
                 const uint64_t rcq = fd_revcomp(kmq, k);
                 const uint64_t canon = kmq < rcq ? kmq : rcq;
-                ko_lookup(wc, q, canon);
+                ko_lookup(wc, q, canon, have_last, last);
                 in_map = wc.ko.c_found && ((wc.ko.c_present >> ((fwd ? kmq : rcq) == canon ? 0 : 1)) & 1u);
                 ko_slot = in_map ? wc.ko.c_slot : ~0ULL;
                 if (potential && !in_map) {                 // registered, but not in the map (yet): not an event; look again from here
-                    ko_absent(fwd, q >> 6) = ko_absent_get(fwd, q >> 6) | (1ULL << (q & 63));
+                    ko_absent_or(wc.ko, fwd, q >> 6, 1ULL << (q & 63));
                     continue;
                 }
             }
@@ -1229,6 +1324,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                     rr_update(last, last_ext_fwd, d);
                     rr_link(last, last_ext_fwd);
                     rr_store_m<MODE>(last);
+                    if (MODE == WALK_KO) ko_cache_wrote(wc.ko, last, wc.jt.recs);
                 }
                 rr_update(cur, ext_bwd, d);
                 rr_link(cur, ext_bwd);
@@ -1267,9 +1363,11 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         wc.nb_processed += 1;
         wc.nb_skipped += (unsigned long long)(d - 1);
         if (MODE == WALK_KO) {   // the previous junction's record is stored: its k-mer goes on; so do the positions the skip jumps over
+            KO_STAMP(wc.ko, 5, q);
             ko_visited(wc);
             const uint32_t q_next = (uint32_t)(t >> 1);
             ko_pass(wc, q_next < nwin ? q_next : nwin, true);
+            KO_STAMP(wc.ko, 6, q);
         }
     }
 
@@ -1534,9 +1632,6 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
             }
             uint64_t todo = __ballot(mine);
             // the whole wave walks the chunk's pieces of large clusters one after the other, every value wave-uniform (see uni64)
-#ifdef FGPU_KO_LANE0
-            if (fd_lane() == 0)      // (diagnostic build: round 2's shape, one lane walks)
-#endif
             while (todo) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
@@ -1551,13 +1646,29 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
                 ko.cur_q = 0;
                 ko.cur_in = 0;
                 ko.n_pend = 0;
+                ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
                 ko.c_q = ko.pf_ord = 0xFFFFFFFFu;
                 ko.pf_val = 0;
+                ko.wait_acc = 0;
+                ko.stamp_base = nullptr;
+                ko.stamp_n = 0;
+#ifdef FGPU_KO_TRACE
+                const unsigned long long trace_t0 = wall_clock64();
+                ko.stamp_t0 = trace_t0;
+                if (kt.trace && ((piece_seq_base + wd.first_piece + li) & 15) == 0) {
+                    unsigned long long slot = 0;
+                    if (fd_lane() == 0) slot = atomicAdd(&kt.trace[1], 1ULL);
+                    slot = uni64(slot);
+                    if (slot < 4096) ko.stamp_base = kt.trace + (1ULL << 23) + slot * 1024;
+                }
+#endif
                 __builtin_amdgcn_wave_barrier();
                 uint32_t n_lk = 0;
                 for (uint32_t c = 0; c < KO_CHUNKS; c++) {
                     const uint64_t w = c * 64 < pc.y ? uni64(fd_bits_at(pl.lk, pc.x + 64 * c)) & chunk_mask(pc.y, c) : 0ULL;
                     ko_lk(c) = w;
+                    if (c == 0) ko.lk0 = w;
+                    if (c == 1) ko.lk1 = w;
                     n_lk += (uint32_t)__popcll(w);
                     ko_absent(true, c) = 0;
                     ko_absent(false, c) = 0;
@@ -1576,6 +1687,19 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
                 walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
                 ko_finish(wc, pc.y);
                 walked++;
+#ifdef FGPU_KO_TRACE
+                if (kt.trace && fd_lane() == 0) {           // one record per walked piece: number, start, end, ticks waited | lk positions << 48
+                    const unsigned long long at = atomicAdd(&kt.trace[0], 1ULL);
+                    if (at < (1ULL << 21)) {
+                        unsigned long long* rec = kt.trace + 4 + 4 * at;
+                        rec[0] = piece_seq_base + wd.first_piece + li;
+                        rec[1] = trace_t0;
+                        rec[2] = wall_clock64();
+                        rec[3] = ko.wait_acc | ((unsigned long long)n_lk << 48);
+                    }
+                }
+                if (ko.stamp_base && fd_lane() == 0) ko.stamp_base[0] = ((piece_seq_base + wd.first_piece + li) << 16) | (ko.stamp_n < 1020 ? ko.stamp_n : 1020);
+#endif
 #ifdef FGPU_KO_TIMING
                 if (fd_lane() == 0) {
                     atomicAdd(&cnt->par_probe[0], wall_clock64() - tp);
@@ -2192,6 +2316,14 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         kt.occ_rank = kt.occ_entry + ctx->ko_occ_cap;
         kt.occ_next = kt.occ_rank + ctx->ko_occ_cap;
         kt.occ_cap = ctx->ko_occ_cap;
+        kt.trace = nullptr;
+#ifdef FGPU_KO_TRACE
+        if (!ctx->ko_trace.p) {
+            if (int trc = fgpu_ensure(ctx, &ctx->ko_trace, ((1ULL << 23) + 4096 * 1024) * 8)) return trc;
+            FGPU_HIP(hipMemsetAsync(ctx->ko_trace.p, 0, 32, ctx->stream));
+        }
+        kt.trace = (unsigned long long*)ctx->ko_trace.p;
+#endif
         kt.state = ctx->ko_piece;                 // 16 words in front of the per-piece arrays
         kt.piece_base = ctx->ko_piece + 16;
         kt.bad = kt.piece_base + ctx->wmax;

@@ -333,6 +333,15 @@ int fgpu_kernel_times_reset(fgpu_ctx* ctx);
 int fgpu_diag_stream_copy(fgpu_ctx* ctx, uint64_t bytes, int iters, double* gb_per_s);
 /* n_access independent random 32-bit accesses into a table of table_bytes (power of two) per iteration.
  * mode 0 = load, 1 = atomicMin (the load pass' first-set times), 2 = test-then-atomicOr (Bloom::add). */
+/* NS1 as a whole probe CHAIN (round 3): n_items x Bloom::contains (n_hash dependent bit tests, early exit) directly, and with the first
+ * level binned by filter slice and the survivors handed back as a dense list (faucet_amd/csrc/diag.hip).  Times per pass in ms; *equal = 1 iff
+ * both forms give the same answers bit for bit.  Diagnostic: nothing of the path calls it. */
+int fgpu_diag_binned_chain(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_items, uint64_t slice_bytes, int n_hash, int fill_byte, int iters,
+                           double* direct_ms, double* bin_ms, double* first_ms, double* rest_ms, double* survivors_share, int* equal);
+/* Per-piece records of the key-ordered walk (measurement builds with -DFGPU_KO_TRACE; *n = 0 otherwise): 4 words per walked piece --
+ * global piece number, start and end in 10 ns ticks, ticks waited for turns | lk positions << 48.  scripts/ko_trace.py reads them. */
+int fgpu_diag_ko_trace(fgpu_ctx* ctx, uint64_t* out, uint64_t cap_records, uint64_t* n);
+int fgpu_diag_ko_stamps(fgpu_ctx* ctx, uint64_t* out, uint64_t cap_words, uint64_t* n_pieces);   /* per-step stamps of one piece in 16 (-DFGPU_KO_TRACE) */
 int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_access, int mode, int iters, double* access_per_s);
 /* NS1's query-side blocking, measured: n_probes single-bit probes at pseudo-random positions of a table of table_bytes (power of two, <= 512 MiB),
  * once directly (one random load each, what the path's kernels do) and once binned by slice of slice_bytes (LDS-staged buckets per 4096 probes,

@@ -1307,3 +1307,16 @@ def test_table_hint_lets_a_later_shard_prepare_lazily_and_never_enters_the_resul
     with pytest.raises(api.FaucetGpuError, match="before any walk"):
         b.import_hint(hint.data_ptr(), n_hint)
     b.scan_end()
+
+
+@pytest.mark.parametrize("table_mib,slice_mib,n_hash,fill", [(64, 4, 3, 0x29), (8, 1, 2, 0x5A), (64, 8, 1, 0x11), (512, 4, 4, 0x7B)])
+def test_binned_probe_chains_answer_like_direct_ones(table_mib, slice_mib, n_hash, fill):
+    """NS1 (north_star's query-side blocking) as built for measurement in csrc/diag.hip: Bloom::contains chains whose FIRST level is binned by filter
+    slice and probed from the XCD that holds the slice, survivors handed back as a dense list, must give the answers of the direct chains bit
+    for bit (the diagnostic had no correctness test)."""
+    ctx = api.Context(31, 1 << 29, 3)
+    r = ctx.diag_binned_chain(table_mib << 20, 1 << 24, slice_mib << 20, n_hash, fill, 1)
+    assert r["equal"], r
+    want = bin(fill).count("1") / 8
+    assert abs(r["survivors_share"] - want) < 0.01, r      # the first level lets through exactly the items whose first bit is set
+    ctx.close()
