@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <string>
 
+#include <chrono>
 #include <thread>
 
 #include "fgpu_ctx.h"
@@ -165,8 +166,15 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     if (!is_pow2(p->tai) || p->tai < 128) { g_create_error = "tai must be a power of two >= 128"; return FGPU_ERR_ARG; }
     if (p->max_spacer_dist < 1) { g_create_error = "max_spacer_dist must be >= 1"; return FGPU_ERR_ARG; }
     if (p->junction_capacity && !is_pow2(p->junction_capacity)) { g_create_error = "junction_capacity must be a power of two"; return FGPU_ERR_ARG; }
+    // FGPU_CLI_TIMES=1: where the context's creation goes (stderr; the CLI's phase clock shows it as one line)
+    const bool tell = getenv("FGPU_CLI_TIMES") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (tell) fprintf(stderr, "[fgpu_create] %-34s at %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    };
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
+    lap("hipGetDeviceCount (runtime start)");
     if (e != hipSuccess || ndev == 0) {
         g_create_error = std::string("no HIP device: ") + (e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
         return FGPU_ERR_HIP;
@@ -179,6 +187,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         return FGPU_ERR_HIP;
     }
     if ((e = hipSetDevice(p->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return FGPU_ERR_HIP; }
+    lap("device properties, hipSetDevice");
 
     fgpu_ctx* ctx = new fgpu_ctx();
     ctx->prm = *p;
@@ -257,6 +266,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
             (void)hipGetLastError();
         });
     }
+    lap("main stream");
     if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
     if (!rc && (e = hipMalloc(&ctx->counters, sizeof(DevCounters))) != hipSuccess) fail("hipMalloc counters", e);
@@ -269,7 +279,9 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream);
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) fail("initial memset", e);
     }
+    lap("filters allocated and cleared");
     warm.join();   // (before the context can be destroyed)
+    lap("pass-1 code objects, text stream");
     if (rc) {
         fgpu_destroy(ctx);
         return rc;

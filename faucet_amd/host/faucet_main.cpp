@@ -49,6 +49,7 @@ struct Options {   // globals of src/Faucet.h:14-53
     int max_spacer_dist = 100;
     uint64_t batch_reads = 0;         // not a reference flag: > 0 = split records on the host, this many reads per device call
     uint64_t chunk_mb = 64;           // not a reference flag: file text handed to the device per call, records split there
+    uint64_t chunk_bytes = 0;         // = chunk_mb << 20, less for regular files that are smaller (main)
 };
 
 void argument_error() {   // src/Faucet.cpp:50-54
@@ -323,7 +324,7 @@ class BatchSource {
 public:
     BatchSource(const Options& o, const std::string& path)
         : host_(o.batch_reads ? new ReadSource(path, o.fastq) : nullptr),
-          text_(o.batch_reads ? nullptr : new TextSource(path, o.fastq, o.chunk_mb << 20)), batch_reads_(o.batch_reads) {}
+          text_(o.batch_reads ? nullptr : new TextSource(path, o.fastq, o.chunk_bytes)), batch_reads_(o.batch_reads) {}
     ~BatchSource() { delete host_; delete text_; }
     bool is_open() const { return host_ ? host_->is_open() : text_->is_open(); }
     int next(fgpu_ctx* ctx, fgpu_reads* out) {
@@ -408,7 +409,13 @@ struct PairFilter {   // a Bloom used through addPair / containsPair only (utils
     void add_pair(uint64_t k1, uint64_t k2, int k) { add_canon(canonical(k1, k), canonical(k2, k)); }
     float weight() const {   // Bloom::weight, utils/Bloom.cpp:191-203
         long w = 0;
-        for (uint8_t b : bits) w += __builtin_popcount(b);
+        size_t i = 0;
+        for (; i + 8 <= bits.size(); i += 8) {       // a word at a time (the filter of a --no_cleaning run is 8 MiB of zeros: 10 ms byte by byte)
+            uint64_t x;
+            memcpy(&x, &bits[i], 8);
+            w += __builtin_popcountll(x);
+        }
+        for (; i < bits.size(); i++) w += __builtin_popcount(bits[i]);
         return (float)w / (float)tai;
     }
     int dump(const std::string& path) const {   // Bloom::dump, utils/Bloom.cpp:571-578
@@ -660,16 +667,36 @@ int main(int argc, char** argv) {
     if (record_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
     prm.flags |= FGPU_FLAG_KEY_ORDER_FROM_START;   // real genomes have repeats: a few launches per window against a first batch walked by cluster
     if (o.mercy) prm.flags |= FGPU_FLAG_MERCY;
+    // The text buffers are page-locked, and pinning costs time in proportion (2 x 80 MB: ~40 ms beside the context's creation, on the same
+    // driver): input files that are smaller than a chunk -- the reference's own test case is 100 KB -- get buffers of their size.
+    o.chunk_bytes = o.chunk_mb << 20;
+    {
+        uint64_t largest = 0;
+        bool all_regular = true;
+        for (const std::string* f : {&o.read_load_file, &o.read_scan_file}) {
+            struct stat st;
+            if (f->empty()) continue;
+            if (stat(f->c_str(), &st) == 0 && S_ISREG(st.st_mode)) largest = std::max<uint64_t>(largest, (uint64_t)st.st_size);
+            else all_regular = false;
+        }
+        if (all_regular && largest + (1u << 20) < o.chunk_bytes) o.chunk_bytes = ((largest >> 20) + 1) << 20;
+    }
     {
         std::thread pin;   // (joined before anything else can fail or read)
         if (!o.batch_reads && !o.from_junctions)
-            pin = std::thread([&o] { for (int i = 0; i < 2; i++) pinned_slot(i, kTextPad + (o.chunk_mb << 20)); });
+            pin = std::thread([&o] { for (int i = 0; i < 2; i++) pinned_slot(i, kTextPad + o.chunk_bytes); });
         int rc = fgpu_create(&prm, &ctx);
         if (pin.joinable()) pin.join();
         if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(nullptr)); return 2; }
     }
     clk.mark("arguments, sizing, fgpu_create");
     std::vector<uint8_t> bloom_bytes(tai / 8);
+    std::thread bloom_writer;
+    bool bloom_write_failed = false;
+    struct JoinWriter {      // every way out of main waits for the .bloom file to be complete
+        std::thread& t;
+        ~JoinWriter() { if (t.joinable()) t.join(); }
+    } join_writer{bloom_writer};
 
     // ---- pass 1 (load_two_filters, utils/Bloom.cpp:267-350) or -bloom_file (Bloom::load, :580-587)
     if (o.from_bloom) {
@@ -718,10 +745,13 @@ int main(int argc, char** argv) {
         const std::string path = o.file_prefix + ".bloom";       // Bloom::dump, utils/Bloom.cpp:571-578
         FILE* f = fopen(path.c_str(), "wb");
         if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
-        fwrite(bloom_bytes.data(), 1, bloom_bytes.size(), f);
-        fclose(f);
+        // the bytes are in host memory; writing them out (64 MiB - 1 GiB) runs beside pass 2 and is waited for before the process ends
+        bloom_writer = std::thread([f, &bloom_bytes, &bloom_write_failed] {
+            if (fwrite(bloom_bytes.data(), 1, bloom_bytes.size(), f) != bloom_bytes.size()) bloom_write_failed = true;
+            if (fclose(f) != 0) bloom_write_failed = true;
+        });
         printf("bloom dumped \n");
-        clk.mark("bloom download + dump");
+        clk.mark("bloom download (dump beside pass 2)");
     }
     // ---- pair filters (src/Faucet.cpp:266-283): created, and their sizes printed, before --just_load_bloom returns
     PairFilter short_pf, long_pf;
@@ -933,7 +963,9 @@ int main(int argc, char** argv) {
     clk.mark("pair filter weights");
     if (!o.no_cleaning)
         fprintf(stderr, "The contig-graph stage is not part of this build: the load and scan outputs have been written; the reference\n"
-                        "can continue from them (-bloom_file / -junctions_file).\n");
+                        "continues from the same calls through integration/faucet_binding.cpp (INTEGRATION.md).\n");
+    if (bloom_writer.joinable()) bloom_writer.join();      // (_exit below skips destructors)
+    if (bloom_write_failed) { fprintf(stderr, "cannot write %s.bloom\n", o.file_prefix.c_str()); return 2; }
     const int code = o.no_cleaning ? 0 : 3;
     // Every output file is closed and both passes have ended with a synchronised device.  Returning several hundred HBM buffers one by
     // one, unpinning the text buffers and unloading the HIP runtime took 0.15 s of a 0.9 s run and changes nothing the caller can see:

@@ -30,5 +30,5 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     assert r.returncode == 0, r.stderr
     print(f"run {i}: {dt * 1e3:8.1f} ms wall")
     for line in r.stderr.splitlines():
-        if line.startswith("[cli]"):
+        if line.startswith(("[cli]", "[fgpu_create]")):
             print("    " + line)
