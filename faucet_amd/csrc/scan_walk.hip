@@ -111,8 +111,15 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
 }
 
 // a value every lane of the wave holds alike, moved to scalar registers (the key-ordered walk: see the note at `enum { WALK_SEQ ...`)
-__device__ __forceinline__ uint32_t uni32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ uint64_t uni64(uint64_t x) { return ((uint64_t)uni32((uint32_t)(x >> 32)) << 32) | (uint64_t)uni32((uint32_t)x); }
+// -DFGPU_KO_SCALAR: the key-ordered walk on ALL lanes with wave-uniform values (scalar unit); default: on lane 0 (see the note at the enum)
+#ifdef FGPU_KO_SCALAR
+constexpr bool KO_UNIFORM = true;
+#else
+constexpr bool KO_UNIFORM = false;
+#endif
+__device__ __forceinline__ uint32_t bcast32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }   // lane 0's value, always
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return KO_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)x) : x; }
+__device__ __forceinline__ uint64_t uni64(uint64_t x) { return KO_UNIFORM ? ((uint64_t)uni32((uint32_t)(x >> 32)) << 32) | (uint64_t)uni32((uint32_t)x) : x; }
 
 // ---- junction table ---------------------------------------------------------------------------
 // read-only lookup (snapshot kernels): plain loads
@@ -762,7 +769,9 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             // exactness argument of the parallel walk no longer covers this scan.  Rare squared; give up loudly -- the caller
             // repeats the scan with every test evaluated up front (fgpu_scan_set_eager).
             if ((r & 3) && writer<MODE>()) atomicOr(&wc.cnt->error_flags, 4ULL);
-            if (q >= 128 && writer<MODE>()) {   // these words are read from memory (pv_word): publish there
+            // (the walk's own copies are updated under UNIFORM control: as the else-branch of a test of the lane they became lane-dependent in
+            // the compiler's eyes, and with them every plane of the piece -- the whole key-ordered walk fell back to the vector unit)
+            if (q >= 128) { if (writer<MODE>()) {   // these words are read from memory (pv_word): publish there
                 const unsigned long long gm = 1ULL << ((v.p0 + q) & 63);
                 const uint64_t gw = (v.p0 + q) >> 6;
                 if (r & 1) atomicOr((unsigned long long*)&wc.pl.ff[gw], gm);
@@ -772,7 +781,7 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
                 if (r & 16) atomicOr((unsigned long long*)&wc.pl.cb0[gw], gm);
                 if (r & 32) atomicOr((unsigned long long*)&wc.pl.cb1[gw], gm);
                 atomicOr((unsigned long long*)&wc.pl.need[gw], gm);
-            } else if (q < 128) {          // the register copies this walk works from
+            } } else {          // the register copies this walk works from
                 const uint64_t bm = 1ULL << b;
                 if (c == 0) {
                     v.nd0 |= bm;
@@ -1615,7 +1624,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     for (;;) {
         uint32_t ticket = 0;
         if (fd_lane() == 0) ticket = atomicAdd(&kt.state[2], 1u);
-        ticket = uni32(ticket);
+        ticket = bcast32(ticket);
         if ((uint64_t)ticket * KO_TICKET >= wd.n) break;
         for (uint32_t sub = 0; sub < KO_TICKET / 64; sub++) {
             const uint32_t first = ticket * KO_TICKET + sub * 64;
@@ -1658,7 +1667,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
                 if (kt.trace && ((piece_seq_base + wd.first_piece + li) & 15) == 0) {
                     unsigned long long slot = 0;
                     if (fd_lane() == 0) slot = atomicAdd(&kt.trace[1], 1ULL);
-                    slot = uni64(slot);
+                    slot = ((unsigned long long)bcast32((uint32_t)(slot >> 32)) << 32) | bcast32((uint32_t)slot);
                     if (slot < 4096) ko.stamp_base = kt.trace + (1ULL << 23) + slot * 1024;
                 }
 #endif
@@ -1684,8 +1693,10 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
 #ifdef FGPU_KO_TIMING
                 const unsigned long long tp = wall_clock64();
 #endif
-                walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
-                ko_finish(wc, pc.y);
+                if (KO_UNIFORM || fd_lane() == 0) {
+                    walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
+                    ko_finish(wc, pc.y);
+                }
                 walked++;
 #ifdef FGPU_KO_TRACE
                 if (kt.trace && fd_lane() == 0) {           // one record per walked piece: number, start, end, ticks waited | lk positions << 48
