@@ -110,17 +110,6 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// a value every lane of the wave holds alike, moved to scalar registers (the key-ordered walk: see the note at `enum { WALK_SEQ ...`)
-// -DFGPU_KO_SCALAR: the key-ordered walk on ALL lanes with wave-uniform values (scalar unit); default: on lane 0 (see the note at the enum)
-#ifdef FGPU_KO_SCALAR
-constexpr bool KO_UNIFORM = true;
-#else
-constexpr bool KO_UNIFORM = false;
-#endif
-__device__ __forceinline__ uint32_t bcast32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }   // lane 0's value, always
-__device__ __forceinline__ uint32_t uni32(uint32_t x) { return KO_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)x) : x; }
-__device__ __forceinline__ uint64_t uni64(uint64_t x) { return KO_UNIFORM ? ((uint64_t)uni32((uint32_t)(x >> 32)) << 32) | (uint64_t)uni32((uint32_t)x) : x; }
-
 // ---- junction table ---------------------------------------------------------------------------
 // read-only lookup (snapshot kernels): plain loads
 __device__ __forceinline__ uint32_t jt_present_snapshot(const JTable& jt, uint64_t canon) {
@@ -141,18 +130,6 @@ __device__ __forceinline__ bool jt_find_live(const JTable& jt, uint64_t canon, u
         uint64_t w = ld_agent(&jt.keys[s]);
         if (w == J_EMPTY) return false;
         if ((w & J_KEYMASK) == canon) { slot = s; present = (uint32_t)(w >> 62); return true; }
-        s = (s + 1) & jt.mask;
-    }
-    return false;
-}
-
-// the same for the key-ordered walk, whose values are wave-uniform (uni64): every lane asks, the answer lives in scalar registers
-__device__ __forceinline__ bool jt_find_live_u(const JTable& jt, uint64_t canon, uint64_t& slot, uint32_t& present) {
-    uint64_t s = fd_mix(canon) & jt.mask;
-    for (uint64_t n = 0; n <= jt.mask; n++) {
-        const uint64_t wu = uni64(ld_agent(&jt.keys[s]));
-        if (wu == J_EMPTY) return false;
-        if ((wu & J_KEYMASK) == canon) { slot = s; present = (uint32_t)(wu >> 62); return true; }
         s = (s + 1) & jt.mask;
     }
     return false;
@@ -441,8 +418,6 @@ struct PieceView {
     uint64_t lk0, lk1;             // positions holding a registered candidate k-mer (where created keys can sit)
     uint64_t nd0, nd1;             // positions whose flags the pure stage evaluated (need plane)
     uint64_t cbase;                // stream position of the first base held in cw0 (multiple of 32)
-    uint32_t col;                  // column of the piece's code words in LDS: the lane, or 0 when the whole wave walks ONE piece (WALK_KO)
-    bool uni;                      // WALK_KO: every value of the walk is wave-uniform and is kept in scalar registers (see uni64)
 };
 
 // ---- the key-ordered walk of large clusters (k_walk_ko) ------------------------------------------------------------------------------------
@@ -485,11 +460,6 @@ __device__ __forceinline__ uint64_t* ko_masks() {
 }
 __device__ __forceinline__ uint64_t& ko_lk(uint32_t c) { return ko_masks()[c]; }
 __device__ __forceinline__ uint64_t& ko_absent(bool fwd, uint32_t c) { return ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]; }
-// the piece's occurrences (entry and rank of its lk positions, in position order): fetched by all lanes at once before the walk starts
-__device__ __forceinline__ uint32_t* ko_occ_lds() {
-    __shared__ uint32_t s_occ[2 * 64 * KO_CHUNKS];
-    return s_occ;
-}
 
 struct KoHold {   // a k-mer whose turn this piece holds: entry, rank of its first occurrence here, occurrences merged into the hold
     uint32_t e, r, n;
@@ -503,38 +473,11 @@ struct KoState {
     KoHold last, cur, fake; // held: the last junction's k-mer (until its record is stored), the position under the cursor, the fake candidate
     uint32_t cur_q;         // the position under the cursor
     int cur_in;             // which hold carries the cursor's k-mer: 0 cur, 1 last, 2 fake (the same k-mer twice on one piece shares a hold)
-    // turns given back but not stored yet (ko_give / ko_flush): entry and the counter's new value
-    uint32_t n_pend, pe0, pv0, pe1, pv1, pe2, pv2, pe3, pv3;
-    // what the map held for the k-mer of position c_q when this piece took its turn (ko_lookup): while the turn is held nobody else changes the
-    // k-mer's key word or records, so the second facing of the position needs no second look -- key word and BOTH orientations' records of the
-    // home slot come in one round trip
-    uint32_t c_q, c_present;
-    bool c_found;
-    uint64_t c_slot, c_lo0, c_hi0, c_lo1, c_hi1;
-    // the turn counter of the NEXT lk position, requested while this one is being visited (it is only believed when it already shows this
-    // piece's rank: from then on nobody else moves it)
-    uint32_t pf_ord, pf_val, n_lk;     // (pf_val is what the load returned in each lane: made uniform when it is looked at)
     unsigned long long wait_acc;       // -DFGPU_KO_TRACE: ticks (10 ns) this piece has spent waiting for turns
     unsigned long long* stamp_base;    // -DFGPU_KO_TRACE: where this piece leaves its per-step time stamps (nullptr: it does not)
     unsigned long long stamp_t0;
     uint32_t stamp_n;
-    // the first 128 windows' lk / absent words in registers (a 100-base read has 70): an LDS read costs a single wave ~100 cycles of
-    // exposed latency, and the search for the next junction reads six of them per step (1.1 us of a visit's 3-4, scripts/ko_trace.py)
-    uint64_t lk0, lk1, aF0, aF1, aB0, aB1;
 };
-// reads of the piece's position masks: registers for the first two words, LDS (every lane reads the same word; the value goes on in scalar
-// registers) beyond
-__device__ __forceinline__ uint64_t ko_lk_get(const KoState& ko, uint32_t c) { return c == 0 ? ko.lk0 : c == 1 ? ko.lk1 : uni64(ko_masks()[c]); }
-__device__ __forceinline__ uint64_t ko_absent_get(const KoState& ko, bool fwd, uint32_t c) {
-    if (c == 0) return fwd ? ko.aF0 : ko.aB0;
-    if (c == 1) return fwd ? ko.aF1 : ko.aB1;
-    return uni64(ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]);
-}
-__device__ __forceinline__ void ko_absent_or(KoState& ko, bool fwd, uint32_t c, uint64_t bit) {
-    if (c == 0) { if (fwd) ko.aF0 |= bit; else ko.aB0 |= bit; }
-    else if (c == 1) { if (fwd) ko.aF1 |= bit; else ko.aB1 |= bit; }
-    else ko_absent(fwd, c) = uni64(ko_masks()[(fwd ? 1 : 2) * KO_CHUNKS + c]) | bit;
-}
 
 struct WalkCtx {
     Planes pl;
@@ -555,19 +498,9 @@ struct WalkCtx {
 // per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
 // COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
 enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3 };
-// The key-ordered walk gives a whole wave to ONE piece.  Round 2 ran the walk on lane 0 with 63 lanes masked off: every step of its long,
-// branchy, 64-bit integer instruction stream went through the vector ALU at one instruction per >= 4 cycles (a 64-bit shift, popcount or
-// find-first-set is several of them), and that stream -- not memory -- was 5/6 of a piece's 0.4 ms.  Round 3 runs the same
-// code on ALL lanes with wave-uniform values: whatever comes out of memory is passed through v_readfirstlane (uni32 / uni64), so the
-// compiler keeps the walk's state in scalar registers and the arithmetic on the scalar ALU (native 64-bit shift / and / or / bit count /
-// find-first-set / bit reverse, one instruction each); stores and atomics are issued by lane 0 alone.  Same results by construction: every
-// lane computes what lane 0 computed before.
-template <int MODE> __device__ __forceinline__ uint64_t uq(uint64_t x) { return MODE == WALK_KO ? uni64(x) : x; }
-template <int MODE> __device__ __forceinline__ uint32_t ud(uint32_t x) { return MODE == WALK_KO ? uni32(x) : x; }
-template <int MODE> __device__ __forceinline__ bool writer() { return MODE != WALK_KO || (threadIdx.x & 63) == 0; }
 #ifdef FGPU_KO_TIMING
 #define KO_T0() const unsigned long long ko_t0__ = wall_clock64()
-#define KO_T1(cnt, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&(cnt)->ko_time[i], wall_clock64() - ko_t0__); } while (0)
+#define KO_T1(cnt, i) atomicAdd(&(cnt)->ko_time[i], wall_clock64() - ko_t0__)
 #else
 #define KO_T0() do {} while (0)
 #define KO_T1(cnt, i) do {} while (0)
@@ -589,8 +522,7 @@ __device__ __forceinline__ uint64_t pv_word(const PieceView& v, uint64_t r0, uin
     // (walk_fill_flags) and a plain load could be served from a stale L1 line
     const uint64_t p = v.p0 + 64ULL * c;
     const int o = (int)(p & 63);
-    uint64_t lo = ld_agent(&plane[p >> 6]), hi = ld_agent(&plane[(p >> 6) + 1]);
-    if (v.uni) { lo = uni64(lo); hi = uni64(hi); }
+    const uint64_t lo = ld_agent(&plane[p >> 6]), hi = ld_agent(&plane[(p >> 6) + 1]);
     return ((lo >> o) | ((hi << 1) << (63 - o))) & chunk_mask(v.nwin, c);
 }
 
@@ -600,40 +532,40 @@ __device__ __forceinline__ uint64_t pv_word(const PieceView& v, uint64_t r0, uin
 // The walk kernels run blocks of one wave.
 __device__ __forceinline__ uint64_t* pv_codes() {
     __shared__ uint64_t s_codes[6 * 64];
-    return s_codes;
+    return s_codes + (threadIdx.x & 63);
 }
 
-template <int MODE>
 __device__ __forceinline__ void pv_load(PieceView& v, const Planes& pl, uint64_t p0, uint32_t nwin) {
     v.p0 = p0;
     v.nwin = nwin;
-    v.uni = MODE == WALK_KO;
-    v.col = MODE == WALK_KO ? 0u : (threadIdx.x & 63);
     const uint64_t m0 = chunk_mask(nwin, 0), m1 = chunk_mask(nwin, 1);
     const uint64_t p1 = p0 + 64;
     // one burst of independent loads (a piece's second word is skipped when the piece has at most 64 windows)
-#define PV2(a0, a1, plane) a0 = uq<MODE>(fd_bits_at(plane, p0) & m0); a1 = uq<MODE>(fd_bits_at(plane, p1) & m1)
-    PV2(v.inF0, v.inF1, pl.inF);   PV2(v.inB0, v.inB1, pl.inB);
-    PV2(v.fF0, v.fF1, pl.ff);      PV2(v.fB0, v.fB1, pl.fb);
-    PV2(v.c0F0, v.c0F1, pl.cf0);   PV2(v.c1F0, v.c1F1, pl.cf1);
-    PV2(v.c0B0, v.c0B1, pl.cb0);   PV2(v.c1B0, v.c1B1, pl.cb1);
+    v.inF0 = fd_bits_at(pl.inF, p0) & m0;   v.inF1 = fd_bits_at(pl.inF, p1) & m1;
+    v.inB0 = fd_bits_at(pl.inB, p0) & m0;   v.inB1 = fd_bits_at(pl.inB, p1) & m1;
+    v.fF0 = fd_bits_at(pl.ff, p0) & m0;     v.fF1 = fd_bits_at(pl.ff, p1) & m1;
+    v.fB0 = fd_bits_at(pl.fb, p0) & m0;     v.fB1 = fd_bits_at(pl.fb, p1) & m1;
+    v.c0F0 = fd_bits_at(pl.cf0, p0) & m0;   v.c0F1 = fd_bits_at(pl.cf0, p1) & m1;
+    v.c1F0 = fd_bits_at(pl.cf1, p0) & m0;   v.c1F1 = fd_bits_at(pl.cf1, p1) & m1;
+    v.c0B0 = fd_bits_at(pl.cb0, p0) & m0;   v.c0B1 = fd_bits_at(pl.cb0, p1) & m1;
+    v.c1B0 = fd_bits_at(pl.cb1, p0) & m0;   v.c1B1 = fd_bits_at(pl.cb1, p1) & m1;
     v.xF0 = v.xF1 = v.xB0 = v.xB1 = 0;
-    PV2(v.lk0, v.lk1, pl.lk);      PV2(v.nd0, v.nd1, pl.need);
-#undef PV2
+    v.lk0 = fd_bits_at(pl.lk, p0) & m0;     v.lk1 = fd_bits_at(pl.lk, p1) & m1;
+    v.nd0 = fd_bits_at(pl.need, p0) & m0;   v.nd1 = fd_bits_at(pl.need, p1) & m1;
     v.cbase = p0 & ~31ULL;
     const uint64_t* cw = pl.codes + (v.cbase >> 5);   // padded: reading 6 words from any piece start stays inside the buffer
-    uint64_t* l = pv_codes() + v.col;
+    uint64_t* l = pv_codes();
     l[0 * 64] = cw[0]; l[1 * 64] = cw[1]; l[2 * 64] = cw[2]; l[3 * 64] = cw[3]; l[4 * 64] = cw[4]; l[5 * 64] = cw[5];
 }
 
 __device__ __forceinline__ uint64_t pv_cw(const PieceView& v, uint32_t w) {
-    const uint64_t x = pv_codes()[w * 64 + v.col];
-    return v.uni ? uni64(x) : x;
+    (void)v;
+    return pv_codes()[w * 64];
 }
 // k-mer / base at stream position p: from the register copy when it covers p, else from memory
 __device__ __forceinline__ uint64_t pv_kmer(const PieceView& v, const uint64_t* codes, uint64_t p, int k) {
     const uint64_t rel = p - v.cbase;
-    if (rel + (uint64_t)k > 160) { const uint64_t x = fd_kmer_at(codes, p, k); return v.uni ? uni64(x) : x; }
+    if (rel + (uint64_t)k > 160) return fd_kmer_at(codes, p, k);
     const uint32_t w = (uint32_t)(rel >> 5);
     const int o = (int)(rel & 31) * 2;
     const uint64_t hi = pv_cw(v, w), lo = pv_cw(v, w + 1);
@@ -641,7 +573,7 @@ __device__ __forceinline__ uint64_t pv_kmer(const PieceView& v, const uint64_t* 
 }
 __device__ __forceinline__ int pv_base(const PieceView& v, const uint64_t* codes, uint64_t p) {
     const uint64_t rel = p - v.cbase;   // p >= p0 - 1; p0 - 1 can precede cbase only when p0 is a multiple of 32
-    if (p < v.cbase || rel >= 192) { const int x = fd_base_at(codes, p); return v.uni ? (int)uni32((uint32_t)x) : x; }
+    if (p < v.cbase || rel >= 192) return fd_base_at(codes, p);
     return (int)((pv_cw(v, (uint32_t)(rel >> 5)) >> (62 - 2 * (int)(rel & 31))) & 3);
 }
 
@@ -689,9 +621,8 @@ __device__ __forceinline__ void created_bits(const WalkCtx& wc, const PieceView&
 template <int MODE>
 __device__ __forceinline__ void in_map_words(const WalkCtx& wc, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
     if (MODE == WALK_KO) {   // what the map holds is asked when the k-mer's turn has come: until then every registered position may be in it
-        const uint64_t lkw = c < KO_CHUNKS ? ko_lk_get(wc.ko, c) : 0ULL;
-        mF = c < KO_CHUNKS ? (lkw & ~ko_absent_get(wc.ko, true, c)) : 0ULL;
-        mB = c < KO_CHUNKS ? (lkw & ~ko_absent_get(wc.ko, false, c)) : 0ULL;
+        mF = c < KO_CHUNKS ? (ko_lk(c) & ~ko_absent(true, c)) : 0ULL;
+        mB = c < KO_CHUNKS ? (ko_lk(c) & ~ko_absent(false, c)) : 0ULL;
         return;
     }
     mF = pv_word(v, v.inF0, v.inF1, wc.pl.inF, c);
@@ -761,17 +692,15 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             const uint32_t b = (uint32_t)__builtin_ctzll(missing);
             missing &= missing - 1;
             const uint32_t q = c * 64 + b;
-            const uint32_t r = ud<MODE>(walk_fill_flags(wc.pl.codes, wc.bloom, wc.fp, v.p0 + q, q + 1 < v.nwin, q > 0));
+            const uint32_t r = walk_fill_flags(wc.pl.codes, wc.bloom, wc.fp, v.p0 + q, q + 1 < v.nwin, q > 0);
             wc.n_filled++;
             any = true;
             // A junction test that comes out TRUE here is a place where this piece may create a junction, and the window's
             // dependency clusters were built without knowing that (only previewed flags are registered as candidates): the
             // exactness argument of the parallel walk no longer covers this scan.  Rare squared; give up loudly -- the caller
             // repeats the scan with every test evaluated up front (fgpu_scan_set_eager).
-            if ((r & 3) && writer<MODE>()) atomicOr(&wc.cnt->error_flags, 4ULL);
-            // (the walk's own copies are updated under UNIFORM control: as the else-branch of a test of the lane they became lane-dependent in
-            // the compiler's eyes, and with them every plane of the piece -- the whole key-ordered walk fell back to the vector unit)
-            if (q >= 128) { if (writer<MODE>()) {   // these words are read from memory (pv_word): publish there
+            if (r & 3) atomicOr(&wc.cnt->error_flags, 4ULL);
+            if (q >= 128) {   // these words are read from memory (pv_word): publish there
                 const unsigned long long gm = 1ULL << ((v.p0 + q) & 63);
                 const uint64_t gw = (v.p0 + q) >> 6;
                 if (r & 1) atomicOr((unsigned long long*)&wc.pl.ff[gw], gm);
@@ -781,7 +710,7 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
                 if (r & 16) atomicOr((unsigned long long*)&wc.pl.cb0[gw], gm);
                 if (r & 32) atomicOr((unsigned long long*)&wc.pl.cb1[gw], gm);
                 atomicOr((unsigned long long*)&wc.pl.need[gw], gm);
-            } } else {          // the register copies this walk works from
+            } else {          // the register copies this walk works from
                 const uint64_t bm = 1ULL << b;
                 if (c == 0) {
                     v.nd0 |= bm;
@@ -828,34 +757,10 @@ __device__ __forceinline__ void rr_add_cov(RecRegs& r, int nuc) {               
 __device__ __forceinline__ void rr_link(RecRegs& r, int idx) { rr_set(r, 9, rr_get(r, 9) | (1u << idx)); }
 __device__ __forceinline__ void rr_store(const RecRegs& r) { r.addr[0] = r.lo; r.addr[1] = r.hi; }
 // the key-ordered walk hands records from thread to thread inside one launch: 8-byte agent-scope accesses on both sides
-__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) {
-#ifdef FGPU_KO_ONE_XCD
-    // Every wave of the key-ordered walk runs on ONE XCD (the others leave at once, k_walk_ko): what one piece hands to the next stays in that
-    // XCD's L2 -- a plain store keeps the line there, and the agent-scope (sc1) loads on the other side bypass the L1 and are served by the
-    // L2.  An sc1 store drops the line, and the next piece's load then goes to memory (~2 us instead of ~0.3: measured, 6 us per lk position).
-    *(volatile uint64_t*)p = v;
-#else
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ void st_turn(uint32_t* p, uint32_t v) {
-#ifdef FGPU_KO_ONE_XCD
-    *(volatile uint32_t*)p = v;
-#else
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int MODE> __device__ __forceinline__ void rr_store_m(const RecRegs& r) {
-    if (MODE == WALK_KO) { if (fd_lane() == 0) { st_agent(&r.addr[0], r.lo); st_agent(&r.addr[1], r.hi); } }
+    if (MODE == WALK_KO) { st_agent(&r.addr[0], r.lo); st_agent(&r.addr[1], r.hi); }
     else rr_store(r);
-}
-// WALK_KO: the copy of a k-mer's two records kept while its turn is held (ko_lookup) follows what this piece itself writes to them -- the same
-// k-mer twice on a piece (tandem repeats) means a record can be changed between the look-up and the visit that reads the copy
-__device__ __forceinline__ void ko_cache_wrote(KoState& ko, const RecRegs& r, const uint8_t* recs) {
-    if (!ko.c_found) return;
-    const uint64_t* a0 = (const uint64_t*)(recs + ko.c_slot * 32);
-    if (r.addr == a0) { ko.c_lo0 = r.lo; ko.c_hi0 = r.hi; }
-    else if (r.addr == a0 + 2) { ko.c_lo1 = r.lo; ko.c_hi1 = r.hi; }
 }
 
 // find or create the junction keyed by the oriented k-mer `key`; the record comes back in registers
@@ -869,9 +774,10 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     if (MODE == WALK_KO && known_slot != ~0ULL) {   // the key-ordered walk has just found this junction in the map: no second probe
         KO_T0();
         out.addr = (uint64_t*)(wc.jt.recs + (known_slot * 2 + orient) * 16);
-        out.lo = orient ? wc.ko.c_lo1 : wc.ko.c_lo0;          // fetched with the key word when the turn was taken (ko_lookup)
-        out.hi = orient ? wc.ko.c_hi1 : wc.ko.c_hi0;
+        out.lo = ld_agent(&out.addr[0]);
+        out.hi = ld_agent(&out.addr[1]);
         wc.created_now = false;
+        if (out.lo == 0xFFFFFFFFFFFFFFF1ULL) return false;
         KO_T1(wc.cnt, 3);
         return true;
     }
@@ -879,19 +785,9 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     // almost always in its home slot, so an event costs one memory round trip instead of two
     const uint64_t home = fd_mix(canon) & wc.jt.mask;
     const uint64_t* spec = (const uint64_t*)(wc.jt.recs + (home * 2 + orient) * 16);
-    const uint64_t w_first = uq<MODE>(ld_agent(&wc.jt.keys[home]));
-    const uint64_t spec_lo = MODE == WALK_KO ? uni64(ld_agent(&spec[0])) : spec[0], spec_hi = MODE == WALK_KO ? uni64(ld_agent(&spec[1])) : spec[1];
-    if (MODE == WALK_KO) {   // one claim per wave: lane 0 probes and claims, every lane learns the outcome
-        uint64_t s_v = 0;
-        uint32_t p_v = 0, ok_v = 0;
-        if (fd_lane() == 0) ok_v = jt_find_or_claim(wc.jt, canon, home, w_first, s_v, p_v, wc.cnt) ? 1u : 0u;
-        slot = uni64(s_v);
-        present = uni32(p_v);
-        if (!uni32(ok_v)) {
-            if (fd_lane() == 0) atomicOr(&wc.cnt->error_flags, 1ULL);
-            return false;
-        }
-    } else if (!jt_find_or_claim(wc.jt, canon, home, w_first, slot, present, wc.cnt)) {
+    const uint64_t w_first = ld_agent(&wc.jt.keys[home]);
+    const uint64_t spec_lo = MODE == WALK_KO ? ld_agent(&spec[0]) : spec[0], spec_hi = MODE == WALK_KO ? ld_agent(&spec[1]) : spec[1];
+    if (!jt_find_or_claim(wc.jt, canon, home, w_first, slot, present, wc.cnt)) {
         atomicOr(&wc.cnt->error_flags, 1ULL);
         return false;
     }
@@ -899,29 +795,21 @@ __device__ __forceinline__ bool junction_get(WalkCtx& wc, uint64_t key, uint64_t
     wc.created_now = false;
     if (!((present >> orient) & 1u)) {   // JunctionMap::createJunction, JunctionMap.cpp:567-570
         wc.created_now = true;
+        atomicOr(&wc.pl.cr[pos >> 6], 1ULL << (pos & 63));   // later windows (and the next batch) register this key: their snapshot cannot know it
         out.lo = out.hi = 0;
-        if (MODE == WALK_KO) {          // (the piece still holds the k-mer's turn: the second facing of the position reads this, not the table)
-            wc.ko.c_found = true;
-            wc.ko.c_slot = slot;
-            wc.ko.c_present |= 1u << orient;
-            if (orient) wc.ko.c_lo1 = wc.ko.c_hi1 = 0; else wc.ko.c_lo0 = wc.ko.c_hi0 = 0;
-        }
-        if (writer<MODE>()) {
-            atomicOr(&wc.pl.cr[pos >> 6], 1ULL << (pos & 63));   // later windows (and the next batch) register this key: their snapshot cannot know it
-            if (MODE == WALK_KO) st_agent(&wc.jt.stamps[slot * 2 + orient], stamp);
-            else wc.jt.stamps[slot * 2 + orient] = stamp;
-            atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
-            // presence filter in front of the table (phase A of later windows tests it before probing)
-            const uint64_t hb = jt_filter_bit(wc.jt, canon);
-            atomicOr(&wc.jt.filter[hb >> 5], 1u << (hb & 31));
-        }
+        if (MODE == WALK_KO) st_agent(&wc.jt.stamps[slot * 2 + orient], stamp);
+        else wc.jt.stamps[slot * 2 + orient] = stamp;
+        atomicOr((unsigned long long*)&wc.jt.keys[slot], 1ULL << (62 + orient));
+        // presence filter in front of the table (phase A of later windows tests it before probing)
+        const uint64_t hb = jt_filter_bit(wc.jt, canon);
+        atomicOr(&wc.jt.filter[hb >> 5], 1u << (hb & 31));
         wc.n_created++;
     } else if (slot == home) {
         out.lo = spec_lo;
         out.hi = spec_hi;
     } else {
-        out.lo = MODE == WALK_KO ? uni64(ld_agent(&out.addr[0])) : out.addr[0];
-        out.hi = MODE == WALK_KO ? uni64(ld_agent(&out.addr[1])) : out.addr[1];
+        out.lo = MODE == WALK_KO ? ld_agent(&out.addr[0]) : out.addr[0];
+        out.hi = MODE == WALK_KO ? ld_agent(&out.addr[1]) : out.addr[1];
     }
     return true;
 }
@@ -960,45 +848,50 @@ __device__ __forceinline__ void rec_link_atomic(const RecRegs& seen, int idx) {
 }
 
 
+// -DFGPU_KO_TRACE: one piece in 16 also leaves a time stamp at every step of every position it deals with (kt.trace + 2^23 words on:
+// 1024 words per stamped piece: [0] piece << 16 | stamps, then {code << 56 | q << 40 | ticks since the piece's start}; scripts/ko_trace.py)
+#ifdef FGPU_KO_TRACE
+#define KO_STAMP(ko, code, q)                                                                                                         \
+    do {                                                                                                                              \
+        if ((ko).stamp_base && (ko).stamp_n < 1020)                                                                                    \
+            (ko).stamp_base[1 + (ko).stamp_n] = ((unsigned long long)(code) << 56) | ((unsigned long long)(q) << 40) |                 \
+                                                ((wall_clock64() - (ko).stamp_t0) & 0xFFFFFFFFFFULL);                                  \
+        if ((ko).stamp_base) (ko).stamp_n++;                                                                                          \
+    } while (0)
+#else
+#define KO_STAMP(ko, code, q) do {} while (0)
+#endif
 // ---- turn taking of the key-ordered walk (see KoTables) ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ko_ordinal(const KoState& ko, uint32_t q) {   // lk positions of the piece below q
     (void)ko;
     uint32_t n = 0;
-    for (uint32_t c = 0; c < (q >> 6); c++) n += (uint32_t)__popcll(ko_lk_get(ko, c));
-    return n + (uint32_t)__popcll(ko_lk_get(ko, q >> 6) & ((1ULL << (q & 63)) - 1));
+    for (uint32_t c = 0; c < (q >> 6); c++) n += (uint32_t)__popcll(ko_lk(c));
+    return n + (uint32_t)__popcll(ko_lk(q >> 6) & ((1ULL << (q & 63)) - 1));
 }
-__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { return ((ko_lk_get(ko, q >> 6) >> (q & 63)) & 1ULL) != 0; }
+__device__ __forceinline__ bool ko_is_lk(const KoState& ko, uint32_t q) { (void)ko; return ((ko_lk(q >> 6) >> (q & 63)) & 1ULL) != 0; }
 __device__ __noinline__ unsigned long long ko_wait(const uint32_t* turn, uint32_t r, DevCounters* cnt) {
     unsigned spins = 0;
     unsigned long long t0 = 0;
 #ifdef FGPU_KO_TRACE
+    if (ld_agent(turn) == r) return 0;            // (only what is spent AFTER a first look that found the turn elsewhere counts as waiting)
     const unsigned long long t_in = wall_clock64();
 #endif
 #ifdef FGPU_KO_TIMING
     const unsigned long long tw = wall_clock64();
-    if (uni32(ld_agent(turn)) != r) {
-        while (uni32(ld_agent(turn)) != r) __builtin_amdgcn_s_sleep(1);
-        if (fd_lane() == 0) {
-            atomicAdd(&cnt->par_probe[1], wall_clock64() - tw);
-            atomicAdd(&cnt->par_probe[3], 1ULL);
-        }
+    if (ld_agent(turn) != r) {
+        while (ld_agent(turn) != r) __builtin_amdgcn_s_sleep(1);
+        atomicAdd(&cnt->par_probe[1], wall_clock64() - tw);
+        atomicAdd(&cnt->par_probe[3], 1ULL);
     }
     return 0;
 #endif
-    // A piece waits about once, and then for a long time (milliseconds: the pieces before it on a repeat), while hundreds of waves wait on the
-    // counters of the same few hot k-mers: polls every ~1 us queue up in those L2 channels in front of the loads and stores of the pieces that
-    // ARE walking.  So the wait backs off (FGPU_KO_SLEEP: s_sleep units of 64 cycles per poll after the first few).
-#ifndef FGPU_KO_SLEEP
-#define FGPU_KO_SLEEP 32
-#endif
-    while (uni32(ld_agent(turn)) != r) {
-        if (spins < 4) __builtin_amdgcn_s_sleep(1);
-        else __builtin_amdgcn_s_sleep(FGPU_KO_SLEEP);
-        if ((++spins & 255u) == 0) {   // a turn that never comes is a bug, not a state to wait in: say so once and let every piece run out
-            if (uni64(ld_agent((const uint64_t*)&cnt->error_flags)) & 8ULL) break;
+    while (ld_agent(turn) != r) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095u) == 0) {   // a turn that never comes is a bug, not a state to wait in: say so once and let every piece run out
+            if (ld_agent((const uint64_t*)&cnt->error_flags) & 8ULL) break;
             const unsigned long long now = wall_clock64();          // constant 100 MHz
             if (!t0) t0 = now;
-            else if (now - t0 > KO_WAIT_LIMIT_TICKS) { if (fd_lane() == 0) atomicOr(&cnt->error_flags, 8ULL); break; }
+            else if (now - t0 > KO_WAIT_LIMIT_TICKS) { atomicOr(&cnt->error_flags, 8ULL); break; }
         }
     }
     // no cache invalidate: everything one piece hands to the next (turn counters, key words, records) is read with agent-scope loads
@@ -1009,102 +902,21 @@ __device__ __noinline__ unsigned long long ko_wait(const uint32_t* turn, uint32_
 #endif
 }
 __device__ __forceinline__ DevCounters* ko_cnt(const KoState& ko) { return ko.cnt; }
-// A visit of the key-ordered walk is a chain of DEPENDENT memory round trips (occurrence, turn counter, key word, record, and the
-// acknowledgement of the record's store before the turn may move on): measured, those ~5 x 130 ns are the 0.7 us a visit takes, not its
-// instructions (round 3: the walk on the scalar unit instead of one vector lane changed the window time by 3 %).  Two of them are taken off
-// the path: the occurrences come from LDS (fetched by all lanes before the walk), and a turn that is given back is only NOTED here and
-// stored by ko_flush at the next point where the wave has just waited for loads anyway -- by then the earlier stores have long been
-// acknowledged, so the release costs no round trip of its own.
-// Release order is unchanged: records and stamps are stored with agent-scope (write-through, sc1) stores and key words / planes change by
-// device-scope atomics; ko_flush waits until every one of them has been acknowledged (gfx950 counts stores and atomics in vmcnt), then moves
-// the counters.  (A workgroup-scope fence alone emits NO wait on this target -- ADVICE r2 -- and an agent-scope release fence would add a
-// write-back of the whole L2, which nothing here needs: no plain store is shared.)
-__device__ __forceinline__ void ko_flush(KoState& ko) {
-    if (!ko.n_pend) return;
-    KO_T0();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // compiler barrier: no store may sink below the counters'
-#ifndef FGPU_KO_NO_WAITCNT
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-    if (fd_lane() == 0) {
-        st_turn(&ko.kt.hk_turn[ko.pe0], ko.pv0);
-        if (ko.n_pend > 1) st_turn(&ko.kt.hk_turn[ko.pe1], ko.pv1);
-        if (ko.n_pend > 2) st_turn(&ko.kt.hk_turn[ko.pe2], ko.pv2);
-        if (ko.n_pend > 3) st_turn(&ko.kt.hk_turn[ko.pe3], ko.pv3);
+// the k-mer's turn goes to its next occurrence; whatever this piece stored is visible before the counter moves
+__device__ __forceinline__ void ko_give(const KoState& ko, KoHold& h) {
+    // records and stamps are stored with agent-scope (write-through, sc1) stores and key words / planes change by device-scope atomics, so the
+    // release is: wait until every one of them has been acknowledged (gfx950 counts stores and atomics in vmcnt), then move the counter.  A
+    // workgroup-scope fence alone emits NO wait on this target (the turn store followed the record stores with nothing in between: ADVICE r2);
+    // an agent-scope release fence would add a write-back of the whole L2 (buffer_wbl2), which nothing here needs: no plain store is shared.
+    {
+        KO_T0();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // compiler barrier: no store may sink below the counter's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ko.kt.hk_turn[h.e], h.r + h.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        KO_T1(ko_cnt(ko), 1);
     }
-    ko.n_pend = 0;
-    KO_T1(ko_cnt(ko), 1);
-}
-// -DFGPU_KO_TRACE: one piece in 16 also leaves a time stamp at every step of every position it deals with (kt.trace + 2^23 words on:
-// 1024 words per stamped piece: [0] n, then {code << 56 | q << 40 | ticks since the piece's start})
-#ifdef FGPU_KO_TRACE
-#define KO_STAMP(ko, code, q)                                                                                                         \
-    do {                                                                                                                              \
-        if ((ko).stamp_base && (ko).stamp_n < 1020 && (threadIdx.x & 63) == 0) {                                                       \
-            (ko).stamp_base[1 + (ko).stamp_n] = ((unsigned long long)(code) << 56) | ((unsigned long long)(q) << 40) |                 \
-                                                ((wall_clock64() - (ko).stamp_t0) & 0xFFFFFFFFFFULL);                                  \
-        }                                                                                                                             \
-        if ((ko).stamp_base) (ko).stamp_n++;                                                                                          \
-    } while (0)
-#else
-#define KO_STAMP(ko, code, q) do {} while (0)
-#endif
-// the k-mer's turn goes to its next occurrence (stored by the next ko_flush: before this piece waits for any turn, and when it ends)
-__device__ __forceinline__ void ko_give(KoState& ko, KoHold& h) {
-    if (ko.n_pend == 4) ko_flush(ko);
-    // (a shift register, not "slot n_pend": the compiler turns a chain of stores to consecutive members picked by a run-time value into ONE
-    // indexed store, and a struct that is indexed at run time lives in scratch memory -- all of WalkCtx did, 344 scratch loads in the walk)
-    ko.pe3 = ko.pe2; ko.pv3 = ko.pv2;
-    ko.pe2 = ko.pe1; ko.pv2 = ko.pv1;
-    ko.pe1 = ko.pe0; ko.pv1 = ko.pv0;
-    ko.pe0 = h.e;
-    ko.pv0 = h.r + h.n;
-    ko.n_pend++;
     h.n = 0;
-#ifdef FGPU_KO_EAGER_GIVE
-    ko_flush(ko);          // (measurement build: every turn moves on at once, with a wait of its own)
-#endif
 }
-// the map's answer for the k-mer at position q (turn held): found?, slot, presence bits, both records; one round trip when the key sits in its
-// home slot (the table is kept below a quarter full)
-__device__ __forceinline__ void ko_lookup(WalkCtx& wc, uint32_t q, uint64_t canon, bool have_last, const RecRegs& last) {
-    KoState& ko = wc.ko;
-#ifndef FGPU_KO_NO_CACHE
-    if (ko.c_q == q) return;
-#endif
-    KO_T0();
-    const JTable& jt = wc.jt;
-    uint64_t s = fd_mix(canon) & jt.mask;
-    const uint64_t* rp = (const uint64_t*)(jt.recs + s * 32);
-    uint64_t w = ld_agent(&jt.keys[s]);
-    uint64_t a0 = ld_agent(&rp[0]), a1 = ld_agent(&rp[1]), a2 = ld_agent(&rp[2]), a3 = ld_agent(&rp[3]);
-    w = uni64(w);
-    ko.c_q = q;
-    ko.c_found = false;
-    ko.c_present = 0;
-    ko.c_slot = 0;
-    for (uint64_t n = 0; n <= jt.mask; n++) {
-        if (w == J_EMPTY) break;
-        if ((w & J_KEYMASK) == canon) {
-            ko.c_found = true;
-            ko.c_slot = s;
-            ko.c_present = (uint32_t)(w >> 62);
-            if (n) {          // displaced: its records are fetched now
-                rp = (const uint64_t*)(jt.recs + s * 32);
-                a0 = ld_agent(&rp[0]); a1 = ld_agent(&rp[1]); a2 = ld_agent(&rp[2]); a3 = ld_agent(&rp[3]);
-            }
-            ko.c_lo0 = uni64(a0); ko.c_hi0 = uni64(a1); ko.c_lo1 = uni64(a2); ko.c_hi1 = uni64(a3);
-            if (have_last) ko_cache_wrote(ko, last, jt.recs);      // the piece's last junction may be this very k-mer, its record not stored yet
-            break;
-        }
-        s = (s + 1) & jt.mask;
-        w = uni64(ld_agent(&jt.keys[s]));
-    }
-    ko_flush(ko);          // a load has just come back: the noted turns move on for free
-    KO_STAMP(ko, 3, q);
-    KO_T1(wc.cnt, 2);
-}
-
 // the cursor leaves its position without having visited it
 __device__ __forceinline__ void ko_leave_cursor(KoState& ko, bool have_last) {
     if (!ko.cur.n) return;
@@ -1117,39 +929,14 @@ __device__ __forceinline__ void ko_account(WalkCtx& wc, uint32_t q, bool as_curs
     ko_leave_cursor(ko, have_last);
     KO_T0();
     KO_STAMP(ko, 1, q);
-    const uint32_t ord = ko_ordinal(ko, q);
-    const uint32_t e = uni32(ko_occ_lds()[2 * ord]), r = uni32(ko_occ_lds()[2 * ord + 1]);
+    const uint32_t node = ko.base + ko_ordinal(ko, q);
+    const uint32_t e = ko.kt.occ_entry[node], r = ko.kt.occ_rank[node];
     if (as_cursor) ko.cur_q = q;
     if (e == 0xFFFFFFF0u) return;                   // (keeps the loads in front of the clock)
     KO_T1(wc.cnt, 0);
     if (ko.last.n && e == ko.last.e) { ko.last.n++; if (as_cursor) ko.cur_in = 1; return; }     // this piece holds the k-mer already
     if (ko.fake.n && e == ko.fake.e) { ko.fake.n++; if (as_cursor) ko.cur_in = 2; return; }
-    // One look at the counter -- usually the one requested while the previous lk position was being dealt with.  The turns noted since
-    // (ko_give) move on where a load has just come back (the stores before it have been acknowledged long ago: no wait of their own) and
-    // MUST move on before this piece waits for anything: the turn it waits for may be one of its own (the same k-mer twice on a piece).
-    uint32_t seen;
-    bool polled = false;
-#ifdef FGPU_KO_NO_PREFETCH
-    ko.pf_ord = 0xFFFFFFFFu;
-#endif
-    if (ko.pf_ord == ord) seen = uni32(ko.pf_val);
-    else { seen = uni32(ld_agent(&ko.kt.hk_turn[e])); polled = true; }
-#ifndef FGPU_KO_NO_PREFETCH
-    if (ord + 1 < ko.n_lk) {       // the next occurrence's counter: its load travels with whatever this position loads next
-        ko.pf_val = ld_agent(&ko.kt.hk_turn[uni32(ko_occ_lds()[2 * (ord + 1)])]);
-        ko.pf_ord = ord + 1;
-    } else
-#endif
-    {
-        ko.pf_ord = 0xFFFFFFFFu;
-    }
-    if (seen != r && !polled) { seen = uni32(ld_agent(&ko.kt.hk_turn[e])); polled = true; }      // (an early look only counts when it shows this piece's rank)
-    if (seen != r) {
-        ko_flush(ko);
-        ko.wait_acc += ko_wait(&ko.kt.hk_turn[e], r, wc.cnt);
-    } else if (polled) {
-        ko_flush(ko);
-    }
+    ko.wait_acc += ko_wait(&ko.kt.hk_turn[e], r, wc.cnt);
     KO_STAMP(ko, 2, q);
     KoHold h;
     h.e = e; h.r = r; h.n = 1;
@@ -1162,7 +949,7 @@ __device__ __forceinline__ void ko_pass(WalkCtx& wc, uint32_t q_to, bool have_la
     KoState& ko = wc.ko;
     while (ko.done < q_to) {
         if (ko.done >= 64 * KO_CHUNKS) { ko.done = q_to; break; }
-        const uint64_t w = ko_lk_get(ko, ko.done >> 6) >> (ko.done & 63);
+        const uint64_t w = ko_lk(ko.done >> 6) >> (ko.done & 63);
         if (!w) {                                   // no lk position in the rest of this word
             const uint32_t next = ((ko.done >> 6) + 1) * 64;
             ko.done = next < q_to ? next : q_to;
@@ -1180,7 +967,7 @@ __device__ __forceinline__ void ko_cursor(WalkCtx& wc, uint32_t q, bool have_las
     if (q < ko.done) return;                       // second half-step of the same position: its k-mer is still held
     ko_pass(wc, q, have_last);
     if (ko_is_lk(ko, q)) ko_account(wc, q, true, have_last);
-    else { ko_leave_cursor(ko, have_last); if (fd_lane() == 0) atomicOr(&wc.cnt->error_flags, 16ULL); }   // a stop at a k-mer nobody registered: cannot happen
+    else { ko_leave_cursor(ko, have_last); atomicOr(&wc.cnt->error_flags, 16ULL); }   // a stop at a k-mer nobody registered: cannot happen
     ko.done = q + 1;
 }
 // the junction under the cursor has been visited and becomes the piece's last junction; the previous one's record has been stored
@@ -1205,7 +992,6 @@ __device__ __forceinline__ void ko_finish(WalkCtx& wc, uint32_t nwin) {
     if (ko.cur.n) ko_give(ko, ko.cur);
     if (ko.last.n) ko_give(ko, ko.last);
     if (ko.fake.n) ko_give(ko, ko.fake);
-    ko_flush(ko);
 }
 
 // scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin}
@@ -1215,7 +1001,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
     const int tmax = 2 * (int)nwin - 2 - 2 * j;     // last half-step with distToEnd > 2j
     const int spacer = 2 * wc.fp.max_spacer - 1;
     PieceView v;
-    pv_load<MODE>(v, wc.pl, p0, nwin);
+    pv_load(v, wc.pl, p0, nwin);
     if (MODE != WALK_KO) {
         created_bits(wc, v, 0, v.xF0, v.xB0);       // what the snapshot planes cannot know: the live table at the candidate positions
         if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
@@ -1285,11 +1071,18 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                 const uint64_t kmq = pv_kmer(v, wc.pl.codes, p0 + q, k);
                 const uint64_t rcq = fd_revcomp(kmq, k);
                 const uint64_t canon = kmq < rcq ? kmq : rcq;
-                ko_lookup(wc, q, canon, have_last, last);
-                in_map = wc.ko.c_found && ((wc.ko.c_present >> ((fwd ? kmq : rcq) == canon ? 0 : 1)) & 1u);
-                ko_slot = in_map ? wc.ko.c_slot : ~0ULL;
+                uint64_t slot = 0;      // (was compared uninitialised when the k-mer is not in the table: undefined behaviour that one
+                uint32_t present = 0;   // build of round 3 did not survive -- "a k-mer's turn never came" at full size)
+                {
+                    KO_T0();
+                    in_map = jt_find_live(wc.jt, canon, slot, present) && ((present >> ((fwd ? kmq : rcq) == canon ? 0 : 1)) & 1u);
+                    if (slot == 0xFFFFFFFFFFFFFFF0ULL) return;
+                    KO_T1(wc.cnt, 2);
+                }
+                KO_STAMP(wc.ko, 3, q);
+                ko_slot = in_map ? slot : ~0ULL;
                 if (potential && !in_map) {                 // registered, but not in the map (yet): not an event; look again from here
-                    ko_absent_or(wc.ko, fwd, q >> 6, 1ULL << (q & 63));
+                    ko_absent(fwd, q >> 6) |= 1ULL << (q & 63);
                     continue;
                 }
             }
@@ -1315,7 +1108,7 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
         const int ext_bwd = fwd ? 4 : real;          // getExtensionIndex(BACKWARD)
         if (MODE == WALK_SEQ || MODE == WALK_KO) {
             if (!junction_get<MODE>(wc, key, (piece_seq << STAMP_SHIFT) | (uint64_t)tn, p0 + q, cur, ko_slot)) return;
-            if (wc.pl.sF && writer<MODE>()) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
+            if (wc.pl.sF) atomicOr(&(fwd ? wc.pl.sF : wc.pl.sB)[(p0 + q) >> 6], 1ULL << ((p0 + q) & 63));   // result.push_back, :140
             if (MODE == WALK_SEQ && wc.created_now) {   // the new key may recur further along this piece (tandem repeats)
                 created_bits(wc, v, 0, v.xF0, v.xB0);
                 if (nwin > 64) created_bits(wc, v, 1, v.xF1, v.xB1);
@@ -1333,7 +1126,6 @@ __device__ __forceinline__ void walk_piece(WalkCtx& wc, uint64_t p0, uint32_t nw
                     rr_update(last, last_ext_fwd, d);
                     rr_link(last, last_ext_fwd);
                     rr_store_m<MODE>(last);
-                    if (MODE == WALK_KO) ko_cache_wrote(wc.ko, last, wc.jt.recs);
                 }
                 rr_update(cur, ext_bwd, d);
                 rr_link(cur, ext_bwd);
@@ -1598,9 +1390,16 @@ __global__ void __launch_bounds__(256) k_ko_rank(KoTables kt) {
     }
 }
 
+// Round 3 rebuilt this walk three ways and measured all of them SLOWER than the form below (twenty-copy repeat set, same box: 522 ms here;
+// 565 ms with the piece's occurrences prefetched into LDS, key word + both records fetched in one round trip and reused for the second
+// facing, the next turn counter requested a visit ahead and turns stored lazily; 631 ms with all of that on the scalar unit -- the whole wave
+// walking with wave-uniform values; 663 ms confined to one XCD with L2-resident hand-overs).  The walk is bound by the issue rate of ONE wave's
+// instruction stream (~1 000-2 000 instructions per junction visit at one instruction per 4-5 cycles), so every scheme that saves memory
+// round trips by adding bookkeeping loses, and the scalar unit loses to register pressure (the walk's state is ~200 SGPRs' worth against
+// the 100 a wave has: 3 774 spill moves in the kernel).  The experimental code is in the history (commit 530a5c9); the numbers and the
+// per-piece trace are in profiles/r03_ko_walk.txt, the reading in DESIGN.md section 4.1.
 // The walk: waves draw chunks of 64 consecutive pieces from a ticket counter (whoever holds a ticket is running, and every piece a wave can
-// wait for belongs to the same or an earlier ticket); the wave walks the chunk's pieces of large clusters one after the other, on its scalar
-// unit (uni64 above).
+// wait for belongs to the same or an earlier ticket); lane 0 walks the chunk's pieces of large clusters one after the other.
 __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
                                                 const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt,
                                                 KoTables kt, uint32_t heavy, uint32_t KO_TICKET) {
@@ -1624,7 +1423,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     for (;;) {
         uint32_t ticket = 0;
         if (fd_lane() == 0) ticket = atomicAdd(&kt.state[2], 1u);
-        ticket = bcast32(ticket);
+        ticket = (uint32_t)__shfl((int)ticket, 0, 64);
         if ((uint64_t)ticket * KO_TICKET >= wd.n) break;
         for (uint32_t sub = 0; sub < KO_TICKET / 64; sub++) {
             const uint32_t first = ticket * KO_TICKET + sub * 64;
@@ -1640,83 +1439,62 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
                 }
             }
             uint64_t todo = __ballot(mine);
-            // the whole wave walks the chunk's pieces of large clusters one after the other, every value wave-uniform (see uni64)
-            while (todo) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint32_t li = first + b;
-                uint2 pc = pl.pieces[wd.first_piece + li];
-                pc.x = uni32(pc.x);
-                pc.y = uni32(pc.y);
-                ko.base = uni32(kt.piece_base[li]);
-                ko.done = 0;
-                ko.mid = (pc.y + (uint32_t)fp.k - 1) / 2 - (uint32_t)fp.k / 2;
-                ko.last.n = ko.cur.n = ko.fake.n = 0;
-                ko.cur_q = 0;
-                ko.cur_in = 0;
-                ko.n_pend = 0;
-                ko.aF0 = ko.aF1 = ko.aB0 = ko.aB1 = 0;
-                ko.c_q = ko.pf_ord = 0xFFFFFFFFu;
-                ko.pf_val = 0;
-                ko.wait_acc = 0;
-                ko.stamp_base = nullptr;
-                ko.stamp_n = 0;
+            if (fd_lane() == 0) {
+                while (todo) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t li = first + b;
+                    const uint2 pc = pl.pieces[wd.first_piece + li];
+                    ko.base = kt.piece_base[li];
+                    ko.done = 0;
+                    ko.mid = (pc.y + (uint32_t)fp.k - 1) / 2 - (uint32_t)fp.k / 2;
+                    ko.last.n = ko.cur.n = ko.fake.n = 0;
+                    ko.cur_q = 0;
+                    ko.cur_in = 0;
+                    ko.wait_acc = 0;
+                    ko.stamp_base = nullptr;
+                    ko.stamp_n = 0;
+                    uint32_t n_lk = 0;
+                    for (uint32_t c = 0; c < KO_CHUNKS; c++) {
+                        ko_lk(c) = c * 64 < pc.y ? fd_bits_at(pl.lk, pc.x + 64 * c) & chunk_mask(pc.y, c) : 0ULL;
+                        n_lk += (uint32_t)__popcll(ko_lk(c));
+                        ko_absent(true, c) = 0;
+                        ko_absent(false, c) = 0;
+                    }
 #ifdef FGPU_KO_TRACE
-                const unsigned long long trace_t0 = wall_clock64();
-                ko.stamp_t0 = trace_t0;
-                if (kt.trace && ((piece_seq_base + wd.first_piece + li) & 15) == 0) {
-                    unsigned long long slot = 0;
-                    if (fd_lane() == 0) slot = atomicAdd(&kt.trace[1], 1ULL);
-                    slot = ((unsigned long long)bcast32((uint32_t)(slot >> 32)) << 32) | bcast32((uint32_t)slot);
-                    if (slot < 4096) ko.stamp_base = kt.trace + (1ULL << 23) + slot * 1024;
-                }
+                    const unsigned long long trace_t0 = wall_clock64();
+                    ko.stamp_t0 = trace_t0;
+                    if (kt.trace && ((piece_seq_base + wd.first_piece + li) & 15) == 0) {
+                        const unsigned long long slot = atomicAdd(&kt.trace[1], 1ULL);
+                        if (slot < 4096) ko.stamp_base = kt.trace + (1ULL << 23) + slot * 1024;
+                    }
 #endif
-                __builtin_amdgcn_wave_barrier();
-                uint32_t n_lk = 0;
-                for (uint32_t c = 0; c < KO_CHUNKS; c++) {
-                    const uint64_t w = c * 64 < pc.y ? uni64(fd_bits_at(pl.lk, pc.x + 64 * c)) & chunk_mask(pc.y, c) : 0ULL;
-                    ko_lk(c) = w;
-                    if (c == 0) ko.lk0 = w;
-                    if (c == 1) ko.lk1 = w;
-                    n_lk += (uint32_t)__popcll(w);
-                    ko_absent(true, c) = 0;
-                    ko_absent(false, c) = 0;
-                }
-                ko.n_lk = n_lk;
-                for (uint32_t o = (uint32_t)fd_lane(); o < n_lk; o += 64) {     // the piece's occurrences: one coalesced fetch instead of two loads per position
-                    ko_occ_lds()[2 * o] = kt.occ_entry[ko.base + o];
-                    ko_occ_lds()[2 * o + 1] = kt.occ_rank[ko.base + o];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef FGPU_KO_TIMING
-                const unsigned long long tp = wall_clock64();
+                    const unsigned long long tp = wall_clock64();
 #endif
-                if (KO_UNIFORM || fd_lane() == 0) {
                     walk_piece<WALK_KO>(wc, pc.x, pc.y, piece_seq_base + wd.first_piece + li);
                     ko_finish(wc, pc.y);
-                }
-                walked++;
+                    walked++;
 #ifdef FGPU_KO_TRACE
-                if (kt.trace && fd_lane() == 0) {           // one record per walked piece: number, start, end, ticks waited | lk positions << 48
-                    const unsigned long long at = atomicAdd(&kt.trace[0], 1ULL);
-                    if (at < (1ULL << 21)) {
-                        unsigned long long* rec = kt.trace + 4 + 4 * at;
-                        rec[0] = piece_seq_base + wd.first_piece + li;
-                        rec[1] = trace_t0;
-                        rec[2] = wall_clock64();
-                        rec[3] = ko.wait_acc | ((unsigned long long)n_lk << 48);
+                    if (kt.trace) {           // one record per walked piece: number, start, end, ticks waited | lk positions << 48
+                        const unsigned long long at = atomicAdd(&kt.trace[0], 1ULL);
+                        if (at < (1ULL << 21)) {
+                            unsigned long long* rec = kt.trace + 4 + 4 * at;
+                            rec[0] = piece_seq_base + wd.first_piece + li;
+                            rec[1] = trace_t0;
+                            rec[2] = wall_clock64();
+                            rec[3] = ko.wait_acc | ((unsigned long long)n_lk << 48);
+                        }
                     }
-                }
-                if (ko.stamp_base && fd_lane() == 0) ko.stamp_base[0] = ((piece_seq_base + wd.first_piece + li) << 16) | (ko.stamp_n < 1020 ? ko.stamp_n : 1020);
+                    if (ko.stamp_base) ko.stamp_base[0] = ((piece_seq_base + wd.first_piece + li) << 16) | (ko.stamp_n < 1020 ? ko.stamp_n : 1020);
+#else
+                    (void)n_lk;
 #endif
 #ifdef FGPU_KO_TIMING
-                if (fd_lane() == 0) {
                     atomicAdd(&cnt->par_probe[0], wall_clock64() - tp);
                     atomicAdd(&cnt->par_probe[2], 1ULL);
-                }
 #endif
+                }
             }
         }
     }

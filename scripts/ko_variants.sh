@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Round 3's experimental variants -- -DFGPU_KO_SCALAR, -DFGPU_KO_EAGER_GIVE, -DFGPU_KO_NO_PREFETCH, -DFGPU_KO_NO_CACHE, -DFGPU_KO_ONE_XCD, -DFGPU_KO_SLEEP=n --
+# exist in the tree at commit 530a5c9; the walk in the tree now is round 2's algorithm, which measured fastest.  profiles/r03_ko_walk.txt.)
 # Runs ON THE GPU BOX: the key-ordered walk built in several measurement variants; each runs one fuzz case with the walk forced onto every
 # cluster (correctness) and scripts/pe_profile.py (time of walk_ko on the repeat-rich paired-end set).
 #   gpurun -- 'bash scripts/ko_variants.sh "name:-DFLAG ..." ...'
