@@ -1320,3 +1320,32 @@ def test_binned_probe_chains_answer_like_direct_ones(table_mib, slice_mib, n_has
     want = bin(fill).count("1") / 8
     assert abs(r["survivors_share"] - want) < 0.01, r      # the first level lets through exactly the items whose first bit is set
     ctx.close()
+
+
+def test_key_ordered_walk_under_contention_is_repeatable(monkeypatch):
+    """ADVICE r2 (the hand-over's release order): many waves on the turn counters of a few hot k-mers -- twenty copies of a 300-base repeat at
+    high coverage, one large cluster per window -- walked in k-mer order from the first window on, five times over: every run must give the
+    oracle's junction map record for record (a turn that moved before a record's store had landed would show as a lost coverage count or link)."""
+    monkeypatch.setenv("FGPU_WALK_KO", "16")
+    monkeypatch.setenv("FGPU_WALK_KO_ALWAYS", "1")
+    g = synth.make_genome(300_000, 91, repeats=20, repeat_len=300)
+    r = synth.make_reads(g, 120_000, 100, 0.01, 92)           # 40x: every wrong base of the repeat recurs often enough to be in bloo2
+    bases, offs = po.reads_from_matrix(r)
+    k, E, S = 31, 4_000_000, 1_000_000
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    okeys, orecs = osc.junctions("creation")
+    biggest = 0
+    for rep in range(5):
+        ctx = api.Context(k, tai, nh, walk_window_span=1 << (20 + rep % 3))
+        api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, 3))
+        sc = api.ReadScanner(ctx)
+        sst = sc.scanReads(chunks(bases, offs, 2))
+        keys, recs = sc.junctions()
+        assert np.array_equal(keys, okeys), rep
+        for f in ("dist", "cov", "linked"):
+            assert np.array_equal(recs[f], orecs[f]), (rep, f)
+        biggest = max(biggest, sst["walk_max_cluster"])
+        assert sst["walk_parallel"] > 1000
+        ctx.close()
+    assert biggest >= 64
