@@ -517,7 +517,7 @@ def main():
         "kmers_per_step": kmers_total, "lazy_flag_fallbacks": len(FALLBACKS),
         "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
-                    "walk_max_cluster_rank0": int(sst["walk_max_cluster"]),
+                    "walk_max_cluster_rank0": int(sst["walk_max_cluster"]), "walk_key_ordered_pieces_rank0": int(sst["walk_parallel"]),
                     "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"]),
                     "valid_reused_rank0": int(sst["valid_reused"]), "flags_filled_in_walk_rank0": int(sst["flags_filled"]), "nb_processed_rank0": int(sst["nb_processed"]),
                     "nb_skipped_rank0": int(sst["nb_skipped"]), "nb_jcheck_kmer_rank0": int(sst["nb_jcheck_kmer"])},
