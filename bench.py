@@ -324,6 +324,53 @@ def cli_leg(reads, args, kmers, want_junctions):
         shutil.rmtree(d, ignore_errors=True)
 
 
+
+def full_size_leg(name, device, batch_reads):
+    """One of BASELINE.json's other configurations at its FULL size as one cold step (load + scan, reads resident in HBM, junctions and
+    bloo2 back in host memory), on the reads of the committed parity fixture (tests/golden/fullsize.json: faucet_amd/synth_det.py's
+    counter-based generator), so that the step's counters can be compared with the oracle's on the spot.  The digests themselves are
+    checked by tests/test_gpu_fullsize.py; this leg puts a driver-timed rate for the configuration into the bench line."""
+    from faucet_amd import synth_det as sd
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize.json")) as f:
+        fx = json.load(f).get(name)
+    if fx is None:
+        return {"skipped": f"no fixture named {name} in tests/golden/fullsize.json"}
+    c = fx["params"]
+    t0 = time.perf_counter()
+    reads = sd.make_reads(sd.make_genome(c["genome"], c["genome_seed"], device), c["reads"], c["read_len"], c["err"], c["read_seed"], device)
+    tai, nh = api.load_filter_shape(c["E"], c["S"])
+    ctx = api.Context(c["k"], tai, nh, device=device.index or 0, profile=True)
+    batches = device_batches(reads, batch_bounds(c["reads"], batch_reads, 2))
+    torch.cuda.synchronize(device)
+    setup_seconds = time.perf_counter() - t0
+    kmers = c["reads"] * (c["read_len"] - c["k"] + 1)
+    steps = []
+    for _ in range(2):          # the first use of a context (window calibration, junction table grown from its initial size), then a second step
+        ctx.kernel_times_reset()
+        t1 = time.perf_counter()
+        lst, sst, bloo2, keys, recs = step_single(ctx, batches, pinned=True)
+        ctx.synchronize()
+        dt = time.perf_counter() - t1
+        same = {k2: int(sst[k2]) == int(v) for k2, v in fx["counters"].items() if k2 in sst}
+        same["to_bloo2"] = int(lst["to_bloo2"]) == int(fx["to_bloo2"])
+        same["junction_records"] = len(keys) == int(fx["counters"]["n_junctions"])
+        kt = sorted(ctx.kernel_times().items(), key=lambda kv: -kv[1][1])[:6]
+        steps.append({"seconds": dt, "value": kmers / dt, "counters_equal_the_oracles": all(same.values()),
+                      "differing": sorted(k2 for k2, v in same.items() if not v), "kernel_ms": {n: round(ms, 1) for n, (cnt, ms) in kt}})
+    out = {"seconds": steps[1]["seconds"], "value": steps[1]["value"], "unit": "k-mers/s", "kmers": kmers, "junctions": int(len(keys)),
+           "counters_equal_the_oracles": all(st["counters_equal_the_oracles"] for st in steps),
+           "first_step_of_the_context": steps[0], "second_step": steps[1], "setup_seconds": setup_seconds,
+           "workload": f"{c['reads']} x {c['read_len']} bp of a {c['genome']} bp genome, {100 * c['err']:.0f} % substitutions, k={c['k']}, estimated_kmers={c['E']}, "
+                       f"singletons={c['S']}: filters 2 x {tai // 8 >> 20} MiB, {nh} hash functions",
+           "note": "two whole steps (load + scan, reads resident in HBM, bloo2 and the junctions back in host memory): the first use of the context "
+                   "(window calibration, junction table grown from its initial size) and a second one, which `value` quotes; counters, to_bloo2 "
+                   "and the junction count of both compared with the oracle's in tests/golden/fullsize.json"}
+    ctx.close()
+    del reads, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def config3_cli_leg(device):
     """BASELINE config 3's shape at its real size -- 2.5 M pairs of 100-base reads of a 4.6 Mb genome with planted repeats, interleaved FASTQ,
     `--fastq --paired_ends` with cleaning -- file to files through faucet_amd/faucet: the configuration on which the path is SLOWEST (the
@@ -401,6 +448,7 @@ def main():
     ap.add_argument("--profile-walk", action="store_true", help="time the per-window walk kernels individually")
     ap.add_argument("--host-input", action="store_true",
                     help="hand the reads over as HOST buffers (PCIe copy inside the timed region); diagnostic only, never the headline value")
+    ap.add_argument("--no-full-size", action="store_true", help="skip the full-size legs of BASELINE configs 5 and 4 (N = 1; about half a minute)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the extra PCIe-inclusive steps reported as `host_input` (N = 1)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="replicas of the all-cores CPU leg (0 = min(host cores, 16))")
     args = ap.parse_args()
@@ -698,6 +746,17 @@ def main():
             res["config3_cli"] = config3_cli_leg(device)
         except Exception as e:   # noqa: BLE001
             res["config3_cli"] = {"error": repr(e)[:300]}
+    # ---- BASELINE's other configurations at full size, one cold step each (only config 2 had a driver-timed number)
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not args.no_full_size:
+        ctx.close()
+        del reads, batches
+        torch.cuda.empty_cache()
+        res["full_size"] = {}
+        for name, br in (("config5", 2_000_000), ("config4", 2_500_000)):
+            try:
+                res["full_size"][name] = full_size_leg(name, device, br)
+            except Exception as e:   # noqa: BLE001
+                res["full_size"][name] = {"error": repr(e)[:300]}
     emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

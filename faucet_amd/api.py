@@ -401,6 +401,12 @@ class Context:
         self._c(self.lib.fgpu_diag_scan_replays(self.h, C.byref(n)))
         return int(n.value)
 
+    def diag_late_flags(self) -> dict:
+        """after scan_end: late junction tests that came out true at an unregistered k-mer, and how many of them voided the scan"""
+        out = (C.c_uint64 * 3)()
+        self._c(self.lib.fgpu_diag_late_flags(self.h, out))
+        return {"noted": int(out[0]), "conflicts": int(out[1]), "swept": int(out[2])}
+
     def diag_load_split(self) -> dict:
         """where the last load pass settled its occurrences: routed to bloo2 by the marking kernel itself / left to the resolution"""
         a, b = C.c_uint64(0), C.c_uint64(0)

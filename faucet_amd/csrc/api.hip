@@ -539,6 +539,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     journal_recycle(ctx);
     ctx->journal_on = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
     ctx->eager_scan = ctx->lazy_failed = false;
+    ctx->late_acc[0] = ctx->late_acc[1] = ctx->late_acc[2] = 0;
     ctx->stops_delivered = 0;
     if (ctx->short_pf) FGPU_HIP(hipMemsetAsync(ctx->short_pf, 0, ctx->short_pf_tai / 8, ctx->stream));   // a scan starts with empty pair filters
     ctx->have_import = false;
@@ -697,6 +698,11 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->stop_queue.clear();
     if (!rc) rc = fgpu_scan_reset(ctx);
     if (rc) { ctx->in_replay = false; return rc; }
+    {   // what fgpu_diag_late_flags reports of the voided attempt (everything has completed: sync_all above)
+        unsigned long long ln[3] = {0, 0, 0};
+        if (hipMemcpy(ln, ctx->counters->late_n, sizeof(ln), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < 3; i++) ctx->late_acc[i] += ln[i];
+    }
     FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
     FGPU_HIP(hipMemcpyAsync(&ctx->counters->max_read_len, &ctx->journal_max_read_len, 8, hipMemcpyHostToDevice, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
@@ -1084,6 +1090,12 @@ int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_
 int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays) {
     if (!ctx || !replays) return FGPU_ERR_ARG;
     *replays = ctx->scan_replays;
+    return FGPU_OK;
+}
+
+int fgpu_diag_late_flags(fgpu_ctx* ctx, uint64_t out[3]) {   // after fgpu_scan_end, see the header
+    if (!ctx || !out) return FGPU_ERR_ARG;
+    for (int i = 0; i < 3; i++) out[i] = ctx->late_acc[i] + ctx->counters_host->late_n[i];
     return FGPU_OK;
 }
 

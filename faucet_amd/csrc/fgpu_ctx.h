@@ -106,6 +106,7 @@ struct PendingEvent {
 };
 
 // counters that kernels bump (one device struct, zeroed at *_begin)
+constexpr unsigned FGPU_LATE_CAP = 256;   // (k_delta_collect loads them with one block of 256 threads)
 struct DevCounters {
     unsigned long long kmers;
     unsigned long long to_bloo2;
@@ -135,6 +136,11 @@ struct DevCounters {
     unsigned long long walk_parallel;   // pieces of large clusters walked out of order (k_walk_par)
     unsigned long long par_probe[4];    // probed pieces by outcome: order-free, would create, would raise a distance, untested positions
     unsigned long long ko_time[8];      // -DFGPU_KO_TIMING: ticks (10 ns) of k_walk_ko by part, see scripts/pe_profile.py
+    // late junction tests (scan_walk.hip, fill_missing): a test the walk ran itself came out TRUE at a k-mer the window's clusters were
+    // built without.  [0] entries noted by the walk, [1] of those, the ones k_delta_collect found elsewhere in their window (error bit 4);
+    // entries: stream position, number of the window
+    unsigned long long late_n[3];       // ([2] noted positions the check has passed over: every one of [0], once)
+    unsigned long long late[2 * FGPU_LATE_CAP];
 };
 
 struct TextSet { DevBuf buf, nl, rank, tmp, rec; };
@@ -253,6 +259,7 @@ struct fgpu_ctx {
     bool short_pf_lists_to_host = true;
     uint64_t stops_delivered = 0;         // batches whose lists the caller has taken (a replay does not hand them out again)
     uint64_t scan_replays = 0;            // replays since the context was made (fgpu_diag_scan_replays)
+    uint64_t late_acc[3] = {0, 0, 0};        // late junction tests of this scan's voided attempts (DevCounters::late_n is reset with the replay)
     uint64_t journal_max_read_len = 0;
     DevBuf import_copy;                   // the table handed over by the previous shard, kept for a replay
     uint64_t import_n = 0;

@@ -489,6 +489,7 @@ struct WalkCtx {
     unsigned long long nb_processed, nb_skipped, nb_jcheck, nb_no_juncs, n_created, n_filled;
     bool created_now;   // set by junction_get
     KoState ko;         // WALK_KO: the piece's turn bookkeeping (by value: through a pointer it lived in scratch memory)
+    uint32_t win_seq;   // number of the window being walked (late junction tests are noted with it)
     int fail;           // WALK_PROBE: why this piece cannot be walked out of order (see k_walk_par): 1 would create, 2 would raise a distance, 3 untested positions
     int dbg;            // FGPU_DEBUG_WALK bits (timing experiments only; results are wrong when non-zero)
 };
@@ -695,11 +696,27 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             const uint32_t r = walk_fill_flags(wc.pl.codes, wc.bloom, wc.fp, v.p0 + q, q + 1 < v.nwin, q > 0);
             wc.n_filled++;
             any = true;
-            // A junction test that comes out TRUE here is a place where this piece may create a junction, and the window's
-            // dependency clusters were built without knowing that (only previewed flags are registered as candidates): the
-            // exactness argument of the parallel walk no longer covers this scan.  Rare squared; give up loudly -- the caller
-            // repeats the scan with every test evaluated up front (fgpu_scan_set_eager).
-            if (r & 3) atomicOr(&wc.cnt->error_flags, 4ULL);
+            // A junction test that comes out TRUE here is a place where this piece may create a junction, and the window's dependency
+            // clusters were built without knowing that (only previewed flags are registered as candidates).  If the k-mer is a registered
+            // one all the same (another position's flag, a junction of the map: the lk bit), every piece that holds it is in this cluster and
+            // looks it up live: nothing is lost.  Otherwise the walk goes on -- exact as long as NO OTHER position of the window holds that
+            // k-mer: no other piece reads or writes its record during this window, and later windows learn of it through the created-keys
+            // lists like of any other new junction -- and notes the position; k_delta_collect, which passes over the window's positions right
+            // after the walk anyway, looks for the k-mer's hash elsewhere in the window and only then voids the scan (error bit 4: the
+            // library scans its journal again with every test evaluated).  Config 4's 2*10^10 positions meet this case about once per run;
+            // a window there covers the genome 0.1x, so a second occurrence in the same window is the exception.
+            if ((r & 3) && !((pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) >> b) & 1ULL)) {
+                bool noted = false;
+                if (MODE == WALK_SEQ) {
+                    const unsigned long long at = atomicAdd(&wc.cnt->late_n[0], 1ULL);
+                    if (at < FGPU_LATE_CAP) {
+                        wc.cnt->late[2 * at] = v.p0 + q;
+                        wc.cnt->late[2 * at + 1] = wc.win_seq;
+                        noted = true;
+                    }
+                }
+                if (!noted) atomicOr(&wc.cnt->error_flags, 4ULL);     // (the key-ordered walk stops only at registered k-mers)
+            }
             if (q >= 128) {   // these words are read from memory (pv_word): publish there
                 const unsigned long long gm = 1ULL << ((v.p0 + q) & 63);
                 const uint64_t gw = (v.p0 + q) >> 6;
@@ -1214,10 +1231,10 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
                                              uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg,
                                              const uint32_t* __restrict__ par_fail, uint32_t heavy, const uint32_t* __restrict__ ko_bad,
-                                             const uint32_t* __restrict__ ko_state, uint32_t ko_heavy) {
+                                             const uint32_t* __restrict__ ko_state, uint32_t ko_heavy, uint32_t win_seq) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     WalkCtx wc;
-    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = win_seq;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
     wc.created_now = false; wc.fail = 0; wc.dbg = dbg; 
     const WinDesc wd = *wdp;
@@ -1293,7 +1310,7 @@ __global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable 
                                                  uint32_t heavy) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     WalkCtx wc;
-    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = 0;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
     wc.created_now = false; wc.fail = 0; wc.dbg = 0; 
     const WinDesc wd = *wdp;
@@ -1407,7 +1424,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     if (kt.state[1] & 1u) return;                                      // a table overflowed: k_walk takes every cluster
     WalkCtx wc;
     KoState& ko = wc.ko;
-    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = 0;
     wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
     wc.created_now = false; wc.fail = 0; wc.dbg = 0;
     ko.kt = kt;
@@ -1514,12 +1531,51 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
 // (run after every window over the words that window's pieces reach; the bits are cleared as they are taken, so a word that two
 // consecutive windows share is collected twice without listing anything twice)
 __global__ void __launch_bounds__(256) k_delta_collect(unsigned long long* __restrict__ cr, const uint32_t* __restrict__ kh, uint64_t w_first, uint64_t n_words,
-                                                       uint32_t* __restrict__ list, unsigned long long* __restrict__ count) {
+                                                       uint32_t* __restrict__ list, unsigned long long* __restrict__ count, Planes pl,
+                                                       const WinDesc* __restrict__ wdp, DevCounters* cnt, uint32_t win_seq) {
     __shared__ unsigned s_wave[4];
     __shared__ unsigned long long s_base;
+    // The late junction tests of this window (fill_missing; nearly always none): does the k-mer of such a position occur anywhere else on
+    // a piece of the window?  Then a piece outside the creating piece's cluster may have passed a junction it should have seen: void.
+    __shared__ uint32_t s_late_h[FGPU_LATE_CAP];
+    __shared__ uint64_t s_late_p[FGPU_LATE_CAP];
+    __shared__ uint32_t s_late_n;
+    if (threadIdx.x == 0) s_late_n = 0;
+    __syncthreads();
+    const unsigned long long n_noted = cnt->late_n[0] < FGPU_LATE_CAP ? cnt->late_n[0] : FGPU_LATE_CAP;
+    if (n_noted) {
+        if (threadIdx.x < n_noted && cnt->late[2 * threadIdx.x + 1] == win_seq) {
+            const uint32_t at = atomicAdd(&s_late_n, 1u);
+            s_late_p[at] = cnt->late[2 * threadIdx.x];
+            s_late_h[at] = kh[cnt->late[2 * threadIdx.x]];
+        }
+        __syncthreads();
+    }
+    const uint32_t n_late = s_late_n;
     const int wave = (int)(threadIdx.x >> 6);
     for (uint64_t w0 = w_first + (uint64_t)blockIdx.x * 256; w0 < n_words; w0 += (uint64_t)gridDim.x * 256) {   // uniform trip count per block
         const uint64_t w = w0 + threadIdx.x;
+        if (n_late && w < n_words) {
+            const WinDesc wd = *wdp;
+            uint64_t inside = pl.pm[w];
+            while (inside) {
+                const uint64_t pos = w * 64 + (uint64_t)__builtin_ctzll(inside);
+                inside &= inside - 1;
+                const uint32_t h = kh[pos];
+                for (uint32_t e = 0; e < n_late; e++) {
+                    uint32_t li;
+                    uint2 pc;
+                    if (h == s_late_h[e] && piece_in_window(pl, wd, pos, li, pc)) {
+                        if (pos == s_late_p[e]) {
+                            atomicAdd(&cnt->late_n[2], 1ULL);      // (the sweep has seen the noted position itself: fgpu_diag_late_flags)
+                        } else {
+                            atomicOr(&cnt->error_flags, 4ULL);
+                            atomicAdd(&cnt->late_n[1], 1ULL);
+                        }
+                    }
+                }
+            }
+        }
         unsigned long long m = w < n_words ? cr[w] : 0ULL;
         if (m) cr[w] = 0;
         unsigned mine = (unsigned)__popcll(m), incl = mine;
@@ -1569,13 +1625,24 @@ __global__ void __launch_bounds__(256) k_iota_u32(uint32_t* p, uint64_t n) {
 }
 
 // FGPU_DEBUG_NEED_DROP=1 (tests): after the flags kernel, forget the evaluation of about half of the windows whose tests came out
-// false -- need bit and NbJCheckKmer bits cleared -- so that the walk has to evaluate them itself wherever it scans them.
-__global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, const uint64_t* __restrict__ ff, const uint64_t* __restrict__ fb,
-                                                         uint64_t* need, uint64_t* cf0, uint64_t* cf1, uint64_t* cb0, uint64_t* cb1) {
+// false -- need bit and NbJCheckKmer bits cleared -- so that the walk has to evaluate them itself wherever it scans them.  =2: see below.
+__global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, uint64_t* __restrict__ ff, uint64_t* __restrict__ fb,
+                                                         uint64_t* need, uint64_t* cf0, uint64_t* cf1, uint64_t* cb0, uint64_t* cb1, int mode,
+                                                         const uint64_t* __restrict__ pm, const uint32_t* __restrict__ kh) {
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t drop = need[w] & ~(ff[w] | fb[w]) & fd_mix(w * 0x9E3779B97F4A7C15ULL + 12345);
+        uint64_t drop = need[w] & ~(ff[w] | fb[w]) & fd_mix(w * 0x9E3779B97F4A7C15ULL + 12345);
+        // mode 2: the evaluated positions of one k-mer in 16 (chosen by the k-mer's hash: all its occurrences alike) go whatever the answer
+        // was, so that the walk meets tests that come out TRUE at k-mers nobody registered (fill_missing's late junction tests)
+        if (mode == 2) {
+            drop = 0;
+            for (uint64_t m = need[w] & pm[w]; m; m &= m - 1) {
+                const int b = __builtin_ctzll(m);
+                if ((fd_mix((uint64_t)kh[w * 64 + (uint64_t)b] + 0x1234567ULL) & 15) == 0) drop |= 1ULL << b;
+            }
+        }
         need[w] &= ~drop;
         cf0[w] &= ~drop; cf1[w] &= ~drop; cb0[w] &= ~drop; cb1[w] &= ~drop;
+        if (mode == 2) { ff[w] &= ~drop; fb[w] &= ~drop; }
     }
 }
 
@@ -1590,8 +1657,8 @@ __global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, const
 //     same junction and re-links the same distance, so that distance is never raised;
 //   * after any other skip (distance not yet converged) everything up to the end of the piece is marked.
 // New junctions created inside a scanned stretch (flagged, spacer, fake) start with distance 0, i.e. the walk goes on
-// scanning: they do not change which positions are visited.  The walk double-checks: scanning a position whose need bit
-// is clear raises error bit 4 (surfaced as FGPU_ERR_STATE), it never silently uses a flag that was not computed.
+// scanning: they do not change which positions are visited.  The walk double-checks: before it scans a position whose need bit
+// is clear it evaluates that position's tests itself (fill_missing); it never silently uses a flag that was not computed.
 __global__ void __launch_bounds__(256) k_need_lookup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm, uint64_t n_words,
                                                      FdParams fp, JTable jt, uint64_t* __restrict__ nF, uint64_t* __restrict__ nB,
                                                      uint32_t* __restrict__ kh, uint64_t w_first) {
@@ -1942,11 +2009,14 @@ int fgpu_stage_scan_need(fgpu_ctx* ctx) {
 }
 
 int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx) {
-    static const bool drop = getenv("FGPU_DEBUG_NEED_DROP") && getenv("FGPU_DEBUG_NEED_DROP")[0] == '1';
+    static const int drop = getenv("FGPU_DEBUG_NEED_DROP") ? atoi(getenv("FGPU_DEBUG_NEED_DROP")) : 0;
     BatchBufs& bb = *ctx->cur;
     if (!drop || !bb.n_pieces) return FGPU_OK;
-    FGPU_LAUNCH("debug_need_drop", k_debug_need_drop, fgpu_grid(bb.n_words, 256), 256, bb.n_words, (const uint64_t*)bb.ff.p, (const uint64_t*)bb.fb.p,
-                (uint64_t*)bb.need.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p, (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p);
+    // (mode 2 makes the walk meet junction tests that come out true, which may void a LAZY scan; the eager scan that follows has to stand)
+    if (drop == 2 && ((ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime || ctx->eager_scan)) return FGPU_OK;
+    FGPU_LAUNCH("debug_need_drop", k_debug_need_drop, fgpu_grid(bb.n_words, 256), 256, bb.n_words, (uint64_t*)bb.ff.p, (uint64_t*)bb.fb.p,
+                (uint64_t*)bb.need.p, (uint64_t*)bb.cf0.p, (uint64_t*)bb.cf1.p, (uint64_t*)bb.cb0.p, (uint64_t*)bb.cb1.p, drop,
+                (const uint64_t*)bb.pm.p, (const uint32_t*)bb.kh.p);
     return FGPU_OK;
 }
 
@@ -2128,7 +2198,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                     (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
-                    (const uint32_t*)kt.state, ko_heavy);
+                    (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows);
         if (ko_heavy)
             FGPU_LAUNCH("walk_ko", k_walk_ko, ko_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
                         seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket);
@@ -2138,7 +2208,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         {   // the keys this window created join the batch's list (and leave the plane): the next window's delta
             const uint64_t w_first = lo >> 6, w_last = std::min<uint64_t>(bb.n_words, (pos_end + 63) / 64);
             FGPU_LAUNCH("walk_delta", k_delta_collect, (unsigned)std::min<uint64_t>(fgpu_blocks(w_last - w_first, 256), 256), 256, (unsigned long long*)bb.cr.p,
-                        (const uint32_t*)bb.kh.p, w_first, w_last, (uint32_t*)mine_list.list.p, (unsigned long long*)mine_list.count.p);
+                        (const uint32_t*)bb.kh.p, w_first, w_last, (uint32_t*)mine_list.list.p, (unsigned long long*)mine_list.count.p, pl,
+                        (const WinDesc*)ctx->wdesc, ctx->counters, (uint32_t)ctx->scan_windows);
         }
         // this window's set is reset on the side stream while the next window (the other set) is looked up and linked
         FGPU_HIP(hipEventRecord(ctx->ev_walked, walk_stream));

@@ -224,7 +224,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats);
 /* The scan evaluates testForJunction only where its preview of the walk says the walk can stop (lazy
  * flags); where the walk scans a window outside that preview it evaluates the tests itself, so the results are exact either
  * way.  The one case the walk cannot absorb on the spot is such a late test coming out TRUE (a junction at a k-mer the window's dependency
- * clusters did not know).  The library absorbs that too: while a scan is lazy it keeps the packed form of every batch in HBM (3 bits per
+ * clusters did not know, AND whose k-mer occurs on another piece of the same window).  The library absorbs that too: while a scan is lazy it keeps the packed form of every batch in HBM (3 bits per
  * base, up to an eighth of the device memory) and, should the case arise, resets the junction map and scans those batches again by itself
  * with every test evaluated -- the caller sees an ordinary scan and never has to hand its reads over twice (they may come from a pipe).
  * A scan that outgrows that journal is verified up to there and goes on with eager tests.  fgpu_diag_scan_replays counts the replays;
@@ -354,6 +354,11 @@ int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_prob
  * [2] would raise a distance, [3] crosses positions whose junction tests the preview left out */
 int fgpu_diag_walk_probe(fgpu_ctx* ctx, uint64_t out[4]);
 int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays);
+/* after fgpu_scan_end: [0] junction tests the walk had to run itself (the preview had left the position out) that came out TRUE at a
+ * k-mer no piece of the window had registered -- the walk goes on and the window is checked afterwards --, [1] of those, the ones whose
+ * k-mer was then found on another piece of the same window: only these void a lazy scan (the library scans its journal again, see above),
+ * [2] noted positions the check itself passed over (= [0] when it works: a self-test of the sweep). */
+int fgpu_diag_late_flags(fgpu_ctx* ctx, uint64_t out[3]);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */

@@ -1048,6 +1048,61 @@ def test_walk_evaluates_the_junction_tests_the_preview_left_out():
     assert r.returncode == 0 and "filled" in r.stdout, r.stdout + r.stderr
 
 
+def test_a_late_junction_test_that_comes_out_true_voids_the_scan_only_if_its_kmer_is_shared():
+    """A junction test the walk has to run itself (the preview left the position out) may come out TRUE at a k-mer no piece of the window
+    registered: the walk goes on, and the window is checked afterwards -- only if that k-mer occurs on another piece of the same window
+    is the scan void (and scanned again from the journal, eagerly).  Config 4's 2*10^10 positions meet the case about once per run.
+    FGPU_DEBUG_NEED_DROP=2 (child processes: the variable is read once) throws away the evaluation of every position of one k-mer in 16 whatever the
+    answer.  (a) reads that cover their genome 0.025x in one window: late tests noted, no second occurrence, NO replay, results the
+    oracle's; (b) 50x: second occurrences, replay, results the oracle's; (c) the scan tests of this file under the same switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGPU_DEBUG_NEED_DROP="2")
+    code = ("import numpy as np\n"
+            "from faucet_amd import _lib as L, api\n"
+            "from oracle import pyoracle as po\n"
+            "from tests.test_gpu_parity import _random_case, chunks\n"
+            "k, E, S = 31, 20_000_000, 4_000_000\n"
+            "tai, nh = api.load_filter_shape(E, S)\n"
+            "seen = []\n"
+            "for G, n_load, n_scan, seed in ((2_000_000, 200_000, 500, 5), (2_000_000, 200_000, 500, 6), (2_000_000, 200_000, 4_000, 5), (40_000, 20_000, 20_000, 7)):\n"
+            "    bases, offs = _random_case(n_load, 100, k, G, 0.01, seed, 0.0, 0)\n"
+            "    ctx = api.Context(k, tai, nh)\n"
+            "    api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, 2))\n"
+            "    b2 = po.Bloom(tai, nh)\n"
+            "    b2.set_bits(ctx.bloom_download(L.BLOO2))\n"
+            "    sb, so = bases[: offs[n_scan]], offs[: n_scan + 1]\n"
+            "    osc = po.Scanner(k, 1, 100, b2)\n"
+            "    osc.scan_reads(sb, so)\n"
+            "    sc = api.ReadScanner(ctx)\n"
+            "    sst = sc.scanReads([api.ReadBatch(sb, so)])\n"
+            "    ost = osc.stats()\n"
+            "    for key in ('n_junctions', 'nb_jcheck_kmer', 'nb_no_juncs', 'nb_processed', 'nb_skipped', 'reads_no_errors'):\n"
+            "        assert sst[key] == ost[key], (key, sst[key], ost[key])\n"
+            "    keys, recs = sc.junctions()\n"
+            "    okeys, orecs = osc.junctions('creation')\n"
+            "    assert np.array_equal(keys, okeys)\n"
+            "    assert np.array_equal(recs['dist'], orecs['dist']) and np.array_equal(recs['cov'], orecs['cov']) and np.array_equal(recs['linked'], orecs['linked'])\n"
+            "    late = ctx.diag_late_flags()\n"
+            "    seen.append((late['noted'], late['conflicts'], ctx.diag_scan_replays()))\n"
+            "    assert late['swept'] == late['noted'] or late['noted'] > 256, late   # the check passed over every noted position\n"
+            "    print('case', G, n_scan, seen[-1], 'junctions', len(keys))\n"
+            "    ctx.close()\n"
+            "assert any(n > 0 and c == 0 and r == 0 for n, c, r in seen), seen      # noted, checked, kept\n"
+            "assert any(c > 0 and r == 1 for n, c, r in seen), seen                # found on another piece: scanned again\n"
+            "assert all(r == 1 for n, c, r in seen if c > 0 or n > 256), seen\n"
+            "print('LATE OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "LATE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    sel = ("test_scan_matches_reference_junctions or test_random_inputs_vs_oracle or test_reads_of_two_thousand_bases or "
+           "test_periodic_genome or test_deeper_jcheck or test_scan_input_read_lists or test_many_tiny_reads")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("mercy", [False, True])
 @pytest.mark.parametrize("ratio", ["0/1", "1/1", "1/4", "1000000/1"])
 def test_load_with_a_lagging_carry_is_exact(ratio, mercy, monkeypatch):
