@@ -9,6 +9,7 @@ Run in the build container (hours of one CPU core in total; every case is indepe
     python tests/golden/make_fullsize.py config5        # 50 M x 150 bp, 5 % errors, S/E = 0.5 -> 2 hashes   oracle, ~1.5 h
     python tests/golden/make_fullsize.py config2_cli    # config 2 as a FASTA file through the reference binary (.bloom / .junctions bytes)
     python tests/golden/make_fullsize.py config4        # 200 M x 100 bp, E = 1e9 / S = 2e8, 2^33-bit filters; streamed in slices   oracle, hours
+    python tests/golden/make_fullsize.py checksum:config4   # (the reads' additive checksum, for an entry made before that existed)
 
 The reads come from faucet_amd/synth_det.py (bit-identical on CPU and GPU); tests/test_gpu_fullsize.py regenerates them in HBM,
 runs the device path and compares digests.  Stored: parameters, digest of the reads themselves (so that a generator mismatch is
@@ -136,10 +137,11 @@ def oracle_case_streamed(name, limit_reads=None):
     t0 = time.time()
     b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)
     h = hashlib.sha256()
-    kmers = to2 = 0
+    kmers = to2 = cks = 0
     ck = []
     for lo, hi, reads in slices():
         h.update(np.ascontiguousarray(reads).tobytes())
+        cks = (cks + sd.checksum(torch.from_numpy(reads), lo)) & ((1 << 64) - 1)
         bases, offs = po.reads_from_matrix(reads)
         lst = po.load_two_filters(b1, b2, bases, offs, c["k"])
         kmers += int(lst.kmers)
@@ -148,7 +150,7 @@ def oracle_case_streamed(name, limit_reads=None):
             ck.append({"reads": hi, "kmers": kmers, "to_bloo2": to2, "bloo1_sha256": sha(b1.bits()), "bloo2_sha256": sha(b2.bits())})
             print("CHECKPOINT load", json.dumps(ck[-1]), flush=True)
         print(f"{name}: load {hi} reads, {time.time() - t0:.0f} s", flush=True)
-    entry.update(reads_sha256=h.hexdigest(), kmers=kmers, to_bloo2=to2, bloo1_sha256=ck[-1]["bloo1_sha256"], bloo2_sha256=ck[-1]["bloo2_sha256"],
+    entry.update(reads_sha256=h.hexdigest(), reads_checksum=cks, kmers=kmers, to_bloo2=to2, bloo1_sha256=ck[-1]["bloo1_sha256"], bloo2_sha256=ck[-1]["bloo2_sha256"],
                  load_checkpoints=ck, load_seconds=round(time.time() - t0))
     del b1
     t0 = time.time()
@@ -173,6 +175,25 @@ def oracle_case_streamed(name, limit_reads=None):
         print(json.dumps(entry)[:2000])
     else:
         merge(name, entry)
+
+
+def reads_checksum_case(name):
+    """the additive checksum of a streamed case's reads (synth_det.checksum: what the GPU test compares instead of a sha256 of 20 GB),
+    added to an entry that was made before the checksum existed"""
+    c = CASES[name]
+    g = sd.make_genome(c["genome"], c["genome_seed"], "cpu")
+    total = 0
+    for lo in range(0, c["reads"], c["slice"]):
+        n = min(c["slice"], c["reads"] - lo)
+        total = (total + sd.checksum(sd.make_reads(g, n, c["read_len"], c["err"], c["read_seed"], "cpu", first_row=lo), lo)) & ((1 << 64) - 1)
+        print(f"{name}: checksum over {lo + n} reads", flush=True)
+    with open(OUT) as f:
+        data = json.load(f)
+    data[name]["reads_checksum"] = total
+    with open(OUT, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print(name, "reads_checksum", total)
 
 
 def reference_cli_case(name):
@@ -227,7 +248,9 @@ def reference_cli_case(name):
 if __name__ == "__main__":
     torch.set_num_threads(2)
     for name in sys.argv[1:]:
-        if name in ("config3", "config2_cli"):
+        if name.startswith("checksum:"):                  # "checksum:config4"
+            reads_checksum_case(name.split(":")[1])
+        elif name in ("config3", "config2_cli"):
             reference_cli_case(name)
         elif name.startswith("config4"):                 # "config4" or the rehearsal "config4:<reads>"
             oracle_case_streamed("config4", int(name.split(":")[1]) if ":" in name else None)
