@@ -356,7 +356,9 @@ def full_size_leg(name, device, batch_reads):
         same["junction_records"] = len(keys) == int(fx["counters"]["n_junctions"])
         kt = sorted(ctx.kernel_times().items(), key=lambda kv: -kv[1][1])[:6]
         steps.append({"seconds": dt, "value": kmers / dt, "counters_equal_the_oracles": all(same.values()),
-                      "differing": sorted(k2 for k2, v in same.items() if not v), "kernel_ms": {n: round(ms, 1) for n, (cnt, ms) in kt}})
+                      "differing": sorted(k2 for k2, v in same.items() if not v), "kernel_ms": {n: round(ms, 1) for n, (cnt, ms) in kt},
+                      "junction_tests_run_by_the_walk": int(sst["flags_filled"]), "late_junction_tests": ctx.diag_late_flags(),
+                      "scan_replays_so_far": ctx.diag_scan_replays()})
     out = {"seconds": steps[1]["seconds"], "value": steps[1]["value"], "unit": "k-mers/s", "kmers": kmers, "junctions": int(len(keys)),
            "counters_equal_the_oracles": all(st["counters_equal_the_oracles"] for st in steps),
            "first_step_of_the_context": steps[0], "second_step": steps[1], "setup_seconds": setup_seconds,
