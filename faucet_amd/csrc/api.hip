@@ -99,11 +99,11 @@ static int check_errors(fgpu_ctx* ctx) {
     // device-side error flags (table overflow) are surfaced at the synchronising calls
     if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
-    if (ctx->counters_host->error_flags & 8ULL) { ctx->err = "key-ordered walk: a k-mer's turn never came (internal error)"; return FGPU_ERR_STATE; }
-    if (ctx->counters_host->error_flags & 16ULL) { ctx->err = "key-ordered walk: a junction at a k-mer nobody registered (internal error)"; return FGPU_ERR_STATE; }
     // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
     static const bool force_lazy_fail = getenv("FGPU_DEBUG_LAZY_FAIL") && getenv("FGPU_DEBUG_LAZY_FAIL")[0] == '1';
     const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime && !ctx->eager_scan;
+    // (before the key-ordered walk's own flags: a late junction test that comes out true inside a large cluster voids the lazy scan
+    // -- bit 4 -- and the piece then stops at a k-mer nobody registered -- bit 16: a consequence, gone with the eager scan that follows)
     if ((ctx->counters_host->error_flags & 4ULL) || (force_lazy_fail && lazy && ctx->phase == 2)) {
         if (ctx->journal_on && ctx->phase == 2 && !ctx->in_replay) {
             ctx->lazy_failed = true;     // every batch of this scan is still in HBM: the next entry point scans them again, eagerly (scan_replay)
@@ -113,6 +113,8 @@ static int check_errors(fgpu_ctx* ctx) {
                    "repeat the scan after fgpu_scan_set_eager(ctx, 1) (or with FGPU_FLAG_EAGER_FLAGS)";
         return FGPU_ERR_STATE;
     }
+    if (ctx->counters_host->error_flags & 8ULL) { ctx->err = "key-ordered walk: a k-mer's turn never came (internal error)"; return FGPU_ERR_STATE; }
+    if (ctx->counters_host->error_flags & 16ULL) { ctx->err = "key-ordered walk: a junction at a k-mer nobody registered (internal error)"; return FGPU_ERR_STATE; }
     return FGPU_OK;
 }
 

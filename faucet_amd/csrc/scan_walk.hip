@@ -705,7 +705,9 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             // after the walk anyway, looks for the k-mer's hash elsewhere in the window and only then voids the scan (error bit 4: the
             // library scans its journal again with every test evaluated).  Config 4's 2*10^10 positions meet this case about once per run;
             // a window there covers the genome 0.1x, so a second occurrence in the same window is the exception.
-            if ((r & 3) && !((pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) >> b) & 1ULL)) {
+            // (The key-ordered walk voids the scan on any late test that comes out true: its cursor may already have passed the position --
+            // taken and given back the k-mer's turn -- when the stretch before the stop it had chosen turns out to hold an earlier one.)
+            if ((r & 3) && (MODE == WALK_KO || !((pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) >> b) & 1ULL))) {
                 bool noted = false;
                 if (MODE == WALK_SEQ) {
                     const unsigned long long at = atomicAdd(&wc.cnt->late_n[0], 1ULL);
@@ -1436,18 +1438,28 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
     // inside one XCD; the accesses keep their agent scope, only their latency is looked at
     if ((__builtin_amdgcn_s_getreg(6164) & 15) != 0) return;           // hwreg(HW_REG_XCC_ID, 0, 4)
 #endif
-    // KO_TICKET pieces per ticket (a multiple of 64): a same-address atomic per 64 pieces cost 0.2 ms per window
+    // Pieces per ticket.  KO_TICKET (a multiple of 64) where the pieces of large clusters are few among the window's pieces -- a
+    // same-address atomic per 64 pieces cost 0.2 ms per window -- so that a ticket holds about one of them.  Where they are dense (a small
+    // genome at high coverage: EVERY piece of the reference's own 1 000-read example is in one cluster) a ticket of 64 would put 64
+    // consecutive pieces of the cluster on one lane, one after the other, and the waves would follow each other through the window: the
+    // whole walk one serial chain (33 ms for those 1 000 reads, twice what the cluster's single thread in k_walk needs).  So the ticket
+    // shrinks with the density, down to one piece: the pieces of a cluster then spread over the waves and overlap as their k-mers allow.
+    uint32_t span = KO_TICKET;
+    {
+        const uint32_t per = wd.n / kt.state[3];          // window pieces per piece of a large cluster (state[3] != 0 here)
+        while (span > 1 && span > per) span >>= 1;
+    }
     for (;;) {
         uint32_t ticket = 0;
         if (fd_lane() == 0) ticket = atomicAdd(&kt.state[2], 1u);
         ticket = (uint32_t)__shfl((int)ticket, 0, 64);
-        if ((uint64_t)ticket * KO_TICKET >= wd.n) break;
-        for (uint32_t sub = 0; sub < KO_TICKET / 64; sub++) {
-            const uint32_t first = ticket * KO_TICKET + sub * 64;
+        if ((uint64_t)ticket * span >= wd.n) break;
+        for (uint32_t sub = 0; sub < (span + 63) / 64; sub++) {
+            const uint32_t first = ticket * span + sub * 64;
             if (first >= wd.n) break;
             const uint32_t i = first + (uint32_t)fd_lane();
             bool mine = false;
-            if (i < wd.n) {
+            if (i < wd.n && (uint32_t)fd_lane() < span) {
                 const uint32_t r = root[i];
                 mine = count[r] + 1 >= heavy && !kt.bad[r];
                 if (mine && r == i) {                     // the statistics k_walk keeps per cluster
