@@ -212,6 +212,7 @@ struct fgpu_ctx {
     uint32_t* ko_piece = nullptr;
     uint32_t ko_hk_cap = 0, ko_occ_cap = 0;
     uint32_t walk_ko = 64;             // clusters of at least this many pieces are walked in k-mer order instead of piece order (0 = never); FGPU_WALK_KO
+    uint32_t walk_ko_weight = 0;     // ... or whose pieces hold at least this many lk positions between them (0: rule off), see ko_cluster
     bool walk_ko_always = false;       // FGPU_WALK_KO_ALWAYS: from a scan's first window on (tests), not from the first large cluster seen
     uint32_t* cl_fail = nullptr;       // per root: the cluster cannot be walked out of order (k_walk_par), two sets like cl_count
     uint32_t walk_heavy = 0;           // clusters of at least this many pieces are tried out of order; 0 = never, the default: measured, it

@@ -383,9 +383,10 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
 // One pass over the pieces of the window (the union-find is final: every union happened in the kernels before):
 // flat root of every piece, and every follower pushes itself onto its root's singly linked list.  No scan, no
 // second launch; the leader of a cluster sorts its (short) list when it walks.
+// weight / heavy_w (key-ordered walk by WEIGHT, see ko_cluster): the lk positions of a cluster's pieces, summed per root.
 __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict__ parent, uint32_t* count, uint32_t* head,
                                                       uint32_t* __restrict__ flat, uint32_t* __restrict__ next, Planes pl, uint64_t lo,
-                                                      uint64_t hi, WinDesc* wd_out, DevCounters* cnt) {
+                                                      uint64_t hi, WinDesc* wd_out, DevCounters* cnt, uint32_t* weight, uint32_t heavy_w) {
     const WinDesc wd = make_window(pl, lo, hi);
     const uint32_t n = wd.n;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -401,7 +402,25 @@ __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict
             next[i] = atomicExch(&head[r], i);
             atomicAdd(&count[r], 1u);
         }
+        if (heavy_w) {
+            const uint2 pc = pl.pieces[wd.first_piece + i];
+            uint32_t w = 0;
+            for (uint32_t c = 0; c < 8 && c * 64 < pc.y; c++) {
+                const uint32_t rem = pc.y - c * 64;
+                w += (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x + 64 * c) & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1)));
+            }
+            if (w) atomicAdd(&weight[r], w);
+        }
     }
+}
+
+// Which clusters the key-ordered walk takes: those of at least `heavy` pieces, and -- heavy_w != 0: callers that expect repeats
+// (FGPU_FLAG_KEY_ORDER_FROM_START) -- those whose pieces hold at least heavy_w lk positions between them.  A piece inside a repeat at high
+// coverage makes a junction visit at nearly every position: a dozen such pieces on their cluster's one thread (k_walk) are a longer chain
+// than seventy ordinary ones, and the longest chain is what a window's k_walk takes (BASELINE config 3's shape through the CLI: k_walk
+// 237 ms of pass 2 beside k_walk_ko's 238 ms, all of it clusters of fewer than 32 repeat pieces).
+__device__ __forceinline__ bool ko_cluster(uint32_t followers, uint32_t weight, uint32_t heavy, uint32_t heavy_w) {
+    return followers + 1 >= heavy || (heavy_w && weight >= heavy_w);
 }
 
 // ---- D: the walk ---------------------------------------------------------------------------------------
@@ -1233,7 +1252,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
                                              const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
                                              uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg,
                                              const uint32_t* __restrict__ par_fail, uint32_t heavy, const uint32_t* __restrict__ ko_bad,
-                                             const uint32_t* __restrict__ ko_state, uint32_t ko_heavy, uint32_t win_seq) {
+                                             const uint32_t* __restrict__ ko_state, uint32_t ko_heavy, uint32_t win_seq, uint32_t ko_heavy_w) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     WalkCtx wc;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = win_seq;
@@ -1249,7 +1268,7 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
 
     // a large cluster whose pieces k_walk_par found to be order-free is walked there, one thread per piece
     const bool walked_out_of_order = (heavy && my_count + 1 >= heavy && !par_fail[ii]) ||
-                                     (ko_heavy && my_count + 1 >= ko_heavy && !ko_bad[ii] && !(ko_state[1] & 1u));   // k_walk_ko has them
+                                     (ko_heavy && ko_cluster(my_count, par_fail[ii], ko_heavy, ko_heavy_w) && !ko_bad[ii] && !(ko_state[1] & 1u));   // k_walk_ko has them (par_fail = the weights then)
     if (i < n && my_root == i && !walked_out_of_order) {
         const uint32_t nm = (dbg & 2) ? 0 : my_count;
         uint32_t local_mem[LOCAL_MEMBERS];
@@ -1359,12 +1378,13 @@ __global__ void __launch_bounds__(256) k_ko_reset(KoTables kt, uint32_t n_pieces
 
 // one thread per piece of the window: the pieces of large clusters list their lk positions as occurrences of their k-mers
 __global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
-                                                    const WinDesc* __restrict__ wdp, KoTables kt, uint32_t heavy, uint32_t parity) {
+                                                    const WinDesc* __restrict__ wdp, KoTables kt, uint32_t heavy, uint32_t parity,
+                                                    const uint32_t* __restrict__ weight, uint32_t heavy_w) {
     const WinDesc wd = *wdp;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= wd.n) return;
     const uint32_t r = root[i];
-    if (count[r] + 1 < heavy) return;
+    if (!ko_cluster(count[r], weight[r], heavy, heavy_w)) return;
     kt.state[4 + parity] = 1u;                                        // the tables are in use: the next window resets them
     atomicAdd(&kt.state[3], 1u);
     const uint2 pc = pl.pieces[wd.first_piece + i];
@@ -1421,7 +1441,7 @@ __global__ void __launch_bounds__(256) k_ko_rank(KoTables kt) {
 // wait for belongs to the same or an earlier ticket); lane 0 walks the chunk's pieces of large clusters one after the other.
 __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
                                                 const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt,
-                                                KoTables kt, uint32_t heavy, uint32_t KO_TICKET) {
+                                                KoTables kt, uint32_t heavy, uint32_t KO_TICKET, const uint32_t* __restrict__ weight, uint32_t heavy_w) {
     const WinDesc wd = *wdp;
     if (kt.state[1] & 1u) return;                                      // a table overflowed: k_walk takes every cluster
     WalkCtx wc;
@@ -1461,7 +1481,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
             bool mine = false;
             if (i < wd.n && (uint32_t)fd_lane() < span) {
                 const uint32_t r = root[i];
-                mine = count[r] + 1 >= heavy && !kt.bad[r];
+                mine = ko_cluster(count[r], weight[r], heavy, heavy_w) && !kt.bad[r];
                 if (mine && r == i) {                     // the statistics k_walk keeps per cluster
                     atomicAdd(&cnt->followers, (unsigned long long)count[r]);
                     atomicMax(&cnt->max_cluster, (unsigned long long)count[r] + 1);
@@ -1918,6 +1938,9 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     ctx->walk_ko_always = getenv("FGPU_WALK_KO_ALWAYS") != nullptr || (ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) != 0;
     // a caller that expects repeats also gets the lower bar: with small batches a window holds only a few dozen pieces of a repeat's cluster
     if ((ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) && !getenv("FGPU_WALK_KO")) ctx->walk_ko = 32;
+    // ... and the rule by weight: clusters whose pieces hold 128 lk positions and more between them (three pieces inside a repeat, thirty ordinary ones)
+    ctx->walk_ko_weight = (ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) ? 128u : 0u;
+    if (const char* e = getenv("FGPU_WALK_KO_WEIGHT")) ctx->walk_ko_weight = (uint32_t)std::max(0, atoi(e));
     ctx->ko_hk_cap = 1u << 20;
     ctx->ko_occ_cap = 1u << 22;
     FGPU_HIP(hipMalloc(&ctx->ko_hk, (size_t)ctx->ko_hk_cap * 4 * 3));
@@ -2167,14 +2190,18 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                         word_blocks, piece_blocks, ds);
         }
         FGPU_LAUNCH("walk_link", k_walk_link, std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end);
-        // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
-        FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
-                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters);
         // The key-ordered walk costs four small launches per window whether or not the window holds a large cluster, so it is switched on by
         // what the scan has shown so far: the largest cluster among the windows whose counters the host has seen (every batch's pure stage
         // brings them along).  Data without such clusters never pays; data with them walks its first batch by cluster.  Either way the
         // results are the same.  FGPU_WALK_KO_ALWAYS=1: from the first window (tests).
         const uint32_t ko_heavy = (dbg_walk || !ctx->walk_ko || !(ctx->walk_ko_always || ctx->counters_host->max_cluster >= ctx->walk_ko)) ? 0u : ctx->walk_ko;
+        // ... and, for callers that expect repeats, the clusters whose pieces hold many lk positions between them (ko_cluster): the weights
+        // are summed by k_walk_cluster into cl_fail, which the out-of-order walk (k_walk_par, the other way of taking clusters out of k_walk)
+        // does not use then
+        const uint32_t ko_heavy_w = ko_heavy ? ctx->walk_ko_weight : 0u;
+        // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
+        FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
+                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters, cl_fail, ko_heavy_w);
         static const uint32_t ko_ticket = getenv("FGPU_KO_TICKET") ? (uint32_t)std::max(64, atoi(getenv("FGPU_KO_TICKET")) / 64 * 64) : 64u;
         const uint32_t heavy = (dbg_walk || ko_heavy) ? 0u : ctx->walk_heavy;   // (one way of taking large clusters out of k_walk at a time)
         KoTables kt;
@@ -2201,7 +2228,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         if (ko_heavy) {
             FGPU_LAUNCH("walk_ko_prepare", k_ko_reset, 256, 256, kt, (uint32_t)ctx->wmax, (uint32_t)parity);
             FGPU_LAUNCH("walk_ko_prepare", k_ko_prepare, piece_blocks_ko, 256, pl, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
-                        (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity);
+                        (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity, (const uint32_t*)cl_fail, ko_heavy_w);
             FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt);
         }
         if (heavy)
@@ -2210,10 +2237,10 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                     (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
-                    (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows);
+                    (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
         if (ko_heavy)
             FGPU_LAUNCH("walk_ko", k_walk_ko, ko_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
-                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket);
+                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket, (const uint32_t*)cl_fail, ko_heavy_w);
         if (heavy)
             FGPU_LAUNCH("walk_commit", k_walk_par<WALK_COMMIT>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
                         (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);

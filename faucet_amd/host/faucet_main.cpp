@@ -435,8 +435,8 @@ struct PairLogic {
     PairFilter* short_pf = nullptr;
     PairFilter* long_pf = nullptr;
     bool first_end = true;
-    std::vector<uint64_t> back1, back2;   // the two ends' lists, as canonical k-mers (all a JuncPair is hashed by)
     int empty_count = 0, not_empty_count = 0;
+    double prepare_ms = 0;                // FGPU_CLI_TIMES: of the worker's time, what `prepare` took
 
     void piece(const fgpu_stop* s, size_t n) {   // one scan_forward call
         if (no_cleaning || !short_pf) return;
@@ -460,9 +460,24 @@ struct PairLogic {
             for (size_t i = 0; i + 2 < n; i++) short_pf->add_pair(s[i].ext, s[i + 2].ext, k);
         }
     }
-    void read(const fgpu_stop* s, size_t n) {   // one iteration of the loop in scanReads
-        std::vector<uint64_t>& back = first_end ? back1 : back2;
-        back.clear();
+    // One end's list as the long-pair loop needs it: the canonical k-mers (all a JuncPair is hashed by) and their two hashes, masked.
+    // containsPair / addPair hash the SMALLER k-mer of a pair with one seed and the larger with the other (PairFilter::contains_canon /
+    // add_canon), so the |end 1| x |end 2| checks of a read pair need one pair of hashes per list entry, not one per check.
+    struct EndList {                       // a view into the batch's arrays (prepare); end 1 is copied when its pair straddles two batches
+        const uint64_t *canon = nullptr, *h0 = nullptr, *h1 = nullptr;
+        size_t n = 0;
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+    };
+    EndList end1, end2;
+    std::vector<uint64_t> kept_c, kept_0, kept_1;
+    // canonical form and hashes of every stop of a batch, made by helper threads before the sequential loop (prepare): per stop a reverse
+    // complement and two oldHash -- 23 M stops on BASELINE config 3's shape, half of what the worker thread used to spend
+    std::vector<uint64_t> bc, b0, b1;
+
+    void read(const fgpu_stop* s, size_t n, size_t first) {   // one iteration of the loop in scanReads; `first`: index of s[0] in the batch
+        EndList& e = first_end ? end1 : end2;
+        e.n = 0;
         size_t a = 0;
         while (short_pf && !no_cleaning && a < n) {
             size_t b = a + 1;
@@ -470,32 +485,88 @@ struct PairLogic {
             piece(s + a, b - a);
             a = b;
         }
-        if (paired_ends)
-            for (size_t i = 0; i < n; i++) back.push_back(canonical(s[i].ext, k));
+        if (paired_ends) {
+            e.canon = bc.data() + first;
+            if (!b0.empty()) { e.h0 = b0.data() + first; e.h1 = b1.data() + first; }   // (no hashes without cleaning)
+            e.n = n;
+        }
         if (paired_ends && !first_end) {
-            if (!back1.empty() && !back2.empty()) {
+            if (!end1.empty() && !end2.empty()) {
                 not_empty_count++;
-                for (uint64_t pair1 : back1) {
-                    bool paired = false;
-                    if (!no_cleaning) {
-                        for (uint64_t pair2 : back2)
-                            if (long_pf->contains_canon(pair1, pair2)) { paired = true; break; }
-                        if (!paired) long_pf->add_canon(pair1, back2.front());
-                    }
-                }
+                if (!no_cleaning) long_pairs();
             } else {
                 empty_count++;
             }
         }
         first_end = !first_end;
     }
+    // The check-then-insert loop over the two ends' lists (src/ReadScanner.cpp:317-343): for every k-mer of the first end, is it paired
+    // with ANY k-mer of the second end already?  If not, it is paired with the second end's first one.
+    void long_pairs() {
+        const uint64_t mask = long_pf->tai - 1;
+        const int nh = long_pf->n_hash;
+        uint8_t* const bits = long_pf->bits.data();
+        const size_t n1 = end1.size(), n2 = end2.size();
+        for (size_t i = 0; i < n1; i++) {
+            const uint64_t p1 = end1.canon[i];
+            bool paired = false;
+            for (size_t j = 0; j < n2 && !paired; j++) {
+                const bool first_is_smaller = p1 <= end2.canon[j];           // std::min / std::max of the two canonical k-mers
+                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[j];
+                if (!((bits[h0 >> 3] >> (h0 & 7)) & 1u)) continue;            // most pairs are new: one probe
+                const uint64_t h1 = first_is_smaller ? end2.h1[j] : end1.h1[i];
+                bool all = true;
+                for (int t = 1; t < nh && all; t++) { h0 = (h0 + h1) & mask; all = ((bits[h0 >> 3] >> (h0 & 7)) & 1u) != 0; }
+                paired = all;
+            }
+            if (!paired) {                                                    // addPair(pair1, back2.front())
+                const bool first_is_smaller = p1 <= end2.canon[0];
+                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[0];
+                const uint64_t h1 = first_is_smaller ? end2.h1[0] : end1.h1[i];
+                for (int t = 0; t < nh; t++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & mask; }
+            }
+        }
+    }
+    void prepare(const fgpu_stop* stops, size_t n) {
+        bc.resize(n);
+        const bool hashes = !no_cleaning && long_pf;
+        if (hashes) { b0.resize(n); b1.resize(n); }
+        const uint64_t mask = hashes ? long_pf->tai - 1 : 0;
+        auto part = [&](size_t from, size_t to) {
+            for (size_t i = from; i < to; i++) {
+                const uint64_t c = canonical(stops[i].ext, k);
+                bc[i] = c;
+                if (hashes) { b0[i] = old_hash(c, kSeed0) & mask; b1[i] = old_hash(c, kSeed1) & mask; }
+            }
+        };
+        const size_t kPerThread = 1 << 16;
+        const size_t n_threads = std::min<size_t>(4, n / kPerThread);
+        if (n_threads < 2) { part(0, n); return; }
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n_threads; t++) th.emplace_back(part, n * t / n_threads, n * (t + 1) / n_threads);
+        part(0, n / n_threads);
+        for (std::thread& t : th) t.join();
+    }
     void batch(const fgpu_stop* stops, size_t n_stops, uint64_t n_reads) {   // reads of a batch, in file order
+        const auto t0 = std::chrono::steady_clock::now();
+        if (paired_ends) prepare(stops, n_stops);
+        prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         size_t a = 0;
         for (uint64_t r = 0; r < n_reads; r++) {
             size_t b = a;
             while (b < n_stops && stops[b].read == r) b++;
-            read(stops + a, b - a);
+            read(stops + a, b - a, a);
             a = b;
+        }
+        if (paired_ends && !first_end) {          // a first end waits for its mate in the next batch: its list leaves the batch's arrays
+            kept_c.assign(end1.canon, end1.canon + end1.n);
+            end1.canon = kept_c.data();
+            if (!no_cleaning && long_pf) {
+                kept_0.assign(end1.h0, end1.h0 + end1.n);
+                kept_1.assign(end1.h1, end1.h1 + end1.n);
+                end1.h0 = kept_0.data();
+                end1.h1 = kept_1.data();
+            }
         }
     }
 };
@@ -918,6 +989,7 @@ int main(int argc, char** argv) {
         time(&stop);
         if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_take_stops, %.2f ms applying the lists to the pair filters (worker thread)\n",
                             clk.scan_ms, clk.take_ms, clk.pairs_ms);
+        if (clk.on && o.paired_ends) fprintf(stderr, "[cli]   of the worker's time, %.2f ms preparing canonical forms and hashes (helper threads)\n", pairs.prepare_ms);
         clk.mark("pass 2 (read + scan)");
         printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);
         printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);

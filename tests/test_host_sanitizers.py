@@ -84,3 +84,42 @@ def test_fifo_input_is_clean_and_equals_the_reference(cli, tmp_path):
         assert f.read() == c.bloom().tobytes()
     with open(prefix + ".junctions") as f:
         assert f.read().split("\n")[:-1] == c.junction_lines()
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "faucet_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/faucet_ref is built where /root/reference is mounted (make -C oracle ref)")
+def test_read_pairs_inside_repeats_equal_the_compiled_reference(cli, tmp_path):
+    """Both ends of a pair inside a repeat at high coverage hold dozens of junctions each.  The long-pair loop (src/ReadScanner.cpp:317-343;
+    PairLogic::long_pairs) works from canonical forms and hashes that helper threads made per batch of lists (PairLogic::prepare) -- under
+    the thread sanitizer here -- and the four files equal what the COMPILED REFERENCE writes on the same FASTQ text."""
+    import numpy as np
+    from faucet_amd import synth
+    g = synth.make_genome(12_000, 5, repeats=8, repeat_len=400)
+    r = synth.make_pairs(g, 60_000, 100, 260, 20, 0.01, 6)                # 1 000x: enough stops per batch for the helper threads
+    inp = str(tmp_path / "reads.fq")
+    synth.write_fastq(inp, np.ascontiguousarray(r))
+    args = ["-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "400000", "-singletons", "150000", "--fastq", "--paired_ends"]
+    exe, _ = cli
+    prefix = str(tmp_path / "out")
+    got = subprocess.run([exe, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + args,
+                         capture_output=True, text=True, env=dict(_env(), FGPU_CLI_TIMES="1"), timeout=900)
+    _check(got, 3)
+    ref_prefix = str(tmp_path / "ref")
+    ref = subprocess.Popen(["stdbuf", "-o0", REF_BIN, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", ref_prefix] + args,
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    buf = b""
+    while True:                  # its four files are closed when it prints the junction count (src/Faucet.cpp:296-306); the contig graph is not needed
+        chunk = ref.stdout.read1(65536)
+        if not chunk:
+            break
+        buf += chunk
+        if b"Number of junctions:" in buf:
+            break
+    ref.kill()
+    ref.wait()
+    assert b"Number of junctions:" in buf, buf[-1500:]
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        with open(prefix + "." + ext, "rb") as f, open(ref_prefix + "." + ext, "rb") as g2:
+            assert f.read() == g2.read(), ext
