@@ -502,7 +502,14 @@ struct PairLogic {
     }
     // The check-then-insert loop over the two ends' lists (src/ReadScanner.cpp:317-343): for every k-mer of the first end, is it paired
     // with ANY k-mer of the second end already?  If not, it is paired with the second end's first one.
+#ifdef FGPU_CLI_PROFILE
+    unsigned long long tk_long = 0, tk_ins = 0, tk_read = 0, n_chain = 0, n_first_fail = 0, n_hit = 0;
+#define TK() __builtin_ia32_rdtsc()
+#else
+#define TK() 0ULL
+#endif
     void long_pairs() {
+        const unsigned long long tk0 = TK();
         const uint64_t mask = long_pf->tai - 1;
         const int nh = long_pf->n_hash;
         uint8_t* const bits = long_pf->bits.data();
@@ -510,22 +517,46 @@ struct PairLogic {
         for (size_t i = 0; i < n1; i++) {
             const uint64_t p1 = end1.canon[i];
             bool paired = false;
+            // The first probe of a check goes to the SMALLER k-mer's first bit -- set as soon as any pair with that k-mer has been inserted,
+            // i.e. nearly always inside a repeat (89 % of 4.2e7 checks on BASELINE config 3's shape): it is the second and third probe that
+            // tell pairs apart, and a branch per probe was a misprediction per probe.  The first three probes are taken without branching.
+            const uint64_t a0 = end1.h0[i], a1 = end1.h1[i];
+            const int nb = nh < 3 ? nh : 3;
             for (size_t j = 0; j < n2 && !paired; j++) {
                 const bool first_is_smaller = p1 <= end2.canon[j];           // std::min / std::max of the two canonical k-mers
-                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[j];
-                if (!((bits[h0 >> 3] >> (h0 & 7)) & 1u)) continue;            // most pairs are new: one probe
-                const uint64_t h1 = first_is_smaller ? end2.h1[j] : end1.h1[i];
-                bool all = true;
-                for (int t = 1; t < nh && all; t++) { h0 = (h0 + h1) & mask; all = ((bits[h0 >> 3] >> (h0 & 7)) & 1u) != 0; }
-                paired = all;
+                uint64_t h0 = first_is_smaller ? a0 : end2.h0[j];
+                const uint64_t h1 = first_is_smaller ? end2.h1[j] : a1;
+                unsigned all = (bits[h0 >> 3] >> (h0 & 7)) & 1u;
+                for (int t = 1; t < nb; t++) { h0 = (h0 + h1) & mask; all &= (bits[h0 >> 3] >> (h0 & 7)) & 1u; }
+#ifdef FGPU_CLI_PROFILE
+                n_first_fail += !all;
+                n_chain += all;
+#endif
+                if (!all) continue;
+                for (int t = nb; t < nh && all; t++) { h0 = (h0 + h1) & mask; all = (bits[h0 >> 3] >> (h0 & 7)) & 1u; }
+                paired = all != 0;
             }
+#ifdef FGPU_CLI_PROFILE
+            n_hit += paired;
+#endif
             if (!paired) {                                                    // addPair(pair1, back2.front())
+                const unsigned long long tk1 = TK();
                 const bool first_is_smaller = p1 <= end2.canon[0];
                 uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[0];
                 const uint64_t h1 = first_is_smaller ? end2.h1[0] : end1.h1[i];
                 for (int t = 0; t < nh; t++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & mask; }
+#ifdef FGPU_CLI_PROFILE
+                tk_ins += TK() - tk1;
+#else
+                (void)tk1;
+#endif
             }
         }
+#ifdef FGPU_CLI_PROFILE
+        tk_long += TK() - tk0;
+#else
+        (void)tk0;
+#endif
     }
     void prepare(const fgpu_stop* stops, size_t n) {
         bc.resize(n);
@@ -990,6 +1021,10 @@ int main(int argc, char** argv) {
         if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_take_stops, %.2f ms applying the lists to the pair filters (worker thread)\n",
                             clk.scan_ms, clk.take_ms, clk.pairs_ms);
         if (clk.on && o.paired_ends) fprintf(stderr, "[cli]   of the worker's time, %.2f ms preparing canonical forms and hashes (helper threads)\n", pairs.prepare_ms);
+#ifdef FGPU_CLI_PROFILE
+        fprintf(stderr, "[cli-profile] long_pairs %.1f Mticks, of which inserts %.1f; first-probe failures %llu, chains %llu, first-end k-mers found paired %llu\n",
+                pairs.tk_long / 1e6, pairs.tk_ins / 1e6, pairs.n_first_fail, pairs.n_chain, pairs.n_hit);
+#endif
         clk.mark("pass 2 (read + scan)");
         printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);
         printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);
