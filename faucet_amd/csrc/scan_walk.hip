@@ -419,8 +419,11 @@ __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict
 // coverage makes a junction visit at nearly every position: a dozen such pieces on their cluster's one thread (k_walk) are a longer chain
 // than seventy ordinary ones, and the longest chain is what a window's k_walk takes (BASELINE config 3's shape through the CLI: k_walk
 // 237 ms of pass 2 beside k_walk_ko's 238 ms, all of it clusters of fewer than 32 repeat pieces).
+// (measured, FGPU_WALK_KO_WEIGHT: on config 3's shape k_walk + k_walk_ko take 381 / 293 / 249 ms at 256 / 128 / 48 positions; on config 2,
+// where a piece holds 2-5 of them, the walk stage grows from 42.9 ms to 45.0 / 63.4 / 80.1 ms at 128 / 64 / 48.  Hence two bars: heavy_w
+// positions in all, or three eighths of that where the pieces hold a dozen each -- which ordinary pieces never do.)
 __device__ __forceinline__ bool ko_cluster(uint32_t followers, uint32_t weight, uint32_t heavy, uint32_t heavy_w) {
-    return followers + 1 >= heavy || (heavy_w && weight >= heavy_w);
+    return followers + 1 >= heavy || (heavy_w && (weight >= heavy_w || (8 * weight >= 3 * heavy_w && weight >= 12 * (followers + 1))));
 }
 
 // ---- D: the walk ---------------------------------------------------------------------------------------
