@@ -12,6 +12,8 @@
 // scanInputRead's per-read lists (fgpu_scan_take_stops) exactly as ReadScanner does it.
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -451,6 +453,8 @@ struct PairFilter {   // a Bloom used through addPair / containsPair only (utils
 
 // What ReadScanner does with scanInputRead's lists: the short-pair rules at the end of scan_forward
 // (src/ReadScanner.cpp:208-225) per valid piece, and the paired-end loop of scanReads (:317-343) per read pair.
+const uint64_t kNoSpec = ~0ULL;   // PairLogic::spec_base: a stop whose read pair is not speculated
+
 struct PairLogic {
     int k = 0;
     bool paired_ends = false, no_cleaning = false;
@@ -493,6 +497,19 @@ struct PairLogic {
     };
     EndList end1, end2;
     std::vector<uint64_t> kept_c, kept_0, kept_1;
+    // The long-pair loop in two phases per batch of lists (speculate, then settle in order).  Phase 1, helper threads, the filter only READ:
+    // every first-end k-mer of every read pair of the batch is checked against the filter as it stands when the batch begins.  Bits are only
+    // ever set, so "paired" found there is final -- that k-mer does nothing when its turn comes.  For the others phase 1 leaves, per mate, the
+    // position of the FIRST bit it found missing.  Phase 2, this thread, file order: a k-mer that was not paired looks at those positions
+    // again -- one probe per mate; a bit that is still clear means the pair is still absent, exactly -- does a full check only where the bit
+    // has been set since (by this batch's earlier inserts), and inserts if nothing turned up.  Same answers and same inserts in the same
+    // order as the plain loop (long_pairs_plain), which still takes pairs that straddle two batches and filters of more than 2^32 bits.
+    std::vector<uint8_t> spec_found;       // per stop of the batch: (first-end entries) 1 = paired when the batch began
+    std::vector<uint64_t> spec_base;       // per stop of the batch: where its mates' positions start in spec_miss, kNoSpec = not speculated
+    std::vector<uint32_t> spec_miss;
+    struct SpecPair { size_t a1, n1, a2, n2; };
+    std::vector<SpecPair> spec_pairs;
+    std::vector<size_t> first_stop;        // of every read of the batch (+ one past the end)
     // canonical form and hashes of every stop of a batch, made by helper threads before the sequential loop (prepare): per stop a reverse
     // complement and two oldHash -- 23 M stops on BASELINE config 3's shape, half of what the worker thread used to spend
     std::vector<uint64_t> bc, b0, b1;
@@ -531,6 +548,78 @@ struct PairLogic {
 #define TK() 0ULL
 #endif
     void long_pairs() {
+#ifdef FGPU_CLI_PROFILE
+        const unsigned long long tq = TK();
+        long_pairs_inner();
+        tk_all += TK() - tq;
+    }
+    unsigned long long tk_all = 0;
+    void long_pairs_inner() {
+#endif
+        if (!spec_base.empty() && end1.canon >= bc.data() && end1.canon < bc.data() + bc.size() && spec_base[(size_t)(end1.canon - bc.data())] != kNoSpec) {
+            long_pairs_settle();
+            return;
+        }
+        long_pairs_plain();
+    }
+    // phase 2 of the speculated form (see spec_found)
+    void long_pairs_settle() {
+        const uint64_t mask = long_pf->tai - 1;
+        const int nh = long_pf->n_hash;
+        uint8_t* const bits = long_pf->bits.data();
+        const size_t n1 = end1.size(), n2 = end2.size();
+        const size_t at1 = (size_t)(end1.canon - bc.data());
+        for (size_t i = 0; i < n1; i++) {
+            if (spec_found[at1 + i]) continue;                               // paired when the batch began: paired now
+            const uint32_t* const miss = spec_miss.data() + spec_base[at1 + i];
+            const uint64_t p1 = end1.canon[i];
+            bool paired = false;
+            for (size_t j = 0; j < n2 && !paired; j++) {
+                const uint32_t pos = miss[j];
+                if (!((bits[pos >> 3] >> (pos & 7)) & 1u)) continue;          // the bit that was missing still is: the pair is still absent
+                const bool first_is_smaller = p1 <= end2.canon[j];
+                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[j];
+                const uint64_t h1 = first_is_smaller ? end2.h1[j] : end1.h1[i];
+                bool all = true;
+                for (int t = 0; t < nh && all; t++) { all = ((bits[h0 >> 3] >> (h0 & 7)) & 1u) != 0; h0 = (h0 + h1) & mask; }
+                paired = all;
+            }
+            if (!paired) {                                                    // addPair(pair1, back2.front())
+                const bool first_is_smaller = p1 <= end2.canon[0];
+                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[0];
+                const uint64_t h1 = first_is_smaller ? end2.h1[0] : end1.h1[i];
+                for (int t = 0; t < nh; t++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & mask; }
+            }
+        }
+    }
+    // phase 1 for the read pairs [from, to) of spec_pairs: read-only on the filter, writes only its own entries of spec_found / spec_miss
+    void speculate(size_t from, size_t to) {
+        const uint64_t mask = long_pf->tai - 1;
+        const int nh = long_pf->n_hash;
+        const uint8_t* const bits = long_pf->bits.data();
+        for (size_t p = from; p < to; p++) {
+            const SpecPair sp = spec_pairs[p];
+            for (size_t i = 0; i < sp.n1; i++) {
+                const uint64_t p1 = bc[sp.a1 + i];
+                uint32_t* const miss = spec_miss.data() + spec_base[sp.a1 + i];
+                bool found = false;
+                for (size_t j = 0; j < sp.n2 && !found; j++) {
+                    const bool first_is_smaller = p1 <= bc[sp.a2 + j];
+                    uint64_t h0 = first_is_smaller ? b0[sp.a1 + i] : b0[sp.a2 + j];
+                    const uint64_t h1 = first_is_smaller ? b1[sp.a2 + j] : b1[sp.a1 + i];
+                    int t = 0;
+                    for (; t < nh; t++) {
+                        if (!((bits[h0 >> 3] >> (h0 & 7)) & 1u)) break;
+                        h0 = (h0 + h1) & mask;
+                    }
+                    if (t == nh) found = true;
+                    else miss[j] = (uint32_t)h0;
+                }
+                spec_found[sp.a1 + i] = found ? 1 : 0;
+            }
+        }
+    }
+    void long_pairs_plain() {
         const unsigned long long tk0 = TK();
         const uint64_t mask = long_pf->tai - 1;
         const int nh = long_pf->n_hash;
@@ -600,17 +689,58 @@ struct PairLogic {
         part(0, n / n_threads);
         for (std::thread& t : th) t.join();
     }
+    double sec_ms[6] = {0, 0, 0, 0, 0, 0};   // -DFGPU_CLI_PROFILE: prepare, read offsets, pair list, phase 1, the loop over reads, of which long_pairs
     void batch(const fgpu_stop* stops, size_t n_stops, uint64_t n_reads) {   // reads of a batch, in file order
         const auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](int which, std::chrono::steady_clock::time_point& from) {
+            const auto now = std::chrono::steady_clock::now();
+            sec_ms[which] += std::chrono::duration<double, std::milli>(now - from).count();
+            from = now;
+        };
+        auto tl = t0;
         if (paired_ends) prepare(stops, n_stops);
-        prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        size_t a = 0;
-        for (uint64_t r = 0; r < n_reads; r++) {
-            size_t b = a;
-            while (b < n_stops && stops[b].read == r) b++;
-            read(stops + a, b - a, a);
-            a = b;
+        lap(0, tl);
+        first_stop.resize(n_reads + 1);
+        {
+            size_t a = 0;
+            for (uint64_t r = 0; r < n_reads; r++) {
+                first_stop[r] = a;
+                while (a < n_stops && stops[a].read == r) a++;
+            }
+            first_stop[n_reads] = a;
         }
+        lap(1, tl);
+        // the read pairs that lie inside this batch, and room for their mates' positions (at most 2^26 per batch: what is beyond takes the plain loop)
+        spec_base.clear();
+        static const bool no_spec = getenv("FGPU_CLI_NO_SPEC") != nullptr;     // (measurement: the plain loop for every pair)
+        if (!no_spec && paired_ends && !no_cleaning && long_pf && long_pf->tai <= (1ULL << 32) && n_stops) {
+            spec_base.assign(n_stops, kNoSpec);
+            spec_found.assign(n_stops, 0);
+            spec_pairs.clear();
+            uint64_t room = 0;
+            for (uint64_t r = first_end ? 0 : 1; r + 1 < n_reads; r += 2) {   // (first_end: read 0 opens a pair; else it closes one that began in the last batch)
+                const SpecPair sp = {first_stop[r], first_stop[r + 1] - first_stop[r], first_stop[r + 1], first_stop[r + 2] - first_stop[r + 1]};
+                if (!sp.n1 || !sp.n2 || room + (uint64_t)sp.n1 * sp.n2 > (1ULL << 26)) continue;
+                for (size_t i = 0; i < sp.n1; i++) { spec_base[sp.a1 + i] = room; room += sp.n2; }
+                spec_pairs.push_back(sp);
+            }
+            spec_miss.resize((size_t)room);
+            lap(2, tl);
+            const size_t n_threads = std::min<size_t>(6, spec_pairs.size() / 4096);
+            if (n_threads < 2) {
+                speculate(0, spec_pairs.size());
+            } else {
+                std::vector<std::thread> th;
+                for (size_t t = 1; t < n_threads; t++)
+                    th.emplace_back(&PairLogic::speculate, this, spec_pairs.size() * t / n_threads, spec_pairs.size() * (t + 1) / n_threads);
+                speculate(0, spec_pairs.size() / n_threads);
+                for (std::thread& t : th) t.join();
+            }
+        }
+        prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lap(3, tl);
+        for (uint64_t r = 0; r < n_reads; r++) read(stops + first_stop[r], first_stop[r + 1] - first_stop[r], first_stop[r]);
+        lap(4, tl);
         if (paired_ends && !first_end) {          // a first end waits for its mate in the next batch: its list leaves the batch's arrays
             kept_c.assign(end1.canon, end1.canon + end1.n);
             end1.canon = kept_c.data();
@@ -951,7 +1081,36 @@ int main(int argc, char** argv) {
                 bool closing = false;
                 std::thread t;
                 ListWorker(PairLogic& p, double& ms) : pairs(p), busy_ms(ms), t([this] { run(); }) {}
+                // The worker probes the long pair filter (tens of MB) at random for the whole pass: it stays with the cores that share the
+                // last-level cache it starts on, so that the filter stays in that cache instead of following the thread around the machine.
+                static void stay_with_this_cache() {
+                    const int cpu = sched_getcpu();
+                    if (cpu < 0) return;
+                    char path[128];
+                    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+                    FILE* f = fopen(path, "r");
+                    if (!f) return;
+                    char list[512] = {0};
+                    const size_t got = fread(list, 1, sizeof(list) - 1, f);
+                    fclose(f);
+                    if (!got) return;
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    int n_set = 0;
+                    for (char* p2 = list; *p2;) {           // "0-7,128-135"
+                        char* e;
+                        const long a = strtol(p2, &e, 10);
+                        if (e == p2) break;
+                        long b = a;
+                        if (*e == '-') { p2 = e + 1; b = strtol(p2, &e, 10); }
+                        for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &set); n_set++; }
+                        p2 = (*e == ',') ? e + 1 : e;
+                        if (*e != ',') break;
+                    }
+                    if (n_set) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+                }
                 void run() {
+                    if (!getenv("FGPU_CLI_NO_PIN")) stay_with_this_cache();
                     for (;;) {
                         std::pair<std::vector<fgpu_stop>, uint64_t> item;
                         {
@@ -1042,8 +1201,10 @@ int main(int argc, char** argv) {
         time(&stop);
         if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_take_stops, %.2f ms applying the lists to the pair filters (worker thread)\n",
                             clk.scan_ms, clk.take_ms, clk.pairs_ms);
-        if (clk.on && o.paired_ends) fprintf(stderr, "[cli]   of the worker's time, %.2f ms preparing canonical forms and hashes (helper threads)\n", pairs.prepare_ms);
+        if (clk.on && o.paired_ends) fprintf(stderr, "[cli]   of the worker's time, %.2f ms preparing canonical forms and hashes and speculating the long-pair checks (helper threads)\n", pairs.prepare_ms);
 #ifdef FGPU_CLI_PROFILE
+        fprintf(stderr, "[cli-profile] batch(): prepare %.1f ms, read offsets %.1f, pair list %.1f, phase 1 %.1f, loop over reads %.1f ms (long_pairs in it: %.1f Mticks)\n",
+                pairs.sec_ms[0], pairs.sec_ms[1], pairs.sec_ms[2], pairs.sec_ms[3], pairs.sec_ms[4], pairs.tk_all / 1e6);
         fprintf(stderr, "[cli-profile] long_pairs %.1f Mticks, of which inserts %.1f; first-probe failures %llu, chains %llu, first-end k-mers found paired %llu\n",
                 pairs.tk_long / 1e6, pairs.tk_ins / 1e6, pairs.n_first_fail, pairs.n_chain, pairs.n_hit);
 #endif
