@@ -453,8 +453,6 @@ struct PairFilter {   // a Bloom used through addPair / containsPair only (utils
 
 // What ReadScanner does with scanInputRead's lists: the short-pair rules at the end of scan_forward
 // (src/ReadScanner.cpp:208-225) per valid piece, and the paired-end loop of scanReads (:317-343) per read pair.
-const uint64_t kNoSpec = ~0ULL;   // PairLogic::spec_base: a stop whose read pair is not speculated
-
 struct PairLogic {
     int k = 0;
     bool paired_ends = false, no_cleaning = false;
@@ -505,10 +503,10 @@ struct PairLogic {
     // has been set since (by this batch's earlier inserts), and inserts if nothing turned up.  Same answers and same inserts in the same
     // order as the plain loop (long_pairs_plain), which still takes pairs that straddle two batches and filters of more than 2^32 bits.
     std::vector<uint8_t> spec_found;       // per stop of the batch: (first-end entries) 1 = paired when the batch began
-    std::vector<uint64_t> spec_base;       // per stop of the batch: where its mates' positions start in spec_miss, kNoSpec = not speculated
     std::vector<uint32_t> spec_miss;
-    struct SpecPair { size_t a1, n1, a2, n2; };
+    struct SpecPair { size_t a1, n1, a2, n2; uint64_t base; };   // base: where the pair's n1 x n2 positions start in spec_miss
     std::vector<SpecPair> spec_pairs;
+    size_t spec_next = 0;                  // phase 2: the next speculated pair in file order
     std::vector<size_t> first_stop;        // of every read of the batch (+ one past the end)
     // canonical form and hashes of every stop of a batch, made by helper threads before the sequential loop (prepare): per stop a reverse
     // complement and two oldHash -- 23 M stops on BASELINE config 3's shape, half of what the worker thread used to spend
@@ -556,14 +554,15 @@ struct PairLogic {
     unsigned long long tk_all = 0;
     void long_pairs_inner() {
 #endif
-        if (!spec_base.empty() && end1.canon >= bc.data() && end1.canon < bc.data() + bc.size() && spec_base[(size_t)(end1.canon - bc.data())] != kNoSpec) {
-            long_pairs_settle();
+        if (spec_next < spec_pairs.size() && end1.canon == bc.data() + spec_pairs[spec_next].a1) {   // the pair phase 1 looked at
+            long_pairs_settle(spec_pairs[spec_next].base);
+            spec_next++;
             return;
         }
         long_pairs_plain();
     }
     // phase 2 of the speculated form (see spec_found)
-    void long_pairs_settle() {
+    void long_pairs_settle(uint64_t base) {
         const uint64_t mask = long_pf->tai - 1;
         const int nh = long_pf->n_hash;
         uint8_t* const bits = long_pf->bits.data();
@@ -571,7 +570,7 @@ struct PairLogic {
         const size_t at1 = (size_t)(end1.canon - bc.data());
         for (size_t i = 0; i < n1; i++) {
             if (spec_found[at1 + i]) continue;                               // paired when the batch began: paired now
-            const uint32_t* const miss = spec_miss.data() + spec_base[at1 + i];
+            const uint32_t* const miss = spec_miss.data() + base + i * n2;
             const uint64_t p1 = end1.canon[i];
             bool paired = false;
             for (size_t j = 0; j < n2 && !paired; j++) {
@@ -601,7 +600,7 @@ struct PairLogic {
             const SpecPair sp = spec_pairs[p];
             for (size_t i = 0; i < sp.n1; i++) {
                 const uint64_t p1 = bc[sp.a1 + i];
-                uint32_t* const miss = spec_miss.data() + spec_base[sp.a1 + i];
+                uint32_t* const miss = spec_miss.data() + sp.base + i * sp.n2;
                 bool found = false;
                 for (size_t j = 0; j < sp.n2 && !found; j++) {
                     const bool first_is_smaller = p1 <= bc[sp.a2 + j];
@@ -669,25 +668,34 @@ struct PairLogic {
         (void)tk0;
 #endif
     }
-    void prepare(const fgpu_stop* stops, size_t n) {
+    // canonical forms, hashes and -- the same pass over the stops -- where every read's stops begin (first_stop)
+    void prepare(const fgpu_stop* stops, size_t n, uint64_t n_reads) {
         bc.resize(n);
         const bool hashes = !no_cleaning && long_pf;
         if (hashes) { b0.resize(n); b1.resize(n); }
         const uint64_t mask = hashes ? long_pf->tai - 1 : 0;
+        first_stop.resize(n_reads + 1);
         auto part = [&](size_t from, size_t to) {
             for (size_t i = from; i < to; i++) {
                 const uint64_t c = canonical(stops[i].ext, k);
                 bc[i] = c;
                 if (hashes) { b0[i] = old_hash(c, kSeed0) & mask; b1[i] = old_hash(c, kSeed1) & mask; }
+                // stop i is the first one of its read (and of the reads without stops before it)
+                const uint64_t r_here = stops[i].read, r_before = i ? stops[i - 1].read + 1 : 0;
+                for (uint64_t r = r_before; r <= r_here && r <= n_reads; r++) first_stop[r] = i;
             }
         };
         const size_t kPerThread = 1 << 16;
         const size_t n_threads = std::min<size_t>(4, n / kPerThread);
-        if (n_threads < 2) { part(0, n); return; }
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < n_threads; t++) th.emplace_back(part, n * t / n_threads, n * (t + 1) / n_threads);
-        part(0, n / n_threads);
-        for (std::thread& t : th) t.join();
+        if (n_threads < 2) {
+            part(0, n);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < n_threads; t++) th.emplace_back(part, n * t / n_threads, n * (t + 1) / n_threads);
+            part(0, n / n_threads);
+            for (std::thread& t : th) t.join();
+        }
+        for (uint64_t r = n ? stops[n - 1].read + 1 : 0; r <= n_reads; r++) first_stop[r] = n;   // the reads after the last stop's, and the end
     }
     double sec_ms[6] = {0, 0, 0, 0, 0, 0};   // -DFGPU_CLI_PROFILE: prepare, read offsets, pair list, phase 1, the loop over reads, of which long_pairs
     void batch(const fgpu_stop* stops, size_t n_stops, uint64_t n_reads) {   // reads of a batch, in file order
@@ -698,10 +706,10 @@ struct PairLogic {
             from = now;
         };
         auto tl = t0;
-        if (paired_ends) prepare(stops, n_stops);
-        lap(0, tl);
-        first_stop.resize(n_reads + 1);
-        {
+        if (paired_ends) {
+            prepare(stops, n_stops, n_reads);
+        } else {
+            first_stop.resize(n_reads + 1);
             size_t a = 0;
             for (uint64_t r = 0; r < n_reads; r++) {
                 first_stop[r] = a;
@@ -709,19 +717,18 @@ struct PairLogic {
             }
             first_stop[n_reads] = a;
         }
-        lap(1, tl);
+        lap(0, tl);
         // the read pairs that lie inside this batch, and room for their mates' positions (at most 2^26 per batch: what is beyond takes the plain loop)
-        spec_base.clear();
+        spec_pairs.clear();
+        spec_next = 0;
         static const bool no_spec = getenv("FGPU_CLI_NO_SPEC") != nullptr;     // (measurement: the plain loop for every pair)
         if (!no_spec && paired_ends && !no_cleaning && long_pf && long_pf->tai <= (1ULL << 32) && n_stops) {
-            spec_base.assign(n_stops, kNoSpec);
-            spec_found.assign(n_stops, 0);
-            spec_pairs.clear();
+            spec_found.resize(n_stops);
             uint64_t room = 0;
             for (uint64_t r = first_end ? 0 : 1; r + 1 < n_reads; r += 2) {   // (first_end: read 0 opens a pair; else it closes one that began in the last batch)
-                const SpecPair sp = {first_stop[r], first_stop[r + 1] - first_stop[r], first_stop[r + 1], first_stop[r + 2] - first_stop[r + 1]};
+                const SpecPair sp = {first_stop[r], first_stop[r + 1] - first_stop[r], first_stop[r + 1], first_stop[r + 2] - first_stop[r + 1], room};
                 if (!sp.n1 || !sp.n2 || room + (uint64_t)sp.n1 * sp.n2 > (1ULL << 26)) continue;
-                for (size_t i = 0; i < sp.n1; i++) { spec_base[sp.a1 + i] = room; room += sp.n2; }
+                room += (uint64_t)sp.n1 * sp.n2;
                 spec_pairs.push_back(sp);
             }
             spec_miss.resize((size_t)room);
