@@ -136,6 +136,13 @@ static int pull_counters(fgpu_ctx* ctx) {
     return check_errors(ctx);
 }
 
+// the page-locked buffers of harvested lists go back to the pool (stop_queue.clear() would leak them)
+static void stop_queue_recycle(fgpu_ctx* ctx) {
+    for (StopBatch& sb : ctx->stop_queue)
+        if (sb.data) { StopBatch f; f.data = sb.data; f.cap = sb.cap; ctx->stop_pool.push_back(f); }
+    ctx->stop_queue.clear();
+}
+
 static bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
 
 static void journal_recycle(fgpu_ctx* ctx);
@@ -311,6 +318,9 @@ void fgpu_destroy(fgpu_ctx* ctx) {
                     ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
+    stop_queue_recycle(ctx);
+    for (StopBatch& f : ctx->stop_pool) hipHostFree(f.data);
+    ctx->stop_pool.clear();
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
     if (ctx->fb_host) hipHostFree(ctx->fb_host);
     if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
@@ -560,7 +570,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->scan_batch_seq = 0;
     for (BatchBufs* b : ctx->to_harvest) b->stops_pending = false;   // lists of an earlier scan nobody asked for
     ctx->to_harvest.clear();
-    ctx->stop_queue.clear();
+    stop_queue_recycle(ctx);
     for (BatchBufs* b : ctx->prepared) ctx->pool.push_back(b);
     ctx->prepared.clear();
     ctx->cur = &ctx->bb_default;
@@ -697,7 +707,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->prepared.clear();
     for (BatchBufs* b : ctx->to_harvest) b->stops_pending = false;
     ctx->to_harvest.clear();
-    ctx->stop_queue.clear();
+    stop_queue_recycle(ctx);
     if (!rc) rc = fgpu_scan_reset(ctx);
     if (rc) { ctx->in_replay = false; return rc; }
     {   // what fgpu_diag_late_flags reports of the voided attempt (everything has completed: sync_all above)
@@ -922,11 +932,12 @@ int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* 
     }
     if (ctx->stop_queue.empty()) return FGPU_OK;
     StopBatch& sb = ctx->stop_queue.front();
-    *n_out = sb.stops.size();
+    *n_out = sb.n;
     *batch_seq = (int64_t)sb.seq;
-    if (sb.stops.size() > cap || (sb.stops.size() && !out)) return FGPU_ERR_CAPACITY;
-    if (!sb.stops.empty()) memcpy(out, sb.stops.data(), sb.stops.size() * sizeof(fgpu_stop));
+    if (sb.n > cap || (sb.n && !out)) return FGPU_ERR_CAPACITY;
+    if (sb.n) memcpy(out, sb.data, sb.n * sizeof(fgpu_stop));
     ctx->stops_delivered = sb.seq + 1;
+    if (sb.data) { StopBatch f; f.data = sb.data; f.cap = sb.cap; ctx->stop_pool.push_back(f); }
     ctx->stop_queue.pop_front();
     return FGPU_OK;
 }

@@ -89,9 +89,10 @@ struct JournalBatch {
 };
 #define FGPU_INTERNAL_REPLAY 1000   // internal status: the lazy-flag check fired, the journal has to be replayed before this call goes on
 
-struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_scan_take_stops
-    uint64_t seq;
-    std::vector<fgpu_stop> stops;
+struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_scan_take_stops: in a page-locked buffer of the context's pool
+    uint64_t seq = 0;   // (the copy off the device runs at link speed into it, and the buffers are reused: a fresh pageable vector per
+    fgpu_stop* data = nullptr;   // batch cost a staged copy plus its page faults, 0.15 s of a 0.5 s pass on config 3's shape)
+    size_t n = 0, cap = 0;
 };
 
 struct KernelStat {
@@ -270,6 +271,7 @@ struct fgpu_ctx {
     bool eager_runtime = false;           // fgpu_scan_set_eager: evaluate testForJunction everywhere in the following scans
     std::vector<BatchBufs*> to_harvest;   // walked batches whose stops are still on the device, in scan order
     std::deque<StopBatch> stop_queue;     // harvested, not yet taken
+    std::vector<StopBatch> stop_pool;     // page-locked buffers not in use (data / cap)
     uint64_t scan_batch_seq = 0;
     uint64_t walked_pieces = 0;           // pieces handed to the ordered walk so far in this scan
     DevBuf probe_buf, export_stamps;

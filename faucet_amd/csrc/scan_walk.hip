@@ -2459,9 +2459,23 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
                            (const uint32_t*)offset, np, PairFilterDev{ctx->short_pf, ctx->short_pf_tai - 1, ctx->short_pf_hashes}, ctx->fd.k);
     if (to_host) {
         StopBatch& sb = ctx->stop_queue.back();
-        sb.stops.resize(total);
-        FGPU_HIP(hipMemcpyAsync(sb.stops.data(), b->stop_out.p, total * sizeof(fgpu_stop), hipMemcpyDeviceToHost, ctx->stream));
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        if (total) {
+            size_t best = ctx->stop_pool.size();                       // the smallest free buffer that is large enough
+            for (size_t i = 0; i < ctx->stop_pool.size(); i++)
+                if (ctx->stop_pool[i].cap >= total && (best == ctx->stop_pool.size() || ctx->stop_pool[i].cap < ctx->stop_pool[best].cap)) best = i;
+            if (best < ctx->stop_pool.size()) {
+                sb.data = ctx->stop_pool[best].data;
+                sb.cap = ctx->stop_pool[best].cap;
+                ctx->stop_pool.erase(ctx->stop_pool.begin() + (ptrdiff_t)best);
+            } else {
+                const size_t cap = (size_t)(total + total / 4);
+                FGPU_HIP(hipHostMalloc((void**)&sb.data, cap * sizeof(fgpu_stop)));
+                sb.cap = cap;
+            }
+            FGPU_HIP(hipMemcpyAsync(sb.data, b->stop_out.p, total * sizeof(fgpu_stop), hipMemcpyDeviceToHost, ctx->stream));
+            FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        sb.n = total;
     }
     return FGPU_OK;
 }

@@ -1085,6 +1085,13 @@ int main(int argc, char** argv) {
                 std::mutex m;
                 std::condition_variable cv;
                 std::deque<std::pair<std::vector<fgpu_stop>, uint64_t> > q;
+                std::vector<std::vector<fgpu_stop> > spare;
+                std::vector<fgpu_stop> take_spare() {
+                    std::lock_guard<std::mutex> g(m);
+                    std::vector<fgpu_stop> v;
+                    if (!spare.empty()) { v = std::move(spare.back()); spare.pop_back(); }
+                    return v;
+                }
                 bool closing = false;
                 std::thread t;
                 ListWorker(PairLogic& p, double& ms) : pairs(p), busy_ms(ms), t([this] { run(); }) {}
@@ -1132,6 +1139,7 @@ int main(int argc, char** argv) {
                         {
                             std::lock_guard<std::mutex> g(m);
                             q.pop_front();                    // only now: `finish` waits for an empty queue
+                            spare.push_back(std::move(item.first));   // (its pages are mapped: the next batch's lists go into it without page faults)
                         }
                         cv.notify_all();
                     }
@@ -1160,7 +1168,7 @@ int main(int argc, char** argv) {
                 uint64_t n = 0;
                 int64_t seq = -1;
                 const auto t_take = std::chrono::steady_clock::now();
-                std::vector<fgpu_stop> stops;
+                std::vector<fgpu_stop> stops = worker.take_spare();
                 int trc = fgpu_scan_take_stops(ctx, nullptr, 0, &n, &seq);
                 if (trc == FGPU_ERR_CAPACITY) {
                     stops.resize(n);
