@@ -366,11 +366,15 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
             return FGPU_ERR_NOMEM;
         }
     }
-    // The carry of the next batch: one sweep of first[] per batch (4 bytes per filter bit, streaming) up to 2^30 bits; beyond
-    // that the sweep costs more than re-hashing the batch's new k-mers (k_carry_set): at 2^32 bits / 1 M-read batches 25 vs
-    // 44 ms per 10 M reads, at 2^33 bits the sweep would read 32 GiB per batch.
+    // The carry of the following batches: brought up to date by sweeps of first[] (4 bytes per filter bit, streaming) that close epochs of
+    // batches -- after batches 0, 1, 3, 7 ... the carry may lag, see fgpu_stage_load -- or, in between, by re-hashing a batch's new
+    // k-mers right after it (k_carry_set: the carry never lags, one pass over the batch more).  Measured with both on the shapes that have
+    // large filters (scripts/carry_mode_sweep.sh, round 3; per step, set / sweep): 2^31 bits, 10 M reads 185 / 192 ms; 2^32 bits, 10 M reads
+    // 232 / 227; 2^33 bits: 25 M reads 581 / 554, config 5 (50 M x 150) 1 425 / 1 236, config 4 whole (200 M reads) 3 160 / 2 941 --
+    // the longer the pass and the thinner the coverage of an epoch, the less an up-to-date carry is worth its pass.  So: sweeps,
+    // except at 2^31 bits.  (Round 2 re-hashed from 2^31 bits up; it had only measured short passes.)
     static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
-    ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai > (1ULL << 30);
+    ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai == (1ULL << 31);
     ctx->shard_times = (keep_carry & FGPU_LOAD_SHARD_TIMES) != 0;
     ctx->fixup_ready = false;
     ctx->pass_positions = ctx->pass_batches = 0;
