@@ -372,7 +372,9 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     // large filters (scripts/carry_mode_sweep.sh, round 3; per step, set / sweep): 2^31 bits, 10 M reads 185 / 192 ms; 2^32 bits, 10 M reads
     // 232 / 227; 2^33 bits: 25 M reads 581 / 554, config 5 (50 M x 150) 1 425 / 1 236, config 4 whole (200 M reads) 3 160 / 2 941 --
     // the longer the pass and the thinner the coverage of an epoch, the less an up-to-date carry is worth its pass.  So: sweeps,
-    // except at 2^31 bits.  (Round 2 re-hashed from 2^31 bits up; it had only measured short passes.)
+    // except at 2^31 bits.  (One rank's passes of the 8-rank shape, 2^32 bits, same box, re-hashing / sweeping: the presence protocol's
+    // load on a carried-in state 88-97 / 95 ms, the fix-up protocol's own load 146-163 / 143 ms.  Round 2 re-hashed from 2^31 bits up;
+    // it had only measured short passes.)
     static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
     ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai == (1ULL << 31);
     ctx->shard_times = (keep_carry & FGPU_LOAD_SHARD_TIMES) != 0;
