@@ -235,6 +235,11 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     ctx->record_stops = (p->flags & FGPU_FLAG_RECORD_STOPS) != 0;
     { const char* e = getenv("FGPU_PROFILE_WALK"); ctx->prof_walk_detail = e && e[0] == '1'; }
     ctx->bloom_bytes = p->tai / 8;
+    // Thin coverage per window -- a large genome, hence a large filter -- leaves clusters tiny however long the window: the bound grows
+    // with the filter, 2^26 positions up to 2^30 filter bits, 2^28 from 2^32 on (config 5's walk stage 404 / 347 / 317 ms at 2^26 / 2^27 /
+    // 2^28, config 4's 1 266 / 1 020 / 921 ms; config 2 settles at 2^25-2^26 whatever the bound).  The window table is 32 bytes per position
+    // of the bound.
+    ctx->max_span = std::min<uint64_t>(std::max<uint64_t>(p->tai >> 4, FGPU_MAX_SPAN), 1ULL << 28);
     if (const char* e = getenv("FGPU_MAX_SPAN_LOG2")) {   // experiment knob
         int l = atoi(e);
         if (l >= 12 && l <= 28) ctx->max_span = 1ULL << l;
