@@ -453,6 +453,8 @@ def main():
     ap.add_argument("--no-full-size", action="store_true", help="skip the full-size legs of BASELINE configs 5 and 4 (N = 1; about half a minute)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the extra PCIe-inclusive steps reported as `host_input` (N = 1)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="replicas of the all-cores CPU leg (0 = min(host cores, 16))")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="timed steps WITHOUT HIP events around every kernel (A/B of what FGPU_FLAG_PROFILE costs; no roofline / kernel times in the line)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL prints its version banner there) go to stderr
@@ -508,10 +510,10 @@ def main():
         # the host never waits between them (sharded.GpuShard.fence is a no-op then)
         tstream = torch.cuda.Stream(device)
         torch.cuda.set_stream(tstream)
-        ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")), stream=tstream.cuda_stream)
+        ctx = api.Context(k, tai, nh, device=local_rank, profile=not args.no_profile, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")), stream=tstream.cuda_stream)
         shard = sharded.GpuShard(ctx, device)
     else:
-        ctx = api.Context(k, tai, nh, device=local_rank, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
+        ctx = api.Context(k, tai, nh, device=local_rank, profile=not args.no_profile, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
         shard = None
 
     def one_step():

@@ -100,6 +100,9 @@ SIGNATURES = {
     "fgpu_scan_import_hint": (C.c_int, [_vp, _vp, _u64]),
     "fgpu_scan_short_pairs": (C.c_int, [_vp, _u64, _i32, _i32]),
     "fgpu_scan_short_pairs_download": (C.c_int, [_vp, _vp, _u64]),
+    "fgpu_scan_long_pairs": (C.c_int, [_vp, _u64, _i32, _i32]),
+    "fgpu_scan_long_pairs_download": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
+    "fgpu_diag_long_pairs": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
     "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),

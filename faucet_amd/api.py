@@ -355,6 +355,23 @@ class Context:
         self._c(self.lib.fgpu_scan_short_pairs_download(self.h, out.ctypes.data, len(out)))
         return out
 
+    def scan_long_pairs(self, tai: int, n_hash: int, mode: int = 2):
+        """keep the long pair filter (scanReads' paired-end loop, src/ReadScanner.cpp:317-343) on the device from the next scan on;
+        mode 0 = off, 1 = only the empty / not-empty pair counts (--no_cleaning), 2 = counts and filter"""
+        self._c(self.lib.fgpu_scan_long_pairs(self.h, int(tai), int(n_hash), int(mode)))
+
+    def scan_long_pairs_download(self, tai: int = 0):
+        """(filter bytes or None, empty count, not-empty count) after scan_end"""
+        out = np.zeros(tai // 8, dtype=np.uint8) if tai else None
+        e, ne = C.c_uint64(0), C.c_uint64(0)
+        self._c(self.lib.fgpu_scan_long_pairs_download(self.h, out.ctypes.data if tai else None, len(out) if tai else 0, C.byref(e), C.byref(ne)))
+        return out, int(e.value), int(ne.value)
+
+    def diag_long_pairs(self):
+        out = (C.c_uint64 * 6)()
+        self._c(self.lib.fgpu_diag_long_pairs(self.h, out))
+        return dict(zip(("items", "paired_by_carry", "inserts", "rounds", "max_rounds", "batches"), (int(v) for v in out)))
+
     def stage3_set_junctions(self, keys, recs):
         """the junction map Stage 3's walks look into (keys as JunctionMap keys them; records as junctions() returns them)"""
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

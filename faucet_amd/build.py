@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfaucet_gpu.so")
 CLI = os.path.join(HERE, "faucet")
-HIP_SOURCES = ["api.hip", "pack.hip", "load.hip", "scan_pure.hip", "scan_walk.hip", "diag.hip", "text.hip", "stage3.hip"]
+HIP_SOURCES = ["api.hip", "pack.hip", "load.hip", "scan_pure.hip", "scan_walk.hip", "diag.hip", "text.hip", "stage3.hip", "pairs.hip"]
 CPP_SOURCES = ["sizing.cpp"]
 HEADERS = ["fgpu_ctx.h", "fgpu_device.h", "fgpu_flags.h", os.path.join(ROOT, "include", "faucet_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

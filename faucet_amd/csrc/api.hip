@@ -319,7 +319,8 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
-    void* ptrs[] = {ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
+    if (ctx->lp.flips_host) hipHostFree(ctx->lp.flips_host);
+    void* ptrs[] = {ctx->lp.bits, ctx->lp.first, ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
                     ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -565,6 +566,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->late_acc[0] = ctx->late_acc[1] = ctx->late_acc[2] = 0;
     ctx->stops_delivered = 0;
     if (ctx->short_pf) FGPU_HIP(hipMemsetAsync(ctx->short_pf, 0, ctx->short_pf_tai / 8, ctx->stream));   // a scan starts with empty pair filters
+    if ((rc = fgpu_long_pairs_reset(ctx))) return rc;
     ctx->have_import = false;
     ctx->journal_max_read_len = 0;
     ctx->hint_in_table = false;

@@ -95,6 +95,23 @@ struct StopBatch {   // harvested stops of one scanned batch, waiting for fgpu_s
     size_t n = 0, cap = 0;
 };
 
+// The long pair filter on the device (pairs.hip): scanReads' paired-end loop over the harvested lists
+struct LongPairs {
+    int mode = 0;                    // FGPU_LONG_PAIRS_OFF / _COUNT / _FILTER
+    uint64_t tai = 0;
+    int n_hash = 0;
+    uint32_t* bits = nullptr;        // the filter, tai / 8 bytes
+    uint32_t* first = nullptr;       // first-set time per filter bit of the batch in hand, 4 * tai bytes (all "never" between batches)
+    DevBuf canon, h0, h1, vread, rs, state, dev;   // per list element / per read scratch; dev: counters and flip counts
+    DevBuf kept_set[2];              // a waiting first end's list (canonical forms, then the two hashes): two buffers used in turn
+    int kept_cur = 0;
+    uint32_t* flips_host = nullptr;  // page-locked read-back
+    bool pending_first = false;      // the last harvested batch ended with a first end whose mate opens the next one
+    uint64_t n_kept = 0;             // elements of that first end's list (in kept_set[kept_cur])
+    uint64_t empty_host = 0;         // pairs counted as empty without a kernel (batches whose lists are all empty)
+    uint64_t rounds = 0, max_rounds = 0, batches = 0;   // fgpu_diag_long_pairs
+};
+
 struct KernelStat {
     std::string name;
     uint64_t launches = 0;
@@ -259,6 +276,7 @@ struct fgpu_ctx {
     uint64_t short_pf_tai = 0;
     int short_pf_hashes = 0;
     bool short_pf_lists_to_host = true;
+    LongPairs lp;                         // the long pair filter on the device (fgpu_scan_long_pairs)
     uint64_t stops_delivered = 0;         // batches whose lists the caller has taken (a replay does not hand them out again)
     uint64_t scan_replays = 0;            // replays since the context was made (fgpu_diag_scan_replays)
     uint64_t late_acc[3] = {0, 0, 0};        // late junction tests of this scan's voided attempts (DevCounters::late_n is reset with the replay)
@@ -373,6 +391,8 @@ int fgpu_util_probe_contains(fgpu_ctx* ctx, const uint32_t* bloom, const uint64_
 int fgpu_util_probe_stage3(fgpu_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int mode, signed char* d_out);
 int fgpu_scan_alloc(fgpu_ctx* ctx);
 int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b);
+int fgpu_long_pairs_batch(fgpu_ctx* ctx, const fgpu_stop* d_stops, uint64_t n_stops, uint64_t n_reads);
+int fgpu_long_pairs_reset(fgpu_ctx* ctx);
 int fgpu_scan_reset(fgpu_ctx* ctx);
 int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap);
 int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records);

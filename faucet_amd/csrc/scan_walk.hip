@@ -2425,7 +2425,9 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
     }
     b->stops_pending = false;
     if (b->seq < ctx->stops_delivered) return FGPU_OK;   // scanned again by a replay: the caller has this batch's lists already
-    const bool to_host = !ctx->short_pf || ctx->short_pf_lists_to_host;
+    // the lists come to the host unless their consumers on the device said otherwise (fgpu_scan_short_pairs' lists_to_host; a scan that only
+    // feeds the long pair filter on the device, fgpu_scan_long_pairs, hands none out)
+    const bool to_host = ctx->short_pf ? ctx->short_pf_lists_to_host : !ctx->lp.mode;
     if (to_host) {
         ctx->stop_queue.emplace_back();
         ctx->stop_queue.back().seq = b->seq;
@@ -2433,7 +2435,7 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
         ctx->stops_delivered = b->seq + 1;                // nobody takes them: the lists end in the device's pair filter
     }
     const uint64_t np = b->n_pieces;
-    if (!np) return FGPU_OK;
+    if (!np) return fgpu_long_pairs_batch(ctx, nullptr, 0, b->n_reads);   // (its reads still count as ends of pairs)
     int rc;
     if ((rc = fgpu_ensure(ctx, &b->stop_off, (2 * np + 2) * 4))) return rc;
     uint32_t* count = (uint32_t*)b->stop_off.p;
@@ -2457,6 +2459,8 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
     if (ctx->short_pf)
         hipLaunchKernelGGL(k_short_pairs, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const fgpu_stop*)b->stop_out.p, (const uint32_t*)count,
                            (const uint32_t*)offset, np, PairFilterDev{ctx->short_pf, ctx->short_pf_tai - 1, ctx->short_pf_hashes}, ctx->fd.k);
+    // scanReads' paired-end loop over the same lists (pairs.hip): check-then-insert in file order, exact, on the device
+    if ((rc = fgpu_long_pairs_batch(ctx, (const fgpu_stop*)b->stop_out.p, total, b->n_reads))) return rc;
     if (to_host) {
         StopBatch& sb = ctx->stop_queue.back();
         if (total) {

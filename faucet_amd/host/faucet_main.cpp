@@ -8,17 +8,14 @@
 // contig graph; the reference itself can be restarted from these files with -bloom_file / -junctions_file).
 // No k-mer window, filter probe or junction is computed on the host: everything goes through fgpu_*; if the library
 // finds no gfx950 device the program fails (there is no CPU path).  What stays on the host is what SURVEY.md 8(b)
-// leaves there: the JunctionMap container that fixes the dump order, and the two pair filters, which are fed from
-// scanInputRead's per-read lists (fgpu_scan_take_stops) exactly as ReadScanner does it.
+// leaves there: the JunctionMap container that fixes the dump order, and the files.  Both pair filters are filled on the
+// device from scanInputRead's per-read lists (fgpu_scan_short_pairs, fgpu_scan_long_pairs) and come back as bytes.
 #include <errno.h>
 #include <fcntl.h>
-#include <pthread.h>
-#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -26,10 +23,8 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
-#include <deque>
 #include <fstream>
 #include <mutex>
-#include <new>
 #include <thread>
 #include <string>
 #include <unordered_map>
@@ -361,53 +356,11 @@ struct Junction {   // utils/Junction.h:10-18
 
 const char kDecode[4] = {'A', 'C', 'T', 'G'};   // utils/Kmer.cpp:21
 
-// ---- the pair filters (host side, as in the reference) ---------------------------------------------------------
-uint64_t revcomp(uint64_t x, int k) {   // utils/Kmer.cpp:238-252: complement every 2-bit code (x ^ 2), reverse their order
-    x ^= 0xAAAAAAAAAAAAAAAAULL;
-    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-    return __builtin_bswap64(x) >> (64 - 2 * k);
-}
-uint64_t canonical(uint64_t x, int k) { const uint64_t r = revcomp(x, k); return x < r ? x : r; }   // utils/Kmer.cpp:531-533
-
-uint64_t old_hash(uint64_t key, uint64_t seed) {   // Bloom::oldHash, utils/Bloom.h:134-145
-    uint64_t h = seed;
-    h ^= (h << 7) ^ key * (h >> 3) ^ (~((h << 11) + (key ^ (h >> 5))));
-    h = (~h) + (h << 21);
-    h = h ^ (h >> 24);
-    h = (h + (h << 3)) + (h << 8);
-    h = h ^ (h >> 14);
-    h = (h + (h << 2)) + (h << 4);
-    h = h ^ (h >> 28);
-    h = h + (h << 31);
-    return h;
-}
-const uint64_t kSeed0 = 0xffaa54ffe6e6e6e7ULL, kSeed1 = 0x1140aada557088a4ULL;   // seed_tab[0..1], utils/Bloom.h:56-68 with user_seed 0
-
-// The pair filters' bit arrays on 2 MiB pages where the kernel gives them (transparent huge pages, madvise): the long-pair loop probes
-// tens of MB at random, and with 4 KiB pages most of its probes missed the TLB as well (-17 % per check in a stand-alone copy of the loop).
-template <class T>
-struct HugePageAlloc {
-    typedef T value_type;
-    HugePageAlloc() {}
-    template <class U> HugePageAlloc(const HugePageAlloc<U>&) {}
-    T* allocate(size_t n) {
-        const size_t kHuge = (size_t)1 << 21;
-        const size_t bytes = (n * sizeof(T) + kHuge - 1) / kHuge * kHuge;
-        void* p = nullptr;
-        if (posix_memalign(&p, kHuge, bytes)) throw std::bad_alloc();
-        (void)madvise(p, bytes, MADV_HUGEPAGE);      // advice only: without it the array lives on ordinary pages
-        return (T*)p;
-    }
-    void deallocate(T* p, size_t) { free(p); }
-    template <class U> bool operator==(const HugePageAlloc<U>&) const { return true; }
-    template <class U> bool operator!=(const HugePageAlloc<U>&) const { return false; }
-};
-
-struct PairFilter {   // a Bloom used through addPair / containsPair only (utils/Bloom.cpp:127-154, Bloom.h:217-258)
+// ---- the pair filters: sized and written by the host, filled on the device ---------------------------------------
+struct PairFilter {   // a Bloom used through addPair / containsPair only (utils/Bloom.cpp:127-154): here just its bytes, which the device fills
     uint64_t tai = 0;
     int n_hash = 0;
-    std::vector<uint8_t, HugePageAlloc<uint8_t> > bits;
+    std::vector<uint8_t> bits;
     void create(uint64_t elements, float fp) {   // create_bloom_filter_optimal, utils/Bloom.cpp:229-247
         int32_t bpk = 0, nh = 0;
         fgpu_size_optimal(elements, fp, &bpk, &tai, &nh);
@@ -417,20 +370,6 @@ struct PairFilter {   // a Bloom used through addPair / containsPair only (utils
         printf("Number of hash functions: %d \n", n_hash);
         bits.assign(tai / 8, 0);
     }
-    // e1, e2: the canonical forms of the two k-mers of a JuncPair
-    void add_canon(uint64_t e1, uint64_t e2) {
-        uint64_t h0 = old_hash(std::min(e1, e2), kSeed0) & (tai - 1);
-        const uint64_t h1 = old_hash(std::max(e1, e2), kSeed1) & (tai - 1);
-        for (int i = 0; i < n_hash; i++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & (tai - 1); }
-    }
-    bool contains_canon(uint64_t e1, uint64_t e2) const {
-        uint64_t h0 = old_hash(std::min(e1, e2), kSeed0) & (tai - 1);
-        if (!(bits[h0 >> 3] & (1u << (h0 & 7)))) return false;      // most pairs are new: one hash, one probe
-        const uint64_t h1 = old_hash(std::max(e1, e2), kSeed1) & (tai - 1);
-        for (int i = 1; i < n_hash; i++) { h0 = (h0 + h1) & (tai - 1); if (!(bits[h0 >> 3] & (1u << (h0 & 7)))) return false; }
-        return true;
-    }
-    void add_pair(uint64_t k1, uint64_t k2, int k) { add_canon(canonical(k1, k), canonical(k2, k)); }
     float weight() const {   // Bloom::weight, utils/Bloom.cpp:191-203
         long w = 0;
         size_t i = 0;
@@ -445,319 +384,9 @@ struct PairFilter {   // a Bloom used through addPair / containsPair only (utils
     int dump(const std::string& path) const {   // Bloom::dump, utils/Bloom.cpp:571-578
         FILE* f = fopen(path.c_str(), "wb");
         if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
-        fwrite(bits.data(), 1, bits.size(), f);
-        fclose(f);
+        const bool ok = fwrite(bits.data(), 1, bits.size(), f) == bits.size();
+        if (fclose(f) != 0 || !ok) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
         return 0;
-    }
-};
-
-// What ReadScanner does with scanInputRead's lists: the short-pair rules at the end of scan_forward
-// (src/ReadScanner.cpp:208-225) per valid piece, and the paired-end loop of scanReads (:317-343) per read pair.
-struct PairLogic {
-    int k = 0;
-    bool paired_ends = false, no_cleaning = false;
-    PairFilter* short_pf = nullptr;
-    PairFilter* long_pf = nullptr;
-    bool first_end = true;
-    int empty_count = 0, not_empty_count = 0;
-    double prepare_ms = 0;                // FGPU_CLI_TIMES: of the worker's time, what `prepare` took
-
-    void piece(const fgpu_stop* s, size_t n) {   // one scan_forward call
-        if (no_cleaning || !short_pf) return;
-        if (n == 2) {
-            bool have_first_back = false, have_last_fwd = false;
-            uint32_t rev_pos = 0, for_pos = 0;
-            uint64_t first_back = 0, last_fwd = 0;
-            for (size_t i = 0; i < n; i++) {
-                const uint32_t pos = s[i].info & FGPU_STOP_POS_MASK;
-                if (s[i].info & FGPU_STOP_FAKE) continue;
-                if (!(s[i].info & FGPU_STOP_FORWARD)) {
-                    if (!have_first_back) { have_first_back = true; first_back = s[i].ext; rev_pos = pos; }
-                } else {
-                    if (!have_last_fwd) { have_last_fwd = true; for_pos = pos; }
-                    last_fwd = s[i].ext;
-                }
-            }
-            if (have_first_back && have_last_fwd && !(rev_pos > for_pos)) short_pf->add_pair(first_back, last_fwd, k);
-            if ((have_first_back && !have_last_fwd) || (!have_first_back && have_last_fwd)) short_pf->add_pair(s[0].ext, s[1].ext, k);
-        } else if (n > 2) {
-            for (size_t i = 0; i + 2 < n; i++) short_pf->add_pair(s[i].ext, s[i + 2].ext, k);
-        }
-    }
-    // One end's list as the long-pair loop needs it: the canonical k-mers (all a JuncPair is hashed by) and their two hashes, masked.
-    // containsPair / addPair hash the SMALLER k-mer of a pair with one seed and the larger with the other (PairFilter::contains_canon /
-    // add_canon), so the |end 1| x |end 2| checks of a read pair need one pair of hashes per list entry, not one per check.
-    struct EndList {                       // a view into the batch's arrays (prepare); end 1 is copied when its pair straddles two batches
-        const uint64_t *canon = nullptr, *h0 = nullptr, *h1 = nullptr;
-        size_t n = 0;
-        bool empty() const { return n == 0; }
-        size_t size() const { return n; }
-    };
-    EndList end1, end2;
-    std::vector<uint64_t> kept_c, kept_0, kept_1;
-    // The long-pair loop in two phases per batch of lists (speculate, then settle in order).  Phase 1, helper threads, the filter only READ:
-    // every first-end k-mer of every read pair of the batch is checked against the filter as it stands when the batch begins.  Bits are only
-    // ever set, so "paired" found there is final -- that k-mer does nothing when its turn comes.  For the others phase 1 leaves, per mate, the
-    // position of the FIRST bit it found missing.  Phase 2, this thread, file order: a k-mer that was not paired looks at those positions
-    // again -- one probe per mate; a bit that is still clear means the pair is still absent, exactly -- does a full check only where the bit
-    // has been set since (by this batch's earlier inserts), and inserts if nothing turned up.  Same answers and same inserts in the same
-    // order as the plain loop (long_pairs_plain), which still takes pairs that straddle two batches and filters of more than 2^32 bits.
-    std::vector<uint8_t> spec_found;       // per stop of the batch: (first-end entries) 1 = paired when the batch began
-    std::vector<uint32_t> spec_miss;
-    struct SpecPair { size_t a1, n1, a2, n2; uint64_t base; };   // base: where the pair's n1 x n2 positions start in spec_miss
-    std::vector<SpecPair> spec_pairs;
-    size_t spec_next = 0;                  // phase 2: the next speculated pair in file order
-    std::vector<size_t> first_stop;        // of every read of the batch (+ one past the end)
-    // canonical form and hashes of every stop of a batch, made by helper threads before the sequential loop (prepare): per stop a reverse
-    // complement and two oldHash -- 23 M stops on BASELINE config 3's shape, half of what the worker thread used to spend
-    std::vector<uint64_t> bc, b0, b1;
-
-    void read(const fgpu_stop* s, size_t n, size_t first) {   // one iteration of the loop in scanReads; `first`: index of s[0] in the batch
-        EndList& e = first_end ? end1 : end2;
-        e.n = 0;
-        size_t a = 0;
-        while (short_pf && !no_cleaning && a < n) {
-            size_t b = a + 1;
-            while (b < n && !(s[b].info & FGPU_STOP_FIRST)) b++;
-            piece(s + a, b - a);
-            a = b;
-        }
-        if (paired_ends) {
-            e.canon = bc.data() + first;
-            if (!b0.empty()) { e.h0 = b0.data() + first; e.h1 = b1.data() + first; }   // (no hashes without cleaning)
-            e.n = n;
-        }
-        if (paired_ends && !first_end) {
-            if (!end1.empty() && !end2.empty()) {
-                not_empty_count++;
-                if (!no_cleaning) long_pairs();
-            } else {
-                empty_count++;
-            }
-        }
-        first_end = !first_end;
-    }
-    // The check-then-insert loop over the two ends' lists (src/ReadScanner.cpp:317-343): for every k-mer of the first end, is it paired
-    // with ANY k-mer of the second end already?  If not, it is paired with the second end's first one.
-#ifdef FGPU_CLI_PROFILE
-    unsigned long long tk_long = 0, tk_ins = 0, tk_read = 0, n_chain = 0, n_first_fail = 0, n_hit = 0;
-#define TK() __builtin_ia32_rdtsc()
-#else
-#define TK() 0ULL
-#endif
-    void long_pairs() {
-#ifdef FGPU_CLI_PROFILE
-        const unsigned long long tq = TK();
-        long_pairs_inner();
-        tk_all += TK() - tq;
-    }
-    unsigned long long tk_all = 0;
-    void long_pairs_inner() {
-#endif
-        if (spec_next < spec_pairs.size() && end1.canon == bc.data() + spec_pairs[spec_next].a1) {   // the pair phase 1 looked at
-            long_pairs_settle(spec_pairs[spec_next].base);
-            spec_next++;
-            return;
-        }
-        long_pairs_plain();
-    }
-    // phase 2 of the speculated form (see spec_found)
-    void long_pairs_settle(uint64_t base) {
-        const uint64_t mask = long_pf->tai - 1;
-        const int nh = long_pf->n_hash;
-        uint8_t* const bits = long_pf->bits.data();
-        const size_t n1 = end1.size(), n2 = end2.size();
-        const size_t at1 = (size_t)(end1.canon - bc.data());
-        for (size_t i = 0; i < n1; i++) {
-            if (spec_found[at1 + i]) continue;                               // paired when the batch began: paired now
-            const uint32_t* const miss = spec_miss.data() + base + i * n2;
-            const uint64_t p1 = end1.canon[i];
-            bool paired = false;
-            for (size_t j = 0; j < n2 && !paired; j++) {
-                const uint32_t pos = miss[j];
-                if (!((bits[pos >> 3] >> (pos & 7)) & 1u)) continue;          // the bit that was missing still is: the pair is still absent
-                const bool first_is_smaller = p1 <= end2.canon[j];
-                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[j];
-                const uint64_t h1 = first_is_smaller ? end2.h1[j] : end1.h1[i];
-                bool all = true;
-                for (int t = 0; t < nh && all; t++) { all = ((bits[h0 >> 3] >> (h0 & 7)) & 1u) != 0; h0 = (h0 + h1) & mask; }
-                paired = all;
-            }
-            if (!paired) {                                                    // addPair(pair1, back2.front())
-                const bool first_is_smaller = p1 <= end2.canon[0];
-                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[0];
-                const uint64_t h1 = first_is_smaller ? end2.h1[0] : end1.h1[i];
-                for (int t = 0; t < nh; t++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & mask; }
-            }
-        }
-    }
-    // phase 1 for the read pairs [from, to) of spec_pairs: read-only on the filter, writes only its own entries of spec_found / spec_miss
-    void speculate(size_t from, size_t to) {
-        const uint64_t mask = long_pf->tai - 1;
-        const int nh = long_pf->n_hash;
-        const uint8_t* const bits = long_pf->bits.data();
-        for (size_t p = from; p < to; p++) {
-            const SpecPair sp = spec_pairs[p];
-            for (size_t i = 0; i < sp.n1; i++) {
-                const uint64_t p1 = bc[sp.a1 + i];
-                uint32_t* const miss = spec_miss.data() + sp.base + i * sp.n2;
-                bool found = false;
-                for (size_t j = 0; j < sp.n2 && !found; j++) {
-                    const bool first_is_smaller = p1 <= bc[sp.a2 + j];
-                    uint64_t h0 = first_is_smaller ? b0[sp.a1 + i] : b0[sp.a2 + j];
-                    const uint64_t h1 = first_is_smaller ? b1[sp.a2 + j] : b1[sp.a1 + i];
-                    int t = 0;
-                    for (; t < nh; t++) {
-                        if (!((bits[h0 >> 3] >> (h0 & 7)) & 1u)) break;
-                        h0 = (h0 + h1) & mask;
-                    }
-                    if (t == nh) found = true;
-                    else miss[j] = (uint32_t)h0;
-                }
-                spec_found[sp.a1 + i] = found ? 1 : 0;
-            }
-        }
-    }
-    void long_pairs_plain() {
-        const unsigned long long tk0 = TK();
-        const uint64_t mask = long_pf->tai - 1;
-        const int nh = long_pf->n_hash;
-        uint8_t* const bits = long_pf->bits.data();
-        const size_t n1 = end1.size(), n2 = end2.size();
-        for (size_t i = 0; i < n1; i++) {
-            const uint64_t p1 = end1.canon[i];
-            bool paired = false;
-            // The first probe of a check goes to the SMALLER k-mer's first bit -- set as soon as any pair with that k-mer has been inserted,
-            // i.e. nearly always inside a repeat (89 % of 4.2e7 checks on BASELINE config 3's shape): it is the second and third probe that
-            // tell pairs apart, and a branch per probe was a misprediction per probe.  The first three probes are taken without branching.
-            const uint64_t a0 = end1.h0[i], a1 = end1.h1[i];
-            const int nb = nh < 3 ? nh : 3;
-            for (size_t j = 0; j < n2 && !paired; j++) {
-                const bool first_is_smaller = p1 <= end2.canon[j];           // std::min / std::max of the two canonical k-mers
-                uint64_t h0 = first_is_smaller ? a0 : end2.h0[j];
-                const uint64_t h1 = first_is_smaller ? end2.h1[j] : a1;
-                unsigned all = (bits[h0 >> 3] >> (h0 & 7)) & 1u;
-                for (int t = 1; t < nb; t++) { h0 = (h0 + h1) & mask; all &= (bits[h0 >> 3] >> (h0 & 7)) & 1u; }
-#ifdef FGPU_CLI_PROFILE
-                n_first_fail += !all;
-                n_chain += all;
-#endif
-                if (!all) continue;
-                for (int t = nb; t < nh && all; t++) { h0 = (h0 + h1) & mask; all = (bits[h0 >> 3] >> (h0 & 7)) & 1u; }
-                paired = all != 0;
-            }
-#ifdef FGPU_CLI_PROFILE
-            n_hit += paired;
-#endif
-            if (!paired) {                                                    // addPair(pair1, back2.front())
-                const unsigned long long tk1 = TK();
-                const bool first_is_smaller = p1 <= end2.canon[0];
-                uint64_t h0 = first_is_smaller ? end1.h0[i] : end2.h0[0];
-                const uint64_t h1 = first_is_smaller ? end2.h1[0] : end1.h1[i];
-                for (int t = 0; t < nh; t++) { bits[h0 >> 3] |= (uint8_t)(1u << (h0 & 7)); h0 = (h0 + h1) & mask; }
-#ifdef FGPU_CLI_PROFILE
-                tk_ins += TK() - tk1;
-#else
-                (void)tk1;
-#endif
-            }
-        }
-#ifdef FGPU_CLI_PROFILE
-        tk_long += TK() - tk0;
-#else
-        (void)tk0;
-#endif
-    }
-    // canonical forms, hashes and -- the same pass over the stops -- where every read's stops begin (first_stop)
-    void prepare(const fgpu_stop* stops, size_t n, uint64_t n_reads) {
-        bc.resize(n);
-        const bool hashes = !no_cleaning && long_pf;
-        if (hashes) { b0.resize(n); b1.resize(n); }
-        const uint64_t mask = hashes ? long_pf->tai - 1 : 0;
-        first_stop.resize(n_reads + 1);
-        auto part = [&](size_t from, size_t to) {
-            for (size_t i = from; i < to; i++) {
-                const uint64_t c = canonical(stops[i].ext, k);
-                bc[i] = c;
-                if (hashes) { b0[i] = old_hash(c, kSeed0) & mask; b1[i] = old_hash(c, kSeed1) & mask; }
-                // stop i is the first one of its read (and of the reads without stops before it)
-                const uint64_t r_here = stops[i].read, r_before = i ? stops[i - 1].read + 1 : 0;
-                for (uint64_t r = r_before; r <= r_here && r <= n_reads; r++) first_stop[r] = i;
-            }
-        };
-        const size_t kPerThread = 1 << 16;
-        const size_t n_threads = std::min<size_t>(4, n / kPerThread);
-        if (n_threads < 2) {
-            part(0, n);
-        } else {
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < n_threads; t++) th.emplace_back(part, n * t / n_threads, n * (t + 1) / n_threads);
-            part(0, n / n_threads);
-            for (std::thread& t : th) t.join();
-        }
-        for (uint64_t r = n ? stops[n - 1].read + 1 : 0; r <= n_reads; r++) first_stop[r] = n;   // the reads after the last stop's, and the end
-    }
-    double sec_ms[6] = {0, 0, 0, 0, 0, 0};   // -DFGPU_CLI_PROFILE: prepare, read offsets, pair list, phase 1, the loop over reads, of which long_pairs
-    void batch(const fgpu_stop* stops, size_t n_stops, uint64_t n_reads) {   // reads of a batch, in file order
-        const auto t0 = std::chrono::steady_clock::now();
-        auto lap = [&](int which, std::chrono::steady_clock::time_point& from) {
-            const auto now = std::chrono::steady_clock::now();
-            sec_ms[which] += std::chrono::duration<double, std::milli>(now - from).count();
-            from = now;
-        };
-        auto tl = t0;
-        if (paired_ends) {
-            prepare(stops, n_stops, n_reads);
-        } else {
-            first_stop.resize(n_reads + 1);
-            size_t a = 0;
-            for (uint64_t r = 0; r < n_reads; r++) {
-                first_stop[r] = a;
-                while (a < n_stops && stops[a].read == r) a++;
-            }
-            first_stop[n_reads] = a;
-        }
-        lap(0, tl);
-        // the read pairs that lie inside this batch, and room for their mates' positions (at most 2^26 per batch: what is beyond takes the plain loop)
-        spec_pairs.clear();
-        spec_next = 0;
-        static const bool no_spec = getenv("FGPU_CLI_NO_SPEC") != nullptr;     // (measurement: the plain loop for every pair)
-        if (!no_spec && paired_ends && !no_cleaning && long_pf && long_pf->tai <= (1ULL << 32) && n_stops) {
-            spec_found.resize(n_stops);
-            uint64_t room = 0;
-            for (uint64_t r = first_end ? 0 : 1; r + 1 < n_reads; r += 2) {   // (first_end: read 0 opens a pair; else it closes one that began in the last batch)
-                const SpecPair sp = {first_stop[r], first_stop[r + 1] - first_stop[r], first_stop[r + 1], first_stop[r + 2] - first_stop[r + 1], room};
-                if (!sp.n1 || !sp.n2 || room + (uint64_t)sp.n1 * sp.n2 > (1ULL << 26)) continue;
-                room += (uint64_t)sp.n1 * sp.n2;
-                spec_pairs.push_back(sp);
-            }
-            spec_miss.resize((size_t)room);
-            lap(2, tl);
-            const size_t n_threads = std::min<size_t>(6, spec_pairs.size() / 4096);
-            if (n_threads < 2) {
-                speculate(0, spec_pairs.size());
-            } else {
-                std::vector<std::thread> th;
-                for (size_t t = 1; t < n_threads; t++)
-                    th.emplace_back(&PairLogic::speculate, this, spec_pairs.size() * t / n_threads, spec_pairs.size() * (t + 1) / n_threads);
-                speculate(0, spec_pairs.size() / n_threads);
-                for (std::thread& t : th) t.join();
-            }
-        }
-        prepare_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        lap(3, tl);
-        for (uint64_t r = 0; r < n_reads; r++) read(stops + first_stop[r], first_stop[r + 1] - first_stop[r], first_stop[r]);
-        lap(4, tl);
-        if (paired_ends && !first_end) {          // a first end waits for its mate in the next batch: its list leaves the batch's arrays
-            kept_c.assign(end1.canon, end1.canon + end1.n);
-            end1.canon = kept_c.data();
-            if (!no_cleaning && long_pf) {
-                kept_0.assign(end1.h0, end1.h0 + end1.n);
-                kept_1.assign(end1.h1, end1.h1 + end1.n);
-                end1.h0 = kept_0.data();
-                end1.h1 = kept_1.data();
-            }
-        }
     }
 };
 
@@ -920,11 +549,11 @@ int main(int argc, char** argv) {
     prm.max_spacer_dist = o.max_spacer_dist;
     prm.n_hash = n_hash;
     prm.tai = tai;
-    // scanInputRead's lists feed the pair filters and the pair counts: the short filter's adds are order-free and happen on the device
-    // (fgpu_scan_short_pairs); the lists come to the host only for the paired-end loop (long filter: check-then-insert in file order)
+    // scanInputRead's lists feed the pair filters and the pair counts, all on the device: the short filter's adds are order-free
+    // (fgpu_scan_short_pairs), the long filter's check-then-insert loop is iterated to the sequential result (fgpu_scan_long_pairs); with
+    // --no_cleaning only the paired-end loop's two counts are left of them
     const bool record_lists = !o.no_cleaning || o.paired_ends;
     const bool device_short_pairs = !o.no_cleaning;
-    const bool want_lists = o.paired_ends;
     if (record_lists) prm.flags |= FGPU_FLAG_RECORD_STOPS;
     prm.flags |= FGPU_FLAG_KEY_ORDER_FROM_START;   // real genomes have repeats: a few launches per window against a first batch walked by cluster
     if (o.mercy) prm.flags |= FGPU_FLAG_MERCY;
@@ -950,6 +579,13 @@ int main(int argc, char** argv) {
         if (pin.joinable()) pin.join();
         if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(nullptr)); return 2; }
     }
+    // fgpu_create returns while a thread of the library is still creating the walk's streams and loading code objects: every way out of main
+    // goes through fgpu_destroy, which joins it, before the HIP runtime is torn down.  The one exception is the _exit at the very
+    // end, after both passes -- the first scan call has joined the thread by then.
+    struct CloseContext {
+        fgpu_ctx*& c;
+        ~CloseContext() { if (c) { fgpu_destroy(c); c = nullptr; } }
+    } close_context{ctx};
     clk.mark("arguments, sizing, fgpu_create");
     std::vector<uint8_t> bloom_bytes(tai / 8);
     std::thread bloom_writer;
@@ -958,6 +594,12 @@ int main(int argc, char** argv) {
         std::thread& t;
         ~JoinWriter() { if (t.joinable()) t.join(); }
     } join_writer{bloom_writer};
+    // ... and every SUCCESSFUL way out looks at how that write went (a short write of --just_load_bloom's only output is not exit code 0)
+    auto bloom_file_complete = [&]() -> bool {
+        if (bloom_writer.joinable()) bloom_writer.join();
+        if (bloom_write_failed) fprintf(stderr, "cannot write %s.bloom\n", o.file_prefix.c_str());
+        return !bloom_write_failed;
+    };
 
     // ---- pass 1 (load_two_filters, utils/Bloom.cpp:267-350) or -bloom_file (Bloom::load, :580-587)
     if (o.from_bloom) {
@@ -1022,7 +664,7 @@ int main(int argc, char** argv) {
         short_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 10 : E / 20, 0.01f);
         if (o.paired_ends) long_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 5 : E / 10, 0.01f);
     }
-    if (o.just_load) { fgpu_destroy(ctx); return 0; }
+    if (o.just_load) return bloom_file_complete() ? 0 : 2;
 
     // ---- -junctions_file <prefix> (src/Faucet.cpp:104-109,289-293): the scan's three files are reloaded instead of being made.  What the
     // reference does next is its contig graph, which is not part of this build: the files are parsed and checked (sizes as the flags imply),
@@ -1038,10 +680,9 @@ int main(int argc, char** argv) {
         printf("Weight of short pair filter: %f\n", short_pf.weight());
         if (o.paired_ends) printf("Weight of long pair filter: %f\n", long_pf.weight());
         printf("Number of junctions: %llu\n", (unsigned long long)junction_map.size());
-        fgpu_destroy(ctx);
         fprintf(stderr, "The contig-graph stage is not part of this build: -bloom_file / -junctions_file inputs have been read and checked; the\n"
                         "reference continues from them.\n");
-        return 3;
+        return bloom_file_complete() ? 3 : 2;
     }
 
     // ---- pass 2 (ReadScanner::scanReads, src/ReadScanner.cpp:284-359; printScanSummary :19-27)
@@ -1051,7 +692,7 @@ int main(int argc, char** argv) {
         float w2 = 0;
         CHECK(fgpu_bloom_weight(ctx, FGPU_BLOO2, &w2));
         printf("Weight before read scan: %f \n", w2);
-        PairLogic pairs;
+        uint64_t empty_count = 0, not_empty_count = 0;
         fgpu_scan_stats ss;
         // One scan of the file.  0 = done, 2 = fatal (-1: a status only library versions before the scan journal could return).
         auto scan_once = [&]() -> int {
@@ -1063,149 +704,36 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "%s failed (%d): %s\n", what, rc, msg.c_str());
                 return 2;
             };
-            int rc = device_short_pairs ? fgpu_scan_short_pairs(ctx, short_pf.tai, short_pf.n_hash, want_lists ? 1 : 0) : FGPU_OK;
+            int rc = device_short_pairs ? fgpu_scan_short_pairs(ctx, short_pf.tai, short_pf.n_hash, 0) : FGPU_OK;
             if (rc != FGPU_OK) return failed("fgpu_scan_short_pairs", rc);
+            // scanReads' paired-end loop (src/ReadScanner.cpp:317-343): on the device, from the same lists, in file order
+            if (o.paired_ends) {
+                rc = o.no_cleaning ? fgpu_scan_long_pairs(ctx, 0, 0, FGPU_LONG_PAIRS_COUNT) : fgpu_scan_long_pairs(ctx, long_pf.tai, long_pf.n_hash, FGPU_LONG_PAIRS_FILTER);
+                if (rc != FGPU_OK) return failed("fgpu_scan_long_pairs", rc);
+            }
             rc = fgpu_scan_begin(ctx);
             if (rc != FGPU_OK) return failed("fgpu_scan_begin", rc);
             uint64_t scanned = 0;
-            pairs = PairLogic();
-            pairs.k = o.k;
-            pairs.paired_ends = o.paired_ends;
-            pairs.no_cleaning = o.no_cleaning;
-            pairs.short_pf = device_short_pairs ? nullptr : &short_pf;   // (nullptr: the device keeps that filter)
-            pairs.long_pf = o.paired_ends ? &long_pf : nullptr;
-            std::fill(short_pf.bits.begin(), short_pf.bits.end(), 0);
-            std::fill(long_pf.bits.begin(), long_pf.bits.end(), 0);
-            std::vector<uint64_t> batch_n_reads;
-            // The lists are applied to the long pair filter by a worker thread, in batch order, while this thread goes on feeding the device
-            // (the rules are sequential -- check, then insert -- but they need nothing from the scan except the lists).
-            struct ListWorker {
-                PairLogic& pairs;
-                double& busy_ms;
-                std::mutex m;
-                std::condition_variable cv;
-                std::deque<std::pair<std::vector<fgpu_stop>, uint64_t> > q;
-                std::vector<std::vector<fgpu_stop> > spare;
-                std::vector<fgpu_stop> take_spare() {
-                    std::lock_guard<std::mutex> g(m);
-                    std::vector<fgpu_stop> v;
-                    if (!spare.empty()) { v = std::move(spare.back()); spare.pop_back(); }
-                    return v;
-                }
-                bool closing = false;
-                std::thread t;
-                ListWorker(PairLogic& p, double& ms) : pairs(p), busy_ms(ms), t([this] { run(); }) {}
-                // The worker probes the long pair filter (tens of MB) at random for the whole pass: it stays with the cores that share the
-                // last-level cache it starts on, so that the filter stays in that cache instead of following the thread around the machine.
-                static void stay_with_this_cache() {
-                    const int cpu = sched_getcpu();
-                    if (cpu < 0) return;
-                    char path[128];
-                    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-                    FILE* f = fopen(path, "r");
-                    if (!f) return;
-                    char list[512] = {0};
-                    const size_t got = fread(list, 1, sizeof(list) - 1, f);
-                    fclose(f);
-                    if (!got) return;
-                    cpu_set_t set;
-                    CPU_ZERO(&set);
-                    int n_set = 0;
-                    for (char* p2 = list; *p2;) {           // "0-7,128-135"
-                        char* e;
-                        const long a = strtol(p2, &e, 10);
-                        if (e == p2) break;
-                        long b = a;
-                        if (*e == '-') { p2 = e + 1; b = strtol(p2, &e, 10); }
-                        for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &set); n_set++; }
-                        p2 = (*e == ',') ? e + 1 : e;
-                        if (*e != ',') break;
-                    }
-                    if (n_set) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
-                }
-                void run() {
-                    if (!getenv("FGPU_CLI_NO_PIN")) stay_with_this_cache();
-                    for (;;) {
-                        std::pair<std::vector<fgpu_stop>, uint64_t> item;
-                        {
-                            std::unique_lock<std::mutex> g(m);
-                            cv.wait(g, [&] { return closing || !q.empty(); });
-                            if (q.empty()) return;
-                            item = std::move(q.front());
-                        }
-                        const auto t0 = std::chrono::steady_clock::now();
-                        pairs.batch(item.first.data(), item.first.size(), item.second);
-                        busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                        {
-                            std::lock_guard<std::mutex> g(m);
-                            q.pop_front();                    // only now: `finish` waits for an empty queue
-                            spare.push_back(std::move(item.first));   // (its pages are mapped: the next batch's lists go into it without page faults)
-                        }
-                        cv.notify_all();
-                    }
-                }
-                void put(std::vector<fgpu_stop>&& stops, uint64_t n_reads) {
-                    std::unique_lock<std::mutex> g(m);
-                    cv.wait(g, [&] { return q.size() < 3; });     // at most three batches of lists in flight
-                    q.emplace_back(std::move(stops), n_reads);
-                    cv.notify_all();
-                }
-                void finish() {
-                    if (!t.joinable()) return;
-                    {
-                        std::unique_lock<std::mutex> g(m);
-                        cv.wait(g, [&] { return q.empty(); });
-                        closing = true;
-                    }
-                    cv.notify_all();
-                    t.join();
-                }
-                ~ListWorker() { finish(); }
-            } worker(pairs, clk.pairs_ms);
-            // lists of the oldest batch whose walk is done (the newest one keeps walking while the next batch is prepared)
-            auto take = [&](bool& got) -> int {
-                got = false;
-                uint64_t n = 0;
-                int64_t seq = -1;
-                const auto t_take = std::chrono::steady_clock::now();
-                std::vector<fgpu_stop> stops = worker.take_spare();
-                int trc = fgpu_scan_take_stops(ctx, nullptr, 0, &n, &seq);
-                if (trc == FGPU_ERR_CAPACITY) {
-                    stops.resize(n);
-                    trc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n, &seq);
-                }
-                clk.take_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_take).count();
-                if (trc != FGPU_OK) return failed("fgpu_scan_take_stops", trc);
-                if (seq < 0) return 0;
-                got = true;
-                stops.resize(n);
-                worker.put(std::move(stops), batch_n_reads[(size_t)seq]);
-                return 0;
-            };
             fgpu_reads r;
             for (int more; (more = src.next(ctx, &r)) != 0;) {
                 if (more < 0) return failed("fgpu_text_split", -more);
                 const auto t_scan = std::chrono::steady_clock::now();
                 if ((rc = fgpu_scan_batch(ctx, &r)) != FGPU_OK) return failed("fgpu_scan_batch", rc);
                 clk.scan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count();
-                batch_n_reads.push_back(r.n_reads);
-                if (want_lists && batch_n_reads.size() > 1) {
-                    bool got;
-                    if (int trc = take(got)) return trc;
-                }
                 scanned += r.n_reads;
                 fprintf(stdout, "\rreads scanned: %lld", (long long)scanned);
                 fflush(stdout);
             }
+            const auto t_end = std::chrono::steady_clock::now();
             if ((rc = fgpu_scan_end(ctx, &ss)) != FGPU_OK) return failed("fgpu_scan_end", rc);
+            clk.take_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_end).count();
             if (device_short_pairs && (rc = fgpu_scan_short_pairs_download(ctx, short_pf.bits.data(), short_pf.bits.size())) != FGPU_OK)
                 return failed("fgpu_scan_short_pairs_download", rc);
-            if (want_lists) {
-                bool got = true;
-                while (got)
-                    if (int trc = take(got)) return trc;
+            if (o.paired_ends) {
+                rc = o.no_cleaning ? fgpu_scan_long_pairs_download(ctx, nullptr, 0, &empty_count, &not_empty_count)
+                                   : fgpu_scan_long_pairs_download(ctx, long_pf.bits.data(), long_pf.bits.size(), &empty_count, &not_empty_count);
+                if (rc != FGPU_OK) return failed("fgpu_scan_long_pairs_download", rc);
             }
-            worker.finish();
             return 0;
         };
         // (a preview of the junction walk that the library cannot repair is absorbed inside the library: it keeps the scan's batches in HBM and
@@ -1214,17 +742,17 @@ int main(int argc, char** argv) {
         if (src_rc == -1) { fprintf(stderr, "scan failed: %s\n", fgpu_last_error(ctx)); return 2; }
         if (src_rc) return src_rc;
         time(&stop);
-        if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_take_stops, %.2f ms applying the lists to the pair filters (worker thread)\n",
-                            clk.scan_ms, clk.take_ms, clk.pairs_ms);
-        if (clk.on && o.paired_ends) fprintf(stderr, "[cli]   of the worker's time, %.2f ms preparing canonical forms and hashes and speculating the long-pair checks (helper threads)\n", pairs.prepare_ms);
-#ifdef FGPU_CLI_PROFILE
-        fprintf(stderr, "[cli-profile] batch(): prepare %.1f ms, read offsets %.1f, pair list %.1f, phase 1 %.1f, loop over reads %.1f ms (long_pairs in it: %.1f Mticks)\n",
-                pairs.sec_ms[0], pairs.sec_ms[1], pairs.sec_ms[2], pairs.sec_ms[3], pairs.sec_ms[4], pairs.tk_all / 1e6);
-        fprintf(stderr, "[cli-profile] long_pairs %.1f Mticks, of which inserts %.1f; first-probe failures %llu, chains %llu, first-end k-mers found paired %llu\n",
-                pairs.tk_long / 1e6, pairs.tk_ins / 1e6, pairs.n_first_fail, pairs.n_chain, pairs.n_hit);
-#endif
+        if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_end (the last walks, the last lists, the pair filters' last batches)\n",
+                            clk.scan_ms, clk.take_ms);
+        if (clk.on && o.paired_ends && !o.no_cleaning) {
+            uint64_t d[6] = {0, 0, 0, 0, 0, 0};
+            if (fgpu_diag_long_pairs(ctx, d) == FGPU_OK)
+                fprintf(stderr, "[cli]   long pair filter on the device: %llu first-end k-mers checked, %llu paired by the filter as their batch found it, %llu inserted; "
+                                "%llu evaluation rounds over %llu batches (at most %llu in one)\n",
+                        (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3], (unsigned long long)d[5], (unsigned long long)d[4]);
+        }
         clk.mark("pass 2 (read + scan)");
-        printf("Empty count: %d, not empty count: %d\n", pairs.empty_count, pairs.not_empty_count);
+        printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);
         printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);
         printf("Unambiguous reads: %llu\n", (unsigned long long)ss.unambiguous_reads);
         printf("Time in seconds for read scan: %f \n", difftime(stop, start));
@@ -1269,8 +797,7 @@ int main(int argc, char** argv) {
     if (!o.no_cleaning)
         fprintf(stderr, "The contig-graph stage is not part of this build: the load and scan outputs have been written; the reference\n"
                         "continues from the same calls through integration/faucet_binding.cpp (INTEGRATION.md).\n");
-    if (bloom_writer.joinable()) bloom_writer.join();      // (_exit below skips destructors)
-    if (bloom_write_failed) { fprintf(stderr, "cannot write %s.bloom\n", o.file_prefix.c_str()); return 2; }
+    if (!bloom_file_complete()) return 2;                  // (_exit below skips destructors)
     const int code = o.no_cleaning ? 0 : 3;
     // Every output file is closed and both passes have ended with a synchronised device.  Returning several hundred HBM buffers one by
     // one, unpinning the text buffers and unloading the HIP runtime took 0.15 s of a 0.9 s run and changes nothing the caller can see:
@@ -1281,6 +808,7 @@ int main(int argc, char** argv) {
         _exit(code);
     }
     fgpu_destroy(ctx);
+    ctx = nullptr;
     clk.mark("fgpu_destroy");
     return code;
 }

@@ -236,11 +236,31 @@ int fgpu_scan_set_eager(fgpu_ctx* ctx, int on);
  * After fgpu_scan_short_pairs(tai, n_hash) -- the filter create_bloom_filter_optimal would make, src/Faucet.cpp:266-283 -- every scan keeps
  * that filter in HBM and applies the rules to each batch's lists as they are harvested; fgpu_scan_short_pairs_download (after
  * fgpu_scan_end) returns its tai / 8 bytes, the content of the reference's .short_pair_filter.  lists_to_host = 0: the lists are not
- * brought to the host at all (single-end runs: nothing else reads them; fgpu_scan_take_stops then reports no batches); != 0: they are
- * still handed out (paired ends: the long pair filter is check-then-insert in file order and stays with the caller).
+ * brought to the host at all (nothing else reads them, or their other reader -- the long pair filter, fgpu_scan_long_pairs -- is on the
+ * device as well; fgpu_scan_take_stops then reports no batches); != 0: they are still handed out (a caller that applies the paired-end
+ * loop itself).
  * Needs FGPU_FLAG_RECORD_STOPS; tai = 0 switches it off again.  Only between passes. */
 int fgpu_scan_short_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t lists_to_host);
 int fgpu_scan_short_pairs_download(fgpu_ctx* ctx, uint8_t* out, uint64_t n_bytes);
+
+/* The long pair filter on the device (src/ReadScanner.cpp:317-343 with Bloom::containsPair / addPair, utils/Bloom.cpp:127-154).
+ * With --paired_ends the reference treats consecutive records of the scan file as the two ends of a pair and, when both of their
+ * scanInputRead lists are non-empty, CHECKS every k-mer of the first end's list for a partner among the second end's
+ * (long_pair_filter->containsPair) and INSERTS (k-mer, second end's first k-mer) when there is none -- check-then-insert in file order.
+ * After fgpu_scan_long_pairs(tai, n_hash, FGPU_LONG_PAIRS_FILTER) -- the filter create_bloom_filter_optimal would make, src/Faucet.cpp:268-281 --
+ * every scan keeps that filter in HBM and applies the loop to each batch's lists as they are harvested, exactly: every list element gets
+ * its file-order time, inserts post first-set times per filter bit, and the check / insert decisions are iterated to their fixed point,
+ * which is the sequential run's (faucet_amd/csrc/pairs.hip; 4 bytes of HBM per filter bit beside the filter).  Reads 2p and 2p+1 of the
+ * SCAN (counted over all its batches, empty records included) are a pair; a first end at the end of a batch waits for the next batch.
+ * FGPU_LONG_PAIRS_COUNT: only the reference's "Empty count / not empty count" (what --no_cleaning leaves of the loop); tai, n_hash unused.
+ * fgpu_scan_long_pairs_download (after fgpu_scan_end): the tai / 8 bytes of the reference's .long_pair_filter (out may be NULL) and the two
+ * counts.  Lists then leave the device only if fgpu_scan_short_pairs(..., lists_to_host != 0) asks for them.
+ * Needs FGPU_FLAG_RECORD_STOPS; FGPU_LONG_PAIRS_OFF switches it off again.  Only between passes. */
+#define FGPU_LONG_PAIRS_OFF 0
+#define FGPU_LONG_PAIRS_COUNT 1
+#define FGPU_LONG_PAIRS_FILTER 2
+int fgpu_scan_long_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t mode);
+int fgpu_scan_long_pairs_download(fgpu_ctx* ctx, uint8_t* out, uint64_t n_bytes, uint64_t* empty_count, uint64_t* not_empty_count);
 
 /* scanInputRead's lists of one scanned batch, flattened in processing order (reads in file order; inside a read the
  * valid pieces in the order scanInputRead walks them; inside a piece by half-step).  Batches come out in scan order,
@@ -359,6 +379,10 @@ int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays);
  * k-mer was then found on another piece of the same window: only these void a lazy scan (the library scans its journal again, see above),
  * [2] noted positions the check itself passed over (= [0] when it works: a self-test of the sweep). */
 int fgpu_diag_late_flags(fgpu_ctx* ctx, uint64_t out[3]);
+/* after a scan with the long pair filter on the device: [0] items (first-end k-mers of read pairs with two non-empty lists), [1] of those, found
+ * paired against the filter as their batch found it, [2] addPair calls, [3] evaluation rounds over all batches, [4] most rounds one batch
+ * needed, [5] batches */
+int fgpu_diag_long_pairs(fgpu_ctx* ctx, uint64_t out[6]);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */

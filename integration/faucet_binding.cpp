@@ -30,12 +30,15 @@ extern int maxSpacerDist;   // src/Faucet.h:48
 static fgpu_ctx* g_ctx;
 // what the run will ask of the scan, known before pass 1 (the context is made there): set from main() right after handle_arguments,
 // e.g. `gpu_configure(!no_cleaning, paired_ends);`.  With cleaning on the scan has to keep scanInputRead's lists (FGPU_FLAG_RECORD_STOPS:
-// the short pair filter is filled from them on the device, the long one by gpu_scan_paired below).
+// both pair filters are filled from them on the device); with --paired_ends the lists are kept in any case (the pair counts).
 static bool g_want_pairs = false, g_paired_ends = false;
 void gpu_configure(bool cleaning, bool paired_ends) { g_want_pairs = cleaning; g_paired_ends = paired_ends; }
 
 static void gpu_die(const char* what, int rc) {
     fprintf(stderr, "%s failed (%d): %s\n", what, rc, fgpu_last_error(g_ctx));
+    // fgpu_create leaves a thread of the library setting up the scan's streams; fgpu_destroy joins it, so that exit() does not tear the HIP
+    // runtime down under it
+    if (g_ctx) { fgpu_destroy(g_ctx); g_ctx = NULL; }
     exit(2);
 }
 #define GPU_CHECK(call) do { int rc__ = (call); if (rc__ != FGPU_OK) gpu_die(#call, rc__); } while (0)
@@ -80,7 +83,7 @@ void gpu_load_two_filters(Bloom* bloo1, Bloom* bloo2, std::string reads_filename
     p.max_spacer_dist = maxSpacerDist;
     p.n_hash = bloo1->getNumHash();
     p.tai = bloo1->tai;
-    p.flags = (mercy ? FGPU_FLAG_MERCY : 0) | (g_want_pairs ? (FGPU_FLAG_RECORD_STOPS | FGPU_FLAG_KEY_ORDER_FROM_START) : 0);
+    p.flags = (mercy ? FGPU_FLAG_MERCY : 0) | ((g_want_pairs || g_paired_ends) ? (FGPU_FLAG_RECORD_STOPS | FGPU_FLAG_KEY_ORDER_FROM_START) : 0);
     int rc = fgpu_create(&p, &g_ctx);
     if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(NULL)); exit(2); }
     GPU_CHECK(fgpu_load_begin(g_ctx, 0));
@@ -144,87 +147,28 @@ void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, 
 // ---- paired ends (--paired_ends; BASELINE config 3) -------------------------------------------------------------------------------------
 // scanReads' paired-end loop (src/ReadScanner.cpp:317-343) keeps the lists of the two ends of a pair and, for every element of the first
 // end's list, CHECKS the long pair filter for a partner among the second end's and INSERTS one if there is none -- check-then-insert in file
-// order, so it stays host code, here on the reference's own Bloom::containsPair / addPair and JuncPair.  The lists themselves
-// (scanInputRead's return values) come from the device: fgpu_scan_take_stops hands out one scanned batch per call, one batch behind the scan
-// so that the walk of the newest batch stays overlapped.  The short pair filter is filled on the device as in gpu_scan.
-struct GpuPairedEnds {
-    Bloom* long_pair_filter;
-    bool no_cleaning, first_end;
-    std::vector<kmer_type> back1, back2;
-    int empty_count, not_empty_count;
-    std::vector<fgpu_stop> buf;
-
-    void read(const fgpu_stop* s, size_t n) {               // one iteration of the reference's while loop
-        std::vector<kmer_type>& back = first_end ? back1 : back2;
-        back.clear();
-        for (size_t i = 0; i < n; i++) back.push_back((kmer_type)s[i].ext);
-        if (!first_end) {
-            if (!back1.empty() && !back2.empty()) {
-                not_empty_count++;
-                for (size_t a = 0; a < back1.size(); a++) {
-                    bool paired = false;
-                    if (!no_cleaning) {
-                        for (size_t b = 0; b < back2.size() && !paired; b++)
-                            if (long_pair_filter->containsPair(JuncPair(back1[a], back2[b]))) paired = true;
-                        if (!paired) long_pair_filter->addPair(JuncPair(back1[a], back2[0]));
-                    }
-                }
-            } else {
-                empty_count++;
-            }
-        }
-        first_end = !first_end;
-    }
-    // the lists of every batch that has been walked: returns an fgpu status
-    int drain(const std::vector<uint64_t>& reads_of_batch, bool all) {
-        for (;;) {
-            uint64_t n = 0;
-            int64_t seq = -1;
-            int rc = fgpu_scan_take_stops(g_ctx, buf.data(), buf.size(), &n, &seq);
-            if (rc == FGPU_ERR_CAPACITY) { buf.resize(n); continue; }
-            if (rc != FGPU_OK) return rc;
-            if (seq < 0) return FGPU_OK;
-            size_t a = 0;
-            for (uint64_t r = 0; r < reads_of_batch[(size_t)seq]; r++) {     // reads of the batch in file order; a read's elements are adjacent
-                size_t b = a;
-                while (b < n && buf[b].read == r) b++;
-                read(buf.data() + a, b - a);
-                a = b;
-            }
-            if (!all) return FGPU_OK;                       // between two scan calls: one batch, the walk of the newest one keeps running
-        }
-    }
-};
-
+// order.  Since round 4 that loop runs on the device as well (fgpu_scan_long_pairs: every list element carries its file-order time, the
+// decisions are iterated to the fixed point that IS the sequential result), on the lists where they are made: nothing but the finished
+// filter's bytes and the two pair counts come back.  The short pair filter is filled on the device as in gpu_scan.
 // replaces buildJunctionMapFromReads() for `--paired_ends`: gpu_configure(!no_cleaning, true) before pass 1.  long_pair_filter is the Bloom
 // made at src/Faucet.cpp:268-281; short_pair_filter may be NULL (--no_cleaning: the reference then only counts empty / non-empty pairs).
 void gpu_scan_paired(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, Bloom* short_pair_filter, Bloom* long_pair_filter,
                      bool no_cleaning) {
-    GpuPairedEnds pe;
-    pe.long_pair_filter = long_pair_filter;
-    pe.no_cleaning = no_cleaning;
-    pe.first_end = true;
-    pe.empty_count = pe.not_empty_count = 0;
-    pe.buf.resize(1 << 16);
+    const bool filters = !no_cleaning && long_pair_filter;
     if (short_pair_filter && !no_cleaning)
-        GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 1));   // lists still come to the host
-    std::vector<uint64_t> reads_of_batch;
+        GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 0));
+    if (filters) GPU_CHECK(fgpu_scan_long_pairs(g_ctx, long_pair_filter->tai, long_pair_filter->getNumHash(), FGPU_LONG_PAIRS_FILTER));
+    else GPU_CHECK(fgpu_scan_long_pairs(g_ctx, 0, 0, FGPU_LONG_PAIRS_COUNT));
     fgpu_scan_stats st;
-    int rc = fgpu_scan_begin(g_ctx);
-    if (rc == FGPU_OK)
-        rc = for_each_batch(read_scan_file, fastq, [&](const fgpu_reads* r) -> int {
-            reads_of_batch.push_back(r->n_reads);
-            int brc = fgpu_scan_batch(g_ctx, r);
-            return brc != FGPU_OK ? brc : pe.drain(reads_of_batch, false);
-        });
-    const int end_rc = fgpu_scan_end(g_ctx, &st);
-    if (rc == FGPU_OK) rc = end_rc;
-    if (rc == FGPU_OK) rc = pe.drain(reads_of_batch, true);
+    const int rc = gpu_scan_pass(read_scan_file, fastq, &st);
     if (rc != FGPU_OK) gpu_die("paired-end junction scan", rc);
     if (short_pair_filter && !no_cleaning)
         GPU_CHECK(fgpu_scan_short_pairs_download(g_ctx, short_pair_filter->blooma, short_pair_filter->tai / 8));
+    uint64_t empty_count = 0, not_empty_count = 0;
+    GPU_CHECK(fgpu_scan_long_pairs_download(g_ctx, filters ? long_pair_filter->blooma : NULL, filters ? long_pair_filter->tai / 8 : 0, &empty_count,
+                                            &not_empty_count));
     gpu_fill_junction_map(junctionMap);
-    printf("Empty count: %d, not empty count: %d\n", pe.empty_count, pe.not_empty_count);
+    printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);
     gpu_print_scan_summary(st);
 }
 

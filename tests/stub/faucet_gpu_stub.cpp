@@ -26,7 +26,11 @@ struct StubStops {
 
 struct fgpu_ctx {
     fgpu_params prm;
-    fo_bloom *b1, *b2, *short_pf;
+    fo_bloom *b1, *b2, *short_pf, *long_pf;
+    int long_mode;                           // fgpu_scan_long_pairs: FGPU_LONG_PAIRS_*
+    bool first_end;                          // scanReads' firstEnd toggle (src/ReadScanner.cpp:303,350)
+    std::vector<uint64_t> back1;             // the first end's list while its mate is awaited
+    uint64_t empty_count, not_empty_count;
     fo_scanner* sc;
     uint64_t short_tai;
     int short_lists_to_host;
@@ -63,6 +67,10 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     c->b1 = fo_bloom_new(p->tai, p->n_hash);
     c->b2 = fo_bloom_new(p->tai, p->n_hash);
     c->short_pf = NULL;
+    c->long_pf = NULL;
+    c->long_mode = FGPU_LONG_PAIRS_OFF;
+    c->first_end = true;
+    c->empty_count = c->not_empty_count = 0;
     c->sc = NULL;
     c->short_tai = 0;
     c->short_lists_to_host = 1;
@@ -78,6 +86,7 @@ void fgpu_destroy(fgpu_ctx* c) {
     if (!c) return;
     if (c->sc) fo_scanner_free(c->sc);
     if (c->short_pf) fo_bloom_free(c->short_pf);
+    if (c->long_pf) fo_bloom_free(c->long_pf);
     fo_bloom_free(c->b1);
     fo_bloom_free(c->b2);
     delete c;
@@ -220,10 +229,59 @@ int fgpu_scan_short_pairs_download(fgpu_ctx* c, uint8_t* out, uint64_t n) {
     return FGPU_OK;
 }
 
+// scanReads' paired-end loop (src/ReadScanner.cpp:317-343) as the product applies it on the device; here, the loop itself on the oracle's Bloom
+int fgpu_scan_long_pairs(fgpu_ctx* c, uint64_t tai, int32_t n_hash, int32_t mode) {
+    if (!c) return FGPU_ERR_ARG;
+    if (c->phase) return fail(c, FGPU_ERR_STATE, "only between passes");
+    if (mode != FGPU_LONG_PAIRS_OFF && !(c->prm.flags & FGPU_FLAG_RECORD_STOPS)) return fail(c, FGPU_ERR_STATE, "fgpu_scan_long_pairs needs FGPU_FLAG_RECORD_STOPS");
+    if (c->long_pf) { fo_bloom_free(c->long_pf); c->long_pf = NULL; }
+    c->long_mode = mode;
+    if (mode == FGPU_LONG_PAIRS_FILTER) {
+        if (!tai || (tai & (tai - 1)) || n_hash < 1) return fail(c, FGPU_ERR_ARG, "bad long pair filter shape");
+        c->long_pf = fo_bloom_new(tai, n_hash);
+    }
+    return FGPU_OK;
+}
+int fgpu_scan_long_pairs_download(fgpu_ctx* c, uint8_t* out, uint64_t n, uint64_t* empty_count, uint64_t* not_empty_count) {
+    if (!c || c->long_mode == FGPU_LONG_PAIRS_OFF) return FGPU_ERR_ARG;
+    if (out) {
+        if (!c->long_pf || n != fo_bloom_nbytes(c->long_pf)) return FGPU_ERR_ARG;
+        memcpy(out, fo_bloom_bits(c->long_pf), n);
+    }
+    if (empty_count) *empty_count = c->empty_count;
+    if (not_empty_count) *not_empty_count = c->not_empty_count;
+    return FGPU_OK;
+}
+int fgpu_diag_long_pairs(fgpu_ctx* c, uint64_t out[6]) {
+    if (!c || !out) return FGPU_ERR_ARG;
+    memset(out, 0, 6 * sizeof(uint64_t));
+    return FGPU_OK;
+}
+static void stub_paired_end(fgpu_ctx* c, const uint64_t* ext, uint64_t n) {
+    if (c->long_mode == FGPU_LONG_PAIRS_OFF) return;
+    if (c->first_end) {
+        c->back1.assign(ext, ext + n);
+    } else if (!c->back1.empty() && n) {
+        c->not_empty_count++;
+        for (size_t a = 0; c->long_pf && a < c->back1.size(); a++) {
+            bool paired = false;
+            for (uint64_t b = 0; b < n && !paired; b++) paired = fo_bloom_contains_pair(c->long_pf, c->back1[a], ext[b], c->prm.k) != 0;
+            if (!paired) fo_bloom_add_pair(c->long_pf, c->back1[a], ext[0], c->prm.k);
+        }
+    } else {
+        c->empty_count++;
+    }
+    c->first_end = !c->first_end;
+}
+
 int fgpu_scan_begin(fgpu_ctx* c) {
     if (!c) return FGPU_ERR_ARG;
     if (c->sc) fo_scanner_free(c->sc);
     if (c->short_pf) memset(fo_bloom_bits(c->short_pf), 0, fo_bloom_nbytes(c->short_pf));
+    if (c->long_pf) memset(fo_bloom_bits(c->long_pf), 0, fo_bloom_nbytes(c->long_pf));
+    c->first_end = true;
+    c->back1.clear();
+    c->empty_count = c->not_empty_count = 0;
     c->sc = fo_scanner_new(c->prm.k, c->prm.j, c->prm.max_spacer_dist, c->b2, c->short_pf, NULL);
     c->scan_reads = c->scan_kmers = 0;
     c->batch_seq = 0;
@@ -247,6 +305,7 @@ int fgpu_scan_batch(fgpu_ctx* c, const fgpu_reads* r) {
         const uint64_t len = offs[i + 1] - offs[i];
         uint64_t n = fo_scan_input_read_ex(c->sc, bases + offs[i], len, c->short_pf ? 0 : 1, ext.data(), info.data(), ext.size());
         if (n > ext.size()) return fail(c, FGPU_ERR_CAPACITY, "stub: more than 4096 list elements on one read");
+        stub_paired_end(c, ext.data(), n);
         if (record)
             for (uint64_t e = 0; e < n; e++) {
                 fgpu_stop s;
@@ -257,7 +316,7 @@ int fgpu_scan_batch(fgpu_ctx* c, const fgpu_reads* r) {
             }
         c->scan_reads++;
     }
-    if (record && (c->short_lists_to_host || !c->short_pf)) c->queue.push_back(sb);
+    if (record && (c->short_pf ? c->short_lists_to_host != 0 : c->long_mode == FGPU_LONG_PAIRS_OFF)) c->queue.push_back(sb);
     return FGPU_OK;
 }
 

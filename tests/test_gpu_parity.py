@@ -613,6 +613,111 @@ def test_short_pair_filter_on_the_device_equals_the_oracles(lists_to_host):
         api.Context(k, tai, nh).scan_short_pairs(ptai, pnh)              # needs FGPU_FLAG_RECORD_STOPS
 
 
+def _paired_oracle(bases, offs, k, tai, nh, E, no_cleaning=False):
+    """the oracle's scan with both pair filters: (bloo2, short filter, long filter, scanner)"""
+    b1, b2, lst, _ = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    _, stai, snh = api.size_optimal(E // 20, np.float32(0.01))       # src/Faucet.cpp:266-283
+    _, ltai, lnh = api.size_optimal(E // 10, np.float32(0.01))
+    short, long_ = po.Bloom(stai, snh), po.Bloom(ltai, lnh)
+    osc = po.Scanner(k, 1, 100, b2, short_pf=short, long_pf=long_)
+    osc.scan_reads(bases, offs, paired_ends=True, no_cleaning=no_cleaning)
+    return b2, short, long_, osc
+
+
+def _pairs_in_repeats(n_pairs, seed):
+    """read pairs of a small genome with planted repeats at very high coverage: both ends of a pair hold dozens of junctions, the same
+    (k-mer, k-mer) pairs recur in many read pairs -- the lists on which the long-pair loop's check-then-insert order matters"""
+    g = synth.make_genome(12_000, seed, repeats=8, repeat_len=400)
+    r = synth.make_pairs(g, n_pairs, 100, 260, 20, 0.01, seed + 1)
+    return po.reads_from_matrix(np.ascontiguousarray(r))
+
+
+@pytest.mark.parametrize("n_chunks", [1, 4, 7])
+def test_long_pair_filter_on_the_device_equals_the_oracles(n_chunks):
+    """fgpu_scan_long_pairs: scanReads' paired-end loop (src/ReadScanner.cpp:317-343; check with Bloom::containsPair, insert with addPair, in
+    file order) on the device.  Both pair filters and the two pair counts equal the oracle's whatever the batching -- 7 chunks of an odd
+    number of reads each leave first ends waiting for the next batch -- and nothing is handed to the host."""
+    k, E, S = 21, 400_000, 150_000
+    bases, offs = _pairs_in_repeats(20_001, 5)            # an odd number of pairs and chunks that cut pairs in two
+    tai, nh = api.load_filter_shape(E, S)
+    b2, short, long_, osc = _paired_oracle(bases, offs, k, tai, nh, E)
+    ost = osc.stats()
+    ctx = api.Context(k, tai, nh, record_stops=True)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    ctx.scan_short_pairs(short.tai, short.n_hash, False)
+    ctx.scan_long_pairs(long_.tai, long_.n_hash, 2)
+    for attempt in range(2):                               # a second scan starts from empty filters and counts again
+        ctx.scan_begin()
+        for part in chunks(bases, offs, n_chunks):
+            ctx.scan_batch(part)
+        sst = ctx.scan_end()
+        assert ctx.take_stops() is None
+        bits, empty, not_empty = ctx.scan_long_pairs_download(long_.tai)
+        assert (empty, not_empty) == (ost["empty_count"], ost["not_empty_count"])
+        assert bits.any() and np.array_equal(bits, long_.bits())
+        assert np.array_equal(ctx.scan_short_pairs_download(short.tai), short.bits())
+        d = ctx.diag_long_pairs()
+        assert d["items"] > 0 and 0 < d["inserts"] <= d["items"] - d["paired_by_carry"] and d["rounds"] >= d["batches"] - 1
+    _scan_equals_oracle(ctx, sst, osc)
+
+
+def test_long_pair_filter_with_ragged_reads_and_empty_records():
+    """reads with N (several pieces per read, lists spliced over the pieces), empty records between them (each still toggles firstEnd) and
+    batches without a single valid piece"""
+    k, E, S = 25, 1_000_000, 200_000
+    bases, offs = _random_case(12001, 110, k, 30000, 0.012, 99, 0.003, 3)
+    lines = [bytes(bases[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
+    for at in (5, 6, 400, 2001, 2002, 2003, 9000):         # empty records shift which reads are mates
+        lines.insert(at, b"")
+    junk = [b"NNNN", b"", b"ACGTN"] * 7                     # a batch of 21 reads without any valid piece, in the middle
+    batches = [api.ReadBatch.from_lines(x) for x in (lines[:3001], junk, lines[3001:3002], lines[3002:])]
+    whole = api.ReadBatch.from_lines(lines[:3001] + junk + lines[3001:])
+    allb, allo = whole.bases, whole.offsets
+    tai, nh = api.load_filter_shape(E, S)
+    b2, short, long_, osc = _paired_oracle(allb, allo, k, tai, nh, E)
+    ost = osc.stats()
+    ctx = api.Context(k, tai, nh, record_stops=True)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    ctx.scan_short_pairs(short.tai, short.n_hash, False)
+    ctx.scan_long_pairs(long_.tai, long_.n_hash, 2)
+    ctx.scan_begin()
+    for b in batches:
+        ctx.scan_batch(b)
+    ctx.scan_end()
+    bits, empty, not_empty = ctx.scan_long_pairs_download(long_.tai)
+    assert (empty, not_empty) == (ost["empty_count"], ost["not_empty_count"])
+    assert np.array_equal(bits, long_.bits())
+
+
+def test_long_pair_counts_only_and_argument_checks():
+    """--no_cleaning leaves only the two counts of the loop (FGPU_LONG_PAIRS_COUNT); the filter mode needs a power-of-two size and recorded lists"""
+    k, E, S = 21, 400_000, 150_000
+    bases, offs = _pairs_in_repeats(3000, 9)
+    tai, nh = api.load_filter_shape(E, S)
+    b2, short, long_, osc = _paired_oracle(bases, offs, k, tai, nh, E, no_cleaning=True)
+    ost = osc.stats()
+    assert not long_.bits().any()
+    ctx = api.Context(k, tai, nh, record_stops=True)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    ctx.scan_long_pairs(0, 0, 1)
+    ctx.scan_begin()
+    for part in chunks(bases, offs, 3):
+        ctx.scan_batch(part)
+    ctx.scan_end()
+    assert ctx.take_stops() is None
+    bits, empty, not_empty = ctx.scan_long_pairs_download()
+    assert bits is None and (empty, not_empty) == (ost["empty_count"], ost["not_empty_count"]) and not_empty > 0
+    with pytest.raises(api.FaucetGpuError):
+        ctx.scan_long_pairs(1000, 6, 2)                                   # not a power of two
+    with pytest.raises(api.FaucetGpuError):
+        api.Context(k, tai, nh).scan_long_pairs(long_.tai, long_.n_hash, 2)   # needs FGPU_FLAG_RECORD_STOPS
+    ctx.scan_long_pairs(0, 0, 0)                                           # off again: the lists come to the host as before
+    ctx.scan_begin()
+    ctx.scan_batch(api.ReadBatch(bases, offs))
+    ctx.scan_end()
+    assert ctx.take_stops() is not None
+
+
 def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
     k, E, S = 25, 1_000_000, 200_000
     bases, offs = _random_case(9000, 100, k, 30000, 0.01, 5, 0.0, 2)
