@@ -6,11 +6,18 @@
 
 A step = one pass of the hot path (Bloom load pass + junction scan pass) over the whole synthetic read set,
 which is resident in HBM before the timed region starts.  N = 1: BASELINE.json configs[1] — 10 M synthetic
-100 bp reads, k = 31, -estimated_kmers 1e8 -singletons 2e7 (64 MiB filters, 3 hash functions).  N > 1: weak
-scaling — every rank holds 10 M reads of an N x 20 Mb genome and the filters are sized for N x 1e8 k-mers; reads
-are sharded in file order, the exclusive prefix-OR of the shards' bloo1 and the OR-all-reduce of their bloo2 run as
-slice-wise reduce-scatter / all-gather (grouped RCCL send/recv + local OR kernel), the pure scan stage runs on every rank
-at once and the ordered junction walk is handed from rank to rank (table export -> send/recv -> import).
+100 bp reads, k = 31, -estimated_kmers 1e8 -singletons 2e7 (64 MiB filters, 3 hash functions).  N > 1 (default
+`--scaling strong`): BASELINE.json configs[3], the configuration the 8-GPU target is stated on -- 200 M x 100 bp reads of a
+400 Mb genome, -estimated_kmers 1e9 -singletons 2e8 (2 x 1 GiB filters) -- cut into N file-order shards (25 M reads per rank at
+N = 8): the same reads as the N = 1 line's `full_size.config4` leg and as tests/golden/fullsize.json, so the line also says whether
+bloo2 and the junction keys came out as the oracle's.  `--scaling weak` is the round 1-3 mode: every rank holds 10 M reads of an
+N x 20 Mb genome and the filters are sized for N x 1e8 k-mers.  Either way reads are sharded in file order, the exclusive
+prefix-OR of the shards' bloo1 and the OR-all-reduce of their bloo2 run as slice-wise reduce-scatter / all-gather (grouped RCCL
+send/recv + local OR kernel), the pure scan stage runs on every rank at once and the ordered junction walk is handed from rank to
+rank (table export -> send/recv -> import); `rank_stage_ms` lists every rank's stages of the last timed step.
+
+The timed steps run WITHOUT HIP events around the kernels (they cost 1.5 % of a step, profiles/r04_profile_flag_ab.txt); kernel
+times, `roofline` and `device_time_share` come from separate bracketed steps of the same context right behind them (`profiled_steps`).
 
 The timed region of a step ends when the pass outputs are final in HOST memory: the bloo2 bit array and the
 junction records in creation order.  Prints ONE JSON line on rank 0.
@@ -420,7 +427,11 @@ def config3_cli_leg(device):
             return h.hexdigest()
 
         same = {ext: sha(os.path.join(d, "out." + ext)) == fx[ext + "_sha256"] for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter")}
+        p12 = [v for n, v in (phases or {}).items() if n.startswith("pass 1")] + [v for n, v in (phases or {}).items() if n.startswith("pass 2")]
         return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "kmers": kmers, "input_bytes": size, "pass_ms": phases,
+                # SURVEY 8d's definition of the metric: N / (t_load + t_scan), each pass from its first input byte to its outputs final in host
+                # memory -- the CLI's own clock around the two passes (file reading included), without HIP start-up, file dumps and process exit
+                "load_scan_value": kmers / (sum(p12) / 1e3) if len(p12) == 2 else None,
                 "junctions": int(m.group(1)) if m else None, "junctions_equal_the_references": bool(m) and int(m.group(1)) == fx["distinct_junctions"],
                 "files_equal_the_references": same,
                 "note": "wall time of the whole `faucet --fastq --paired_ends` process (start-up, both passes over a 1.07 GB interleaved FASTQ file in tmpfs, "
@@ -434,14 +445,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--fixture", default="config4", help="--scaling strong: whose reads (seeds) and default totals, an entry of tests/golden/fullsize.json")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong (default) = BASELINE config 4's 200 M reads cut into N file-order shards; weak = 10 M reads per rank. "
+                         "With strong, --reads / --genome / --estimated-kmers / --singletons are TOTALS (defaults: config 4's)")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (weak; default 10 M) / in all (strong; default 200 M)")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--genome", type=int, default=20_000_000, help="genome bases per GPU")
-    ap.add_argument("--estimated-kmers", type=int, default=100_000_000, help="per GPU")
-    ap.add_argument("--singletons", type=int, default=20_000_000, help="per GPU")
+    ap.add_argument("--genome", type=int, default=None, help="genome bases per GPU (weak; default 20 Mb) / in all (strong; default 400 Mb)")
+    ap.add_argument("--estimated-kmers", type=int, default=None, help="per GPU (weak; default 1e8) / in all (strong; default 1e9)")
+    ap.add_argument("--singletons", type=int, default=None, help="per GPU (weak; default 2e7) / in all (strong; default 2e8)")
     ap.add_argument("--err", type=float, default=0.01)
-    ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--batch-reads", type=int, default=None, help="reads per device call (default 1 M; 2.5 M with --scaling strong)")
     ap.add_argument("--ramp", type=int, default=int(os.environ.get("FAUCET_BENCH_RAMP", "2")),
                     help="grow the first batches from batch_reads / 2^RAMP by doubling and shrink the last ones (0 = equal batches)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
@@ -492,11 +507,39 @@ def main():
             dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 
     k, L_ = args.k, args.read_len
-    E, S = args.estimated_kmers * world, args.singletons * world
+    strong = (args.scaling or ("strong" if world > 1 else "weak")) == "strong"
+    fixture4 = None
+    if strong:
+        # BASELINE config 4, the reads of tests/golden/fullsize.json (faucet_amd/synth_det.py: a row is a function of (seed, row), so every rank
+        # makes its own file-order shard of the ONE read set); other totals may be given for functional runs at reduced size
+        from faucet_amd import synth_det as sd
+        with open(os.path.join(ROOT, "tests", "golden", "fullsize.json")) as f:
+            fixture4 = json.load(f)[args.fixture]
+        c4 = fixture4["params"]
+        total_reads = args.reads or c4["reads"]
+        total_genome = args.genome or c4["genome"]
+        E, S = args.estimated_kmers or c4["E"], args.singletons or c4["S"]
+        if (total_reads, total_genome, E, S, L_, k, args.err) != (c4["reads"], c4["genome"], c4["E"], c4["S"], c4["read_len"], c4["k"], c4["err"]):
+            fixture4 = None                                   # not the fixture's workload: nothing to compare digests with
+        shard_lo, shard_hi = total_reads * rank // world, total_reads * (rank + 1) // world
+        args.reads = shard_hi - shard_lo                      # (this rank's; `total_reads` is the job's)
+        args.batch_reads = args.batch_reads or 2_500_000
+        genome = sd.make_genome(total_genome, c4["genome_seed"], device)
+        reads = sd.make_reads(genome, args.reads, L_, args.err, c4["read_seed"], device, first_row=shard_lo)
+        args.genome, args.estimated_kmers, args.singletons = total_genome, E, S
+    else:
+        args.reads = args.reads or 10_000_000
+        args.genome = args.genome or 20_000_000
+        args.estimated_kmers = args.estimated_kmers or 100_000_000
+        args.singletons = args.singletons or 20_000_000
+        args.batch_reads = args.batch_reads or 1_000_000
+        total_reads, total_genome = args.reads * world, args.genome * world
+        E, S = args.estimated_kmers * world, args.singletons * world
+        genome = make_genome(total_genome, 2, device)
+        reads = make_reads(genome, args.reads, L_, args.err, 1000 + rank, device)
     tai, nh = api.load_filter_shape(E, S)
-    genome = make_genome(args.genome * world, 2, device)
-    reads = make_reads(genome, args.reads, L_, args.err, 1000 + rank, device)
     del genome
+    torch.cuda.empty_cache()
     bounds = batch_bounds(args.reads, args.batch_reads, args.ramp)
     if args.host_input:
         host = reads.cpu().numpy()
@@ -510,15 +553,16 @@ def main():
         # the host never waits between them (sharded.GpuShard.fence is a no-op then)
         tstream = torch.cuda.Stream(device)
         torch.cuda.set_stream(tstream)
-        ctx = api.Context(k, tai, nh, device=local_rank, profile=not args.no_profile, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")), stream=tstream.cuda_stream)
+        ctx = api.Context(k, tai, nh, device=local_rank, profile=False, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")), stream=tstream.cuda_stream)
         shard = sharded.GpuShard(ctx, device)
     else:
-        ctx = api.Context(k, tai, nh, device=local_rank, profile=not args.no_profile, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
+        ctx = api.Context(k, tai, nh, device=local_rank, profile=False, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
         shard = None
 
     def one_step():
         if world == 1 and not force_sharded:
             return step_single(ctx, batches, pinned=True)
+        sharded.CLOCK.enable(True)                 # stage boundaries of this step as events on the stream (no synchronisation)
         return step_multi(shard, batches, rank, world)
 
     def fence():
@@ -540,6 +584,41 @@ def main():
     elapsed = time.perf_counter() - t0
     lst, sst, bloo2, keys, recs = out
     kmers_local = lst["kmers"]
+    stage_ms = sharded.CLOCK.report() if (world > 1 or force_sharded) else None      # this rank's stages of the last timed step
+    sharded.CLOCK.enable(False)
+    # ---- did the sharded run produce the sequential run's outputs?  (strong scaling on the fixture's reads: digests of tests/golden/fullsize.json)
+    checks = None
+    if strong:
+        import hashlib
+        mine = {}
+        if bloo2 is not None:          # (rank 0 holds pass 1's output, the last rank pass 2's)
+            mine["bloo2_sha256"] = hashlib.sha256(np.ascontiguousarray(bloo2)).hexdigest()
+            if fixture4 is not None:
+                mine["bloo2_equals_the_oracles"] = mine["bloo2_sha256"] == fixture4["bloo2_sha256"]
+        if keys is not None:
+            mine["junction_keys_sha256"] = hashlib.sha256(np.ascontiguousarray(keys)).hexdigest()
+            mine["junction_records_sha256"] = hashlib.sha256(np.ascontiguousarray(recs)).hexdigest()
+            mine["junctions"] = int(len(keys))
+            if fixture4 is not None:
+                mine["junction_keys_equal_the_oracles"] = (len(keys) == int(fixture4["counters"]["n_junctions"]) and
+                                                           mine["junction_keys_sha256"] == fixture4["keys_sha256"])
+                mine["junction_records_equal_the_oracles"] = mine["junction_records_sha256"] == fixture4["recs_sha256"]
+                mine["scan_counters_equal_the_oracles"] = all(int(sst[c]) == int(v) for c, v in fixture4["counters"].items() if c in sst)
+        checks = mine
+    # ---- kernel times from separate, bracketed steps (the timed ones above ran without events)
+    prof_steps, prof_elapsed = 0, 0.0
+    if not args.no_profile:
+        prof_steps = max(1, min(args.steps, 5))
+        ctx.profile_enable(True)
+        ctx.kernel_times_reset()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            out = one_step()
+        fence()
+        prof_elapsed = time.perf_counter() - t1
+        sharded.CLOCK.enable(False)
+        lst, sst, bloo2, keys, recs = out
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -550,6 +629,15 @@ def main():
     else:
         kmers_total = kmers_local
     ktimes = ctx.kernel_times()
+    if prof_steps:
+        ctx.profile_enable(False)
+    all_stage_ms = all_checks = None
+    if world > 1:
+        all_stage_ms, all_checks = [None] * world, [None] * world
+        dist.all_gather_object(all_stage_ms, stage_ms)
+        dist.all_gather_object(all_checks, checks)
+    else:
+        all_stage_ms, all_checks = ([stage_ms] if force_sharded else None), [checks]
 
     if rank != 0:
         dist.barrier()
@@ -559,10 +647,11 @@ def main():
     value = kmers_total * args.steps / elapsed
     res = {
         "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic" + (" (host buffers: PCIe copies inside the timed region)" if args.host_input else ""),
-        "config": {"workload": f"{args.reads * world} synthetic {L_} bp reads ({args.reads} per GPU), k={k}, "
-                               f"estimated_kmers={E}, singletons={S}, genome {args.genome * world} bp, {args.err:.0%} substitutions; "
+        "config": {"workload": (f"BASELINE {args.fixture.replace('config', 'config ')}: " if strong and fixture4 else "") +
+                               f"{total_reads} synthetic {L_} bp reads ({args.reads} per GPU), k={k}, "
+                               f"estimated_kmers={E}, singletons={S}, genome {total_genome} bp, {args.err:.0%} substitutions; "
                                f"filters 2 x {tai // 8 >> 20} MiB, {nh} hash functions",
                    "reads_per_gpu": args.reads, "read_len": L_, "k": k, "tai": tai, "n_hash": nh, "batch_reads": args.batch_reads,
                    "sharding": "reads in file order; slice-wise prefix-OR(bloo1) + OR-allreduce(bloo2) over RCCL send/recv; walk handed rank to rank" if world > 1 else "single GPU"},
@@ -573,13 +662,26 @@ def main():
                     "flag_positions_rank0": int(sst["flag_positions"]), "piece_positions_rank0": int(sst["piece_positions"]),
                     "valid_reused_rank0": int(sst["valid_reused"]), "flags_filled_in_walk_rank0": int(sst["flags_filled"]), "nb_processed_rank0": int(sst["nb_processed"]),
                     "nb_skipped_rank0": int(sst["nb_skipped"]), "nb_jcheck_kmer_rank0": int(sst["nb_jcheck_kmer"])},
-        "kernel_ms_per_step_rank0": {n: round(ms / args.steps, 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
+        "kernel_ms_per_step_rank0": {n: round(ms / max(prof_steps, 1), 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
+        "profiled_steps": {"steps": prof_steps, "ms_per_step": 1e3 * prof_elapsed / prof_steps if prof_steps else None,
+                           "note": "separate steps of the same context with HIP events around every kernel, right behind the timed ones: where "
+                                   "kernel_ms_per_step_rank0, roofline and device_time_share come from"},
     }
+    if all_stage_ms is not None:
+        res["rank_stage_ms"] = [None if st is None else [[n, round(ms, 3)] for n, ms in st] for st in all_stage_ms]
+    if strong:
+        merged = {}
+        for c in all_checks or []:
+            merged.update(c or {})
+        res["outputs_check"] = merged or None
+    # everything below that divides kernel times by steps / wall time refers to the bracketed steps
+    steps_timed, elapsed_timed = args.steps, elapsed
+    args.steps, elapsed = max(prof_steps, 1), (prof_elapsed if prof_steps else elapsed)
 
     # ---- roofline of the dominant kernel, from HIP events recorded on the context's stream inside the timed region
     T = None
     if not args.no_cpu:
-        T = reference_bit_counts(k, L_, args.err, args.reads * L_ / args.genome, tai / E)
+        T = reference_bit_counts(k, L_, args.err, total_reads * L_ / total_genome, tai / E)
     heavy = {n: v for n, v in ktimes.items() if n in ("pack", "load_mark", "load_resolve", "scan_valid", "scan_flags")}
     if heavy:
         name = max(heavy, key=lambda n: heavy[n][1])
@@ -639,7 +741,7 @@ def main():
             for n in ("k_walk_register", "k_walk_link", "k_walk", "k_walk_cluster", "k_walk_reset_uf"):   # the walk stage is timed as one entry
                 if n in pl and "walk_stage" in ktimes:
                     tot += pl[n] * sst["walk_windows"]
-            res["pipeline_measured"] = {"hbm_bytes_per_step": tot, "GBps": tot / (elapsed / args.steps) / 1e9, "frac_of_hbm_peak": tot / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+            res["pipeline_measured"] = {"hbm_bytes_per_step": tot, "GBps": tot / (elapsed_timed / steps_timed) / 1e9, "frac_of_hbm_peak": tot / (elapsed_timed / steps_timed) / 1e9 / HBM_PEAK_GBPS,
                                         "source": "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, separate passes) x launches of this run",
                                         "kernels_without_counters": missing}
     if T:
@@ -701,7 +803,7 @@ def main():
                                                               "work rate an ideal parallel port is bounded by, not the reference's result for the whole sample"}
     # ---- the PCIe-inclusive rate: the same step with the reads handed over as HOST buffers, 2 x 1 GB of copies inside
     # the timed region.  Reported beside `value`, never as `value`.
-    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not strong:
         host = reads.cpu().numpy()
         hb = [api.ReadBatch.from_matrix(host[lo:hi]) for lo, hi in bounds]
         step_single(ctx, hb, pinned=True)
@@ -716,7 +818,7 @@ def main():
                              "note": "reads handed over as pageable host buffers: both passes copy them to the device inside the timed region"}
     # ---- Stage 3's walks on the step's own result: JunctionMap::findNeighbor from every junction along every covered
     # extension, whole walks on the device, host to host.  Beside `value`, never part of it.
-    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not strong:
         try:
             starts, idx = [], []
             for i in range(5):
@@ -739,19 +841,19 @@ def main():
     # ---- file to files ("from the first byte of input consumed"): the `faucet` command line on the same reads as a FASTA file,
     # both passes reading it, `.bloom` and `.junctions` written.  Wall time of the whole process -- runtime start-up, context, output files
     # included -- beside `value`, never as `value`; the junction count must be the step's.
-    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not strong:
         try:
             res["cli_file_to_files"] = cli_leg(reads, args, kmers_local, res["outputs"]["junctions"])
         except Exception as e:   # noqa: BLE001  (a missing /tmp or binary must not cost the bench line)
             res["cli_file_to_files"] = {"error": repr(e)[:300]}
     # ---- the slowest configuration in the driver's line: BASELINE config 3's shape through the CLI, file to files
-    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded:
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not strong:
         try:
             res["config3_cli"] = config3_cli_leg(device)
         except Exception as e:   # noqa: BLE001
             res["config3_cli"] = {"error": repr(e)[:300]}
     # ---- BASELINE's other configurations at full size, one cold step each (only config 2 had a driver-timed number)
-    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not args.no_full_size:
+    if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not strong and not args.no_full_size:
         ctx.close()
         del reads, batches
         torch.cuda.empty_cache()

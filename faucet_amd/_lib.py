@@ -103,6 +103,7 @@ SIGNATURES = {
     "fgpu_scan_long_pairs": (C.c_int, [_vp, _u64, _i32, _i32]),
     "fgpu_scan_long_pairs_download": (C.c_int, [_vp, _vp, _u64, _P(_u64), _P(_u64)]),
     "fgpu_diag_long_pairs": (C.c_int, [_vp, _P(_u64)]),
+    "fgpu_diag_ovw": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
     "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "fgpu_stage3_contig_words": (_u64, [_i32, _i32]),
     "fgpu_kernel_times": (C.c_int, [_vp, _P(KernelTime), C.c_int]),
     "fgpu_kernel_times_reset": (C.c_int, [_vp]),
+    "fgpu_profile_enable": (C.c_int, [_vp, C.c_int]),
     "fgpu_diag_stream_copy": (C.c_int, [_vp, _u64, C.c_int, _P(_f64)]),
     "fgpu_diag_random_access": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_int, _P(_f64)]),
     "fgpu_diag_ko_trace": (C.c_int, [_vp, _vp, _u64, _P(_u64)]),

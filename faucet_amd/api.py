@@ -372,6 +372,12 @@ class Context:
         self._c(self.lib.fgpu_diag_long_pairs(self.h, out))
         return dict(zip(("items", "paired_by_carry", "inserts", "rounds", "max_rounds", "batches"), (int(v) for v in out)))
 
+    def diag_ovw(self):
+        """the optimistic walk of large clusters during the last scan: pieces walked, rounds run, windows settled, windows left to the key-ordered walk"""
+        out = (C.c_uint64 * 4)()
+        self._c(self.lib.fgpu_diag_ovw(self.h, out))
+        return dict(zip(("pieces", "rounds", "windows", "fallback_windows"), (int(v) for v in out)))
+
     def stage3_set_junctions(self, keys, recs):
         """the junction map Stage 3's walks look into (keys as JunctionMap keys them; records as junctions() returns them)"""
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
@@ -402,6 +408,10 @@ class Context:
         arr = (L.KernelTime * 64)()
         n = self.lib.fgpu_kernel_times(self.h, arr, 64)
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n, 64))}
+
+    def profile_enable(self, on: bool):
+        """HIP events around every kernel on / off (between passes)"""
+        self._c(self.lib.fgpu_profile_enable(self.h, int(on)))
 
     def kernel_times_reset(self):
         self._c(self.lib.fgpu_kernel_times_reset(self.h))

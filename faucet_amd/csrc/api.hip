@@ -133,6 +133,14 @@ static int pull_counters(fgpu_ctx* ctx) {
     FGPU_HIP(hipStreamSynchronize(ctx->cstream));
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    // A late junction test that came out true at an unregistered k-mer leaves the lazy scan standing only because k_delta_collect has looked
+    // for that k-mer on the window's other pieces.  Every walk and every sweep issued so far has completed here, so each
+    // noted position must have been passed over by its window's sweep -- [2] == [0]; if one was not, the scan is treated as void and scanned
+    // again eagerly rather than trusted (the self-test as a run-time guard, not only a diagnostic).
+    if (ctx->phase == 2) {
+        DevCounters& c = *ctx->counters_host;
+        if (c.late_n[0] <= FGPU_LATE_CAP && c.late_n[2] != c.late_n[0]) c.error_flags |= 4ULL;
+    }
     return check_errors(ctx);
 }
 
@@ -578,6 +586,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->calib_f = ctx->calib_p = 0;
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
+    ctx->adapt_overflows = 0;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     ctx->scan_batch_seq = 0;
@@ -599,7 +608,13 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
     const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
-        if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
+        if (ctx->counters_host->ko_overflows > ctx->adapt_overflows && ctx->window_span > 4096) {
+            // a window's large clusters outgrew the tables of the large-cluster walks and were walked piece after piece by their one thread:
+            // far too large a window for this data
+            ctx->window_span = std::max<uint64_t>(4096, ctx->window_span / 4);
+            ctx->calib_left = 0;
+        }
+        else if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
         else if (f * 3 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN)) {
             // clusters percolate at a sharp threshold (about one genome coverage per window): a whole batch at a size that turns out to be
             // beyond it costs seconds, so the first windows at the new size are looked at one by one again
@@ -610,6 +625,7 @@ static void adapt_window(fgpu_ctx* ctx) {
     }
     ctx->adapt_followers = ctx->counters_host->followers;
     ctx->adapt_pieces = ctx->walked_pieces;
+    ctx->adapt_overflows = ctx->counters_host->ko_overflows;
 }
 
 static BatchBufs* acquire_batch(fgpu_ctx* ctx) {
@@ -745,7 +761,7 @@ static int scan_replay(fgpu_ctx* ctx) {
                                                  : std::min<uint64_t>(std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4), ctx->max_span);
     ctx->calib_left = 16;
     ctx->calib_f = ctx->calib_p = 0;
-    ctx->adapt_followers = ctx->adapt_pieces = 0;
+    ctx->adapt_followers = ctx->adapt_pieces = ctx->adapt_overflows = 0;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     memset(&ctx->carried, 0, sizeof(ctx->carried));
@@ -1174,6 +1190,12 @@ int fgpu_diag_load_split(fgpu_ctx* ctx, uint64_t* in_mark, uint64_t* pending) {
     return FGPU_OK;
 }
 
+int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return FGPU_ERR_ARG;
+    for (int i = 0; i < 4; i++) out[i] = ctx->counters_host->ovw[i];   // as of the scan's last synchronising call (fgpu_scan_end)
+    return FGPU_OK;
+}
+
 int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap) {
     if (!ctx) return 0;
     if (fgpu_prof_collect(ctx) != FGPU_OK) return 0;
@@ -1185,6 +1207,14 @@ int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap) {
         out[i].total_ms = ctx->kstats[i].total_ms;
     }
     return n;
+}
+
+int fgpu_profile_enable(fgpu_ctx* ctx, int on) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "fgpu_profile_enable while a pass is open"; return FGPU_ERR_STATE; }
+    int rc = fgpu_prof_collect(ctx);
+    ctx->profile = on != 0;
+    return rc;
 }
 
 int fgpu_kernel_times_reset(fgpu_ctx* ctx) {

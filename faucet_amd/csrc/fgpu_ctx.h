@@ -157,6 +157,8 @@ struct DevCounters {
     // late junction tests (scan_walk.hip, fill_missing): a test the walk ran itself came out TRUE at a k-mer the window's clusters were
     // built without.  [0] entries noted by the walk, [1] of those, the ones k_delta_collect found elsewhere in their window (error bit 4);
     // entries: stream position, number of the window
+    unsigned long long ko_overflows;    // windows whose large clusters did not fit the key-ordered / optimistic walks' tables
+    unsigned long long ovw[4];          // optimistic walk of large clusters: pieces walked, rounds run, windows settled, windows left to the key-ordered walk
     unsigned long long late_n[3];       // ([2] noted positions the check has passed over: every one of [0], once)
     unsigned long long late[2 * FGPU_LATE_CAP];
 };
@@ -228,6 +230,11 @@ struct fgpu_ctx {
     uint32_t* ko_hk = nullptr;         // key-ordered walk (KoTables, scan_walk.hip): k-mer table, occurrence arrays, per-piece arrays
     uint32_t* ko_occ = nullptr;
     uint32_t* ko_piece = nullptr;
+    // the optimistic walk of large clusters (scan_walk.hip, k_ovw_round): event tables, logs and per-piece results of two consecutive rounds,
+    // three presence filters used in turn, the list of pieces; allocated when a scan first meets a large cluster
+    DevBuf ovw_ev, ovw_filt, ovw_log, ovw_res, ovw_list, ovw_state, ovw_longp;
+    uint32_t ovw_epoch = 0;            // epoch of the newest events (1..255; the tables are wiped when it wraps)
+    int ovw_rounds = 12;               // rounds issued per window (FGPU_OVW_ROUNDS; 0 = the key-ordered walk takes every large cluster)
     uint32_t ko_hk_cap = 0, ko_occ_cap = 0;
     uint32_t walk_ko = 64;             // clusters of at least this many pieces are walked in k-mer order instead of piece order (0 = never); FGPU_WALK_KO
     uint32_t walk_ko_weight = 0;     // ... or whose pieces hold at least this many lk positions between them (0: rule off), see ko_cluster
@@ -255,6 +262,7 @@ struct fgpu_ctx {
     uint64_t scan_pieces_seen = 0;   // pieces counted by previous batches of this scan
 
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
+    uint64_t adapt_overflows = 0;
     int calib_left = 0;              // windows the controller still waits for individually (start of a scan, after a bad batch)
     uint64_t calib_f = 0, calib_p = 0;
     unsigned long long* fb_host = nullptr;   // pinned: {followers, walked pieces} read back during calibration

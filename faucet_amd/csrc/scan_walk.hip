@@ -422,8 +422,11 @@ __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict
 // (measured, FGPU_WALK_KO_WEIGHT: on config 3's shape k_walk + k_walk_ko take 381 / 293 / 249 ms at 256 / 128 / 48 positions; on config 2,
 // where a piece holds 2-5 of them, the walk stage grows from 42.9 ms to 45.0 / 63.4 / 80.1 ms at 128 / 64 / 48.  Hence two bars: heavy_w
 // positions in all, or three eighths of that where the pieces hold a dozen each -- which ordinary pieces never do.)
+// heavy_w packs the rule by weight: bits 0-15 the bar for a cluster's lk positions in all, bits 16-23 the positions per piece that make its
+// pieces "repeat pieces", bits 24-31 the bar in all for clusters of such pieces (fgpu_stage_scan_walk; 0 = rule off)
 __device__ __forceinline__ bool ko_cluster(uint32_t followers, uint32_t weight, uint32_t heavy, uint32_t heavy_w) {
-    return followers + 1 >= heavy || (heavy_w && (weight >= heavy_w || (8 * weight >= 3 * heavy_w && weight >= 12 * (followers + 1))));
+    const uint32_t total = heavy_w & 0xFFFFu, per_piece = (heavy_w >> 16) & 0xFFu, total_rep = heavy_w >> 24;
+    return followers + 1 >= heavy || (heavy_w && (weight >= total || (per_piece && weight >= total_rep && weight >= per_piece * (followers + 1))));
 }
 
 // ---- D: the walk ---------------------------------------------------------------------------------------
@@ -520,7 +523,7 @@ struct WalkCtx {
 // reference's semantics as they stand).  WALK_PROBE / WALK_COMMIT: the two halves of the out-of-order walk of a large cluster, one thread
 // per piece (k_walk_par): PROBE walks read-only and notes whether the piece would change anything a later piece's path can depend on,
 // COMMIT walks the same path again and applies what is left -- coverage counts and link flags, both order-free -- with atomics.
-enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3 };
+enum { WALK_SEQ = 0, WALK_PROBE = 1, WALK_COMMIT = 2, WALK_KO = 3, WALK_OVW = 4 };
 #ifdef FGPU_KO_TIMING
 #define KO_T0() const unsigned long long ko_t0__ = wall_clock64()
 #define KO_T1(cnt, i) atomicAdd(&(cnt)->ko_time[i], wall_clock64() - ko_t0__)
@@ -729,7 +732,9 @@ __device__ __forceinline__ bool fill_missing(WalkCtx& wc, PieceView& v, int t0, 
             // a window there covers the genome 0.1x, so a second occurrence in the same window is the exception.
             // (The key-ordered walk voids the scan on any late test that comes out true: its cursor may already have passed the position --
             // taken and given back the k-mer's turn -- when the stretch before the stop it had chosen turns out to hold an earlier one.)
-            if ((r & 3) && (MODE == WALK_KO || !((pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) >> b) & 1ULL))) {
+            if ((r & 3) && MODE == WALK_OVW) {
+                wc.fail = 4;            // the optimistic walk only notes it: a path that does not settle voids nothing (k_ovw_commit looks at the settled one)
+            } else if ((r & 3) && (MODE == WALK_KO || !((pv_word(v, v.lk0, v.lk1, wc.pl.lk, c) >> b) & 1ULL))) {
                 bool noted = false;
                 if (MODE == WALK_SEQ) {
                     const unsigned long long at = atomicAdd(&wc.cnt->late_n[0], 1ULL);
@@ -1263,6 +1268,8 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
     wc.created_now = false; wc.fail = 0; wc.dbg = dbg; 
     const WinDesc wd = *wdp;
     const uint32_t n = wd.n, first_piece = wd.first_piece;
+    // the large-cluster tables did not hold this window (its clusters are walked here, in order): the host shrinks the windows that follow
+    if (ko_heavy && blockIdx.x == 0 && threadIdx.x == 0 && (ko_state[1] & 1u)) atomicAdd(&cnt->ko_overflows, 1ULL);
     unsigned long long n_follow = 0, biggest = 0;
     // everything the thread needs to start is requested at once (no dependent loads before the plane burst)
     const uint32_t ii = i < n ? i : 0;
@@ -1366,6 +1373,42 @@ __global__ void __launch_bounds__(64) k_walk_par(Planes pl, FdParams fp, JTable 
     }
 }
 
+// (tables of the optimistic walk, k_ovw_round further down: k_ko_prepare lists its pieces, k_walk_ko looks at its outcome)
+constexpr int OVW_MAX_ROUNDS = 24;
+constexpr uint32_t OVW_CREATION = 5;       // event index of "the record is created" (0..4: the distances)
+constexpr uint64_t OVW_EPOCH_MASK = 0xFFULL << 56;
+enum : uint32_t { OVW_F_CREATED = 1, OVW_F_REAL = 6 /* bits 1-2 */, OVW_F_LINK_B = 8, OVW_F_LINK_F = 16, OVW_F_FAKE = 32, OVW_F_DF = 64, OVW_F_PRESENT = 128 };
+
+struct OvwEv {   // the events of one round: open addressing, one entry per (key, non-dominated event); entries of another epoch are free slots
+    unsigned long long* key;   // epoch << 56 | record << 3 | index
+    unsigned long long* val;   // epoch << 56 | time << 8 | value
+    uint32_t* bits;            // presence filter in front (by hash of record and index)
+    uint64_t mask;
+    uint64_t epoch;
+    uint32_t fshift;
+};
+struct OvwTables {
+    OvwEv prev, cur;           // read / written by the round being launched
+    uint32_t* filt_next;       // the filter the NEXT round writes: cleared by this one
+    uint32_t filt_words;
+    uint4* log_new;            // this round's logs, 2 x (lk positions of the piece) entries from 2 x kt.piece_base[piece]
+    const uint4* log_old;      // the previous round's (nullptr in round 0)
+    uint32_t* res_new;         // 8 words per listed piece: entries, NbProcessed, NbSkipped, NbJCheckKmer, NbNoJuncs, tests run on the spot, late true test
+    const uint32_t* res_old;
+    uint32_t* list;            // window-local indices of the pieces walked this way (k_ko_prepare)
+    uint32_t list_cap;
+    uint32_t* state;           // [0] pieces listed, [1] failed (overflow), [2] rounds run, [3] some cluster holds a long piece, [8 + r] some log changed in round r
+    uint32_t* longp;           // per root: the cluster holds a piece of more than 128 windows
+};
+
+// the round whose logs are the settled ones: the first round >= 1 in which no log changed; -1: none (yet), or the tables overflowed
+__device__ __forceinline__ int ovw_settled_round(const uint32_t* state, int rounds) {
+    if (state[1]) return -1;
+    for (int r = 1; r < rounds; r++)
+        if (state[8 + r] == 0) return r;
+    return -1;
+}
+
 // ---- key-ordered walk: preparation and the walk itself (see KoTables) ----------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ko_reset(KoTables kt, uint32_t n_pieces, uint32_t parity) {
     // the tables are only touched by windows that hold a large cluster (state[4 + parity of that window]): most windows find them clean
@@ -1382,7 +1425,7 @@ __global__ void __launch_bounds__(256) k_ko_reset(KoTables kt, uint32_t n_pieces
 // one thread per piece of the window: the pieces of large clusters list their lk positions as occurrences of their k-mers
 __global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
                                                     const WinDesc* __restrict__ wdp, KoTables kt, uint32_t heavy, uint32_t parity,
-                                                    const uint32_t* __restrict__ weight, uint32_t heavy_w) {
+                                                    const uint32_t* __restrict__ weight, uint32_t heavy_w, OvwTables ot) {
     const WinDesc wd = *wdp;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= wd.n) return;
@@ -1392,6 +1435,13 @@ __global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* _
     atomicAdd(&kt.state[3], 1u);
     const uint2 pc = pl.pieces[wd.first_piece + i];
     if (pc.y > 64 * KO_CHUNKS) { kt.bad[r] = 1u; return; }           // the turn bookkeeping keeps KO_CHUNKS words of positions per piece
+    if (ot.list) {                                                    // the optimistic walk takes the clusters whose pieces all fit its register view
+        if (pc.y > 128) { ot.longp[r] = 1u; ot.state[3] = 1u; }
+        else {
+            const uint32_t at = atomicAdd(&ot.state[0], 1u);
+            if (at < ot.list_cap) ot.list[at] = i; else ot.state[1] = 1u;
+        }
+    }
     uint32_t n = 0;
     for (uint32_t c = 0; c < KO_CHUNKS && c * 64 < pc.y; c++) n += (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x + 64 * c) & chunk_mask(pc.y, c));
     const uint32_t base = atomicAdd(&kt.state[0], n);
@@ -1421,8 +1471,9 @@ __global__ void __launch_bounds__(256) k_ko_prepare(Planes pl, const uint32_t* _
 }
 
 // rank of every occurrence among the occurrences of its k-mer, by (piece, position)
-__global__ void __launch_bounds__(256) k_ko_rank(KoTables kt) {
+__global__ void __launch_bounds__(256) k_ko_rank(KoTables kt, const uint32_t* __restrict__ ovw_state, int ovw_rounds) {
     if (kt.state[1] & 1u) return;
+    if (ovw_state && !ovw_state[3] && ovw_settled_round(ovw_state, ovw_rounds) >= 0) return;   // the optimistic walk has left nothing for the turns to order
     const uint32_t n = kt.state[0];
     for (uint32_t node = blockIdx.x * blockDim.x + threadIdx.x; node < n; node += gridDim.x * blockDim.x) {
         const uint64_t mine = kt.occ_id[node];
@@ -1444,9 +1495,13 @@ __global__ void __launch_bounds__(256) k_ko_rank(KoTables kt) {
 // wait for belongs to the same or an earlier ticket); lane 0 walks the chunk's pieces of large clusters one after the other.
 __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
                                                 const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt,
-                                                KoTables kt, uint32_t heavy, uint32_t KO_TICKET, const uint32_t* __restrict__ weight, uint32_t heavy_w) {
+                                                KoTables kt, uint32_t heavy, uint32_t KO_TICKET, const uint32_t* __restrict__ weight, uint32_t heavy_w,
+                                                const uint32_t* __restrict__ ovw_state, const uint32_t* __restrict__ ovw_longp, int ovw_rounds) {
     const WinDesc wd = *wdp;
     if (kt.state[1] & 1u) return;                                      // a table overflowed: k_walk takes every cluster
+    // the optimistic walk has settled and applied the clusters without long pieces: only the others are left
+    const bool ovw_done = ovw_state && ovw_settled_round(ovw_state, ovw_rounds) >= 0;
+    if (ovw_done && !ovw_state[3]) return;
     WalkCtx wc;
     KoState& ko = wc.ko;
     wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = 0;
@@ -1484,7 +1539,7 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
             bool mine = false;
             if (i < wd.n && (uint32_t)fd_lane() < span) {
                 const uint32_t r = root[i];
-                mine = ko_cluster(count[r], weight[r], heavy, heavy_w) && !kt.bad[r];
+                mine = ko_cluster(count[r], weight[r], heavy, heavy_w) && !kt.bad[r] && !(ovw_done && !ovw_longp[r]);
                 if (mine && r == i) {                     // the statistics k_walk keeps per cluster
                     atomicAdd(&cnt->followers, (unsigned long long)count[r]);
                     atomicMax(&cnt->max_cluster, (unsigned long long)count[r] + 1);
@@ -1558,6 +1613,527 @@ __global__ void __launch_bounds__(64) k_walk_ko(Planes pl, FdParams fp, JTable j
         if (wc.n_created) atomicAdd(&cnt->n_junctions, wc.n_created);
         if (wc.n_filled) atomicAdd(&cnt->flags_filled, wc.n_filled);
         if (walked) atomicAdd(&cnt->walk_parallel, walked);
+    }
+}
+
+// ---- the optimistic walk of large clusters (k_ovw_round, k_ovw_commit) ------------------------------------------------------------------------
+// Round 4.  The key-ordered walk above keeps the sequential order access by access, and what it pays for that is one wave's instruction stream
+// per piece and a chain of hand-overs: ~300 us per repeat piece, ~4 pieces at a time (profiles/r03_ko_walk.txt).  But the walk of a piece is a
+// FUNCTION of what it reads in the junction map, and it reads little: whether the keys at its registered positions exist, and one distance per
+// visit (its skip).  What it writes splits into what other pieces' paths can depend on -- creations and raised distances -- and what they
+// cannot (coverage counts, link flags: order-free).  So the pieces of a large cluster are walked ALL AT ONCE, read-only against the map as the
+// window found it, every piece noting what it WOULD write in a private log and posting the path-relevant part as EVENTS with its file-order
+// time (the index of the piece in the window):
+//      (record, distance index) -> (time, value)         a distance raised above the stored one
+//      (record, creation)       -> time                  a key that is not in the map yet
+// and reading, besides the stored record, the events of EARLIER pieces as the previous round left them:
+//      exists at time t   <=>  present in the map  or  a creation event with time < t  (or created by the piece itself)
+//      distance at time t  =   max(stored, events with time < t, the piece's own earlier contributions).
+// Round after round every piece walks again on the previous round's events, until no piece's log differs from its log of the round before.
+// That fixed point is the sequential walk: the earliest piece of the cluster reads no events at all, so its log is final after round 0; a piece
+// whose predecessors' logs are final reads exactly what the sequential run shows it, so its log is final one round later -- induction over the
+// file order, the argument of pass 1's first-set times and of the long pair filter (pairs.hip).  Rounds needed = the longest
+// chain of pieces that really hand information on (creations while a repeat is first met; two rounds once its records stand), not the number
+// of pieces.  The settled logs are then applied with atomics -- coverage saturating, distances by maximum, link flags by OR, each creation by
+// its one creator -- and the counters of the settled paths are added up.  Nothing of a round that did not settle reaches the map except claimed
+// slots, which mean nothing without their presence bits.
+// Pieces of up to 128 windows (the register view); a cluster that holds a longer one, rounds that do not settle within OVW_MAX_ROUNDS, or tables
+// that overflow leave the cluster to the key-ordered walk, which runs behind and looks at the outcome first.
+__device__ __forceinline__ uint32_t ovw_filter_bit(const OvwEv& ev, uint64_t k) { return ((uint32_t)fd_mix(k) * 0x85EBCA6Bu) >> ev.fshift; }
+__device__ __forceinline__ unsigned long long ld_agent_ull(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// post (record, index) -> (time, value).  An event is DOMINATED by one of the same key that is not later and not smaller: it can never decide a
+// reader's maximum, so it is dropped (or replaced where it dominates) -- the entries of a key stay a short staircase however many pieces of a
+// repeat post the same distance.  false: table full.
+__device__ __forceinline__ bool ovw_post(const OvwEv& ev, uint32_t rec, uint32_t idx, uint32_t time, uint32_t value) {
+    const uint64_t k = ((uint64_t)rec << 3) | idx;
+    const unsigned long long kw_mine = ev.epoch | k, vw_mine = ev.epoch | ((unsigned long long)time << 8) | value;
+    uint64_t s = fd_mix(k) & ev.mask;
+    const uint64_t limit = ev.mask < 4096 ? ev.mask : 4096;
+    for (uint64_t n = 0; n <= limit; n++) {
+        unsigned long long kw = ld_agent_ull(&ev.key[s]);
+        if ((kw & OVW_EPOCH_MASK) != ev.epoch) {                      // free: claim it
+            const unsigned long long old = atomicCAS(&ev.key[s], kw, kw_mine);
+            if (old == kw) {
+                __hip_atomic_store(&ev.val[s], vw_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b = ovw_filter_bit(ev, k);
+                atomicOr(&ev.bits[b >> 5], 1u << (b & 31));
+                return true;
+            }
+            kw = old;
+        }
+        if (kw == kw_mine) {
+            for (;;) {
+                const unsigned long long vw = ld_agent_ull(&ev.val[s]);
+                if ((vw & OVW_EPOCH_MASK) != ev.epoch) break;          // claimed, value not stored yet: nothing can be concluded from it
+                const uint32_t t2 = (uint32_t)(vw >> 8), v2 = (uint32_t)(vw & 0xFF);
+                if (t2 <= time && v2 >= value) return true;            // dominated
+                if (!(time <= t2 && value >= v2)) break;               // neither dominates: both stay
+                if (atomicCAS(&ev.val[s], vw, vw_mine) == vw) return true;
+            }
+        }
+        s = (s + 1) & ev.mask;
+    }
+    return false;
+}
+// max value over the events of (record, index) with a time before `time` (0: none)
+__device__ __forceinline__ uint32_t ovw_before(const OvwEv& ev, uint32_t rec, uint32_t idx, uint32_t time) {
+    const uint64_t k = ((uint64_t)rec << 3) | idx;
+    const uint32_t b = ovw_filter_bit(ev, k);
+    if (!((ev.bits[b >> 5] >> (b & 31)) & 1u)) return 0;
+    const unsigned long long kw_mine = ev.epoch | k;
+    uint64_t s = fd_mix(k) & ev.mask;
+    uint32_t best = 0;
+    for (uint64_t n = 0; n <= ev.mask; n++) {
+        const unsigned long long kw = ev.key[s];
+        if ((kw & OVW_EPOCH_MASK) != ev.epoch) break;
+        if (kw == kw_mine) {
+            const unsigned long long vw = ev.val[s];
+            const uint32_t t2 = (uint32_t)(vw >> 8), v2 = (uint32_t)(vw & 0xFF);
+            if (t2 < time && v2 > best) best = v2;
+        }
+        s = (s + 1) & ev.mask;
+    }
+    return best;
+}
+
+struct OvwWalk {
+    OvwEv prev, cur;
+    bool have_prev;
+    uint4* log_new;
+    const uint4* log_old;
+    uint32_t n_old, n_new, cap;
+    uint32_t time;
+    bool changed, overflow;
+};
+// Which records does the piece have an entry for already?  A filter of 1024 bits per lane in LDS, two bits per record: a hit sends the visit
+// through the piece's own log (the same junction twice on a piece: tandem repeats, twice in a row) -- with the 64 bits of a register a piece
+// inside a repeat, a hundred records, went through its log at every visit (10^4 log reads per piece and round).
+constexpr uint32_t OVW_SEEN_WORDS = 32;
+__device__ __forceinline__ uint32_t* ovw_seen_words() {
+    __shared__ uint32_t s_seen[OVW_SEEN_WORDS * 64];
+    return s_seen + (threadIdx.x & 63);
+}
+__device__ __forceinline__ void ovw_seen_clear() {
+    uint32_t* w = ovw_seen_words();
+    for (uint32_t i = 0; i < OVW_SEEN_WORDS; i++) w[i * 64] = 0;
+}
+__device__ __forceinline__ bool ovw_seen_test_and_set(uint32_t rec) {
+    const uint64_t h = fd_mix(rec);
+    const uint32_t a = (uint32_t)h & (OVW_SEEN_WORDS * 32 - 1), b = (uint32_t)(h >> 32) & (OVW_SEEN_WORDS * 32 - 1);
+    uint32_t* w = ovw_seen_words();
+    const uint32_t wa = w[(a >> 5) * 64], wb = w[(b >> 5) * 64];
+    const bool hit = ((wa >> (a & 31)) & 1u) && ((wb >> (b & 31)) & 1u);
+    w[(a >> 5) * 64] = wa | (1u << (a & 31));
+    w[(b >> 5) * 64] |= 1u << (b & 31);
+    return hit;
+}
+// entry: record | half-step, flags, backward distance | forward distance, the STORED record's dist[4] | its dist[0..3] -- the stored bytes ride
+// along so that the next round's visit of the same half-step needs no table access at all (the map does not change between rounds)
+__device__ __forceinline__ uint4 ovw_pack(uint32_t rec, uint32_t tn, uint32_t flags, uint32_t d_bwd, uint32_t d_fwd, uint64_t stored_lo) {
+    return make_uint4(rec, tn | (flags << 16) | (d_bwd << 24), d_fwd | ((uint32_t)((stored_lo >> 32) & 0xFF) << 8), (uint32_t)stored_lo);
+}
+__device__ __forceinline__ void ovw_emit(OvwWalk& ow, const uint4& e) {
+    if (ow.n_new >= ow.cap) { ow.overflow = true; return; }
+    if (!ow.log_old || ow.n_new >= ow.n_old) ow.changed = true;
+    else {
+        const uint4 o = ow.log_old[ow.n_new];
+        if (o.x != e.x || o.y != e.y || o.z != e.z) ow.changed = true;
+    }
+    ow.log_new[ow.n_new++] = e;
+}
+// the piece's own earlier contributions to (record, index) -- the same junction twice on a piece: tandem repeats, or twice in a row
+__device__ __forceinline__ uint32_t ovw_own(const OvwWalk& ow, uint32_t rec, uint32_t idx, const uint4& pending, bool have_pending) {
+    uint32_t best = 0;
+    for (uint32_t i = 0; i <= ow.n_new; i++) {
+        if (i == ow.n_new && !have_pending) break;
+        const uint4 e = i == ow.n_new ? pending : ow.log_new[i];
+        if (e.x != rec) continue;
+        const uint32_t tn = e.y & 0xFFFF, flags = (e.y >> 16) & 0xFF, real = (flags & OVW_F_REAL) >> 1;
+        const bool fwd = tn & 1;
+        const uint32_t ib = fwd ? 4u : real, iff = fwd ? real : 4u;
+        if (ib == idx) best = max(best, e.y >> 24);
+        if (iff == idx && (flags & OVW_F_DF)) best = max(best, e.z & 0xFF);
+    }
+    return best;
+}
+__device__ __forceinline__ bool ovw_own_created(const OvwWalk& ow, uint32_t rec) {
+    for (uint32_t i = 0; i < ow.n_new; i++) {
+        const uint4 e = ow.log_new[i];
+        if (e.x == rec && ((e.y >> 16) & OVW_F_CREATED)) return true;
+    }
+    return false;
+}
+
+// What the snapshot planes cannot know at the piece's registered positions (see created_bits): the live table, plus the creations earlier
+// pieces posted in the previous round.
+__device__ __noinline__ uint4 ovw_live_bits(const uint64_t* __restrict__ codes, int k, uint64_t p, uint64_t where, uint64_t* jkeys, uint64_t jmask,
+                                            const OvwEv* prev, uint32_t time) {
+    JTable jt;
+    jt.keys = jkeys;
+    jt.mask = jmask;
+    jt.recs = nullptr; jt.stamps = nullptr; jt.filter = nullptr; jt.filter_mask = 0;
+    uint64_t mF = 0, mB = 0;
+    while (where) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(where);
+        where &= where - 1;
+        const uint64_t km = fd_kmer_at(codes, p + i, k);
+        const uint64_t rc = fd_revcomp(km, k);
+        const uint64_t canon = km < rc ? km : rc;
+        uint64_t slot;
+        uint32_t present;
+        if (jt_find_live(jt, canon, slot, present)) {
+            const uint32_t oF = km == canon ? 0u : 1u, oB = rc == canon ? 0u : 1u;
+            bool f = (present >> oF) & 1u, b = (present >> oB) & 1u;
+            if (prev) {
+                if (!f) f = ovw_before(*prev, (uint32_t)(slot * 2 + oF), OVW_CREATION, time) != 0;
+                if (!b) b = oB == oF ? f : ovw_before(*prev, (uint32_t)(slot * 2 + oB), OVW_CREATION, time) != 0;
+            }
+            if (f) mF |= 1ULL << i;
+            if (b) mB |= 1ULL << i;
+        }
+    }
+    return make_uint4((uint32_t)mF, (uint32_t)(mF >> 32), (uint32_t)mB, (uint32_t)(mB >> 32));
+}
+__device__ __forceinline__ void ovw_created_bits(const WalkCtx& wc, const OvwWalk& ow, const PieceView& v, uint32_t c, uint64_t& mF, uint64_t& mB) {
+    const uint64_t lk = c == 0 ? v.lk0 : v.lk1, inF = c == 0 ? v.inF0 : v.inF1, inB = c == 0 ? v.inB0 : v.inB1;
+    const uint64_t where = lk & ~(inF & inB);
+    if (!where) { mF = mB = 0; return; }
+    const uint4 r = ovw_live_bits(wc.pl.codes, wc.fp.k, v.p0 + 64 * c, where, wc.jt.keys, wc.jt.mask, ow.have_prev ? &ow.prev : nullptr, ow.time);
+    mF = (uint64_t)r.x | ((uint64_t)r.y << 32);
+    mB = (uint64_t)r.z | ((uint64_t)r.w << 32);
+}
+// the piece has just created the record keyed by `key`: the same k-mer further along the piece (tandem repeats) is in the map from now on
+__device__ __forceinline__ void ovw_mark_created(const WalkCtx& wc, PieceView& v, uint64_t key) {
+    const int k = wc.fp.k;
+    for (uint32_t c = 0; c < 2; c++) {
+        uint64_t w = c == 0 ? v.lk0 : v.lk1;
+        while (w) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(w);
+            w &= w - 1;
+            const uint64_t km = pv_kmer(v, wc.pl.codes, v.p0 + 64 * c + b, k);
+            if (km == key) { if (c == 0) v.xF0 |= 1ULL << b; else v.xF1 |= 1ULL << b; }
+            if (fd_revcomp(km, k) == key) { if (c == 0) v.xB0 |= 1ULL << b; else v.xB1 |= 1ULL << b; }
+        }
+    }
+}
+
+// one junction visit (or add_fake_junction's): the record is found (a key that has no slot yet gets one), its stored distances are read, the
+// contribution of this visit to `idx_b` is posted if it raises the stored value.  Returns false on a full table.
+struct OvwRec {
+    uint32_t rec;
+    uint64_t lo;       // the stored record's low word (distances in bytes 0-4); zero for a record that is not in the map
+    bool present;
+};
+__device__ __forceinline__ bool ovw_record(WalkCtx& wc, uint64_t key, OvwRec& out) {
+    const uint64_t rc = fd_revcomp(key, wc.fp.k);
+    const uint64_t canon = key < rc ? key : rc;
+    const int orient = key == canon ? 0 : 1;
+    const uint64_t home = fd_mix(canon) & wc.jt.mask;
+    const uint64_t* spec = (const uint64_t*)(wc.jt.recs + (home * 2 + orient) * 16);
+    const uint64_t w_first = ld_agent(&wc.jt.keys[home]);
+    const uint64_t spec_lo = spec[0];
+    uint64_t slot;
+    uint32_t present;
+    if (!jt_find_or_claim(wc.jt, canon, home, w_first, slot, present, wc.cnt)) return false;
+    out.rec = (uint32_t)(slot * 2 + orient);
+    out.present = (present >> orient) & 1u;
+    out.lo = !out.present ? 0ULL : slot == home ? spec_lo : ((const uint64_t*)(wc.jt.recs + (slot * 2 + orient) * 16))[0];
+    return true;
+}
+
+// scan_forward (ReadScanner.cpp:112-206) for the piece {p0, nwin <= 128}, read-only: see the section's header.  wc.fail: 1 table full, 4 a junction
+// test the preview had left out came out true (the lazy scan is void if this path settles).
+__device__ __forceinline__ void ovw_walk_piece(WalkCtx& wc, OvwWalk& ow, uint64_t p0, uint32_t nwin) {
+    const int k = wc.fp.k, j = wc.fp.j;
+    const int tmax = 2 * (int)nwin - 2 - 2 * j;
+    const int spacer = 2 * wc.fp.max_spacer - 1;
+    PieceView v;
+    pv_load(v, wc.pl, p0, nwin);
+    ovw_created_bits(wc, ow, v, 0, v.xF0, v.xB0);
+    if (nwin > 64) ovw_created_bits(wc, ow, v, 1, v.xF1, v.xB1);
+    int t = 2 * j + 1;
+    int last_pos = 0;
+    bool have_last = false;
+    uint4 pend = make_uint4(0, 0, 0, 0);            // the last visit's entry: its forward distance is known at the next visit (or at the end)
+    uint64_t last_lo = 0;                           // stored distances of the last visit's record
+    int last_t = 0, last_ext_fwd = 0;
+
+    while (t <= tmax) {
+        int t_sp = last_pos + spacer;
+        if (t_sp < t) t_sp = t;
+        int tn;
+        uint32_t q = 0;
+        bool fwd = false, in_map = false, by_spacer = false;
+        for (;;) {
+            int t_ev = 0x7fffffff;
+            bool ev_in_map = false;
+            {
+                const uint32_t q0 = (uint32_t)(t >> 1);
+                const int t_stop = tmax < t_sp ? tmax : t_sp;
+                for (uint32_t c = q0 >> 6; c * 64 < nwin && 2 * (int)(c * 64) <= t_stop; c++) {
+                    const uint64_t mF = c == 0 ? (v.inF0 | v.xF0) : (v.inF1 | v.xF1), mB = c == 0 ? (v.inB0 | v.xB0) : (v.inB1 | v.xB1);
+                    uint64_t eF = mF | (c == 0 ? v.fF0 : v.fF1);
+                    uint64_t eB = mB | (c == 0 ? v.fB0 : v.fB1);
+                    if (c == (q0 >> 6)) {
+                        const uint64_t from = ~0ULL << (q0 & 63);
+                        eF &= from;
+                        eB &= from;
+                        if (t & 1) eB &= ~(1ULL << (q0 & 63));
+                    }
+                    const int tb = eB ? 2 * (int)(c * 64 + __builtin_ctzll(eB)) : 0x7fffffff;
+                    const int tf = eF ? 2 * (int)(c * 64 + __builtin_ctzll(eF)) + 1 : 0x7fffffff;
+                    const int te = tb < tf ? tb : tf;
+                    if (te != 0x7fffffff) {
+                        t_ev = te;
+                        ev_in_map = ((te & 1) ? mF : mB) >> ((te >> 1) & 63) & 1ULL;
+                        break;
+                    }
+                }
+            }
+            tn = t_ev < t_sp ? t_ev : t_sp;
+            if (tn > tmax) {
+                if (fill_missing<WALK_OVW>(wc, v, t, tmax + 1)) continue;
+                break;
+            }
+            q = (uint32_t)(tn >> 1);
+            fwd = tn & 1;
+            if (tn == t_ev) {
+                in_map = ev_in_map;
+            } else {
+                const uint32_t c = q >> 6;
+                const uint64_t mF = c == 0 ? (v.inF0 | v.xF0) : (v.inF1 | v.xF1), mB = c == 0 ? (v.inB0 | v.xB0) : (v.inB1 | v.xB1);
+                in_map = ((fwd ? mF : mB) >> (q & 63)) & 1ULL;
+            }
+            by_spacer = !in_map && (tn - last_pos >= spacer);
+            if (fill_missing<WALK_OVW>(wc, v, t, (in_map || by_spacer) ? tn : tn + 1)) continue;
+            break;
+        }
+        if (tn > tmax) {
+            wc.nb_processed += (unsigned long long)(tmax - t + 1);
+            wc.nb_jcheck += jcheck_sum(wc, v, t, tmax + 1);
+            break;
+        }
+        wc.nb_processed += (unsigned long long)(tn - t);
+        wc.nb_jcheck += jcheck_sum(wc, v, t, (in_map || by_spacer) ? tn : tn + 1);
+
+        // ---- junction at (q, fwd)  (ReadScanner.cpp:133-192)
+        const uint64_t km = pv_kmer(v, wc.pl.codes, p0 + q, k);
+        const uint64_t key = fwd ? km : fd_revcomp(km, k);
+        const int real = fwd ? pv_base(v, wc.pl.codes, p0 + q + k) : (pv_base(v, wc.pl.codes, p0 + q - 1) ^ 2);
+        const int ext_fwd = fwd ? real : 4, ext_bwd = fwd ? 4 : real;
+        OvwRec r;
+        {   // the previous round's visit of this very half-step knows the record and what is stored in it
+            const uint4 o = ow.log_old && ow.n_new < ow.n_old ? ow.log_old[ow.n_new] : make_uint4(0, 0xFFFFFFFFu, 0, 0);
+            if ((o.y & 0xFFFF) == (uint32_t)tn && !((o.y >> 16) & OVW_F_FAKE)) {
+                r.rec = o.x;
+                r.present = ((o.y >> 16) & OVW_F_PRESENT) != 0;
+                r.lo = (uint64_t)o.w | ((uint64_t)((o.z >> 8) & 0xFF) << 32);
+            } else if (!ovw_record(wc, key, r)) { wc.fail = 1; return; }
+        }
+        const bool revisit = ovw_seen_test_and_set(r.rec);
+        last_pos = tn;
+        const uint32_t d_in = (uint32_t)((have_last ? tn - last_t : tn - 2 * j) & 0xFF);    // Junction::update narrows to a byte
+        if (have_last) {       // directLinkJunctions (JunctionMap.cpp:551-561): the last junction's forward distance, this one's backward distance
+            pend.y |= (OVW_F_LINK_F | OVW_F_DF) << 16;
+            pend.z = (pend.z & ~0xFFu) | d_in;
+            if (d_in > ((last_lo >> (8 * last_ext_fwd)) & 0xFF) && !ovw_post(ow.cur, pend.x, (uint32_t)last_ext_fwd, ow.time, d_in)) { wc.fail = 1; return; }
+            ovw_emit(ow, pend);    // (before the log is asked about this record: the last visit may have been to the same junction)
+        }
+        // createJunction (JunctionMap.cpp:567-570): the key is neither stored, nor created by an earlier piece, nor by this piece earlier on
+        const bool created = !r.present && !(ow.have_prev && ovw_before(ow.prev, r.rec, OVW_CREATION, ow.time)) && !(revisit && ovw_own_created(ow, r.rec));
+        uint32_t flags = (created ? OVW_F_CREATED : 0u) | ((uint32_t)real << 1) | (have_last ? OVW_F_LINK_B : 0u) | (r.present ? OVW_F_PRESENT : 0u);
+        pend = ovw_pack(r.rec, (uint32_t)tn, flags, d_in, 0, r.lo);
+        if (created && !ovw_post(ow.cur, r.rec, OVW_CREATION, ow.time, 1)) { wc.fail = 1; return; }
+        if (d_in > ((r.lo >> (8 * ext_bwd)) & 0xFF) && !ovw_post(ow.cur, r.rec, (uint32_t)ext_bwd, ow.time, d_in)) { wc.fail = 1; return; }
+        if (created) ovw_mark_created(wc, v, key);
+        // the skip: the junction's forward distance as the sequential run shows it to this piece
+        uint32_t d = (uint32_t)((r.lo >> (8 * ext_fwd)) & 0xFF);
+        if (ow.have_prev) d = max(d, ovw_before(ow.prev, r.rec, (uint32_t)ext_fwd, ow.time));
+        if (revisit) d = max(d, ovw_own(ow, r.rec, (uint32_t)ext_fwd, pend, true));
+        have_last = true;
+        last_lo = r.lo;
+        last_t = tn;
+        last_ext_fwd = ext_fwd;
+        if (d < 1) d = 1;
+        t = tn + (int)d;
+        wc.nb_processed += 1;
+        wc.nb_skipped += (unsigned long long)(d - 1);
+        if (ow.overflow) { wc.fail = 1; return; }
+    }
+
+    if (!have_last) {   // add_fake_junction (ReadScanner.cpp:92-104)
+        wc.nb_no_juncs++;
+        const int len = (int)nwin + k - 1;
+        const int m = len / 2 - k / 2;
+        const uint64_t key = pv_kmer(v, wc.pl.codes, p0 + m, k);
+        const int real = pv_base(v, wc.pl.codes, p0 + m + k);
+        const int tm = 2 * m + 1;
+        OvwRec r;
+        if (!ovw_record(wc, key, r)) { wc.fail = 1; return; }
+        const bool created = !r.present && !(ow.have_prev && ovw_before(ow.prev, r.rec, OVW_CREATION, ow.time));
+        const uint32_t d_b = (uint32_t)((tm - 2 * j) & 0xFF), d_f = (uint32_t)(((2 * (int)nwin - 1 - tm) - 2 * j) & 0xFF);
+        if (created && !ovw_post(ow.cur, r.rec, OVW_CREATION, ow.time, 1)) { wc.fail = 1; return; }
+        if (d_b > ((r.lo >> 32) & 0xFF) && !ovw_post(ow.cur, r.rec, 4u, ow.time, d_b)) { wc.fail = 1; return; }
+        if (d_f > ((r.lo >> (8 * real)) & 0xFF) && !ovw_post(ow.cur, r.rec, (uint32_t)real, ow.time, d_f)) { wc.fail = 1; return; }
+        uint4 e = ovw_pack(r.rec, (uint32_t)tm, (created ? OVW_F_CREATED : 0u) | ((uint32_t)real << 1) | OVW_F_FAKE | OVW_F_DF | (r.present ? OVW_F_PRESENT : 0u), d_b, d_f, r.lo);
+        ovw_emit(ow, e);
+    } else {            // ReadScanner.cpp:202-206: the last junction's distance to the end of the read
+        const uint32_t d_f = (uint32_t)(((2 * (int)nwin - 1 - last_t) - 2 * j) & 0xFF);
+        pend.y |= OVW_F_DF << 16;
+        pend.z = (pend.z & ~0xFFu) | d_f;
+        if (d_f > ((last_lo >> (8 * last_ext_fwd)) & 0xFF) && !ovw_post(ow.cur, pend.x, (uint32_t)last_ext_fwd, ow.time, d_f)) { wc.fail = 1; return; }
+        ovw_emit(ow, pend);
+    }
+    if (ow.overflow) wc.fail = 1;
+}
+
+// a window begins: nothing listed, nothing settled, clean filters
+__global__ void __launch_bounds__(256) k_ovw_reset(uint32_t* state, uint32_t* filt, uint32_t filt_words3, uint32_t* longp, uint32_t n_pieces) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i < 8 + OVW_MAX_ROUNDS) state[i] = 0;
+    for (uint32_t a = i; a < filt_words3; a += stride) filt[a] = 0;
+    for (uint32_t a = i; a < n_pieces; a += stride) longp[a] = 0;
+}
+
+// One round: every listed piece of a cluster without long pieces walks on the events of the round before.
+__global__ void __launch_bounds__(64) k_ovw_round(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const WinDesc* __restrict__ wdp,
+                                                  KoTables kt, OvwTables ot, uint32_t round, const uint32_t* __restrict__ bloom, DevCounters* cnt) {
+    if ((kt.state[1] & 1u) || kt.state[3] == 0 || ot.state[1]) return;
+    if (round >= 1 && ot.state[8 + round - 1] == 0) return;            // settled (round 0 always counts as a change)
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < ot.filt_words; a += gridDim.x * blockDim.x) ot.filt_next[a] = 0;
+    const uint32_t n = ot.state[0] < ot.list_cap ? ot.state[0] : ot.list_cap;
+    bool changed = false, failed = false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ot.state[2] = round + 1;
+    const WinDesc wd = *wdp;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const uint32_t li = ot.list[idx];
+        if (!ot.longp[root[li]] && !kt.bad[root[li]]) {      // (a cluster with a piece of more than 512 windows stays with k_walk, all of it)
+            WalkCtx wc;
+            wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = 0;
+            wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
+            wc.created_now = false; wc.fail = 0; wc.dbg = 0;
+            OvwWalk ow;
+            ow.prev = ot.prev; ow.cur = ot.cur;
+            ow.have_prev = round > 0;
+            const uint2 pc = pl.pieces[wd.first_piece + li];
+            uint32_t n_lk = (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0));
+            if (pc.y > 64) n_lk += (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1));
+            const uint64_t base = 2ULL * kt.piece_base[li];
+            ow.log_new = ot.log_new + base;
+            ow.log_old = ot.log_old ? ot.log_old + base : nullptr;
+            ow.cap = 2 * n_lk;
+            ow.n_old = ot.res_old ? ot.res_old[8 * idx] : 0;
+            ow.n_new = 0;
+            ow.time = li;
+            ow.changed = false;
+            ow.overflow = false;
+            ovw_seen_clear();
+            ovw_walk_piece(wc, ow, pc.x, pc.y);
+            if (ow.n_new != ow.n_old || !ot.res_old) ow.changed = true;
+            uint32_t* res = ot.res_new + 8 * idx;
+            res[0] = ow.n_new;
+            res[1] = (uint32_t)wc.nb_processed; res[2] = (uint32_t)wc.nb_skipped; res[3] = (uint32_t)wc.nb_jcheck; res[4] = (uint32_t)wc.nb_no_juncs;
+            res[5] = (uint32_t)wc.n_filled; res[6] = wc.fail == 4 ? 1u : 0u; res[7] = 0;
+            changed |= ow.changed;
+            failed |= wc.fail == 1;
+        }
+    }
+    if (__ballot(changed) && fd_lane() == 0) atomicOr(&ot.state[8 + round], 1u);
+    if (__ballot(failed) && fd_lane() == 0) atomicOr(&ot.state[1], 1u);
+}
+
+// Junction::addCoverage / update / the link flags of one log entry, on a record other pieces update at the same time
+__device__ __forceinline__ void ovw_apply(uint64_t* rec_addr, uint32_t tn, uint32_t flags, uint32_t d_bwd, uint32_t d_fwd) {
+    const bool fwd = tn & 1;
+    const uint32_t real = (flags & OVW_F_REAL) >> 1, ib = fwd ? 4u : real, iff = fwd ? real : 4u;
+    unsigned long long* w0 = (unsigned long long*)rec_addr;
+    unsigned long long old = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        unsigned long long nw = old;
+        if (((nw >> (8 * ib)) & 0xFF) < d_bwd) nw = (nw & ~(0xFFULL << (8 * ib))) | ((unsigned long long)d_bwd << (8 * ib));
+        if ((flags & OVW_F_DF) && ((nw >> (8 * iff)) & 0xFF) < d_fwd) nw = (nw & ~(0xFFULL << (8 * iff))) | ((unsigned long long)d_fwd << (8 * iff));
+        if (real < 3 && ((nw >> (8 * (5 + real))) & 0xFF) != 255) nw += 1ULL << (8 * (5 + real));       // coverage saturates at 255 (Junction.cpp:59-67)
+        if (nw == old) break;
+        const unsigned long long was = atomicCAS(w0, old, nw);
+        if (was == old) break;
+        old = was;
+    }
+    unsigned long long* w1 = w0 + 1;
+    unsigned long long add = 0;
+    if (flags & OVW_F_LINK_B) add |= 1ULL << (8 + ib);
+    if (flags & OVW_F_LINK_F) add |= 1ULL << (8 + iff);
+    if (real == 3 || add) {
+        old = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            unsigned long long nw = old | add;
+            if (real == 3 && (nw & 0xFF) != 255) nw += 1;
+            if (nw == old) break;
+            const unsigned long long was = atomicCAS(w1, old, nw);
+            if (was == old) break;
+            old = was;
+        }
+    }
+}
+
+// the settled logs are applied; the counters of the settled paths are added up
+__global__ void __launch_bounds__(64) k_ovw_commit(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
+                                                   const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, KoTables kt, OvwTables ot, const uint4* log0,
+                                                   const uint4* log1, const uint32_t* res0, const uint32_t* res1, int rounds, DevCounters* cnt, int count_followers) {
+    if ((kt.state[1] & 1u) || kt.state[3] == 0) return;
+    const int settled = ovw_settled_round(ot.state, rounds);
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // processed, skipped, jcheck, no_juncs, created, filled, walked, rounds
+    if (settled >= 0) {
+        const uint4* log = (settled & 1) ? log1 : log0;
+        const uint32_t* res_all = (settled & 1) ? res1 : res0;
+        const uint32_t n = ot.state[0] < ot.list_cap ? ot.state[0] : ot.list_cap;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n) v[7] = (unsigned long long)settled + 1;
+        const WinDesc wd = *wdp;
+        for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+            const uint32_t li = ot.list[idx];
+            const uint32_t r = root[li];
+            if (!ot.longp[r] && !kt.bad[r]) {
+                if (r == li) {
+                    if (count_followers) atomicAdd(&cnt->followers, (unsigned long long)count[r]);
+                    atomicMax(&cnt->max_cluster, (unsigned long long)count[r] + 1);
+                }
+                const uint2 pc = pl.pieces[wd.first_piece + li];
+                const uint32_t* res = res_all + 8 * idx;
+                const uint4* lg = log + 2ULL * kt.piece_base[li];
+                const uint64_t seq = piece_seq_base + wd.first_piece + li;
+                for (uint32_t i = 0; i < res[0]; i++) {
+                    const uint4 e = lg[i];
+                    const uint32_t tn = e.y & 0xFFFF, flags = (e.y >> 16) & 0xFF;
+                    const uint64_t pos = pc.x + (tn >> 1);
+                    if (flags & OVW_F_CREATED) {   // JunctionMap::createJunction: one creator per key in a settled state
+                        const uint64_t slot = e.x >> 1;
+                        jt.stamps[e.x] = (seq << STAMP_SHIFT) | ((flags & OVW_F_FAKE) ? STAMP_FAKE : (uint64_t)tn);
+                        atomicOr((unsigned long long*)&jt.keys[slot], 1ULL << (62 + (e.x & 1)));
+                        const uint64_t hb = jt_filter_bit(jt, ld_agent(&jt.keys[slot]) & J_KEYMASK);
+                        atomicOr(&jt.filter[hb >> 5], 1u << (hb & 31));
+                        atomicOr(&pl.cr[pos >> 6], 1ULL << (pos & 63));
+                        v[4]++;
+                    }
+                    if (pl.sF && !(flags & OVW_F_FAKE)) atomicOr(&((tn & 1) ? pl.sF : pl.sB)[pos >> 6], 1ULL << (pos & 63));   // result.push_back, :140
+                    ovw_apply((uint64_t*)(jt.recs + (uint64_t)e.x * 16), tn, flags, e.y >> 24, e.z & 0xFF);
+                }
+                v[0] += res[1]; v[1] += res[2]; v[2] += res[3]; v[3] += res[4]; v[5] += res[5]; v[6] += 1;
+                if (res[6]) atomicOr(&cnt->error_flags, 4ULL);   // a late junction test came out true on a settled path: the lazy scan is void (see fill_missing)
+            }
+        }
+    }
+    for (int c = 0; c < 8; c++)
+        for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_down(v[c], o, 64);
+    if (fd_lane() == 0) {
+        if (v[0]) atomicAdd(&cnt->nb_processed, v[0]);
+        if (v[1]) atomicAdd(&cnt->nb_skipped, v[1]);
+        if (v[2]) atomicAdd(&cnt->nb_jcheck, v[2]);
+        if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
+        if (v[4]) atomicAdd(&cnt->n_junctions, v[4]);
+        if (v[5]) atomicAdd(&cnt->flags_filled, v[5]);
+        if (v[6]) { atomicAdd(&cnt->walk_parallel, v[6]); atomicAdd(&cnt->ovw[0], v[6]); }
+        if (v[7]) { atomicAdd(&cnt->ovw[1], v[7]); atomicAdd(&cnt->ovw[2], 1ULL); }
+        if (blockIdx.x == 0 && settled < 0 && kt.state[3]) atomicAdd(&cnt->ovw[3], 1ULL);   // a window left to the key-ordered walk
     }
 }
 
@@ -1918,24 +2494,7 @@ void fgpu_touch_scan_walk() {
 int fgpu_scan_alloc(fgpu_ctx* ctx) {
     if (ctx->jkeys) return FGPU_OK;
     ctx->jcap = ctx->prm.junction_capacity;
-    FGPU_HIP(hipMalloc(&ctx->jkeys, ctx->jcap * 8));
-    FGPU_HIP(hipMalloc(&ctx->jrecs, ctx->jcap * 32));
-    FGPU_HIP(hipMalloc(&ctx->jstamps, ctx->jcap * 16));
-    FGPU_HIP(hipMalloc(&ctx->jfilter, ctx->jcap * 2 / 8));
-    // Scheduling windows span at most FGPU_MAX_SPAN positions (+ one piece length).  Worst case every position is a
-    // candidate with a distinct k-mer, so the window table holds 2x that; piece starts are >= k+1 apart.
-    while (ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2 >= W_OWNER_MASK) ctx->max_span >>= 1;   // piece indices of a window fit the table's owner field
-    ctx->wcap = 4 * ctx->max_span;
-    ctx->wmax = (uint32_t)(ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2);
-    FGPU_HIP(hipMalloc(&ctx->wdesc, 64));
     if (const char* e = getenv("FGPU_WBITS_LOG2")) ctx->wbits_log2 = std::min(28, std::max(16, atoi(e)));   // measurement aid
-    FGPU_HIP(hipMalloc(&ctx->wkeys, ctx->wcap * 8));
-    FGPU_HIP(hipMalloc(&ctx->wbits, 2 * (1ULL << ctx->wbits_log2) / 8));   // two filters: consecutive windows alternate
-    FGPU_HIP(hipMalloc(&ctx->uf_parent, 2 * ctx->wmax * 4));   // two sets each: consecutive windows alternate (k_walk_reset_uf)
-    FGPU_HIP(hipMalloc(&ctx->cl_count, 2 * ctx->wmax * 4));
-    FGPU_HIP(hipMalloc(&ctx->cl_offset, 2 * ctx->wmax * 4));
-    FGPU_HIP(hipMalloc(&ctx->cl_fill, ctx->wmax * 4));
-    FGPU_HIP(hipMalloc(&ctx->cl_fail, 2 * ctx->wmax * 4));
     // the key-ordered walk's tables (KoTables): 2^20 k-mers and 2^22 occurrences of large clusters per window, else the window is walked by cluster
     if (const char* e = getenv("FGPU_WALK_KO")) ctx->walk_ko = (uint32_t)std::max(0, atoi(e));
     ctx->walk_ko_always = getenv("FGPU_WALK_KO_ALWAYS") != nullptr || (ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) != 0;
@@ -1944,14 +2503,50 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     // ... and the rule by weight: clusters whose pieces hold 128 lk positions and more between them (three pieces inside a repeat, thirty ordinary ones)
     ctx->walk_ko_weight = (ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) ? 128u : 0u;
     if (const char* e = getenv("FGPU_WALK_KO_WEIGHT")) ctx->walk_ko_weight = (uint32_t)std::max(0, atoi(e));
-    ctx->ko_hk_cap = 1u << 20;
-    ctx->ko_occ_cap = 1u << 22;
-    FGPU_HIP(hipMalloc(&ctx->ko_hk, (size_t)ctx->ko_hk_cap * 4 * 3));
-    FGPU_HIP(hipMalloc(&ctx->ko_occ, (size_t)ctx->ko_occ_cap * (4 * 3 + 8)));
-    FGPU_HIP(hipMalloc(&ctx->ko_piece, (size_t)ctx->wmax * 4 * 2 + 64));
+    if (const char* e = getenv("FGPU_OVW_ROUNDS")) ctx->ovw_rounds = std::max(0, atoi(e));   // 0: the key-ordered walk takes every large cluster
+    // (round 4: four times round 3's sizes -- the optimistic walk lets windows of repeat-rich data grow to 10^5 pieces of large clusters and more)
+    ctx->ko_hk_cap = 1u << 22;
+    ctx->ko_occ_cap = 1u << 24;
     if (const char* e = getenv("FGPU_WALK_HEAVY")) ctx->walk_heavy = (uint32_t)std::max(0, atoi(e));   // clusters of at least this many pieces are tried out of order; 0 = never
-    FGPU_HIP(hipMalloc(&ctx->cl_members, ctx->wmax * 4 * 2));
-    return FGPU_OK;
+    // Scheduling windows span at most max_span positions (+ one piece length).  Worst case every position is a candidate with a distinct
+    // k-mer, so the window table holds 4x that -- 32 bytes per position of the bound: 2 GiB at 2^26, 8 GiB at the 2^28 that filters of 2^32
+    // bits and more ask for (fgpu_create).  The larger bounds are a matter of speed, never of results, so they give way to the memory there
+    // is (several contexts on one device, or a smaller device, failed here where round 2 ran): the bound is first brought under
+    // a quarter of the free device memory, and halved again -- everything allocated so far freed -- if an allocation fails all the same.
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            while (ctx->max_span > FGPU_MAX_SPAN && 40ULL * ctx->max_span > free_b / 4) ctx->max_span >>= 1;
+        (void)hipGetLastError();
+    }
+    for (;;) {
+        while (ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2 >= W_OWNER_MASK) ctx->max_span >>= 1;   // piece indices of a window fit the table's owner field
+        ctx->wcap = 4 * ctx->max_span;
+        ctx->wmax = (uint32_t)(ctx->max_span / (uint64_t)(ctx->fd.k + 1) + 2);
+        struct { void** p; uint64_t bytes; } want[] = {
+            {(void**)&ctx->jkeys, ctx->jcap * 8}, {(void**)&ctx->jrecs, ctx->jcap * 32}, {(void**)&ctx->jstamps, ctx->jcap * 16}, {(void**)&ctx->jfilter, ctx->jcap * 2 / 8},
+            {(void**)&ctx->wdesc, 64}, {(void**)&ctx->wkeys, ctx->wcap * 8},
+            {(void**)&ctx->wbits, 2 * (1ULL << ctx->wbits_log2) / 8},                  // two filters: consecutive windows alternate
+            {(void**)&ctx->uf_parent, 2ULL * ctx->wmax * 4},                            // two sets each: consecutive windows alternate (k_walk_reset_uf)
+            {(void**)&ctx->cl_count, 2ULL * ctx->wmax * 4}, {(void**)&ctx->cl_offset, 2ULL * ctx->wmax * 4}, {(void**)&ctx->cl_fill, (uint64_t)ctx->wmax * 4},
+            {(void**)&ctx->cl_fail, 2ULL * ctx->wmax * 4}, {(void**)&ctx->ko_hk, (uint64_t)ctx->ko_hk_cap * 4 * 3},
+            {(void**)&ctx->ko_occ, (uint64_t)ctx->ko_occ_cap * (4 * 3 + 8)}, {(void**)&ctx->ko_piece, (uint64_t)ctx->wmax * 4 * 2 + 64},
+            {(void**)&ctx->cl_members, (uint64_t)ctx->wmax * 4 * 2}};
+        hipError_t err = hipSuccess;
+        uint64_t failed_bytes = 0;
+        for (auto& w : want) {
+            *w.p = nullptr;
+            if ((err = hipMalloc(w.p, w.bytes)) != hipSuccess) { *w.p = nullptr; failed_bytes = w.bytes; break; }
+        }
+        if (err == hipSuccess) return FGPU_OK;
+        (void)hipGetLastError();
+        for (auto& w : want) { if (*w.p) hipFree(*w.p); *w.p = nullptr; }
+        if (ctx->max_span <= FGPU_MAX_SPAN) {
+            ctx->err = std::string("the scan's tables do not fit the device (hipMalloc of ") + std::to_string(failed_bytes) + " bytes: " + hipGetErrorString(err) + ")";
+            return FGPU_ERR_NOMEM;
+        }
+        ctx->max_span >>= 1;                                                            // smaller windows: slower on thin coverage, same results
+    }
 }
 
 int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries, uint64_t* d_stamps, uint64_t* n_entries);
@@ -2201,7 +2796,19 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // ... and, for callers that expect repeats, the clusters whose pieces hold many lk positions between them (ko_cluster): the weights
         // are summed by k_walk_cluster into cl_fail, which the out-of-order walk (k_walk_par, the other way of taking clusters out of k_walk)
         // does not use then
-        const uint32_t ko_heavy_w = ko_heavy ? ctx->walk_ko_weight : 0u;
+        // The rule by weight has two bars: lk positions of a cluster in all (ko_total), and -- for clusters of "repeat pieces", pieces that hold
+        // many of them -- positions per piece and a lower bar in all.  Ordinary pieces hold 2-5, some 8 and more; pieces inside a repeat at high
+        // coverage 40 and more.  Once a scan HAS shown repeats (2 % of the pieces walked so far went to the large-cluster walks) the second bar
+        // drops from (12 per piece, 48 in all) to (8, 16): measured on config 3's shape through the CLI pass 2 goes from 245-250 ms to 190 ms
+        // (the windows grow from 62 to 22: what is left to k_walk no longer queues), while config 2 with the CLI's settings would pay 10 ms per
+        // step for the lower bar (walk stage 52.6 -> 62.6 ms; scripts/ovw_thresholds.sh, gpurun_out/r04_ovw_thresholds2.txt).
+        static const int ko_avg_env = getenv("FGPU_WALK_KO_AVG") ? std::min(255, std::max(0, atoi(getenv("FGPU_WALK_KO_AVG")))) : -1;
+        static const int ko_avg_min_env = getenv("FGPU_WALK_KO_AVG_MIN") ? std::min(255, std::max(1, atoi(getenv("FGPU_WALK_KO_AVG_MIN")))) : -1;
+        const bool repeats_seen = ctx->counters_host->walk_parallel * 50 > ctx->counters_host->walked_pieces;
+        const uint32_t ko_total = std::min<uint32_t>(ctx->walk_ko_weight, 0xFFFFu);
+        const uint32_t ko_avg = ko_avg_env >= 0 ? (uint32_t)ko_avg_env : repeats_seen ? 8u : 12u;
+        const uint32_t ko_total_rep = ko_avg_min_env > 0 ? (uint32_t)ko_avg_min_env : repeats_seen ? 16u : std::min<uint32_t>(255u, 3 * ko_total / 8);
+        const uint32_t ko_heavy_w = (ko_heavy && ko_total) ? (ko_total | (ko_avg << 16) | (ko_total_rep << 24)) : 0u;
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
                     ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters, cl_fail, ko_heavy_w);
@@ -2228,11 +2835,44 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         kt.state = ctx->ko_piece;                 // 16 words in front of the per-piece arrays
         kt.piece_base = ctx->ko_piece + 16;
         kt.bad = kt.piece_base + ctx->wmax;
+        // The optimistic walk (k_ovw_round) takes the large clusters first; the key-ordered walk runs behind it for what it leaves.  Its
+        // rounds are launches whether or not the window holds such a cluster, so -- like the key-ordered walk itself -- it is switched on by
+        // what the scan has shown: pieces of large clusters among the pieces walked so far (callers that expect repeats: from the first window).
+        const int ovw_rounds = !ko_heavy ? 0 : std::min(ctx->ovw_rounds, OVW_MAX_ROUNDS);
+        // the pieces it walks do not queue behind one another, so they do not count as followers for the window-size controller (the key-ordered
+        // walk's did: 68 windows instead of 22 on config 3's shape); FGPU_OVW_FOLLOWERS=1 counts them (measurement aid)
+        static const int ovw_followers = getenv("FGPU_OVW_FOLLOWERS") ? atoi(getenv("FGPU_OVW_FOLLOWERS")) : 0;
+        const bool ovw_on = ovw_rounds > 0 && (ctx->walk_ko_always || ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
+        OvwTables ot;
+        memset(&ot, 0, sizeof(ot));
+        constexpr int kEvLog2 = 21, kFiltLog2 = 22;
+        const uint32_t filt_words = 1u << (kFiltLog2 - 5);
+        const uint32_t list_cap = (uint32_t)std::min<uint64_t>(ctx->wmax, 1u << 20);
+        uint32_t* ovw_filt = nullptr;
+        if (ovw_on) {
+            int rc;
+            const bool fresh = !ctx->ovw_ev.p;
+            if ((rc = fgpu_ensure(ctx, &ctx->ovw_ev, 4ULL * 8 * (1ULL << kEvLog2))) || (rc = fgpu_ensure(ctx, &ctx->ovw_filt, 3ULL * 4 * filt_words)) ||
+                (rc = fgpu_ensure(ctx, &ctx->ovw_log, 2ULL * 2 * ctx->ko_occ_cap * sizeof(uint4))) || (rc = fgpu_ensure(ctx, &ctx->ovw_res, 2ULL * 32 * list_cap)) ||
+                (rc = fgpu_ensure(ctx, &ctx->ovw_list, 4ULL * list_cap)) || (rc = fgpu_ensure(ctx, &ctx->ovw_state, 4ULL * (8 + OVW_MAX_ROUNDS) + 64)) ||
+                (rc = fgpu_ensure(ctx, &ctx->ovw_longp, 4ULL * ctx->wmax)))
+                return rc;
+            if (fresh || ctx->ovw_epoch + (uint32_t)ovw_rounds > 255) {   // event entries carry their round's epoch: a wiped table holds none
+                FGPU_HIP(hipMemsetAsync(ctx->ovw_ev.p, 0, 4ULL * 8 * (1ULL << kEvLog2), walk_stream));
+                ctx->ovw_epoch = 0;
+            }
+            ovw_filt = (uint32_t*)ctx->ovw_filt.p;
+            ot.list = (uint32_t*)ctx->ovw_list.p;
+            ot.list_cap = list_cap;
+            ot.state = (uint32_t*)ctx->ovw_state.p;
+            ot.longp = (uint32_t*)ctx->ovw_longp.p;
+            ot.filt_words = filt_words;
+        }
         if (ko_heavy) {
             FGPU_LAUNCH("walk_ko_prepare", k_ko_reset, 256, 256, kt, (uint32_t)ctx->wmax, (uint32_t)parity);
+            if (ovw_on) FGPU_LAUNCH("walk_ko_prepare", k_ovw_reset, 64, 256, ot.state, ovw_filt, 3 * filt_words, ot.longp, (uint32_t)max_pieces);
             FGPU_LAUNCH("walk_ko_prepare", k_ko_prepare, piece_blocks_ko, 256, pl, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
-                        (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity, (const uint32_t*)cl_fail, ko_heavy_w);
-            FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt);
+                        (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity, (const uint32_t*)cl_fail, ko_heavy_w, ot);
         }
         if (heavy)
             FGPU_LAUNCH("walk_probe", k_walk_par<WALK_PROBE>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
@@ -2241,9 +2881,43 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
                     seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
                     (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
+        if (ovw_on) {
+            unsigned long long* const evb = (unsigned long long*)ctx->ovw_ev.p;
+            uint4* const logs[2] = {(uint4*)ctx->ovw_log.p, (uint4*)ctx->ovw_log.p + 2ULL * ctx->ko_occ_cap};
+            uint32_t* const ress[2] = {(uint32_t*)ctx->ovw_res.p, (uint32_t*)ctx->ovw_res.p + 8ULL * list_cap};
+            const unsigned ovw_grid = (unsigned)std::min<uint64_t>(fgpu_blocks(std::min<uint64_t>(max_pieces, list_cap), 64), 2048);
+            auto table = [&](int r, uint64_t epoch) {
+                OvwEv ev;
+                ev.key = evb + (uint64_t)(r & 1) * 2 * (1ULL << kEvLog2);
+                ev.val = ev.key + (1ULL << kEvLog2);
+                ev.bits = ovw_filt + (uint64_t)(r % 3) * filt_words;
+                ev.mask = (1ULL << kEvLog2) - 1;
+                ev.epoch = epoch << 56;
+                ev.fshift = 32 - kFiltLog2;
+                return ev;
+            };
+            for (int r = 0; r < ovw_rounds; r++) {
+                ctx->ovw_epoch++;
+                ot.cur = table(r, ctx->ovw_epoch);
+                ot.prev = table(r + 1, ctx->ovw_epoch - 1);           // (the other table, the filter of round r - 1: (r + 2) % 3 == (r - 1) % 3)
+                ot.prev.bits = ovw_filt + (uint64_t)((r + 2) % 3) * filt_words;
+                ot.filt_next = ovw_filt + (uint64_t)((r + 1) % 3) * filt_words;
+                ot.log_new = logs[r & 1];
+                ot.log_old = r ? logs[(r - 1) & 1] : nullptr;
+                ot.res_new = ress[r & 1];
+                ot.res_old = r ? ress[(r - 1) & 1] : nullptr;
+                FGPU_LAUNCH("walk_ovw", k_ovw_round, ovw_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const WinDesc*)ctx->wdesc, kt, ot, (uint32_t)r,
+                            (const uint32_t*)ctx->bloo2, ctx->counters);
+            }
+            FGPU_LAUNCH("walk_ovw", k_ovw_commit, ovw_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
+                        seq_base, kt, ot, (const uint4*)logs[0], (const uint4*)logs[1], (const uint32_t*)ress[0], (const uint32_t*)ress[1], ovw_rounds, ctx->counters, ovw_followers);
+        }
+        if (ko_heavy)      // (ranks of the occurrences per k-mer: only the key-ordered walk needs them, and only for what the optimistic walk left)
+            FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt, (const uint32_t*)ot.state, ovw_rounds);
         if (ko_heavy)
             FGPU_LAUNCH("walk_ko", k_walk_ko, ko_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
-                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket, (const uint32_t*)cl_fail, ko_heavy_w);
+                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, kt, ko_heavy, ko_ticket, (const uint32_t*)cl_fail, ko_heavy_w,
+                        (const uint32_t*)ot.state, (const uint32_t*)ot.longp, ovw_rounds);
         if (heavy)
             FGPU_LAUNCH("walk_commit", k_walk_par<WALK_COMMIT>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
                         (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);

@@ -751,6 +751,12 @@ int main(int argc, char** argv) {
                                 "%llu evaluation rounds over %llu batches (at most %llu in one)\n",
                         (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3], (unsigned long long)d[5], (unsigned long long)d[4]);
         }
+        if (clk.on) {
+            uint64_t d[4] = {0, 0, 0, 0};
+            if (fgpu_diag_ovw(ctx, d) == FGPU_OK && (d[2] || d[3]))
+                fprintf(stderr, "[cli]   large clusters, walked optimistically: %llu pieces, %llu rounds over %llu windows; %llu windows left to the key-ordered walk\n",
+                        (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3]);
+        }
         clk.mark("pass 2 (read + scan)");
         printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);
         printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);

@@ -103,6 +103,33 @@ def _recv(t, src):
         dist.recv(t, src=src)
 
 
+class StageClock:
+    """Per-rank stage times of one sharded step without stopping the device: an event on torch's current stream at every stage boundary
+    (the stream the library and the collectives are ordered with, see GpuShard), read out after the step.  Off unless `enable`d (bench.py)."""
+
+    def __init__(self):
+        self.on, self.marks = False, []
+
+    def enable(self, on=True):
+        self.on, self.marks = bool(on), []
+
+    def mark(self, name):
+        if not self.on or not torch.cuda.is_available():
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.marks.append((name, ev))
+
+    def report(self):
+        """[(stage, ms)]: time between the mark that opens a stage and the next one; call after a synchronisation"""
+        out = [(b[0], float(a[1].elapsed_time(b[1]))) for a, b in zip(self.marks[:-1], self.marks[1:])]
+        self.marks = []
+        return out
+
+
+CLOCK = StageClock()
+
+
 def _agree(flag: bool, device=None) -> bool:
     """True iff it is True on every rank (the ranks must take the same protocol: their collectives have to match)"""
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if dist.get_backend() != "gloo" else None)
@@ -219,31 +246,41 @@ def load_sharded_fixup(backend, batches, rank: int, world: int):
     an occurrence the local pass kept out of bloo2 goes there iff each of its bits is in the prefix or was set locally before it
     ->  bloo2 := OR over ranks.  Exact for the same reason as the presence protocol: what the sequential run has in
     bloo1 when it reaches shard r IS that prefix, and within the shard "set before t" is what the first-set times say."""
+    CLOCK.mark("pass1_begin")
     stats = backend.load(batches, keep_carry=False, shard_times=True)
+    CLOCK.mark("pass1_own_load")
     b1 = backend.bloom_tensor(L.BLOO1)
     prefix = backend.scratch(b1.numel(), tag="prefix")
     exclusive_prefix_or(backend, b1, prefix, rank, world)
+    CLOCK.mark("pass1_prefix_or_exchange")
     if rank > 0:
         stats = backend.load_fixup(prefix)
+    CLOCK.mark("pass1_fixup")
     or_allreduce(backend, backend.bloom_tensor(L.BLOO2), rank, world)
     backend.fence()
+    CLOCK.mark("pass1_or_allreduce")
     return stats
 
 
 def load_sharded_presence(backend, batches, rank: int, world: int):
     """presence bitmap of the shard  ->  exclusive prefix-OR over ranks = carried-in bloo1 of rank r  ->  ordered load of the shard  ->
     bloo2 := OR over ranks"""
+    CLOCK.mark("pass1_begin")
     backend.clear_filters()
     for b in batches:
         backend.presence(b)
+    CLOCK.mark("pass1_presence")
     b1 = backend.bloom_tensor(L.BLOO1)
     prefix = backend.scratch(b1.numel(), tag="prefix")
     exclusive_prefix_or(backend, b1, prefix, rank, world)
     b1.copy_(prefix)
     backend.fence()      # the carried-in filter is in place before the library's load kernels read it
+    CLOCK.mark("pass1_prefix_or_exchange")
     stats = backend.load(batches, keep_carry=True)
+    CLOCK.mark("pass1_load")
     or_allreduce(backend, backend.bloom_tensor(L.BLOO2), rank, world)
     backend.fence()
+    CLOCK.mark("pass1_or_allreduce")
     return stats
 
 
@@ -318,6 +355,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
     of every position is evaluated (105-116 ms per 10 M reads instead of ~50).  So the first rank shows them its table once it has
     walked HINT_AFTER of its reads -- an earlier state of the very table they will be handed, which is all the preview of the pure stage
     needs (faucet_gpu.h, fgpu_scan_import_hint) -- and they prepare against that.  The hint is replaced by the real table before a walk."""
+    CLOCK.mark("pass2_begin")
     backend.scan_begin()
     hinting = world > 1
     hint_hdr = backend.header_tensor()[:1] if hinting else None
@@ -342,6 +380,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
         # junction tests), which puts the table on its way ~50 ms per 10 M reads earlier than prepare-all + walk
         stats = backend.scan_stream(batches, after_batch=show)   # ... and closes the pass
         show(len(batches))                                        # (a shard without batches still owes the others their broadcast)
+        CLOCK.mark("pass2_first_shard_scan")
     else:
         # pure stage while the earlier shards walk.  It does not wait for the hint: the receive is posted, the batches prepared until it
         # has landed see an empty table (every test evaluated), the others the hint.  Measured with the per-rank shapes
@@ -353,6 +392,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
             backend.scan_prepare(b)
         if rx:
             rx.finish()                                    # the collective is completed even when it came too late to be of use
+        CLOCK.mark("pass2_pure_stage")
     hdr = backend.header_tensor()
     if rank > 0:
         _recv(hdr, rank - 1)
@@ -361,16 +401,20 @@ def scan_sharded(backend, batches, rank: int, world: int):
         buf = backend.scratch(max(n_in, 1) * L.TABLE_ENTRY_BYTES, tag="table_in")
         _recv(buf, rank - 1)
         backend.fence()
+        CLOCK.mark("pass2_wait_for_table")                 # (the host waits here: the chain of walks of the lower ranks)
         carried = dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]]))
         stats = backend.walk_shard(batches, buf, n_in, carried)   # import (replaces the hint) + ordered walk of this shard + scan_end
+        CLOCK.mark("pass2_import_and_walk")
     if rank < world - 1:
         n_out, buf = backend.export_table()
         backend.fence()
+        CLOCK.mark("pass2_export")
         hdr.zero_()
         hdr[0] = n_out
         hdr[1:1 + len(_STAT_NAMES)] = torch.tensor([stats[n] for n in _STAT_NAMES], dtype=torch.int64)
         _send(hdr, rank + 1)
         _send(buf, rank + 1)
+        CLOCK.mark("pass2_send")
     return stats, rank == world - 1
 
 

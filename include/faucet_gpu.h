@@ -210,7 +210,12 @@ int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_o
                     fgpu_reads* out, uint64_t* consumed);
 
 /* ---- pass 2: junction scan (replaces ReadScanner::scanReads, src/ReadScanner.cpp:284-359) ------- */
-/* Uses bloo2 as resident on the device (after fgpu_load_end or fgpu_bloom_upload). */
+/* Uses bloo2 as resident on the device (after fgpu_load_end or fgpu_bloom_upload).
+ * Device memory: the first scan of a context allocates the junction table (56 bytes per slot of junction_capacity) and the walk's window
+ * tables -- 40 bytes per position of the largest scheduling window: 2.5 GiB for filters up to 2^30 bits, up to 10 GiB (windows of 2^28
+ * positions) for filters of 2^32 bits and more.  The larger windows only buy speed on thin coverage: where a quarter of the free device
+ * memory does not hold them (several contexts on one device, a smaller device) the bound is halved, down to 2^26 positions, before
+ * FGPU_ERR_NOMEM is returned. */
 int fgpu_scan_begin(fgpu_ctx* ctx);
 /* Pure stage + ordered walk for one batch, in file order. */
 int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
@@ -347,6 +352,9 @@ typedef struct {
 /* Requires FGPU_FLAG_PROFILE.  Returns the number of distinct kernels; fills up to cap entries. */
 int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap);
 int fgpu_kernel_times_reset(fgpu_ctx* ctx);
+/* Switch the event bracketing on or off between passes (what FGPU_FLAG_PROFILE sets at creation): the events cost 1.5 % of a step
+ * (profiles/r04_profile_flag_ab.txt), so a caller times its steps without them and takes kernel times from separate, bracketed steps. */
+int fgpu_profile_enable(fgpu_ctx* ctx, int on);
 
 /* ---- measured ceilings (no reference counterpart) ---------------------------------
  * Streaming device-to-device copy of `bytes` (read + write counted), GB/s. */
@@ -383,6 +391,9 @@ int fgpu_diag_late_flags(fgpu_ctx* ctx, uint64_t out[3]);
  * paired against the filter as their batch found it, [2] addPair calls, [3] evaluation rounds over all batches, [4] most rounds one batch
  * needed, [5] batches */
 int fgpu_diag_long_pairs(fgpu_ctx* ctx, uint64_t out[6]);
+/* after fgpu_scan_end: the optimistic walk of large clusters: [0] pieces it walked, [1] rounds it ran, [2] windows it settled,
+ * [3] windows it left to the key-ordered walk (rounds that did not settle, full tables) */
+int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[4]);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */

@@ -265,6 +265,55 @@ def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank, torch_str
     assert "RESULT PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def _bench_line(args, env, nproc=0, timeout=600):
+    """one run of bench.py (plain, or under torch.distributed.run with `nproc` ranks); returns the parsed JSON line"""
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(max(nproc, 1))] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_sharded_path_over_rccl_gives_config2s_digests():
+    """no driver-run test initialised the `nccl` backend.  bench.py's multi-GPU path (sharded.py: slice-wise prefix-OR / OR-allreduce,
+    table hand-over, the library on torch's stream) with RCCL as the process group's backend at world size 1 (FAUCET_FORCE_SHARDED=1), strong
+    mode on BASELINE config 2's fixture reads: bloo2, the junction keys in creation order, the records and the scan's counters equal the
+    oracle's digests in tests/golden/fullsize.json."""
+    d = _bench_line(["--scaling", "strong", "--fixture", "config2", "--batch-reads", "1000000", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-ceilings",
+                     "--no-host-leg", "--no-full-size", "--no-profile"], {"FAUCET_FORCE_SHARDED": "1"})
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["kmers_per_step"] == FULL["config2"]["kmers"]
+    chk = d["outputs_check"]
+    for key in ("bloo2_equals_the_oracles", "junction_keys_equal_the_oracles", "junction_records_equal_the_oracles", "scan_counters_equal_the_oracles"):
+        assert chk[key] is True, (key, chk)
+    stages = dict(d["rank_stage_ms"][0])
+    assert "pass1_or_allreduce" in stages and "pass2_first_shard_scan" in stages
+
+
+def test_bench_strong_scaling_three_ranks_equal_one():
+    """`bench.py --gpus N --scaling strong` (the mode the 8-GPU target is measured in: ONE read set cut into N file-order shards) at reduced
+    size: three ranks in separate processes sharing this GPU (gloo as the transport) give the digests of the one-GPU run of the same reads --
+    bloo2, junction keys in creation order, records -- and report every rank's stage times."""
+    size = ["--scaling", "strong", "--fixture", "config2", "--reads", "3000000", "--genome", "6000000", "--estimated-kmers", "30000000", "--singletons", "6000000",
+            "--batch-reads", "250000", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-ceilings", "--no-host-leg", "--no-full-size", "--no-profile"]
+    one = _bench_line(size, {})
+    three = _bench_line(size, {"FAUCET_SHARE_GPU": "1", "FAUCET_DIST_BACKEND": "gloo", "GLOO_SOCKET_IFNAME": "lo"}, nproc=3)
+    assert one["scaling"] == three["scaling"] == "strong" and one["kmers_per_step"] == three["kmers_per_step"] == 3_000_000 * 70
+    a, b = one["outputs_check"], three["outputs_check"]
+    for key in ("bloo2_sha256", "junction_keys_sha256", "junction_records_sha256", "junctions"):
+        assert a[key] == b[key], key
+    assert len(three["rank_stage_ms"]) == 3 and all(st for st in three["rank_stage_ms"])
+    assert "pass2_wait_for_table" in dict(three["rank_stage_ms"][2]) and "pass2_send" in dict(three["rank_stage_ms"][0])
+
+
 @pytest.mark.skipif("config5" not in FULL, reason="tests/golden/fullsize.json has no config5 entry yet (make_fullsize.py config5: ~1.5 h of one core)")
 def test_config5_full_size_equals_the_oracle():
     """BASELINE config 5 at its FULL size -- 50 M reads of 150 bases, 5 % errors, S/E = 0.5 so that the reference's own sizing gives two

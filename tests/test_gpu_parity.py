@@ -165,6 +165,56 @@ def test_key_ordered_walk_of_clusters_gives_the_same_result(name, monkeypatch):
     assert _check_against_oracle(bases, offs, 21, 500_000, 100_000, 1, scan_chunks=3, key_order_from_start=True)["walk_parallel"] > 100
 
 
+@pytest.mark.parametrize("rounds", ["0", "2", "12"])
+def test_large_clusters_walked_optimistically_settle_or_are_handed_over(rounds, monkeypatch):
+    """The optimistic walk of large clusters (k_ovw_round): every piece of such a cluster walks read-only on the events --
+    creations, raised distances, with file-order times -- the earlier pieces posted in the round before, until no piece's log changes; the
+    settled logs are applied with atomics.  Twenty copies of a 300-base repeat at 40x: junction map and counters equal the oracle's record for
+    record with the default 12 rounds per window (everything settles), with 2 (the first windows, where the repeat's junctions are being
+    created, cannot settle: they are handed to the key-ordered walk, k_walk_ko, which runs behind) and with 0 (key-ordered walk only)."""
+    monkeypatch.setenv("FGPU_WALK_KO", "16")
+    monkeypatch.setenv("FGPU_WALK_KO_ALWAYS", "1")
+    monkeypatch.setenv("FGPU_OVW_ROUNDS", rounds)
+    g = synth.make_genome(150_000, 91, repeats=20, repeat_len=300)
+    r = synth.make_reads(g, 60_000, 100, 0.01, 92)
+    bases, offs = po.reads_from_matrix(r)
+    k, E, S = 31, 2_000_000, 500_000
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    okeys, orecs = osc.junctions("creation")
+    for span, record in ((1 << 20, False), (0, True), (1 << 16, False)):
+        ctx = api.Context(k, tai, nh, walk_window_span=span, record_stops=record)
+        ctx.bloom_upload(L.BLOO2, b2.bits())
+        sc = api.ReadScanner(ctx)
+        sst = sc.scanReads(chunks(bases, offs, 3))
+        _scan_equals_oracle(sc, sst, osc)
+        d = ctx.diag_ovw()
+        assert sst["walk_parallel"] > 1000
+        if rounds == "0":
+            assert d["pieces"] == 0 and d["windows"] == 0
+        elif rounds == "2":
+            assert d["fallback_windows"] > 0, d
+        else:
+            assert d["pieces"] > 1000 and d["fallback_windows"] == 0 and d["rounds"] >= 2 * d["windows"], d
+        if record:     # scanInputRead's lists: the visits of the settled logs (or of the walk they were handed to)
+            _, want = _oracle_lists(bases, offs, k, 1, 100, b2.bits(), tai, nh)
+            got = []
+            while True:
+                t = ctx.take_stops()
+                if t is None:
+                    break
+                lists = [[] for _ in range(int(t[1]["read"].max()) + 1 if len(t[1]) else 0)]
+                for e in t[1]:
+                    lists[int(e["read"])].append(int(e["ext"]))
+                got.append(lists)
+            parts = chunks(bases, offs, 3)
+            flat = []
+            for part, lists in zip(parts, got):
+                flat.extend(lists + [[] for _ in range(part.n_reads - len(lists))])
+            assert flat == want
+        ctx.close()
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_scan_eager_flags_mode_gives_the_same_result(name):
     c = Case(name)
@@ -1172,9 +1222,10 @@ def test_a_late_junction_test_that_comes_out_true_voids_the_scan_only_if_its_kme
             "k, E, S = 31, 20_000_000, 4_000_000\n"
             "tai, nh = api.load_filter_shape(E, S)\n"
             "seen = []\n"
-            "for G, n_load, n_scan, seed in ((2_000_000, 200_000, 500, 5), (2_000_000, 200_000, 500, 6), (2_000_000, 200_000, 4_000, 5), (40_000, 20_000, 20_000, 7)):\n"
+            "for G, n_load, n_scan, seed, span in ((2_000_000, 200_000, 500, 5, 0), (2_000_000, 200_000, 500, 6, 0), (2_000_000, 200_000, 4_000, 5, 0),\n"
+            "                                      (2_000_000, 200_000, 4_000, 6, 1 << 13), (40_000, 20_000, 20_000, 7, 0)):\n"
             "    bases, offs = _random_case(n_load, 100, k, G, 0.01, seed, 0.0, 0)\n"
-            "    ctx = api.Context(k, tai, nh)\n"
+            "    ctx = api.Context(k, tai, nh, walk_window_span=span)     # (span 2^13: the noted positions spread over ~50 windows, each swept by its own)\n"
             "    api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), chunks(bases, offs, 2))\n"
             "    b2 = po.Bloom(tai, nh)\n"
             "    b2.set_bits(ctx.bloom_download(L.BLOO2))\n"
@@ -1192,8 +1243,9 @@ def test_a_late_junction_test_that_comes_out_true_voids_the_scan_only_if_its_kme
             "    assert np.array_equal(recs['dist'], orecs['dist']) and np.array_equal(recs['cov'], orecs['cov']) and np.array_equal(recs['linked'], orecs['linked'])\n"
             "    late = ctx.diag_late_flags()\n"
             "    seen.append((late['noted'], late['conflicts'], ctx.diag_scan_replays()))\n"
-            "    assert late['swept'] == late['noted'] or late['noted'] > 256, late   # the check passed over every noted position\n"
-            "    print('case', G, n_scan, seen[-1], 'junctions', len(keys))\n"
+            "    assert late['swept'] == late['noted'] or late['noted'] > 256, late   # the check passed over every noted position (a run-time guard too: pull_counters)\n"
+            "    if span: assert sst['walk_windows'] > 20 and late['noted'] > 0, (sst['walk_windows'], late)\n"
+            "    print('case', G, n_scan, span, seen[-1], 'junctions', len(keys))\n"
             "    ctx.close()\n"
             "assert any(n > 0 and c == 0 and r == 0 for n, c, r in seen), seen      # noted, checked, kept\n"
             "assert any(c > 0 and r == 1 for n, c, r in seen), seen                # found on another piece: scanned again\n"
