@@ -374,9 +374,9 @@ class Context:
 
     def diag_ovw(self):
         """the optimistic walk of large clusters during the last scan: pieces walked, rounds run, windows settled, windows left to the key-ordered walk"""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 6)()
         self._c(self.lib.fgpu_diag_ovw(self.h, out))
-        return dict(zip(("pieces", "rounds", "windows", "fallback_windows"), (int(v) for v in out)))
+        return dict(zip(("pieces", "rounds", "windows", "fallback_windows", "kept_piece_rounds", "table_overflow_windows"), (int(v) for v in out)))
 
     def stage3_set_junctions(self, keys, recs):
         """the junction map Stage 3's walks look into (keys as JunctionMap keys them; records as junctions() returns them)"""

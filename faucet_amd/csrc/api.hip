@@ -1190,9 +1190,11 @@ int fgpu_diag_load_split(fgpu_ctx* ctx, uint64_t* in_mark, uint64_t* pending) {
     return FGPU_OK;
 }
 
-int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[4]) {
+int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[6]) {
     if (!ctx || !out) return FGPU_ERR_ARG;
     for (int i = 0; i < 4; i++) out[i] = ctx->counters_host->ovw[i];   // as of the scan's last synchronising call (fgpu_scan_end)
+    out[4] = ctx->counters_host->ovw_kept;
+    out[5] = ctx->counters_host->ko_overflows;
     return FGPU_OK;
 }
 

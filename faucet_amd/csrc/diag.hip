@@ -307,7 +307,7 @@ extern "C" int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint
 // whether the two answer planes are equal bit for bit (`equal`).  fill_byte: every byte of the table (popcount / 8 = share of set bits).
 extern "C" int fgpu_diag_binned_chain(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_items, uint64_t slice_bytes, int n_hash, int fill_byte, int iters,
                                       double* direct_ms, double* bin_ms, double* first_ms, double* rest_ms, double* survivors_share, int* equal) {
-    if (!ctx || !direct_ms || !bin_ms || !first_ms || !rest_ms || !survivors_share || !equal || iters < 1 || n_hash < 1 || n_hash > 8 ||
+    if (!ctx || !direct_ms || !bin_ms || !first_ms || !rest_ms || !survivors_share || !equal || iters < 1 || n_hash < 2 || n_hash > 8 ||
         table_bytes < (1u << 16) || (table_bytes & (table_bytes - 1)) || table_bytes > (1ULL << 29) || (slice_bytes & (slice_bytes - 1)) ||
         slice_bytes < 4096 || slice_bytes > table_bytes || table_bytes / slice_bytes > DIAG_MAX_SLICES || n_items < (1u << 16) || n_items > (1ULL << 31))
         return FGPU_ERR_ARG;
@@ -364,7 +364,7 @@ extern "C" int fgpu_diag_binned_chain(fgpu_ctx* ctx, uint64_t table_bytes, uint6
             hipMemcpy(a.data(), ans_a, words * 8, hipMemcpyDeviceToHost);
             hipMemcpy(b.data(), ans_b, words * 8, hipMemcpyDeviceToHost);
             hipMemcpy(&surv_host, n_surv, 8, hipMemcpyDeviceToHost);
-            *equal = n_hash > 1 ? (a == b ? 1 : 0) : 1;
+            *equal = a == b ? 1 : 0;
             *direct_ms = t[0] / iters; *bin_ms = t[1] / iters; *first_ms = t[2] / iters; *rest_ms = t[3] / iters;
             *survivors_share = (double)surv_host / (double)n_items;
         }

@@ -158,6 +158,7 @@ struct DevCounters {
     // built without.  [0] entries noted by the walk, [1] of those, the ones k_delta_collect found elsewhere in their window (error bit 4);
     // entries: stream position, number of the window
     unsigned long long ko_overflows;    // windows whose large clusters did not fit the key-ordered / optimistic walks' tables
+    unsigned long long ovw_kept;        // optimistic walk: piece-rounds in which a piece kept its log (no earlier piece had changed what it reads)
     unsigned long long ovw[4];          // optimistic walk of large clusters: pieces walked, rounds run, windows settled, windows left to the key-ordered walk
     unsigned long long late_n[3];       // ([2] noted positions the check has passed over: every one of [0], once)
     unsigned long long late[2 * FGPU_LATE_CAP];
@@ -232,7 +233,7 @@ struct fgpu_ctx {
     uint32_t* ko_piece = nullptr;
     // the optimistic walk of large clusters (scan_walk.hip, k_ovw_round): event tables, logs and per-piece results of two consecutive rounds,
     // three presence filters used in turn, the list of pieces; allocated when a scan first meets a large cluster
-    DevBuf ovw_ev, ovw_filt, ovw_log, ovw_res, ovw_list, ovw_state, ovw_longp;
+    DevBuf ovw_ev, ovw_filt, ovw_log, ovw_res, ovw_list, ovw_state, ovw_longp, ovw_marks;
     uint32_t ovw_epoch = 0;            // epoch of the newest events (1..255; the tables are wiped when it wraps)
     int ovw_rounds = 12;               // rounds issued per window (FGPU_OVW_ROUNDS; 0 = the key-ordered walk takes every large cluster)
     uint32_t ko_hk_cap = 0, ko_occ_cap = 0;

@@ -1391,10 +1391,16 @@ struct OvwTables {
     OvwEv prev, cur;           // read / written by the round being launched
     uint32_t* filt_next;       // the filter the NEXT round writes: cleared by this one
     uint32_t filt_words;
-    uint4* log_new;            // this round's logs, 2 x (lk positions of the piece) entries from 2 x kt.piece_base[piece]
-    const uint4* log_old;      // the previous round's (nullptr in round 0)
-    uint32_t* res_new;         // 8 words per listed piece: entries, NbProcessed, NbSkipped, NbJCheckKmer, NbNoJuncs, tests run on the spot, late true test
-    const uint32_t* res_old;
+    uint4* log;                // the pieces' logs, 2 x (lk positions of the piece) entries from 2 x kt.piece_base[piece]; a round rewrites a log in
+                               // place, entry by entry behind its reading of the old one
+    uint32_t* res;             // 8 words per listed piece: entries, NbProcessed, NbSkipped, NbJCheckKmer, NbNoJuncs, tests run on the spot, late true test
+    // change marks, by hash of the k-mer: the earliest piece (time) whose entry at that k-mer posts other events in this round than in the round
+    // before.  A piece none of whose registered k-mers carries a mark of an EARLIER piece reads in the next round what it read in this one: it
+    // keeps its log and only posts its events again (the event tables are rebuilt every round).
+    const uint32_t* mark_prev; // written by the round before
+    uint32_t* mark_cur;        // written by this round
+    uint32_t* mark_next;       // cleared by this round
+    uint32_t mark_mask;
     uint32_t* list;            // window-local indices of the pieces walked this way (k_ko_prepare)
     uint32_t list_cap;
     uint32_t* state;           // [0] pieces listed, [1] failed (overflow), [2] rounds run, [3] some cluster holds a long piece, [8 + r] some log changed in round r
@@ -1700,11 +1706,15 @@ __device__ __forceinline__ uint32_t ovw_before(const OvwEv& ev, uint32_t rec, ui
 struct OvwWalk {
     OvwEv prev, cur;
     bool have_prev;
-    uint4* log_new;
-    const uint4* log_old;
+    uint4* log;                // rewritten in place: entry i of the old log is read before entry i of the new one is written
+    bool have_old;
     uint32_t n_old, n_new, cap;
     uint32_t time;
     bool changed, overflow;
+    const uint32_t* kh;        // the batch's k-mer hashes (Planes::kh), for the change marks
+    uint64_t p0;
+    uint32_t* mark;
+    uint32_t mark_mask;
 };
 // Which records does the piece have an entry for already?  A filter of 1024 bits per lane in LDS, two bits per record: a hit sends the visit
 // through the piece's own log (the same junction twice on a piece: tandem repeats, twice in a row) -- with the 64 bits of a register a piece
@@ -1733,21 +1743,59 @@ __device__ __forceinline__ bool ovw_seen_test_and_set(uint32_t rec) {
 __device__ __forceinline__ uint4 ovw_pack(uint32_t rec, uint32_t tn, uint32_t flags, uint32_t d_bwd, uint32_t d_fwd, uint64_t stored_lo) {
     return make_uint4(rec, tn | (flags << 16) | (d_bwd << 24), d_fwd | ((uint32_t)((stored_lo >> 32) & 0xFF) << 8), (uint32_t)stored_lo);
 }
+// what an entry posts: creation, backward distance, forward distance -- each only where it exceeds what is stored (the stored bytes ride in the
+// entry); 0 = the entry posts nothing
+__device__ __forceinline__ uint32_t ovw_event_sig(const uint4& e) {
+    const uint32_t tn = e.y & 0xFFFF, flags = (e.y >> 16) & 0xFF, real = (flags & OVW_F_REAL) >> 1;
+    const bool fwd = tn & 1;
+    const uint32_t ib = fwd ? 4u : real, iff = fwd ? real : 4u;
+    const uint64_t stored = (uint64_t)e.w | ((uint64_t)((e.z >> 8) & 0xFF) << 32);
+    const uint32_t d_bwd = e.y >> 24, d_fwd = e.z & 0xFF;
+    uint32_t sig = (flags & OVW_F_CREATED) ? 1u : 0u;
+    if (d_bwd > ((stored >> (8 * ib)) & 0xFF)) sig |= 2u | (d_bwd << 8);
+    if ((flags & OVW_F_DF) && d_fwd > ((stored >> (8 * iff)) & 0xFF)) sig |= 4u | (d_fwd << 16);
+    return sig;
+}
+__device__ __forceinline__ void ovw_mark(const OvwWalk& ow, const uint4& e) {
+    const uint32_t h = ow.kh[ow.p0 + ((e.y & 0xFFFF) >> 1)];
+    atomicMin(&ow.mark[(h * 0x9E3779B1u) >> 8 & ow.mark_mask], ow.time);
+}
 __device__ __forceinline__ void ovw_emit(OvwWalk& ow, const uint4& e) {
     if (ow.n_new >= ow.cap) { ow.overflow = true; return; }
-    if (!ow.log_old || ow.n_new >= ow.n_old) ow.changed = true;
-    else {
-        const uint4 o = ow.log_old[ow.n_new];
+    const uint32_t sig = ovw_event_sig(e);
+    if (!ow.have_old || ow.n_new >= ow.n_old) {
+        ow.changed = true;
+        if (sig) ovw_mark(ow, e);
+    } else {
+        const uint4 o = ow.log[ow.n_new];
         if (o.x != e.x || o.y != e.y || o.z != e.z) ow.changed = true;
+        const uint32_t osig = ovw_event_sig(o);
+        if (o.x != e.x || osig != sig) {           // the events of this entry are not those of the round before: whoever reads them walks again
+            if (sig) ovw_mark(ow, e);
+            if (osig) ovw_mark(ow, o);
+        }
     }
-    ow.log_new[ow.n_new++] = e;
+    ow.log[ow.n_new++] = e;
+}
+// the events of a log entry, posted again (a piece that keeps its log: the tables are rebuilt every round)
+__device__ __forceinline__ bool ovw_repost(const OvwEv& cur, const uint4& e, uint32_t time) {
+    const uint32_t sig = ovw_event_sig(e);
+    if (!sig) return true;
+    const uint32_t tn = e.y & 0xFFFF, flags = (e.y >> 16) & 0xFF, real = (flags & OVW_F_REAL) >> 1;
+    const bool fwd = tn & 1;
+    const uint32_t ib = fwd ? 4u : real, iff = fwd ? real : 4u;
+    bool ok = true;
+    if (sig & 1u) ok = ok && ovw_post(cur, e.x, OVW_CREATION, time, 1);
+    if (sig & 2u) ok = ok && ovw_post(cur, e.x, ib, time, e.y >> 24);
+    if (sig & 4u) ok = ok && ovw_post(cur, e.x, iff, time, e.z & 0xFF);
+    return ok;
 }
 // the piece's own earlier contributions to (record, index) -- the same junction twice on a piece: tandem repeats, or twice in a row
 __device__ __forceinline__ uint32_t ovw_own(const OvwWalk& ow, uint32_t rec, uint32_t idx, const uint4& pending, bool have_pending) {
     uint32_t best = 0;
     for (uint32_t i = 0; i <= ow.n_new; i++) {
         if (i == ow.n_new && !have_pending) break;
-        const uint4 e = i == ow.n_new ? pending : ow.log_new[i];
+        const uint4 e = i == ow.n_new ? pending : ow.log[i];
         if (e.x != rec) continue;
         const uint32_t tn = e.y & 0xFFFF, flags = (e.y >> 16) & 0xFF, real = (flags & OVW_F_REAL) >> 1;
         const bool fwd = tn & 1;
@@ -1759,7 +1807,7 @@ __device__ __forceinline__ uint32_t ovw_own(const OvwWalk& ow, uint32_t rec, uin
 }
 __device__ __forceinline__ bool ovw_own_created(const OvwWalk& ow, uint32_t rec) {
     for (uint32_t i = 0; i < ow.n_new; i++) {
-        const uint4 e = ow.log_new[i];
+        const uint4 e = ow.log[i];
         if (e.x == rec && ((e.y >> 16) & OVW_F_CREATED)) return true;
     }
     return false;
@@ -1924,7 +1972,8 @@ __device__ __forceinline__ void ovw_walk_piece(WalkCtx& wc, OvwWalk& ow, uint64_
         const int ext_fwd = fwd ? real : 4, ext_bwd = fwd ? 4 : real;
         OvwRec r;
         {   // the previous round's visit of this very half-step knows the record and what is stored in it
-            const uint4 o = ow.log_old && ow.n_new < ow.n_old ? ow.log_old[ow.n_new] : make_uint4(0, 0xFFFFFFFFu, 0, 0);
+            const uint32_t at = ow.n_new + (have_last ? 1u : 0u);          // (the last visit's entry is still pending: this one follows it)
+            const uint4 o = ow.have_old && at < ow.n_old ? ow.log[at] : make_uint4(0, 0xFFFFFFFFu, 0, 0);
             if ((o.y & 0xFFFF) == (uint32_t)tn && !((o.y >> 16) & OVW_F_FAKE)) {
                 r.rec = o.x;
                 r.present = ((o.y >> 16) & OVW_F_PRESENT) != 0;
@@ -1986,61 +2035,91 @@ __device__ __forceinline__ void ovw_walk_piece(WalkCtx& wc, OvwWalk& ow, uint64_
         ovw_emit(ow, pend);
     }
     if (ow.overflow) wc.fail = 1;
+    if (ow.have_old)
+        for (uint32_t i = ow.n_new; i < ow.n_old; i++) {
+            const uint4 o = ow.log[i];
+            if (ovw_event_sig(o)) ovw_mark(ow, o);
+        }
 }
 
 // a window begins: nothing listed, nothing settled, clean filters
-__global__ void __launch_bounds__(256) k_ovw_reset(uint32_t* state, uint32_t* filt, uint32_t filt_words3, uint32_t* longp, uint32_t n_pieces) {
+__global__ void __launch_bounds__(256) k_ovw_reset(uint32_t* state, uint32_t* filt, uint32_t filt_words3, uint32_t* longp, uint32_t n_pieces,
+                                                   uint32_t* marks, uint32_t mark_words3) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (i < 8 + OVW_MAX_ROUNDS) state[i] = 0;
     for (uint32_t a = i; a < filt_words3; a += stride) filt[a] = 0;
     for (uint32_t a = i; a < n_pieces; a += stride) longp[a] = 0;
+    for (uint32_t a = i; a < mark_words3; a += stride) marks[a] = 0xFFFFFFFFu;
 }
 
-// One round: every listed piece of a cluster without long pieces walks on the events of the round before.
+// One round: every listed piece of a cluster without long pieces walks on the events of the round before -- or, where no earlier piece has
+// changed the events at any of its registered k-mers, keeps its log and posts its events again.
 __global__ void __launch_bounds__(64) k_ovw_round(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const WinDesc* __restrict__ wdp,
                                                   KoTables kt, OvwTables ot, uint32_t round, const uint32_t* __restrict__ bloom, DevCounters* cnt) {
     if ((kt.state[1] & 1u) || kt.state[3] == 0 || ot.state[1]) return;
     if (round >= 1 && ot.state[8 + round - 1] == 0) return;            // settled (round 0 always counts as a change)
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < ot.filt_words; a += gridDim.x * blockDim.x) ot.filt_next[a] = 0;
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a <= ot.mark_mask; a += gridDim.x * blockDim.x) ot.mark_next[a] = 0xFFFFFFFFu;
     const uint32_t n = ot.state[0] < ot.list_cap ? ot.state[0] : ot.list_cap;
     bool changed = false, failed = false;
+    unsigned long long kept = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) ot.state[2] = round + 1;
     const WinDesc wd = *wdp;
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         const uint32_t li = ot.list[idx];
-        if (!ot.longp[root[li]] && !kt.bad[root[li]]) {      // (a cluster with a piece of more than 512 windows stays with k_walk, all of it)
-            WalkCtx wc;
-            wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = 0;
-            wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
-            wc.created_now = false; wc.fail = 0; wc.dbg = 0;
-            OvwWalk ow;
-            ow.prev = ot.prev; ow.cur = ot.cur;
-            ow.have_prev = round > 0;
-            const uint2 pc = pl.pieces[wd.first_piece + li];
-            uint32_t n_lk = (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0));
-            if (pc.y > 64) n_lk += (uint32_t)__popcll(fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1));
-            const uint64_t base = 2ULL * kt.piece_base[li];
-            ow.log_new = ot.log_new + base;
-            ow.log_old = ot.log_old ? ot.log_old + base : nullptr;
-            ow.cap = 2 * n_lk;
-            ow.n_old = ot.res_old ? ot.res_old[8 * idx] : 0;
-            ow.n_new = 0;
-            ow.time = li;
-            ow.changed = false;
-            ow.overflow = false;
-            ovw_seen_clear();
-            ovw_walk_piece(wc, ow, pc.x, pc.y);
-            if (ow.n_new != ow.n_old || !ot.res_old) ow.changed = true;
-            uint32_t* res = ot.res_new + 8 * idx;
-            res[0] = ow.n_new;
-            res[1] = (uint32_t)wc.nb_processed; res[2] = (uint32_t)wc.nb_skipped; res[3] = (uint32_t)wc.nb_jcheck; res[4] = (uint32_t)wc.nb_no_juncs;
-            res[5] = (uint32_t)wc.n_filled; res[6] = wc.fail == 4 ? 1u : 0u; res[7] = 0;
-            changed |= ow.changed;
-            failed |= wc.fail == 1;
+        if (ot.longp[root[li]] || kt.bad[root[li]]) continue;      // (a cluster with a piece of more than 512 windows stays with k_walk, all of it)
+        const uint2 pc = pl.pieces[wd.first_piece + li];
+        const uint64_t lk0 = fd_bits_at(pl.lk, pc.x) & chunk_mask(pc.y, 0), lk1 = pc.y > 64 ? fd_bits_at(pl.lk, pc.x + 64) & chunk_mask(pc.y, 1) : 0ULL;
+        uint4* const log = ot.log + 2ULL * kt.piece_base[li];
+        uint32_t* const res = ot.res + 8 * idx;
+        if (round > 0) {
+            // has any EARLIER piece posted other events at one of this piece's registered k-mers than in the round before that?
+            bool walk_again = false;
+            for (uint32_t c = 0; c < 2 && !walk_again; c++)
+                for (uint64_t w = c ? lk1 : lk0; w; w &= w - 1) {
+                    const uint32_t h = pl.kh[pc.x + 64 * c + (uint32_t)__builtin_ctzll(w)];
+                    if (ot.mark_prev[(h * 0x9E3779B1u) >> 8 & ot.mark_mask] < li) { walk_again = true; break; }
+                }
+            if (!walk_again) {       // the log stands; its events go into this round's tables
+                const uint32_t n_log = res[0];
+                for (uint32_t i = 0; i < n_log; i++)
+                    if (!ovw_repost(ot.cur, log[i], li)) failed = true;
+                kept++;
+                continue;
+            }
         }
+        WalkCtx wc;
+        wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = 0;
+        wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
+        wc.created_now = false; wc.fail = 0; wc.dbg = 0;
+        OvwWalk ow;
+        ow.prev = ot.prev; ow.cur = ot.cur;
+        ow.have_prev = round > 0;
+        ow.log = log;
+        ow.have_old = round > 0;
+        ow.cap = 2 * (uint32_t)(__popcll(lk0) + __popcll(lk1));
+        ow.n_old = round > 0 ? res[0] : 0;
+        ow.n_new = 0;
+        ow.time = li;
+        ow.changed = false;
+        ow.overflow = false;
+        ow.kh = pl.kh;
+        ow.p0 = pc.x;
+        ow.mark = ot.mark_cur;
+        ow.mark_mask = ot.mark_mask;
+        ovw_seen_clear();
+        ovw_walk_piece(wc, ow, pc.x, pc.y);
+        if (ow.n_new != ow.n_old || round == 0) ow.changed = true;
+        res[0] = ow.n_new;
+        res[1] = (uint32_t)wc.nb_processed; res[2] = (uint32_t)wc.nb_skipped; res[3] = (uint32_t)wc.nb_jcheck; res[4] = (uint32_t)wc.nb_no_juncs;
+        res[5] = (uint32_t)wc.n_filled; res[6] = wc.fail == 4 ? 1u : 0u; res[7] = 0;
+        changed |= ow.changed;
+        failed |= wc.fail == 1;
     }
     if (__ballot(changed) && fd_lane() == 0) atomicOr(&ot.state[8 + round], 1u);
     if (__ballot(failed) && fd_lane() == 0) atomicOr(&ot.state[1], 1u);
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_down(kept, o, 64);
+    if (kept && fd_lane() == 0) atomicAdd(&cnt->ovw_kept, kept);
 }
 
 // Junction::addCoverage / update / the link flags of one log entry, on a record other pieces update at the same time
@@ -2078,14 +2157,14 @@ __device__ __forceinline__ void ovw_apply(uint64_t* rec_addr, uint32_t tn, uint3
 
 // the settled logs are applied; the counters of the settled paths are added up
 __global__ void __launch_bounds__(64) k_ovw_commit(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
-                                                   const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, KoTables kt, OvwTables ot, const uint4* log0,
-                                                   const uint4* log1, const uint32_t* res0, const uint32_t* res1, int rounds, DevCounters* cnt, int count_followers) {
+                                                   const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, KoTables kt, OvwTables ot, int rounds,
+                                                   DevCounters* cnt, int count_followers) {
     if ((kt.state[1] & 1u) || kt.state[3] == 0) return;
     const int settled = ovw_settled_round(ot.state, rounds);
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // processed, skipped, jcheck, no_juncs, created, filled, walked, rounds
     if (settled >= 0) {
-        const uint4* log = (settled & 1) ? log1 : log0;
-        const uint32_t* res_all = (settled & 1) ? res1 : res0;
+        const uint4* log = ot.log;
+        const uint32_t* res_all = ot.res;
         const uint32_t n = ot.state[0] < ot.list_cap ? ot.state[0] : ot.list_cap;
         if (blockIdx.x == 0 && threadIdx.x == 0 && n) v[7] = (unsigned long long)settled + 1;
         const WinDesc wd = *wdp;
@@ -2845,7 +2924,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const bool ovw_on = ovw_rounds > 0 && (ctx->walk_ko_always || ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
         OvwTables ot;
         memset(&ot, 0, sizeof(ot));
-        constexpr int kEvLog2 = 21, kFiltLog2 = 22;
+        constexpr int kEvLog2 = 21, kFiltLog2 = 22, kMarkLog2 = 20;
         const uint32_t filt_words = 1u << (kFiltLog2 - 5);
         const uint32_t list_cap = (uint32_t)std::min<uint64_t>(ctx->wmax, 1u << 20);
         uint32_t* ovw_filt = nullptr;
@@ -2853,7 +2932,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             int rc;
             const bool fresh = !ctx->ovw_ev.p;
             if ((rc = fgpu_ensure(ctx, &ctx->ovw_ev, 4ULL * 8 * (1ULL << kEvLog2))) || (rc = fgpu_ensure(ctx, &ctx->ovw_filt, 3ULL * 4 * filt_words)) ||
-                (rc = fgpu_ensure(ctx, &ctx->ovw_log, 2ULL * 2 * ctx->ko_occ_cap * sizeof(uint4))) || (rc = fgpu_ensure(ctx, &ctx->ovw_res, 2ULL * 32 * list_cap)) ||
+                (rc = fgpu_ensure(ctx, &ctx->ovw_log, 2ULL * ctx->ko_occ_cap * sizeof(uint4))) || (rc = fgpu_ensure(ctx, &ctx->ovw_res, 32ULL * list_cap)) ||
+                (rc = fgpu_ensure(ctx, &ctx->ovw_marks, 3ULL * 4 * (1ULL << kMarkLog2))) ||
                 (rc = fgpu_ensure(ctx, &ctx->ovw_list, 4ULL * list_cap)) || (rc = fgpu_ensure(ctx, &ctx->ovw_state, 4ULL * (8 + OVW_MAX_ROUNDS) + 64)) ||
                 (rc = fgpu_ensure(ctx, &ctx->ovw_longp, 4ULL * ctx->wmax)))
                 return rc;
@@ -2870,7 +2950,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         }
         if (ko_heavy) {
             FGPU_LAUNCH("walk_ko_prepare", k_ko_reset, 256, 256, kt, (uint32_t)ctx->wmax, (uint32_t)parity);
-            if (ovw_on) FGPU_LAUNCH("walk_ko_prepare", k_ovw_reset, 64, 256, ot.state, ovw_filt, 3 * filt_words, ot.longp, (uint32_t)max_pieces);
+            if (ovw_on) FGPU_LAUNCH("walk_ko_prepare", k_ovw_reset, 64, 256, ot.state, ovw_filt, 3 * filt_words, ot.longp, (uint32_t)max_pieces,
+                                    (uint32_t*)ctx->ovw_marks.p, 3u << kMarkLog2);
             FGPU_LAUNCH("walk_ko_prepare", k_ko_prepare, piece_blocks_ko, 256, pl, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                         (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity, (const uint32_t*)cl_fail, ko_heavy_w, ot);
         }
@@ -2883,8 +2964,10 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                     (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
         if (ovw_on) {
             unsigned long long* const evb = (unsigned long long*)ctx->ovw_ev.p;
-            uint4* const logs[2] = {(uint4*)ctx->ovw_log.p, (uint4*)ctx->ovw_log.p + 2ULL * ctx->ko_occ_cap};
-            uint32_t* const ress[2] = {(uint32_t*)ctx->ovw_res.p, (uint32_t*)ctx->ovw_res.p + 8ULL * list_cap};
+            uint32_t* const marks = (uint32_t*)ctx->ovw_marks.p;
+            ot.log = (uint4*)ctx->ovw_log.p;
+            ot.res = (uint32_t*)ctx->ovw_res.p;
+            ot.mark_mask = (1u << kMarkLog2) - 1;
             const unsigned ovw_grid = (unsigned)std::min<uint64_t>(fgpu_blocks(std::min<uint64_t>(max_pieces, list_cap), 64), 2048);
             auto table = [&](int r, uint64_t epoch) {
                 OvwEv ev;
@@ -2902,15 +2985,14 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                 ot.prev = table(r + 1, ctx->ovw_epoch - 1);           // (the other table, the filter of round r - 1: (r + 2) % 3 == (r - 1) % 3)
                 ot.prev.bits = ovw_filt + (uint64_t)((r + 2) % 3) * filt_words;
                 ot.filt_next = ovw_filt + (uint64_t)((r + 1) % 3) * filt_words;
-                ot.log_new = logs[r & 1];
-                ot.log_old = r ? logs[(r - 1) & 1] : nullptr;
-                ot.res_new = ress[r & 1];
-                ot.res_old = r ? ress[(r - 1) & 1] : nullptr;
+                ot.mark_cur = marks + ((uint64_t)(r % 3) << kMarkLog2);
+                ot.mark_prev = marks + ((uint64_t)((r + 2) % 3) << kMarkLog2);
+                ot.mark_next = marks + ((uint64_t)((r + 1) % 3) << kMarkLog2);
                 FGPU_LAUNCH("walk_ovw", k_ovw_round, ovw_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const WinDesc*)ctx->wdesc, kt, ot, (uint32_t)r,
                             (const uint32_t*)ctx->bloo2, ctx->counters);
             }
             FGPU_LAUNCH("walk_ovw", k_ovw_commit, ovw_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
-                        seq_base, kt, ot, (const uint4*)logs[0], (const uint4*)logs[1], (const uint32_t*)ress[0], (const uint32_t*)ress[1], ovw_rounds, ctx->counters, ovw_followers);
+                        seq_base, kt, ot, ovw_rounds, ctx->counters, ovw_followers);
         }
         if (ko_heavy)      // (ranks of the occurrences per k-mer: only the key-ordered walk needs them, and only for what the optimistic walk left)
             FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt, (const uint32_t*)ot.state, ovw_rounds);

@@ -752,10 +752,12 @@ int main(int argc, char** argv) {
                         (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3], (unsigned long long)d[5], (unsigned long long)d[4]);
         }
         if (clk.on) {
-            uint64_t d[4] = {0, 0, 0, 0};
-            if (fgpu_diag_ovw(ctx, d) == FGPU_OK && (d[2] || d[3]))
-                fprintf(stderr, "[cli]   large clusters, walked optimistically: %llu pieces, %llu rounds over %llu windows; %llu windows left to the key-ordered walk\n",
-                        (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3]);
+            uint64_t d[6] = {0, 0, 0, 0, 0, 0};
+            if (fgpu_diag_ovw(ctx, d) == FGPU_OK && (d[2] || d[3] || d[5]))
+                fprintf(stderr, "[cli]   large clusters, walked optimistically: %llu pieces, %llu rounds over %llu windows (%llu piece-rounds kept their log); "
+                                "%llu windows left to the key-ordered walk, %llu to the walk by cluster\n",
+                        (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[4], (unsigned long long)d[3],
+                        (unsigned long long)d[5]);
         }
         clk.mark("pass 2 (read + scan)");
         printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);

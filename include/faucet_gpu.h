@@ -363,7 +363,7 @@ int fgpu_diag_stream_copy(fgpu_ctx* ctx, uint64_t bytes, int iters, double* gb_p
  * mode 0 = load, 1 = atomicMin (the load pass' first-set times), 2 = test-then-atomicOr (Bloom::add). */
 /* NS1 as a whole probe CHAIN (round 3): n_items x Bloom::contains (n_hash dependent bit tests, early exit) directly, and with the first
  * level binned by filter slice and the survivors handed back as a dense list (faucet_amd/csrc/diag.hip).  Times per pass in ms; *equal = 1 iff
- * both forms give the same answers bit for bit.  Diagnostic: nothing of the path calls it. */
+ * both forms give the same answers bit for bit (n_hash 2..8: with one hash function there is no chain).  Diagnostic: nothing of the path calls it. */
 int fgpu_diag_binned_chain(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_items, uint64_t slice_bytes, int n_hash, int fill_byte, int iters,
                            double* direct_ms, double* bin_ms, double* first_ms, double* rest_ms, double* survivors_share, int* equal);
 /* Per-piece records of the key-ordered walk (measurement builds with -DFGPU_KO_TRACE; *n = 0 otherwise): 4 words per walked piece --
@@ -392,8 +392,9 @@ int fgpu_diag_late_flags(fgpu_ctx* ctx, uint64_t out[3]);
  * needed, [5] batches */
 int fgpu_diag_long_pairs(fgpu_ctx* ctx, uint64_t out[6]);
 /* after fgpu_scan_end: the optimistic walk of large clusters: [0] pieces it walked, [1] rounds it ran, [2] windows it settled,
- * [3] windows it left to the key-ordered walk (rounds that did not settle, full tables) */
-int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[4]);
+ * [3] windows it left to the key-ordered walk (rounds that did not settle, full tables), [4] piece-rounds in which a piece kept its log (no
+ * earlier piece had changed what it reads), [5] windows whose large clusters outgrew the tables of both walks (walked by cluster) */
+int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[6]);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */

@@ -381,7 +381,7 @@ int fgpu_scan_prepare(fgpu_ctx* c, const fgpu_reads*) { return STUB_UNSUPPORTED(
 int fgpu_scan_walk_prepared(fgpu_ctx* c) { return STUB_UNSUPPORTED(c); }
 int fgpu_scan_set_eager(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_profile_enable(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
-int fgpu_diag_ovw(fgpu_ctx* c, uint64_t out[4]) { if (!c || !out) return FGPU_ERR_ARG; memset(out, 0, 4 * sizeof(uint64_t)); return FGPU_OK; }
+int fgpu_diag_ovw(fgpu_ctx* c, uint64_t out[6]) { if (!c || !out) return FGPU_ERR_ARG; memset(out, 0, 6 * sizeof(uint64_t)); return FGPU_OK; }
 int fgpu_scan_table_entries(fgpu_ctx* c, uint64_t*) { return STUB_UNSUPPORTED(c); }
 int fgpu_scan_export_table(fgpu_ctx* c, void*, uint64_t, uint64_t*) { return STUB_UNSUPPORTED(c); }
 int fgpu_scan_import_table(fgpu_ctx* c, const void*, uint64_t, const fgpu_scan_stats*) { return STUB_UNSUPPORTED(c); }

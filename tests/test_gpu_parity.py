@@ -1521,7 +1521,7 @@ def test_table_hint_lets_a_later_shard_prepare_lazily_and_never_enters_the_resul
     b.scan_end()
 
 
-@pytest.mark.parametrize("table_mib,slice_mib,n_hash,fill", [(64, 4, 3, 0x29), (8, 1, 2, 0x5A), (64, 8, 1, 0x11), (512, 4, 4, 0x7B)])
+@pytest.mark.parametrize("table_mib,slice_mib,n_hash,fill", [(64, 4, 3, 0x29), (8, 1, 2, 0x5A), (64, 8, 2, 0x11), (512, 4, 4, 0x7B)])
 def test_binned_probe_chains_answer_like_direct_ones(table_mib, slice_mib, n_hash, fill):
     """NS1 (north_star's query-side blocking) as built for measurement in csrc/diag.hip: Bloom::contains chains whose FIRST level is binned by filter
     slice and probed from the XCD that holds the slice, survivors handed back as a dense list, must give the answers of the direct chains bit
