@@ -280,7 +280,10 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
             hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
             if ((he = hipStreamCreateWithPriority(&ctx->wstream, hipStreamNonBlocking, hi)) != hipSuccess) return bad("hipStreamCreate (walk)", he);
             if ((he = hipStreamCreateWithPriority(&ctx->cstream, hipStreamNonBlocking, hi)) != hipSuccess) return bad("hipStreamCreate (clean)", he);
+            if ((he = hipStreamCreateWithPriority(&ctx->ostream, hipStreamNonBlocking, hi)) != hipSuccess) return bad("hipStreamCreate (optimistic walk)", he);
             if ((he = hipEventCreateWithFlags(&ctx->ev_walked, hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", he);
+            if ((he = hipEventCreateWithFlags(&ctx->ev_listed, hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", he);
+            if ((he = hipEventCreateWithFlags(&ctx->ev_settled, hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", he);
             for (int q = 0; q < 2; q++)
                 if ((he = hipEventCreateWithFlags(&ctx->ev_uf_reset[q], hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate", he);
             fgpu_touch_scan_pure();
@@ -339,7 +342,10 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     if (ctx->fb_host) hipHostFree(ctx->fb_host);
     if (ctx->wstream) { hipStreamSynchronize(ctx->wstream); hipStreamDestroy(ctx->wstream); }
     if (ctx->cstream) { hipStreamSynchronize(ctx->cstream); hipStreamDestroy(ctx->cstream); }
+    if (ctx->ostream) { hipStreamSynchronize(ctx->ostream); hipStreamDestroy(ctx->ostream); }
     if (ctx->ev_walked) hipEventDestroy(ctx->ev_walked);
+    if (ctx->ev_listed) hipEventDestroy(ctx->ev_listed);
+    if (ctx->ev_settled) hipEventDestroy(ctx->ev_settled);
     for (int q = 0; q < 2; q++) if (ctx->ev_uf_reset[q]) hipEventDestroy(ctx->ev_uf_reset[q]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     for (ResidentBatch* r : ctx->resident) delete r;

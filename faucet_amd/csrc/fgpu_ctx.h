@@ -173,6 +173,8 @@ struct fgpu_ctx {
     hipStream_t wstream = nullptr;         // walk stream: the ordered walk of batch b overlaps the pure stage of batch b+1
     hipStream_t cstream = nullptr;         // clean stream: the window table of window w is emptied while w is clustered and walked
     hipEvent_t ev_walked = nullptr, ev_uf_reset[2] = {nullptr, nullptr};
+    hipStream_t ostream = nullptr;         // optimistic stream: the rounds of the large clusters' walk run beside k_walk (disjoint clusters)
+    hipEvent_t ev_listed = nullptr, ev_settled = nullptr;   // walk stream: the large clusters' pieces are listed; optimistic stream: their logs are applied
     hipStream_t launch_stream = nullptr;   // where FGPU_LAUNCH puts kernels (and profiling events) right now
     bool own_stream = false;
     std::string err;

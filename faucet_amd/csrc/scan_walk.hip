@@ -2921,7 +2921,11 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // the pieces it walks do not queue behind one another, so they do not count as followers for the window-size controller (the key-ordered
         // walk's did: 68 windows instead of 22 on config 3's shape); FGPU_OVW_FOLLOWERS=1 counts them (measurement aid)
         static const int ovw_followers = getenv("FGPU_OVW_FOLLOWERS") ? atoi(getenv("FGPU_OVW_FOLLOWERS")) : 0;
-        const bool ovw_on = ovw_rounds > 0 && (ctx->walk_ko_always || ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
+        // (a caller that expects repeats gets it for the scan's first two batches; after that the scan's own counters decide: on ordinary data the
+        // few large clusters cost less with the key-ordered walk alone than with a dozen launches more per window -- config 2 with the CLI's
+        // settings: walk stage 52.6 ms with the rounds always issued, scripts/ovw_config2.sh)
+        const bool ovw_on = ovw_rounds > 0 && ((ctx->walk_ko_always && ctx->delta_next < 2) ||
+                                               ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
         OvwTables ot;
         memset(&ot, 0, sizeof(ot));
         constexpr int kEvLog2 = 21, kFiltLog2 = 22, kMarkLog2 = 20;
@@ -2955,13 +2959,15 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             FGPU_LAUNCH("walk_ko_prepare", k_ko_prepare, piece_blocks_ko, 256, pl, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
                         (const WinDesc*)ctx->wdesc, kt, ko_heavy, (uint32_t)parity, (const uint32_t*)cl_fail, ko_heavy_w, ot);
         }
-        if (heavy)
-            FGPU_LAUNCH("walk_probe", k_walk_par<WALK_PROBE>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
-                        (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);
-        FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
-                    (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
-                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
-                    (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
+        // The rounds run on a stream of their own BESIDE k_walk: the two walk disjoint clusters (a key belongs to the one cluster every piece that
+        // holds it is in), so neither reads a record the other writes; slot claims, counters, planes and filters change by atomics on both sides.
+        static const bool ovw_beside = !(getenv("FGPU_OVW_SERIAL") && getenv("FGPU_OVW_SERIAL")[0] == '1');   // measurement aid: behind k_walk, one stream
+        hipStream_t ovw_stream = (ovw_beside && !no_overlap && ctx->ostream) ? ctx->ostream : walk_stream;
+        if (ovw_on && ovw_stream != walk_stream) {
+            FGPU_HIP(hipEventRecord(ctx->ev_listed, walk_stream));
+            FGPU_HIP(hipStreamWaitEvent(ovw_stream, ctx->ev_listed, 0));
+            ctx->launch_stream = ovw_stream;
+        }
         if (ovw_on) {
             unsigned long long* const evb = (unsigned long long*)ctx->ovw_ev.p;
             uint32_t* const marks = (uint32_t*)ctx->ovw_marks.p;
@@ -2994,6 +3000,18 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             FGPU_LAUNCH("walk_ovw", k_ovw_commit, ovw_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
                         seq_base, kt, ot, ovw_rounds, ctx->counters, ovw_followers);
         }
+        if (ovw_on && ovw_stream != walk_stream) {
+            FGPU_HIP(hipEventRecord(ctx->ev_settled, ovw_stream));
+            ctx->launch_stream = walk_stream;
+        }
+        if (heavy)
+            FGPU_LAUNCH("walk_probe", k_walk_par<WALK_PROBE>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
+                        (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);
+        FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
+                    (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
+                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
+                    (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
+        if (ovw_on && ovw_stream != walk_stream) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_settled, 0));   // the settled logs are in the map
         if (ko_heavy)      // (ranks of the occurrences per k-mer: only the key-ordered walk needs them, and only for what the optimistic walk left)
             FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt, (const uint32_t*)ot.state, ovw_rounds);
         if (ko_heavy)

@@ -12,7 +12,7 @@ python3 - <<PY
 import csv, glob
 f = glob.glob("$out/**/*kernel_stats.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "k_" in r["Name"] and "at::" not in r["Name"] and "rocprim" not in r["Name"]]
-w = csv.writer(open("$out/r03_rocprofv3_kernel_stats_config4.csv", "w"))
+w = csv.writer(open("$out/r04_rocprofv3_kernel_stats_config4.csv", "w"))
 w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
 for r in rows:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
