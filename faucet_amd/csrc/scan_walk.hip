@@ -616,17 +616,43 @@ __device__ __noinline__ uint4 live_bits_impl(const uint64_t* __restrict__ codes,
     jt.mask = jmask;
     jt.recs = nullptr; jt.stamps = nullptr; jt.filter = nullptr; jt.filter_mask = 0;
     uint64_t mF = 0, mB = 0;
-    while (where) {   // only the candidate positions of the chunk
-        const uint32_t i = (uint32_t)__builtin_ctzll(where);
-        where &= where - 1;
-        const uint64_t km = fd_kmer_at(codes, p + i, k);
-        const uint64_t rc = fd_revcomp(km, k);
-        const uint64_t canon = km < rc ? km : rc;
-        uint64_t slot;
-        uint32_t present;
-        if (jt_find_live(jt, canon, slot, present)) {
-            if ((present >> (km == canon ? 0 : 1)) & 1u) mF |= 1ULL << i;   // forward-facing key = the k-mer itself
-            if ((present >> (rc == canon ? 0 : 1)) & 1u) mB |= 1ULL << i;   // backward-facing key = its reverse complement
+    // Four candidate positions at a time, their loads in flight TOGETHER: first the four k-mers, then the key words of their four home slots.
+    // One position after the other this was two dependent round trips per position -- a piece holds 2-5 such positions, i.e. 4-10 of the 8-10
+    // round trips that make a piece's place in its cluster's chain (round 4; k_walk is the longest chain of a window, not throughput).
+    while (where) {
+        uint32_t idx[4];
+        bool on[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            on[j] = where != 0;
+            idx[j] = on[j] ? (uint32_t)__builtin_ctzll(where) : 0u;
+            where &= where - 1;                          // (0 stays 0)
+        }
+        uint64_t km[4], rc[4], canon[4], home[4], w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) km[j] = fd_kmer_at(codes, p + idx[j], k);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            rc[j] = fd_revcomp(km[j], k);
+            canon[j] = km[j] < rc[j] ? km[j] : rc[j];
+            home[j] = fd_mix(canon[j]) & jt.mask;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = on[j] ? ld_agent(&jt.keys[home[j]]) : J_EMPTY;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!on[j] || w[j] == J_EMPTY) continue;
+            uint32_t present = 0;
+            bool found = (w[j] & J_KEYMASK) == canon[j];
+            if (found) present = (uint32_t)(w[j] >> 62);
+            else {                                       // not in its home slot: the rest of the probe sequence (rare at the table's load factor)
+                uint64_t slot;
+                found = jt_find_live(jt, canon[j], slot, present);
+            }
+            if (found) {
+                if ((present >> (km[j] == canon[j] ? 0 : 1)) & 1u) mF |= 1ULL << idx[j];   // forward-facing key = the k-mer itself
+                if ((present >> (rc[j] == canon[j] ? 0 : 1)) & 1u) mB |= 1ULL << idx[j];   // backward-facing key = its reverse complement
+            }
         }
     }
     return make_uint4((uint32_t)mF, (uint32_t)(mF >> 32), (uint32_t)mB, (uint32_t)(mB >> 32));
