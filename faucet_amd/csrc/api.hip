@@ -332,7 +332,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
     if (ctx->lp.flips_host) hipHostFree(ctx->lp.flips_host);
     void* ptrs[] = {ctx->lp.bits, ctx->lp.first, ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
-                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->counters,
+                    ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->cl_roots, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
     stop_queue_recycle(ctx);

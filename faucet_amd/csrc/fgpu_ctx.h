@@ -246,6 +246,7 @@ struct fgpu_ctx {
     uint32_t walk_heavy = 0;           // clusters of at least this many pieces are tried out of order; 0 = never, the default: measured, it
                                        // does not pay; FGPU_WALK_HEAVY sets it
     uint32_t* cl_members = nullptr;
+    uint32_t* cl_roots = nullptr;      // per window: [0] leaders listed, [1] handed out, from word 16 on the list of the clusters' leaders (k_walk_dyn)
     void* wdesc = nullptr;           // device WinDesc of the window in flight
     uint64_t window_span = 1ULL << 17;   // adaptive: stream positions per scheduling window
     uint64_t max_span = FGPU_MAX_SPAN;   // upper bound of window_span (sizes the window table)

@@ -331,10 +331,11 @@ __global__ void __launch_bounds__(256) k_walk_register(Planes pl, FdParams fp, W
 
 // ---- B: link every piece to the owners of the candidate k-mers that occur on it ---------------------
 __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTable wt, uint32_t* parent, uint64_t lo, uint64_t hi,
-                                                   uint64_t pos_end) {
+                                                   uint64_t pos_end, uint32_t* roots_state) {
     // a fixed grid strides over the window, 1024 positions per block and round: the loads of four positions per thread (hash, then
     // filter word) are in flight together -- one position per thread left this kernel waiting on two dependent loads per 256-thread block
     const WinDesc wd = make_window(pl, lo, hi);
+    if (roots_state && blockIdx.x == 0 && threadIdx.x == 0) { roots_state[0] = 0; roots_state[1] = 0; }   // roots listed / handed out (k_walk_cluster, k_walk)
     const uint64_t base0 = wd.lo & ~63ULL;
     constexpr int U = 4;
     for (uint64_t base = base0 + (uint64_t)blockIdx.x * (256 * U); base < pos_end; base += (uint64_t)gridDim.x * (256 * U)) {
@@ -386,7 +387,8 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
 // weight / heavy_w (key-ordered walk by WEIGHT, see ko_cluster): the lk positions of a cluster's pieces, summed per root.
 __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict__ parent, uint32_t* count, uint32_t* head,
                                                       uint32_t* __restrict__ flat, uint32_t* __restrict__ next, Planes pl, uint64_t lo,
-                                                      uint64_t hi, WinDesc* wd_out, DevCounters* cnt, uint32_t* weight, uint32_t heavy_w) {
+                                                      uint64_t hi, WinDesc* wd_out, DevCounters* cnt, uint32_t* weight, uint32_t heavy_w,
+                                                      uint32_t* __restrict__ root_list, uint32_t* roots_state) {
     const WinDesc wd = make_window(pl, lo, hi);
     const uint32_t n = wd.n;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -401,6 +403,17 @@ __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict
         if (r != i) {
             next[i] = atomicExch(&head[r], i);
             atomicAdd(&count[r], 1u);
+        }
+        {   // the clusters' leaders, as a list k_walk hands out (one reservation per wave)
+            const bool is_root = r == i;
+            const unsigned long long m = __ballot(is_root);
+            if (m) {
+                const int first = __builtin_ctzll(m);
+                uint32_t base = 0;
+                if (fd_lane() == first) base = atomicAdd(&roots_state[0], (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, first, 64);
+                if (is_root) root_list[base + (uint32_t)__popcll(m & ((1ULL << fd_lane()) - 1))] = i;
+            }
         }
         if (heavy_w) {
             const uint2 pc = pl.pieces[wd.first_piece + i];
@@ -1330,6 +1343,101 @@ __global__ void __launch_bounds__(64) k_walk(Planes pl, FdParams fp, JTable jt, 
         }
     }
     // wave-level reduction of the counters
+    unsigned long long v[7] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, wc.n_created, n_follow, wc.n_filled};
+    for (int c = 0; c < 7; c++)
+        for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_down(v[c], o, 64);
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(biggest, o, 64); biggest = t > biggest ? t : biggest; }
+    if (fd_lane() == 0) {
+        if (v[5]) atomicAdd(&cnt->followers, v[5]);
+        if (biggest) atomicMax(&cnt->max_cluster, biggest);
+        if (v[0]) atomicAdd(&cnt->nb_processed, v[0]);
+        if (v[1]) atomicAdd(&cnt->nb_skipped, v[1]);
+        if (v[2]) atomicAdd(&cnt->nb_jcheck, v[2]);
+        if (v[3]) atomicAdd(&cnt->nb_no_juncs, v[3]);
+        if (v[4]) atomicAdd(&cnt->n_junctions, v[4]);
+        if (v[6]) atomicAdd(&cnt->flags_filled, v[6]);
+    }
+}
+
+// The same walk with the clusters handed out DYNAMICALLY (round 4).  k_walk gives lane i the cluster led by piece i: lanes whose piece is a
+// follower idle, lanes with a small cluster idle while a neighbour walks a large one, and a wave lives as long as its longest cluster --
+// 7.6 of 64 lanes active per vector instruction on config 2, 13 on config 4's thin windows, a fifth of the wave slots occupied
+// (profiles/r04_walk_counters.txt).  Here the waves of a fixed grid draw clusters from the window's list of leaders (k_walk_cluster) whenever a
+// lane has none, one reservation per wave and round, and every round every lane that holds a cluster walks ONE piece of it: the lanes stay
+// aligned piece by piece, a finished lane is refilled at once, and the grid drains when the list does.  Clusters are independent of each
+// other (that is what makes them clusters), so the order in which they are handed out changes nothing.
+__global__ void __launch_bounds__(64) k_walk_dyn(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root_list, uint32_t* roots_state,
+                                                 const uint32_t* __restrict__ count, const uint32_t* __restrict__ head,
+                                                 const uint32_t* __restrict__ next, uint32_t* pool, const WinDesc* __restrict__ wdp,
+                                                 uint64_t piece_seq_base, const uint32_t* __restrict__ bloom, DevCounters* cnt, int dbg,
+                                                 const uint32_t* __restrict__ par_fail, uint32_t heavy, const uint32_t* __restrict__ ko_bad,
+                                                 const uint32_t* __restrict__ ko_state, uint32_t ko_heavy, uint32_t win_seq, uint32_t ko_heavy_w) {
+    WalkCtx wc;
+    wc.pl = pl; wc.fp = fp; wc.jt = jt; wc.cnt = cnt; wc.bloom = bloom; wc.win_seq = win_seq;
+    wc.nb_processed = wc.nb_skipped = wc.nb_jcheck = wc.nb_no_juncs = wc.n_created = wc.n_filled = 0;
+    wc.created_now = false; wc.fail = 0; wc.dbg = dbg;
+    const WinDesc wd = *wdp;
+    const uint32_t first_piece = wd.first_piece;
+    if (ko_heavy && blockIdx.x == 0 && threadIdx.x == 0 && (ko_state[1] & 1u)) atomicAdd(&cnt->ko_overflows, 1ULL);
+    const uint32_t n_roots = roots_state[0];
+    const bool ko_usable = ko_heavy && !(ko_state[1] & 1u);
+    unsigned long long n_follow = 0, biggest = 0;
+    uint32_t local_mem[LOCAL_MEMBERS];
+    uint32_t* mem = local_mem;
+    uint32_t leader = U_INF, nm = 0, at = 0;          // the lane's cluster: its leader, followers, next piece (0 = the leader itself)
+    bool drained = false;
+    for (;;) {
+        // lanes without a cluster draw the next leaders of the list
+        const bool want = leader == U_INF && !drained;
+        const unsigned long long wm = __ballot(want);
+        if (wm) {
+            const int first = __builtin_ctzll(wm);
+            uint32_t base = 0;
+            if (fd_lane() == first) base = atomicAdd(&roots_state[1], (uint32_t)__popcll(wm));
+            base = (uint32_t)__shfl((int)base, first, 64);
+            if (want) {
+                const uint32_t mine = base + (uint32_t)__popcll(wm & ((1ULL << fd_lane()) - 1));
+                if (mine >= n_roots) drained = true;
+                else {
+                    const uint32_t i = root_list[mine];
+                    const uint32_t my_count = count[i];
+                    // a large cluster that the out-of-order / key-ordered / optimistic walks take is left alone here
+                    const bool elsewhere = (heavy && my_count + 1 >= heavy && !par_fail[i]) ||
+                                           (ko_usable && ko_cluster(my_count, par_fail[i], ko_heavy, ko_heavy_w) && !ko_bad[i]);
+                    if (!elsewhere) {
+                        leader = i;
+                        at = 0;
+                        nm = (dbg & 2) ? 0 : my_count;
+                        mem = local_mem;
+                        if (nm) {   // followers: off the linked list, into ascending piece order (the leader is the smallest index of the cluster)
+                            n_follow += nm;
+                            if (nm + 1 > biggest) biggest = nm + 1;
+                            if (nm > LOCAL_MEMBERS) mem = pool + atomicAdd(&cnt->pad2, (unsigned long long)nm);   // rare: giant cluster, list in global memory
+                            uint32_t j = 0;
+                            for (uint32_t m = head[i]; m != U_INF && j < nm; m = next[m]) mem[j++] = m;
+                            for (uint32_t gap = nm / 2; gap > 0; gap /= 2)          // shell sort: fine for 2 members and for 10^5
+                                for (uint32_t a = gap; a < nm; a++) {
+                                    uint32_t v = mem[a];
+                                    uint32_t b = a;
+                                    while (b >= gap && mem[b - gap] > v) { mem[b] = mem[b - gap]; b -= gap; }
+                                    mem[b] = v;
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        if (!__ballot(leader != U_INF)) {
+            if (!__ballot(!drained)) break;               // nobody holds a cluster and the list is exhausted for every lane
+            continue;                                     // (some lane drew a cluster that is walked elsewhere: it draws again)
+        }
+        if (leader != U_INF) {                            // one piece of the lane's cluster
+            const uint32_t m = at == 0 ? leader : mem[at - 1];
+            const uint2 pc = pl.pieces[first_piece + m];
+            walk_piece<WALK_SEQ>(wc, pc.x, pc.y, piece_seq_base + first_piece + m);
+            if (at++ == nm) leader = U_INF;
+        }
+    }
     unsigned long long v[7] = {wc.nb_processed, wc.nb_skipped, wc.nb_jcheck, wc.nb_no_juncs, wc.n_created, n_follow, wc.n_filled};
     for (int c = 0; c < 7; c++)
         for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_down(v[c], o, 64);
@@ -2636,7 +2744,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
             {(void**)&ctx->cl_count, 2ULL * ctx->wmax * 4}, {(void**)&ctx->cl_offset, 2ULL * ctx->wmax * 4}, {(void**)&ctx->cl_fill, (uint64_t)ctx->wmax * 4},
             {(void**)&ctx->cl_fail, 2ULL * ctx->wmax * 4}, {(void**)&ctx->ko_hk, (uint64_t)ctx->ko_hk_cap * 4 * 3},
             {(void**)&ctx->ko_occ, (uint64_t)ctx->ko_occ_cap * (4 * 3 + 8)}, {(void**)&ctx->ko_piece, (uint64_t)ctx->wmax * 4 * 2 + 64},
-            {(void**)&ctx->cl_members, (uint64_t)ctx->wmax * 4 * 2}};
+            {(void**)&ctx->cl_members, (uint64_t)ctx->wmax * 4 * 2}, {(void**)&ctx->cl_roots, (uint64_t)ctx->wmax * 4 + 64}};
         hipError_t err = hipSuccess;
         uint64_t failed_bytes = 0;
         for (auto& w : want) {
@@ -2892,7 +3000,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             FGPU_LAUNCH("walk_lookup", k_walk_register, word_blocks + piece_blocks + 64, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, ctx->counters,
                         word_blocks, piece_blocks, ds);
         }
-        FGPU_LAUNCH("walk_link", k_walk_link, std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end);
+        uint32_t* const roots_state = ctx->cl_roots;               // [0] leaders listed, [1] handed out; the list follows (16 words in)
+        uint32_t* const root_list = ctx->cl_roots + 16;
+        FGPU_LAUNCH("walk_link", k_walk_link, std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, roots_state);
         // The key-ordered walk costs four small launches per window whether or not the window holds a large cluster, so it is switched on by
         // what the scan has shown so far: the largest cluster among the windows whose counters the host has seen (every batch's pure stage
         // brings them along).  Data without such clusters never pays; data with them walks its first batch by cluster.  Either way the
@@ -2916,7 +3026,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         const uint32_t ko_heavy_w = (ko_heavy && ko_total) ? (ko_total | (ko_avg << 16) | (ko_total_rep << 24)) : 0u;
         // cl_count = followers per root, cl_offset = list heads, cl_fill = flat roots, cl_members = [next links | pool]
         FGPU_LAUNCH("walk_cluster", k_walk_cluster, cluster_grid, 256, (const uint32_t*)uf_parent, cl_count, cl_offset, ctx->cl_fill,
-                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters, cl_fail, ko_heavy_w);
+                    ctx->cl_members, pl, lo, hi, (WinDesc*)ctx->wdesc, ctx->counters, cl_fail, ko_heavy_w, root_list, roots_state);
         static const uint32_t ko_ticket = getenv("FGPU_KO_TICKET") ? (uint32_t)std::max(64, atoi(getenv("FGPU_KO_TICKET")) / 64 * 64) : 64u;
         const uint32_t heavy = (dbg_walk || ko_heavy) ? 0u : ctx->walk_heavy;   // (one way of taking large clusters out of k_walk at a time)
         KoTables kt;
@@ -3033,10 +3143,18 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         if (heavy)
             FGPU_LAUNCH("walk_probe", k_walk_par<WALK_PROBE>, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, cl_fail,
                         (const WinDesc*)ctx->wdesc, (const uint32_t*)ctx->bloo2, ctx->counters, heavy);
-        FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
-                    (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
-                    seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
-                    (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
+        static const bool walk_static = getenv("FGPU_WALK_STATIC") && getenv("FGPU_WALK_STATIC")[0] == '1';   // measurement aid: lane i walks the cluster led by piece i
+        static const unsigned walk_dyn_grid = getenv("FGPU_WALK_DYN_GRID") ? (unsigned)std::max(1, atoi(getenv("FGPU_WALK_DYN_GRID"))) : 1024u;   // (k_walk alone on config 2 / config 4's per-GPU shape, ms per step: static 19.3 / 22.9; 1024 waves 19.6 / 16.6; 2048 20.5 / 17.7; 4096 23.3 / 18.8)
+        if (walk_static)
+            FGPU_LAUNCH("walk", k_walk, walk_grid_w, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count,
+                        (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
+                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
+                        (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
+        else
+            FGPU_LAUNCH("walk", k_walk_dyn, std::min(walk_grid_w, walk_dyn_grid), 64, pl, ctx->fd, jt, (const uint32_t*)root_list, roots_state, (const uint32_t*)cl_count,
+                        (const uint32_t*)cl_offset, (const uint32_t*)ctx->cl_members, ctx->cl_members + ctx->wmax, (const WinDesc*)ctx->wdesc,
+                        seq_base, (const uint32_t*)ctx->bloo2, ctx->counters, dbg_walk, (const uint32_t*)cl_fail, heavy, (const uint32_t*)kt.bad,
+                        (const uint32_t*)kt.state, ko_heavy, (uint32_t)ctx->scan_windows, ko_heavy_w);
         if (ovw_on && ovw_stream != walk_stream) FGPU_HIP(hipStreamWaitEvent(walk_stream, ctx->ev_settled, 0));   // the settled logs are in the map
         if (ko_heavy)      // (ranks of the occurrences per k-mer: only the key-ordered walk needs them, and only for what the optimistic walk left)
             FGPU_LAUNCH("walk_ko_prepare", k_ko_rank, 256, 256, kt, (const uint32_t*)ot.state, ovw_rounds);
