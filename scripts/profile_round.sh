@@ -9,7 +9,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu --no-host-leg > "$out/bench_stats.json" 2> "$out/bench_stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu --no-host-leg > "$out/bench_stats.json" 2> "$out/bench_stats.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o run -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu --no-host-leg > "$out/bench_fetch.json" 2> "$out/bench_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o run -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu --no-host-leg > "$out/bench_write.json" 2> "$out/bench_write.err"
 # the per-dispatch trace is large; the statistics and the counter tables are what is kept

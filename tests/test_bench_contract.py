@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_config2.json")))
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_config2.json")).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "k-mers/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -33,6 +33,16 @@ def test_committed_bench_line_has_the_contract_keys():
     c3 = d["config3_cli"]            # the slowest configuration, file to files, in the driver's line; every file equal to the compiled reference's
     assert c3["junctions_equal_the_references"] and all(c3["files_equal_the_references"].values()) and len(c3["files_equal_the_references"]) == 4
     assert 0 < c3["value"] < f["value"] and c3["kmers"] == 350_000_000
+    # round 4: config 3 by SURVEY 8d's definition of the metric (pass 1 + pass 2 on the CLI's own clock) is above the 1e9 bar, and the line says so
+    p = c3["pass_ms"]
+    assert abs(c3["load_scan_value"] - c3["kmers"] / ((p["pass 1 (read + load)"] + p["pass 2 (read + scan)"]) / 1e3)) / c3["load_scan_value"] < 1e-9
+    assert c3["load_scan_value"] > 1e9
+    # round 4: the headline steps run without HIP events; kernel times and the roofline's launch time come from separate bracketed steps
+    ps = d["profiled_steps"]
+    assert ps["steps"] >= 1 and ps["ms_per_step"] >= 0.99 * d["ms_per_step"]
+    assert abs(d["roofline"]["avg_launch_ms"] * d["roofline"]["launches"] / ps["steps"] - d["kernel_ms_per_step_rank0"]["load_mark"]) < 0.01
+    for name in ("config5", "config4"):
+        assert d["full_size"][name]["counters_equal_the_oracles"] is True and d["full_size"][name]["value"] > 4e9
     # value is consistent with the step time it was derived from
     assert abs(d["value"] - d["kmers_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
