@@ -141,13 +141,18 @@ def load_sharded(backend, batches, rank: int, world: int):
     """Returns this shard's load stats; afterwards every rank holds the global bloo2.  Two exact protocols for pass 1:
     the fix-up one (no presence pass: every rank loads its shard alone, then re-evaluates what it kept out of bloo2 against the
     lower ranks' bits) where every rank can run it, else the presence one."""
-    # Which one: measured on one MI355X with the per-rank shapes of bench.py (scripts/shard_protocol_times.py; 10 M reads per rank):
-    # 2 ranks (2^30-bit filters, 25x coverage per shard): presence 43 + load 56 ms  vs  own load 70 + fix-up 18 ms  -> fix-up;
-    # 8 ranks (2^32 bits, 6x per shard): presence 53 + load 88 ms  vs  own load 146 + fix-up 34 ms -> presence: a shard that thin finds
-    # little in its own carry, and every occurrence it cannot settle alone costs first-set-time atomics into a 16 GiB array.
+    # Which one: the step waits for the SLOWEST rank, and under the presence protocol that is rank 0 -- it pays the presence pass AND the load
+    # on an empty filter (every k-mer new: first-set-time atomics for all of them), while under the fix-up protocol every rank pays that
+    # load once and the fix-up costs less than the presence pass.  Measured on one MI355X with one rank's shapes
+    # (scripts/shard_load_times.py, scripts/shard_protocol_times.py), slowest rank, presence protocol vs fix-up protocol:
+    #   config 4 on 8 ranks (25 M reads per rank, 2^33-bit filters): 162 + 358 = 520 ms  vs  358 + 83 = 441 ms  (a rank > 0: 162 + 256)
+    #   weak shapes, 8 ranks (10 M reads per rank, 2^32 bits):        53 + 146 = 199 ms  vs  146 + 34 = 180 ms  (a rank > 0:  53 + 88)
+    #   weak shapes, 2 ranks (2^30 bits):                              43 +  70 = 113 ms  vs   70 + 18 =  88 ms
+    # Rounds 2-3 compared a rank > 0 only and took presence beyond 2 ranks.  So: the fix-up protocol wherever every rank can run it (the
+    # shard's positions fit 32-bit times and its batches stay in HBM: config 4 from 8 ranks on; 4 ranks would need 5.05e9 times).
     # FAUCET_SHARD_PROTOCOL=fixup|presence overrides the choice.
     want = os.environ.get("FAUCET_SHARD_PROTOCOL", "auto")
-    prefer = want == "fixup" or (want == "auto" and world <= 2)
+    prefer = want != "presence"
     can = getattr(backend, "fixup_possible", None)
     if _agree(bool(prefer and can and can(batches)), getattr(backend, "device", None)):
         return load_sharded_fixup(backend, batches, rank, world)

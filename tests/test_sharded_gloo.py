@@ -164,7 +164,7 @@ def _worker(rank, world, port, name, out_dir, protocol):
     tai, nh, _, _ = po.sizing_from_cli(c.E, c.S)
     be = OracleShard(c.k, tai, nh, c.j, c.spacer, protocol)
     sharded.load_sharded(be, mine, rank, world)
-    assert getattr(be, "fixed_up", False) == ((protocol == "fixup" or (protocol == "auto" and world <= 2)) and rank > 0)
+    assert getattr(be, "fixed_up", False) == (protocol != "presence" and rank > 0)      # auto: the fix-up protocol wherever every rank can run it
     np.save(os.path.join(out_dir, f"bloo2_{rank}.npy"), be.b2.bits().copy())
     st, last = sharded.scan_sharded(be, mine, rank, world)
     if last:
