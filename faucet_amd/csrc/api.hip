@@ -593,6 +593,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->adapt_followers = 0;
     ctx->adapt_pieces = 0;
     ctx->adapt_overflows = 0;
+    ctx->adapt_vote = 0;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     ctx->scan_batch_seq = 0;
@@ -611,26 +612,49 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
 // pieces queue behind an earlier piece of their cluster (2^21: 254 ms, 2^22: 225, 2^23: 213, 2^24: 207, 2^25: 205).
 // counters_host must be fresh with respect to the walks issued so far.
 static void adapt_window(fgpu_ctx* ctx) {
+    // Round 4.  On config 2 the share of queueing pieces is 0.25 / 0.43 / 0.58 at 2^24 / 2^25 / 2^26 positions and one batch's counters are a
+    // noisy sample of it, so the controller of rounds 1-3 moved the size up and down between batches for good -- and every move asked the
+    // host to wait for the next windows one by one, which keeps it from feeding the next batch's pure stage: 12 waits per step
+    // (scripts/timeline.py), 121.4-122.1 ms a step against 116.8-118.9 with any fixed size in that range (scripts/span_fixed_ab.sh).
+    // Now: both counts come from one snapshot of the device's counters (pieces counted behind their window's walks); a share that is not
+    // clear-cut (0.5-0.8, or 0.15-1/3) has to show in two batches running before the size moves; growing waits for windows only beyond the
+    // largest size a batch of this context has been walked at, shrinking only when most pieces queue (the percolation case the waits are
+    // for).  The thresholds themselves are unchanged: a wider dead band, decisions held back for two batches and x4 steps were tried as
+    // well -- they walked config 4 at larger windows than suit it and config 3's repeats at a percolating size now and then.
+    static const bool dbg_span = getenv("FGPU_DEBUG_SPAN") != nullptr;
     const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
-    const uint64_t p = ctx->walked_pieces - ctx->adapt_pieces;
+    const uint64_t p = ctx->counters_host->walked_pieces - ctx->adapt_pieces;
     if (p > 0 && !ctx->prm.walk_window_span) {
+        const uint64_t usual = std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN);
+        int want = 0;             // -1 smaller, +1 larger
+        bool clear = false;
+        if (f * 2 > p) { want = -1; clear = f * 5 > p * 4; }
+        else if (f * 3 < p) { want = 1; clear = f * 20 < p * 3; }
+        const bool act = want != 0 && (clear || want == ctx->adapt_vote);
+        ctx->adapt_vote = act ? 0 : want;
+        if (want >= 0) ctx->proven_span = std::max(ctx->proven_span, ctx->window_span);
         if (ctx->counters_host->ko_overflows > ctx->adapt_overflows && ctx->window_span > 4096) {
             // a window's large clusters outgrew the tables of the large-cluster walks and were walked piece after piece by their one thread:
             // far too large a window for this data
             ctx->window_span = std::max<uint64_t>(4096, ctx->window_span / 4);
             ctx->calib_left = 0;
         }
-        else if (f * 2 > p && ctx->window_span > 4096) { ctx->window_span /= 2; ctx->calib_left = 8; }   // and look again window by window
-        else if (f * 3 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN)) {
+        else if (act && want < 0 && ctx->window_span > 4096) {
+            ctx->window_span /= 2;
+            if (clear) ctx->calib_left = 8;      // most pieces queue: beyond the percolation threshold, look again window by window
+        }
+        else if (act && want > 0 && ctx->window_span < usual) {
             // clusters percolate at a sharp threshold (about one genome coverage per window): a whole batch at a size that turns out to be
-            // beyond it costs seconds, so the first windows at the new size are looked at one by one again
-            ctx->window_span = std::min<uint64_t>(ctx->window_span * 2, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
-            ctx->calib_left = std::max(ctx->calib_left, 2);
+            // beyond it costs seconds, so the first windows at a size this context has not walked yet are looked at one by one
+            ctx->window_span = std::min<uint64_t>(ctx->window_span * 2, usual);
+            if (ctx->window_span > ctx->proven_span) ctx->calib_left = std::max(ctx->calib_left, 2);
         }
         else if (f * 16 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;   // thin coverage per window: see FGPU_MAX_SPAN
     }
+    if (dbg_span) fprintf(stderr, "[span] batch: followers %llu of %llu pieces -> span %llu, looks %d, vote %d\n", (unsigned long long)f, (unsigned long long)p,
+                          (unsigned long long)ctx->window_span, ctx->calib_left, ctx->adapt_vote);
     ctx->adapt_followers = ctx->counters_host->followers;
-    ctx->adapt_pieces = ctx->walked_pieces;
+    ctx->adapt_pieces = ctx->counters_host->walked_pieces;
     ctx->adapt_overflows = ctx->counters_host->ko_overflows;
 }
 
@@ -768,6 +792,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->calib_left = 16;
     ctx->calib_f = ctx->calib_p = 0;
     ctx->adapt_followers = ctx->adapt_pieces = ctx->adapt_overflows = 0;
+    ctx->adapt_vote = 0;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     memset(&ctx->carried, 0, sizeof(ctx->carried));

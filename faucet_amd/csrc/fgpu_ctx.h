@@ -266,6 +266,8 @@ struct fgpu_ctx {
     uint64_t scan_pieces_seen = 0;   // pieces counted by previous batches of this scan
 
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
+    int adapt_vote = 0;                // what the last batch's counters asked for without getting it yet (-1 smaller, +1 larger)
+    uint64_t proven_span = 0;          // largest window size a batch of this context was walked at without most pieces queueing
     uint64_t adapt_overflows = 0;
     int calib_left = 0;              // windows the controller still waits for individually (start of a scan, after a bad batch)
     uint64_t calib_f = 0, calib_p = 0;

@@ -393,7 +393,6 @@ __global__ void __launch_bounds__(256) k_walk_cluster(const uint32_t* __restrict
     const uint32_t n = wd.n;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *wd_out = wd;                  // the walk kernel reads it with one uniform load
-        cnt->walked_pieces += n;       // one writer per launch; feedback for the window-span controller
         cnt->pad2 = 0;                 // pool cursor of the giant-cluster lists of the walk kernel that follows
     }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -2365,6 +2364,9 @@ __global__ void __launch_bounds__(256) k_delta_collect(unsigned long long* __res
     __shared__ uint64_t s_late_p[FGPU_LATE_CAP];
     __shared__ uint32_t s_late_n;
     if (threadIdx.x == 0) s_late_n = 0;
+    // feedback for the window-span controller: the window's pieces are counted here, behind its walks, so that a snapshot of the counters
+    // never holds a window's pieces without the followers among them (one writer per launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->walked_pieces += wdp->n;
     __syncthreads();
     const unsigned long long n_noted = cnt->late_n[0] < FGPU_LATE_CAP ? cnt->late_n[0] : FGPU_LATE_CAP;
     if (n_noted) {
@@ -3203,6 +3205,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                 // (a fraction of a millisecond each, and the wrong size hurts most there); from 2^22 positions on the per-batch
                 // controller (adapt_window, no waiting) takes over unless the last look said "too large"
                 if (!shrunk && span_now >= (1ULL << 22)) ctx->calib_left = 0;
+                static const bool dbg_span = getenv("FGPU_DEBUG_SPAN") != nullptr;
+                if (dbg_span) fprintf(stderr, "[span] look: followers %llu of %llu pieces -> span %llu, looks left %d\n", (unsigned long long)f, (unsigned long long)p,
+                                      (unsigned long long)span_now, ctx->calib_left);
             }
         }
     }

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: kernel trace (start/end per dispatch, queue id) of a short bench run, summarised by scripts/timeline_summary.py
-tag=$1; shift
-for kv in "$@"; do export "$kv"; done
+# ON THE GPU BOX: kernel trace of three steps of bench.py, the last step's timeline (scripts/timeline.py)
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/tl_$tag
-mkdir -p "$out"
+out=$root/gpurun_out/timeline
+rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -o run -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu --no-ceilings > "$out/bench.json" 2> "$out/bench.err"
-python3 "$root/scripts/timeline_summary.py" "$out/trace" > "$out/summary.txt" 2>&1
-find "$out" \( -name "*.db" -o -name "*kernel_trace.csv" \) -delete
-cat "$out/summary.txt"
+rocprofv3 --kernel-trace --output-format csv -d "$out/t" -o run -- python3 "$root/bench.py" --steps 3 --warmup 2 --no-cpu --no-host-leg --no-full-size --no-profile > "$out/bench.json" 2> "$out/bench.err"
+f=$(find "$out/t" -name "*kernel_trace.csv" | head -1)
+head -1 "$f" > "$out/header.txt"
+python3 "$root/scripts/timeline.py" "$f" 1 ${DETAIL:+x} > "$out/timeline.txt" 2>&1
+find "$out" \( -name "*kernel_trace.csv" -o -name "*.db" \) -delete
+tail -c 600 "$out/bench.json"
