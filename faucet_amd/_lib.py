@@ -33,7 +33,7 @@ LOAD_KEEP_CARRY, LOAD_SHARD_TIMES = 1, 2
 
 class Reads(C.Structure):
     _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("on_device", C.c_int32),
-                ("reserved", C.c_int32), ("starts", C.c_void_p)]
+                ("total_bases", C.c_uint32), ("starts", C.c_void_p)]
 
 
 class LoadStats(C.Structure):

@@ -92,7 +92,10 @@ class ReadBatch:
         return cls(np.ascontiguousarray(mat).reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(ln))
 
     def c_struct(self):
-        return L.Reads(self.bases_ptr, self.offsets_ptr, self.n_reads, int(self.on_device), 0, self.starts_ptr)
+        # device batches: the total the caller knows (n_positions = bases + one separator per read) spares the library a read-back of two
+        # offsets, i.e. a wait for everything it has queued, per call
+        total = self.n_positions - self.n_reads if (self.on_device and self.n_positions is not None) else 0
+        return L.Reads(self.bases_ptr, self.offsets_ptr, self.n_reads, int(self.on_device), total if 0 < total < 1 << 32 else 0, self.starts_ptr)
 
 
 STOP_DTYPE = np.dtype([("ext", "<u8"), ("read", "<u4"), ("info", "<u4")])

@@ -99,6 +99,7 @@ static int check_errors(fgpu_ctx* ctx) {
     // device-side error flags (table overflow) are surfaced at the synchronising calls
     if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
+    if (ctx->counters_host->error_flags & 32ULL) { ctx->err = "fgpu_reads.total_bases does not match the batch's offsets"; return FGPU_ERR_ARG; }
     // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
     static const bool force_lazy_fail = getenv("FGPU_DEBUG_LAZY_FAIL") && getenv("FGPU_DEBUG_LAZY_FAIL")[0] == '1';
     const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime && !ctx->eager_scan;
@@ -687,11 +688,15 @@ static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) 
     }
     b->seq = ctx->scan_batch_seq++;
     ctx->cur = b;
+    const double t_a = fgpu_host_now();
     if (b->walk_pending) {   // the walk stream may still be reading this batch's planes
         FGPU_HIP(hipEventSynchronize(b->walk_done));
         b->walk_pending = false;
     }
+    const double t_b = fgpu_host_now();
+    ctx->host_ms[0] += t_b - t_a;
     int rc = fgpu_stage_pack(ctx, reads);
+    ctx->host_ms[1] += fgpu_host_now() - t_b;
     if (!rc) rc = journal_add(ctx, b, reads);
     uint64_t n_pieces = 0;
     if (!rc) rc = fgpu_stage_scan_pure(ctx, &n_pieces);   // ends with the batch's only synchronisation (piece count)
@@ -870,7 +875,9 @@ int fgpu_scan_batch(fgpu_ctx* ctx, const fgpu_reads* reads) {
     if (!rc) rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported);
     if (!rc) {
         adapt_window(ctx);                       // counters as of the pure stage's synchronisation (the walk may lag one batch)
+        const double t_w = fgpu_host_now();
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
+        ctx->host_ms[5] += fgpu_host_now() - t_w;
         ctx->walked_pieces += b->n_pieces;
         if (!rc) note_walked(ctx, b);
     }
@@ -1005,6 +1012,12 @@ int fgpu_scan_take_stops(fgpu_ctx* ctx, fgpu_stop* out, uint64_t cap, uint64_t* 
 int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_end without scan_begin"; return FGPU_ERR_STATE; }
+    static const bool dbg_host = getenv("FGPU_DEBUG_HOST") != nullptr;
+    if (dbg_host) {
+        fprintf(stderr, "[host] scan: wait for the buffers' last walk %.2f ms, pack issue %.2f, pure stage issue (first half) %.2f, wait for the piece count %.2f, "
+                        "pure stage issue (second half) %.2f, walk issue %.2f\n", ctx->host_ms[0], ctx->host_ms[1], ctx->host_ms[2], ctx->host_ms[3], ctx->host_ms[4], ctx->host_ms[5]);
+        for (double& v : ctx->host_ms) v = 0;
+    }
     int rc = pull_counters(ctx);
     if (!rc && ctx->lazy_failed) {                          // the last walks met a preview they could not repair: scan again before closing
         rc = scan_replay(ctx);

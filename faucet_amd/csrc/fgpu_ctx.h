@@ -1,5 +1,6 @@
 // fgpu_ctx.h — host-side context of libfaucet_gpu.so (not part of the ABI).
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -166,6 +167,9 @@ struct DevCounters {
 
 struct TextSet { DevBuf buf, nl, rank, tmp, rec; };
 
+// host wall clock in ms (FGPU_DEBUG_HOST)
+static inline double fgpu_host_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct fgpu_ctx {
     fgpu_params prm;
     FdParams fd;
@@ -266,6 +270,7 @@ struct fgpu_ctx {
     uint64_t scan_pieces_seen = 0;   // pieces counted by previous batches of this scan
 
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
+    double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // FGPU_DEBUG_HOST=1: where the host thread of a scan spends its time (see fgpu_scan_end)
     int adapt_vote = 0;                // what the last batch's counters asked for without getting it yet (-1 smaller, +1 larger)
     uint64_t proven_span = 0;          // largest window size a batch of this context was walked at without most pieces queueing
     uint64_t adapt_overflows = 0;

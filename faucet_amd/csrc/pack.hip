@@ -166,8 +166,10 @@ __global__ void __launch_bounds__(256) k_pack(const unsigned char* __restrict__ 
 // one thread per read that has interior bad characters: rewrite its positions in reverse token order
 __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restrict__ bases, const uint64_t* __restrict__ offs,
                                                   const uint64_t* __restrict__ starts, uint64_t n_reads, unsigned long long* codes, unsigned long long* bad,
-                                                  const unsigned char* __restrict__ readflag, unsigned long long* max_len) {
+                                                  const unsigned char* __restrict__ readflag, unsigned long long* max_len, uint64_t total,
+                                                  unsigned long long* error_flags) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && offs[n_reads] - offs[0] != total) atomicOr(error_flags, 32ULL);     // fgpu_reads.total_bases was not what the offsets say
     {   // longest read of the batch: one look at the running maximum per BLOCK, an atomic only when the block raises it (loads of
         // one address from every wave queue up in its L2 channel just like same-address atomics do)
         __shared__ unsigned long long wave_max[4];
@@ -242,6 +244,8 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
         d_starts = reads->starts;
         if (reads->offsets == ctx->split_offsets && n == ctx->split_n) {   // cut by fgpu_text_split just now: the total came with it
             total = ctx->split_total;
+        } else if (reads->total_bases) {   // the caller's word for it; k_pack_fix compares it with the offsets (error flag 32)
+            total = reads->total_bases;
         } else {
             uint64_t ends[2];
             FGPU_HIP(hipMemcpyAsync(&ends[0], reads->offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -307,6 +311,6 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) / 2 + 1, 256), 256, d_bases, d_offs, d_starts, n, T, bb.n_words, (uint64_t*)bb.codes.p,
                 (uint32_t*)bb.bad.p, (unsigned char*)bb.readflag.p);
     FGPU_LAUNCH("pack_fix", k_pack_fix, fgpu_blocks(n, 256), 256, d_bases, d_offs, d_starts, n, (unsigned long long*)bb.codes.p,
-                (unsigned long long*)bb.bad.p, (const unsigned char*)bb.readflag.p, &ctx->counters->max_read_len);
+                (unsigned long long*)bb.bad.p, (const unsigned char*)bb.readflag.p, &ctx->counters->max_read_len, total, &ctx->counters->error_flags);
     return FGPU_OK;
 }

@@ -560,6 +560,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     for (DevBuf* b : planes)
         if ((rc = fgpu_ensure(ctx, b, wb))) return rc;
     if ((rc = fgpu_ensure(ctx, &bb.ps_prefix, (bb.n_words + FGPU_PADW + bb.n_words / SCAN_BLOCK + 2) * 4))) return rc;
+    const double t_a = fgpu_host_now();
     // valid/pm/ps need zeroed padding (funnel reads run one word past the end); pm is built with atomicOr
     FGPU_HIP(hipMemsetAsync(bb.valid.p, 0, wb, ctx->stream));
     FGPU_HIP(hipMemsetAsync(bb.pm.p, 0, wb, ctx->stream));
@@ -596,7 +597,11 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     FGPU_LAUNCH("prefix_sums", k_prefix_sums, 1, SCAN_BLOCK, block_sums, nblk);
     FGPU_LAUNCH("prefix_apply", k_prefix_apply, fgpu_blocks(nw1, 256), 256, prefix, (const uint32_t*)block_sums, nw1);
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
+    const double t_b = fgpu_host_now();
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    const double t_c = fgpu_host_now();
+    ctx->host_ms[2] += t_b - t_a;
+    ctx->host_ms[3] += t_c - t_b;
     bb.max_piece_span = ctx->counters_host->max_read_len + 64;
     const uint64_t np = ctx->counters_host->pieces - ctx->scan_pieces_seen;
     ctx->scan_pieces_seen = ctx->counters_host->pieces;
@@ -638,5 +643,6 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
                     (unsigned long long*)bb.cb0.p, (unsigned long long*)bb.cb1.p, ctx->counters);
         if ((rc = fgpu_stage_scan_debug_drop(ctx))) return rc;
     }
+    ctx->host_ms[4] += fgpu_host_now() - t_c;
     return FGPU_OK;
 }

@@ -78,13 +78,17 @@ typedef struct {
  * on_device != 0: all pointers are device (HBM) pointers on params.device.
  * starts != NULL (device batches only): the reads are not contiguous in `bases` -- read i is
  * bases[starts[i] .. starts[i] + offsets[i+1] - offsets[i]) (sequence lines inside raw FASTA/FASTQ text,
- * see fgpu_text_split); offsets still carries the lengths as differences. */
+ * see fgpu_text_split); offsets still carries the lengths as differences.
+ * total_bases (device batches only; host batches: ignored): offsets[n_reads] - offsets[0] if the caller knows it, else 0.  With 0 the library
+ * reads the two offsets back from the device, which makes every call wait for everything it has queued before -- the kernels of the batch
+ * before -- before it can queue this batch's: a caller that streams device batches should fill it in (round 4, config 2: the host spent 9 ms of a
+ * 64 ms scan in that wait).  A value that does not match the offsets is an error the pass reports at its next synchronising call (FGPU_ERR_ARG). */
 typedef struct {
     const char*     bases;
     const uint64_t* offsets;    /* n_reads + 1 entries */
     uint64_t        n_reads;
     int32_t         on_device;
-    int32_t         reserved;
+    uint32_t        total_bases;
     const uint64_t* starts;     /* n_reads entries, or NULL */
 } fgpu_reads;
 

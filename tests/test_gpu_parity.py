@@ -1561,3 +1561,40 @@ def test_key_ordered_walk_under_contention_is_repeatable(monkeypatch):
         assert sst["walk_parallel"] > 1000
         ctx.close()
     assert biggest >= 64
+
+
+def test_device_batches_with_the_callers_total_equal_the_ones_without_and_a_wrong_total_is_refused():
+    """fgpu_reads.total_bases (include/faucet_gpu.h): a device batch whose caller says how many bases it holds is packed without the
+    read-back of two offsets; the results are the same three ways (host batches, device batches without and with the total), ragged reads and
+    an offsets[0] that is not 0 included, and a total that does not match the offsets fails the pass instead of packing something else."""
+    import torch
+    bases, offs = _random_case(6000, 100, 21, 9000, 0.01, 77, n_rate=0.002, repeats=2)
+    bases, offs = bases[37:], (offs - 37)[1:]                      # drop the first read's head: offsets[0] = 63
+    k, (tai, nh) = 21, api.load_filter_shape(600_000, 150_000)
+    b1, b2, lst, osc = oracle_run((bases[offs[0]:], offs - offs[0]), k, tai, nh, 1, 100)
+    d_bases = torch.from_numpy(np.ascontiguousarray(bases)).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    cuts = [0, 1500, 1501, 4000, len(offs) - 1]
+
+    def batches(with_total, lie=0):
+        out = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            n_pos = int(offs[hi] - offs[lo]) + (hi - lo) + lie if with_total else None
+            out.append(api.ReadBatch(d_bases.data_ptr(), d_offs[lo:].data_ptr(), n_reads=hi - lo, on_device=True, keepalive=(d_bases, d_offs), n_positions=n_pos))
+        return out
+
+    for with_total in (False, True):
+        assert (batches(with_total)[0].c_struct().total_bases != 0) == with_total
+        ctx = api.Context(k, tai, nh)
+        st = api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), batches(with_total))
+        assert np.array_equal(ctx.bloom_download(L.BLOO2), b2.bits()) and st["to_bloo2"] == lst.to_bloo2
+        sc = api.ReadScanner(ctx)
+        sst = sc.scanReads(batches(with_total))
+        _scan_equals_oracle(sc, sst, osc)
+        ctx.close()
+    for lie in (-1, 64):
+        ctx = api.Context(k, tai, nh)
+        with pytest.raises(api.FaucetGpuError, match="total_bases"):
+            api.load_two_filters(api.Bloom(ctx, L.BLOO1), api.Bloom(ctx, L.BLOO2), batches(True, lie))
+        ctx.close()
