@@ -617,32 +617,39 @@ static void adapt_window(fgpu_ctx* ctx) {
     // noisy sample of it, so the controller of rounds 1-3 moved the size up and down between batches for good -- and every move asked the
     // host to wait for the next windows one by one, which keeps it from feeding the next batch's pure stage: 12 waits per step
     // (scripts/timeline.py), 121.4-122.1 ms a step against 116.8-118.9 with any fixed size in that range (scripts/span_fixed_ab.sh).
-    // Now: both counts come from one snapshot of the device's counters (pieces counted behind their window's walks); a share that is not
-    // clear-cut (0.5-0.8, or 0.15-1/3) has to show in two batches running before the size moves; growing waits for windows only beyond the
-    // largest size a batch of this context has been walked at, shrinking only when most pieces queue (the percolation case the waits are
-    // for).  The thresholds themselves are unchanged: a wider dead band, decisions held back for two batches and x4 steps were tried as
-    // well -- they walked config 4 at larger windows than suit it and config 3's repeats at a percolating size now and then.
+    // Now: both counts come from one snapshot of the device's counters (pieces counted behind their window's walks); growing on a share that
+    // is not clear-cut (0.15-1/3) has to be asked for by two batches running; growing waits for windows only beyond the largest size a batch
+    // of this context has been walked at, shrinking only towards a size it has not walked yet or when most pieces queue (the percolation
+    // case the waits are for).  The thresholds themselves are unchanged, and shrinking still acts at once: a wider dead band, decisions held
+    // back for a batch or two (shrinking included) and x4 steps were tried as well -- they walked config 4 at larger windows than suit it
+    // and config 3's repeats at a percolating size now and then (pass 2 of 170 ms at 310-360).
     static const bool dbg_span = getenv("FGPU_DEBUG_SPAN") != nullptr;
-    const uint64_t f = ctx->counters_host->followers - ctx->adapt_followers;
+    const uint64_t f = ctx->counters_host->followers_seen - ctx->adapt_followers;
     const uint64_t p = ctx->counters_host->walked_pieces - ctx->adapt_pieces;
-    if (p > 0 && !ctx->prm.walk_window_span) {
+    if (p == 0 || ctx->prm.walk_window_span) return;      // (no window has been completed since the last look at the counters)
+    {
         const uint64_t usual = std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN);
         int want = 0;             // -1 smaller, +1 larger
         bool clear = false;
         if (f * 2 > p) { want = -1; clear = f * 5 > p * 4; }
         else if (f * 3 < p) { want = 1; clear = f * 20 < p * 3; }
-        const bool act = want != 0 && (clear || want == ctx->adapt_vote);
+        // too large is dear (a batch at a percolating size), too small is not: shrinking acts at once, growing on a clear share or the second time
+        const bool act = want < 0 || (want > 0 && (clear || ctx->adapt_vote > 0));
         ctx->adapt_vote = act ? 0 : want;
         if (want >= 0) ctx->proven_span = std::max(ctx->proven_span, ctx->window_span);
         if (ctx->counters_host->ko_overflows > ctx->adapt_overflows && ctx->window_span > 4096) {
             // a window's large clusters outgrew the tables of the large-cluster walks and were walked piece after piece by their one thread:
             // far too large a window for this data
             ctx->window_span = std::max<uint64_t>(4096, ctx->window_span / 4);
+            ctx->proven_span = std::min(ctx->proven_span, ctx->window_span);
             ctx->calib_left = 0;
         }
         else if (act && want < 0 && ctx->window_span > 4096) {
             ctx->window_span /= 2;
-            if (clear) ctx->calib_left = 8;      // most pieces queue: beyond the percolation threshold, look again window by window
+            // ... and look again window by window -- unless this context has walked a batch at the smaller size before and the share is not
+            // the percolation case (most pieces queueing) the looks are for
+            if (clear || ctx->window_span > ctx->proven_span) ctx->calib_left = 8;
+            ctx->proven_span = std::min(ctx->proven_span, ctx->window_span);
         }
         else if (act && want > 0 && ctx->window_span < usual) {
             // clusters percolate at a sharp threshold (about one genome coverage per window): a whole batch at a size that turns out to be
@@ -654,7 +661,7 @@ static void adapt_window(fgpu_ctx* ctx) {
     }
     if (dbg_span) fprintf(stderr, "[span] batch: followers %llu of %llu pieces -> span %llu, looks %d, vote %d\n", (unsigned long long)f, (unsigned long long)p,
                           (unsigned long long)ctx->window_span, ctx->calib_left, ctx->adapt_vote);
-    ctx->adapt_followers = ctx->counters_host->followers;
+    ctx->adapt_followers = ctx->counters_host->followers_seen;
     ctx->adapt_pieces = ctx->counters_host->walked_pieces;
     ctx->adapt_overflows = ctx->counters_host->ko_overflows;
 }

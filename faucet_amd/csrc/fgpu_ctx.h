@@ -150,6 +150,7 @@ struct DevCounters {
     unsigned long long valid_reused;    // validity answers taken from the load pass' resident planes instead of probing
     unsigned long long flags_filled;    // windows whose junction tests the walk evaluated itself (the preview had left them out)
     unsigned long long walked_pieces;   // pieces of the windows walked so far (feedback for the window-span controller)
+    unsigned long long followers_seen;  // `followers` as of the last window counted in walked_pieces: the two the controller divides come from one moment
     unsigned long long mark_hits;       // pass 1: occurrences k_load_mark itself routed to bloo2 (all bits already in the carry)
     unsigned long long mark_pending;    // pass 1: occurrences left to k_load_resolve
     unsigned long long walk_parallel;   // pieces of large clusters walked out of order (k_walk_par)

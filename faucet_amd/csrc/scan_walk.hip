@@ -2366,7 +2366,7 @@ __global__ void __launch_bounds__(256) k_delta_collect(unsigned long long* __res
     if (threadIdx.x == 0) s_late_n = 0;
     // feedback for the window-span controller: the window's pieces are counted here, behind its walks, so that a snapshot of the counters
     // never holds a window's pieces without the followers among them (one writer per launch)
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->walked_pieces += wdp->n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt->walked_pieces += wdp->n; cnt->followers_seen = ld_agent((const uint64_t*)&cnt->followers); }
     __syncthreads();
     const unsigned long long n_noted = cnt->late_n[0] < FGPU_LATE_CAP ? cnt->late_n[0] : FGPU_LATE_CAP;
     if (n_noted) {
