@@ -18,7 +18,7 @@ starts = [i for i, r in enumerate(rows) if r[2] == "k_pair_join"]
 if len(starts) < back + 1:
     sys.exit("not enough steps in the trace")
 lo = starts[-back - 1]
-hi = starts[-back]
+hi = starts[-back] if back else len(rows)       # 0 = the last step of the trace, to its end
 step = rows[lo:hi]
 t0 = step[0][0]
 split = next(i for i, r in enumerate(step) if r[2] == "k_pair_split")        # load_end: pass 1 | pass 2
