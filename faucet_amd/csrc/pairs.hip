@@ -367,7 +367,9 @@ int fgpu_diag_long_pairs(fgpu_ctx* ctx, uint64_t out[6]) {
     for (int i = 0; i < 6; i++) out[i] = 0;
     if (!lp.mode) return FGPU_OK;
     unsigned long long c[3] = {0, 0, 0};
-    FGPU_HIP(hipMemcpy(c, lp.dev.p, sizeof(c), hipMemcpyDeviceToHost));
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    FGPU_HIP(hipMemcpyAsync(c, lp.dev.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));   // (behind the batches queued on the context's stream)
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
     out[0] = c[0] + c[1];   // items: first-end k-mers of read pairs with two non-empty lists
     out[1] = c[1];          // of those, paired against the filter as their batch found it
     out[2] = c[2];          // addPair calls
