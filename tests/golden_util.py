@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21", "mercy_k21", "nomercy_k21", "se_cleaning_k21"]
+CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21", "mercy_k21", "nomercy_k21", "se_cleaning_k21",
+         "pe_repeats_k25", "pe_fasta_highcov_k31"]      # (the last two: tests/golden/make_pairs_golden.py, round 4)
 
 
 def _gz(path):
@@ -45,7 +46,13 @@ class Case:
         self.paired = "--paired_ends" in a
         self.no_cleaning = "--no_cleaning" in a
         self.mercy = "--mercy" in a
+        self.high_cov = "--high_cov" in a
         self.counters = self.meta["counters"]
+
+    def pair_filter_elements(self):
+        """(short, long) element counts the reference sizes its pair filters from (src/Faucet.cpp:266-283)"""
+        E = self.E
+        return (E // 2, E // 2) if self.high_cov else (E // 10, E // 5) if self.mercy else (E // 20, E // 10)
 
     def reads_text(self) -> bytes:
         return _gz(os.path.join(self.dir, "reads.fq.gz" if self.fastq else "reads.fa.gz"))

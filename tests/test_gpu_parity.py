@@ -784,15 +784,18 @@ def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
     _scan_equals_oracle(ctx, sst, osc)
 
 
+@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31"])
 @pytest.mark.parametrize("batch_reads", [400, 333, 100000, 0])
-def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, tmp_path):
+def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, case, tmp_path):
     """BASELINE config 3's shape: --fastq --paired_ends WITHOUT --no_cleaning.  All four files the reference writes before
     its contig-graph stage are byte-identical (the long pair filter is check-then-insert, i.e. order-dependent); the
     program then stops with exit code 3 because that stage is not part of this build."""
     import os
     import subprocess
-    c = Case("pe_fastq_k21")
-    reads = tmp_path / "reads.fq"
+    # (round 4: pe_repeats_k25 -- repeats at high coverage, reads with N, truncated reads, records with an empty sequence line, which shift
+    # who is whose mate -- and pe_fasta_highcov_k31 -- FASTA, --high_cov filter sizes, an odd number of records: tests/golden/make_pairs_golden.py)
+    c = Case(case)
+    reads = tmp_path / ("reads.fq" if c.fastq else "reads.fa")
     reads.write_bytes(c.reads_text())
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
     how = ["-batch_reads", str(batch_reads)] if batch_reads else []      # 0: the default, records split on the device

@@ -97,10 +97,11 @@ def test_end_to_end_vs_reference(name):
 
     spf = lpf = None
     if not c.no_cleaning:
-        _, t_s, h_s = po.size_optimal(c.E // 20, np.float32(0.01))
+        n_short, n_long = c.pair_filter_elements()
+        _, t_s, h_s = po.size_optimal(n_short, np.float32(0.01))
         spf = po.Bloom(t_s, h_s)
         if c.paired:
-            _, t_l, h_l = po.size_optimal(c.E // 10, np.float32(0.01))
+            _, t_l, h_l = po.size_optimal(n_long, np.float32(0.01))
             lpf = po.Bloom(t_l, h_l)
     sc = po.Scanner(c.k, c.j, c.spacer, b2, spf, lpf)
     sc.scan_reads(bases, offs, paired_ends=c.paired, no_cleaning=c.no_cleaning)
