@@ -6,6 +6,8 @@ the long one as a fixed point of scanReads' check-then-insert loop, src/ReadScan
                         many read pairs: the order of checks and inserts decides the filter), with reads that hold N, truncated reads and
                         records whose sequence line is empty (each still toggles firstEnd: which reads are mates shifts behind them)
   pe_fasta_highcov_k31  interleaved FASTA (no --fastq), --high_cov (both pair filters sized from E / 2), k = 31, an odd number of records
+  pe_mercy_k21          interleaved FASTQ with --mercy (pass 1 adds low-coverage runs to bloo2; pair filters sized from E / 10 and E / 5)
+  pe_twohash_k27        interleaved FASTQ with --two_hash (the larger two-hash-function filters), reads of 150 bases
 The reference may crash in its contig-graph stage (tolerated): the four files are complete by then."""
 import os
 import sys
@@ -54,3 +56,17 @@ with tempfile.TemporaryDirectory() as td:
     write_records(p, lines, False)
     G.run_case("pe_fasta_highcov_k31", p, False, ["-size_kmer", "31", "-max_read_length", "120", "-estimated_kmers", "120000", "-singletons", "25000",
                                                   "--paired_ends", "--high_cov"], tolerate_crash=True)
+
+    g = synth.make_genome(6000, 71, repeats=3, repeat_len=180)
+    r = synth.make_pairs(g, 320, 100, 280, 25, 0.02, 72)              # 10x, 2 % errors: runs of low-coverage k-mers between solid ones
+    p = os.path.join(td, "pem.fq")
+    write_records(p, [bytes(x) for x in np.ascontiguousarray(r)], True)
+    G.run_case("pe_mercy_k21", p, True, ["-size_kmer", "21", "-max_read_length", "100", "-estimated_kmers", "100000", "-singletons", "20000",
+                                         "--fastq", "--paired_ends", "--mercy"], tolerate_crash=True)
+
+    g = synth.make_genome(8000, 81, repeats=5, repeat_len=260)
+    r = synth.make_pairs(g, 500, 150, 400, 40, 0.01, 82)
+    p = os.path.join(td, "pe2.fq")
+    write_records(p, [bytes(x) for x in np.ascontiguousarray(r)], True)
+    G.run_case("pe_twohash_k27", p, True, ["-size_kmer", "27", "-max_read_length", "150", "-estimated_kmers", "200000", "-singletons", "100000",
+                                           "--fastq", "--paired_ends", "--two_hash"], tolerate_crash=True)

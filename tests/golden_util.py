@@ -7,7 +7,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["c1_k21", "ragged_k31", "twohash_k31_L150", "j2_spacer20_k15", "j0_k15", "pe_fastq_k21", "mercy_k21", "nomercy_k21", "se_cleaning_k21",
-         "pe_repeats_k25", "pe_fasta_highcov_k31"]      # (the last two: tests/golden/make_pairs_golden.py, round 4)
+         "pe_repeats_k25", "pe_fasta_highcov_k31", "pe_mercy_k21", "pe_twohash_k27"]      # (the last four: tests/golden/make_pairs_golden.py, round 4)
 
 
 def _gz(path):

@@ -55,7 +55,7 @@ def run_both(linked, case, tmp_path, extra=()):
     return c, outs
 
 
-@pytest.mark.parametrize("case", ["se_cleaning_k21", "pe_fastq_k21", "c1_k21", "mercy_k21", "pe_repeats_k25", "pe_fasta_highcov_k31"])
+@pytest.mark.parametrize("case", ["se_cleaning_k21", "pe_fastq_k21", "c1_k21", "mercy_k21", "pe_repeats_k25", "pe_fasta_highcov_k31", "pe_mercy_k21", "pe_twohash_k27"])
 def test_reference_with_the_binding_linked_in_ends_like_the_pure_reference(linked, case, tmp_path):
     c, outs = run_both(linked, case, tmp_path)
     (rp, dp), (rb, db) = outs["pure"], outs["bound"]

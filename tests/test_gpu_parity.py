@@ -784,7 +784,7 @@ def test_empty_batch_between_full_ones_does_not_replay_recycled_buffers():
     _scan_equals_oracle(ctx, sst, osc)
 
 
-@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31"])
+@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31", "pe_mercy_k21", "pe_twohash_k27"])
 @pytest.mark.parametrize("batch_reads", [400, 333, 100000, 0])
 def test_cli_paired_end_run_writes_the_reference_pair_filters(batch_reads, case, tmp_path):
     """BASELINE config 3's shape: --fastq --paired_ends WITHOUT --no_cleaning.  All four files the reference writes before

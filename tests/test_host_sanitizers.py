@@ -41,7 +41,7 @@ def _check(r, want_rc):
     assert r.returncode == want_rc, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31"])
+@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31", "pe_mercy_k21", "pe_twohash_k27"])
 @pytest.mark.parametrize("extra", [[], ["-chunk_mb", "1"], ["-batch_reads", "333"]], ids=["chunks_64MB", "chunks_1MB", "host_getline"])
 def test_paired_end_fastq_with_cleaning_is_clean_and_equals_the_reference(cli, extra, case, tmp_path):
     exe, _ = cli
