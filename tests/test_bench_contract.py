@@ -60,3 +60,17 @@ def test_batch_bounds_cover_the_reads_once_in_order():
         assert max(hi - lo for lo, hi in b) <= batch
     sizes = [hi - lo for lo, hi in bench.batch_bounds(10_000_000, 1_000_000, 2)]
     assert sizes[:3] == [250_000, 250_000, 500_000] and sizes[-2:] == [500_000, 250_000] and sizes.count(1_000_000) == 8
+
+
+def test_design_md_quotes_the_committed_bench_line():
+    """DESIGN.md's number tables are printed from profiles/r04_bench_config2.json by scripts/design_tables.py (one number per
+    configuration, one source): every generated table row and summary line has to be in the document as it is printed today."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_tables.py"), os.path.join("profiles", "r04_bench_config2.json")],
+                         capture_output=True, text=True, cwd=ROOT, check=True).stdout
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    rows = [ln for ln in out.splitlines() if ln.strip() and not set(ln) <= set("|- ")]
+    assert len(rows) >= 12
+    missing = [ln for ln in rows if ln not in doc and ("* " + ln) not in doc]
+    assert not missing, missing
