@@ -22,7 +22,9 @@
 // pieces queue behind another piece of their cluster and is halved above a half.  Since the walk takes its in-map bits from the batch's
 // snapshot planes and registers the keys created since then per window (round 2), a window's fixed costs -- the delta registrations, five
 // launches -- weigh more than the longer clusters of a larger window: config 2 measured 131.3 / 127.0 / 126.0 ms per step at 2^24 / 2^25 /
-// 2^26 positions (16 % / 27 % / 36 % of the pieces queueing; round 1's look-up kernel per window had its optimum at 2^24).  The window
+// 2^26 positions (16 % / 27 % / 36 % of the pieces queueing; round 1's look-up kernel per window had its optimum at 2^24; round 4, with
+// dynamic cluster hand-out and no event brackets: 121.9 / 117.4 / 118.7 ms at 25 % / 43 % / 58 %).  How the size moves from batch to batch:
+// adapt_window (api.hip).  The window
 // tables are sized for the context's bound, FGPU_MAX_SPAN (2 GiB) for filters up to 2^30 bits, more for larger ones (fgpu_create).
 #define FGPU_USUAL_SPAN (1ULL << 26)
 #define FGPU_MAX_SPAN (1ULL << 26)
