@@ -1,0 +1,97 @@
+"""What one hop of the strong-scaling chain consists of, kernel by kernel: config 4 as N shards, the first two ranks' pass 2 executed in turn on one
+GPU exactly as scripts/project_strong.py does (rank 0 streams and shows its table after a quarter of its reads; rank 1 prepares on that preview,
+imports rank 0's table, walks), with the walk stage's kernels bracketed one by one (FGPU_PROFILE_WALK=1; the brackets cost a few per cent).
+    FGPU_PROFILE_WALK=1 python scripts/hop_kernels.py [N]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from faucet_amd import _lib as L  # noqa: E402
+from faucet_amd import api, sharded  # noqa: E402
+from faucet_amd import synth_det as sd  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fullsize.json")))["config4"]
+c = fx["params"]
+dev = torch.device("cuda", 0)
+tai, nh = api.load_filter_shape(c["E"], c["S"])
+genome = sd.make_genome(c["genome"], c["genome_seed"], dev)
+per = c["reads"] // N
+ctx = api.Context(c["k"], tai, nh, profile=True)
+b = sharded.GpuShard(ctx, dev, stream_ordered=False)
+
+
+def batches_of(r):
+    reads = sd.make_reads(genome, per, c["read_len"], c["err"], c["read_seed"], dev, first_row=r * per)
+    return reads, bench.device_batches(reads, bench.batch_bounds(per, 2_500_000, 2))
+
+
+def timed(name, fn):
+    ctx.kernel_times_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = 1e3 * (time.perf_counter() - t0)
+    kt = sorted(ctx.kernel_times().items(), key=lambda kv: -kv[1][1])[:12]
+    print(f"{name}: wall {dt:.1f} ms | " + ", ".join(f"{n} {cnt}x {ms:.1f}" for n, (cnt, ms) in kt), flush=True)
+    return out
+
+
+# pass 1 of the two shards the way the library does it (fix-up protocol where it can), so that bloo2 and the kept planes are a rank's own
+prefix = None
+b2 = None
+for r in (0, 1):
+    reads, batches = batches_of(r)
+    b.clear_filters()
+    b.load(batches, keep_carry=False, shard_times=True)
+    if r == 0:
+        prefix = b.bloom_tensor(L.BLOO1).clone()
+        b2 = b.bloom_tensor(L.BLOO2).clone()
+    else:
+        b.load_fixup(prefix)
+        b2 |= b.bloom_tensor(L.BLOO2)
+    del reads, batches
+hint = [None]
+reads0, batches0 = batches_of(0)
+b.clear_filters()
+b.load(batches0, keep_carry=False, shard_times=True)
+b.bloom_tensor(L.BLOO2).copy_(b2)
+ctx.synchronize()
+b.scan_begin()
+done, marks = 0, []
+for x in batches0:
+    done += x.n_reads
+    marks.append(done >= sharded.HINT_AFTER * per)
+hi = marks.index(True)
+
+
+def show(i):
+    if hint[0] is None and i >= hi:
+        n, buf = b.export_table(tag="hint")
+        hint[0] = (buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n)
+
+
+stats0 = timed("rank 0: streaming scan of its shard", lambda: b.scan_stream(batches0, after_batch=show))
+n0, buf0 = b.export_table()
+table0 = buf0[:max(n0, 1) * L.TABLE_ENTRY_BYTES].clone()
+del reads0, batches0
+reads1, batches1 = batches_of(1)
+b.clear_filters()
+b.load(batches1, keep_carry=False, shard_times=True)
+b.load_fixup(prefix)
+b.bloom_tensor(L.BLOO2).copy_(b2)
+ctx.synchronize()
+for rep in range(2):
+    b.scan_begin()
+    b.import_hint(hint[0][0], hint[0][1])
+    timed("rank 1: pure stage on the preview", lambda: [b.scan_prepare(x) for x in batches1])
+    carried = {n: int(stats0[n]) for n in sharded._STAT_NAMES}
+    timed(f"rank 1: import of {n0} records + walk of the prepared shard (the hop)", lambda: b.walk_shard(batches1, table0, n0, carried))
+    timed("rank 1: export", lambda: b.export_table())
