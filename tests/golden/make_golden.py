@@ -63,14 +63,14 @@ def ragged_fasta(path, reads, lens, extra_lines=()):
             f.write(ln)
 
 
-def run_case(name, reads_path, fastq, args, tolerate_crash=False):
-    out = os.path.join(HERE, name)
+def run_case(name, reads_path, fastq, args, tolerate_crash=False, out_root=None):
+    out = os.path.join(out_root or HERE, name)
     os.makedirs(out, exist_ok=True)
     with tempfile.TemporaryDirectory() as td:
         inp = os.path.join(td, "reads.fq" if fastq else "reads.fa")
         shutil.copy(reads_path, inp)
         cmd = [REF_BIN, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", os.path.join(td, "out")] + args
-        p = subprocess.run(["stdbuf", "-o0"] + cmd, capture_output=True, text=True, errors="replace")
+        p = subprocess.run(["stdbuf", "-o0"] + cmd, capture_output=True, text=True, errors="replace", timeout=600)
         if p.returncode != 0 and not tolerate_crash:
             raise RuntimeError(f"{name}: reference exit {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}")
         text = p.stdout
@@ -96,7 +96,8 @@ def run_case(name, reads_path, fastq, args, tolerate_crash=False):
         with open(os.path.join(out, "case.json"), "w") as f:
             json.dump({"name": name, "fastq": fastq, "args": args, "ref_exit": p.returncode, "counters": counters}, f, indent=1)
             f.write("\n")
-    print(name, counters)
+    if out_root is None:
+        print(name, counters)
 
 
 def main():

@@ -27,8 +27,8 @@ def kat(kind):
 
 class Case:
     def __init__(self, name):
-        self.name = name
-        self.dir = os.path.join(GOLDEN, name)
+        self.name = os.path.basename(name)
+        self.dir = name if os.path.isabs(name) else os.path.join(GOLDEN, name)     # (an absolute path: a case made on the spot, same layout)
         with open(os.path.join(self.dir, "case.json")) as f:
             self.meta = json.load(f)
         a = self.meta["args"]

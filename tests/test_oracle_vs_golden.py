@@ -80,9 +80,10 @@ def test_readscan_kats(d):
     assert got == d["junctions"]          # same std::unordered_map, same insertion order -> same iteration order
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_end_to_end_vs_reference(name):
-    c = Case(name)
+def check_oracle_against_case(c):
+    """the oracle's load + scan on the case's reads against everything the compiled reference left of its run: counters it printed, .bloom,
+    .junctions (byte order included), both pair filters"""
+
     bases, offs = po.reads_from_lines(c.lines())
     tai, nh, p1, bits = po.sizing_from_cli(c.E, c.S)
     assert f"{p1:.6g}" == c.counters["p1"]
@@ -126,6 +127,11 @@ def test_end_to_end_vs_reference(name):
         assert np.array_equal(spf.bits(), c.pair_filter("short"))
     if lpf is not None:
         assert np.array_equal(lpf.bits(), c.pair_filter("long"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_end_to_end_vs_reference(name):
+    check_oracle_against_case(Case(name))
 
 
 def test_file_reader_matches_line_splitter(tmp_path):
