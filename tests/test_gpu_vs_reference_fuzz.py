@@ -1,0 +1,44 @@
+"""The PRODUCT against the COMPILED REFERENCE, no oracle in between (GPU box; the reference binary built in the build container travels with the
+tree as test infrastructure): the `faucet` command line and oracle/_ref/faucet_ref run on the same random input -- the runs
+of tests/test_oracle_vs_reference_fuzz.py::random_run -- and every file both write (.bloom, .junctions in dump order, .short_pair_filter,
+.long_pair_filter) has to be the same bytes, and the scan's counters on stdout the same numbers."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "faucet_ref")
+EXE = os.path.join(ROOT, "faucet_amd", "faucet")
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/faucet_ref was not built (make -C oracle ref)")]
+
+LINES = ("Distinct junctions:", "Number of kmers that we j-checked:", "Number of reads with no junctions:", "Number of processed kmers:",
+         "Number of skipped kmers:", "Reads without errors:", "Empty count:", "Reads processed:", "Unambiguous reads:", "Weights after load:")
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
+    from tests.test_oracle_vs_reference_fuzz import random_run
+    path, fastq, args = random_run(seed, tmp_path)
+    outs = {}
+    for tag, exe in (("ref", REF_BIN), ("gpu", EXE)):
+        d = tmp_path / tag
+        d.mkdir()
+        # (unbuffered stdout: the reference may crash in its contig-graph stage, after the files and the counters this test is about)
+        r = subprocess.run(["stdbuf", "-o0", exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", str(d / "out")] + args,
+                           capture_output=True, text=True, errors="replace", timeout=600)
+        outs[tag] = (r, d)
+    (rr, dr), (rg, dg) = outs["ref"], outs["gpu"]
+    assert rg.returncode == (0 if "--no_cleaning" in args else 3), rg.stderr[-2000:]      # (the reference goes on into its contig graph and may crash there)
+    mine = sorted(os.listdir(dg))
+    assert any(f.endswith(".bloom") for f in mine) and any(f.endswith(".junctions") for f in mine)
+    for f in mine:                                   # every file this build writes, the reference wrote too, with the same bytes
+        assert os.path.exists(dr / f), f
+        assert (dg / f).read_bytes() == (dr / f).read_bytes(), f
+    for line in LINES:
+        want = [ln.strip() for ln in rr.stdout.splitlines() if ln.startswith(line)]
+        got = [ln.strip() for ln in rg.stdout.splitlines() if ln.startswith(line)]
+        assert want == got, (line, want, got)
+    assert re.search(r"Distinct junctions: \d+", rg.stdout)

@@ -26,12 +26,9 @@ def _write(path, lines, fastq):
                 f.write(b">r%d\n" % i + s + b"\n")
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_oracle_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
-    import make_golden as G
+def random_run(seed, tmp_path):
+    """(path of the reads file, fastq, arguments) of a run drawn from `seed`"""
     from faucet_amd import synth
-    from tests.golden_util import Case
-    from tests.test_oracle_vs_golden import check_oracle_against_case
     rng = np.random.default_rng(9000 + seed)
     k = int(rng.choice([15, 21, 25, 31]))
     rl = int(rng.choice([60, 100, 150]))
@@ -76,5 +73,14 @@ def test_oracle_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
         args += ["-max_spacer_dist", str(int(rng.choice([5, 20, 60])))]
     path = str(tmp_path / ("in.fq" if fastq else "in.fa"))
     _write(path, lines, fastq)
+    return path, fastq, args
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_oracle_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
+    import make_golden as G
+    from tests.golden_util import Case
+    from tests.test_oracle_vs_golden import check_oracle_against_case
+    path, fastq, args = random_run(seed, tmp_path)
     G.run_case("case", path, fastq, args, tolerate_crash=True, out_root=str(tmp_path))
     check_oracle_against_case(Case(str(tmp_path / "case")))
