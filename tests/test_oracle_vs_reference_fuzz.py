@@ -30,7 +30,7 @@ def random_run(seed, tmp_path):
     """(path of the reads file, fastq, arguments) of a run drawn from `seed`"""
     from faucet_amd import synth
     rng = np.random.default_rng(9000 + seed)
-    k = int(rng.choice([15, 21, 25, 31]))
+    k = int(os.environ.get("FUZZ_K") or rng.choice([15, 21, 25, 31]))       # (FUZZ_K: scripts that draw other k, e.g. even ones)
     rl = int(rng.choice([60, 100, 150]))
     G_ = int(rng.integers(2000, 9000))
     g = synth.make_genome(G_, seed, repeats=int(rng.integers(0, 6)), repeat_len=int(min(G_ // 5, rng.integers(2 * k, 10 * k))))
