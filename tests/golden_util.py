@@ -42,6 +42,7 @@ class Case:
         self.S = opt("-singletons")
         self.j = opt("-j", 1)
         self.spacer = opt("-max_spacer_dist", 100)
+        self.fp = opt("-fp", 0.04, float)
         self.max_read_length = opt("-max_read_length")
         self.paired = "--paired_ends" in a
         self.no_cleaning = "--no_cleaning" in a

@@ -85,7 +85,7 @@ def check_oracle_against_case(c):
     .junctions (byte order included), both pair filters"""
 
     bases, offs = po.reads_from_lines(c.lines())
-    tai, nh, p1, bits = po.sizing_from_cli(c.E, c.S)
+    tai, nh, p1, bits = po.sizing_from_cli(c.E, c.S, c.fp)
     assert f"{p1:.6g}" == c.counters["p1"]
     assert bits == c.counters["bits_per_kmer"] and nh == c.counters["n_hash"]
     b1, b2 = po.Bloom(tai, nh), po.Bloom(tai, nh)

@@ -71,6 +71,11 @@ def random_run(seed, tmp_path):
         args += ["-j", str(int(rng.integers(0, 3)))]
     if rng.integers(0, 3) == 0:
         args += ["-max_spacer_dist", str(int(rng.choice([5, 20, 60])))]
+    if os.environ.get("FUZZ_MORE_FLAGS"):        # (drawn behind everything else, so that the seeds of the suite keep their runs)
+        if rng.integers(0, 3) == 0:
+            args.append("--two_hash")            # sizes a filter restarted from a .bloom file; from reads it must not change anything
+        if rng.integers(0, 3) == 0:
+            args += ["-fp", str(float(rng.choice([0.02, 0.05, 0.1])))]
     path = str(tmp_path / ("in.fq" if fastq else "in.fa"))
     _write(path, lines, fastq)
     return path, fastq, args
