@@ -608,7 +608,12 @@ int main(int argc, char** argv) {
         printf("loading bloom filter from file, nelem %llu \n", (unsigned long long)(tai / 8));
         size_t got = fread(bloom_bytes.data(), 1, bloom_bytes.size(), f);
         fclose(f);
-        if (got != bloom_bytes.size()) { fprintf(stderr, "%s is not %llu bytes\n", o.bloom_input_file.c_str(), (unsigned long long)(tai / 8)); return 2; }
+        // Bloom::load (utils/Bloom.cpp:580-587) reads as many bytes as the filter it has just sized holds and does not look at fread's
+        // count: a longer file gives its head, a shorter one leaves the rest of the (zeroed) filter empty -- e.g. the .bloom of a run that
+        // loaded from reads (sized with p1) restarted with the sizes -fp implies.  Same here; a note on stderr is all that is added.
+        if (got != bloom_bytes.size())
+            fprintf(stderr, "note: %s holds %llu of the %llu bytes this run's filter has: the rest stays empty (as in the reference)\n",
+                    o.bloom_input_file.c_str(), (unsigned long long)got, (unsigned long long)(tai / 8));
         CHECK(fgpu_bloom_upload(ctx, FGPU_BLOO2, bloom_bytes.data(), bloom_bytes.size()));
         printf("bloom loaded\n");
     } else {
