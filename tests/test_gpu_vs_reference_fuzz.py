@@ -87,3 +87,40 @@ def restart_modes_differences(seed, tmp):
 @pytest.mark.parametrize("seed", range(5000, 5006))
 def test_restart_modes_equal_the_compiled_reference(seed, tmp_path):
     assert restart_modes_differences(seed, tmp_path) == []
+
+
+BOUND = os.path.join(ROOT, "oracle", "_ref", "faucet_ref_gpu")
+
+
+def binding_differences(seed, tmp):
+    """the compiled reference with integration/faucet_binding.cpp linked in (its two hot-path call sites on libfaucet_gpu.so, everything else --
+    the contig graph included -- the reference as compiled) against the pure reference on a random run: [] if exit status and every file,
+    contig files included, are the same"""
+    from tests.test_gpu_binding import normalised
+    from tests.test_oracle_vs_reference_fuzz import random_run
+    path, fastq, args = random_run(seed, tmp)
+    res = {}
+    for tag, exe in (("ref", REF_BIN), ("bound", BOUND)):
+        (tmp / tag).mkdir()
+        res[tag] = subprocess.run(["stdbuf", "-o0", exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", str(tmp / tag / "out")] + args,
+                                  capture_output=True, text=True, errors="replace", timeout=600)
+    rr, rb = res["ref"], res["bound"]
+    fr, fb = sorted(os.listdir(tmp / "ref")), sorted(os.listdir(tmp / "bound"))
+    notes = []
+    if rr.returncode != rb.returncode:
+        notes.append(("exit", rr.returncode, rb.returncode, rb.stderr[-200:]))
+    if fr != fb:
+        notes.append(("files", fr, fb))
+    for f in fb:
+        if f in fr:
+            x, y = normalised(str(tmp / "bound" / f)), normalised(str(tmp / "ref" / f))
+            if x != y and not (rr.returncode < 0 and (x[:len(y)] == y or y[:len(x)] == x)):     # (a crash in the contig graph cuts the file being written)
+                notes.append((f, len(x), len(y)))
+    return notes, rr.returncode
+
+
+@pytest.mark.skipif(not os.path.exists(BOUND), reason="oracle/_ref/faucet_ref_gpu was not built (make -C oracle ref_gpu)")
+@pytest.mark.parametrize("seed", range(7000, 7006))
+def test_linked_binding_ends_like_the_pure_reference_on_a_random_run(seed, tmp_path):
+    notes, _ = binding_differences(seed, tmp_path)
+    assert notes == []
