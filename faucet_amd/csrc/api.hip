@@ -595,6 +595,8 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->adapt_pieces = 0;
     ctx->adapt_overflows = 0;
     ctx->adapt_vote = 0;
+    ctx->calib_ovf = 0;
+    ctx->span_ceiling = ~0ULL;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     ctx->scan_batch_seq = 0;
@@ -628,7 +630,7 @@ static void adapt_window(fgpu_ctx* ctx) {
     const uint64_t p = ctx->counters_host->walked_pieces - ctx->adapt_pieces;
     if (p == 0 || ctx->prm.walk_window_span) return;      // (no window has been completed since the last look at the counters)
     {
-        const uint64_t usual = std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN);
+        const uint64_t usual = std::min<uint64_t>(std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN), ctx->span_ceiling);
         int want = 0;             // -1 smaller, +1 larger
         bool clear = false;
         if (f * 2 > p) { want = -1; clear = f * 5 > p * 4; }
@@ -642,6 +644,8 @@ static void adapt_window(fgpu_ctx* ctx) {
             // far too large a window for this data
             ctx->window_span = std::max<uint64_t>(4096, ctx->window_span / 4);
             ctx->proven_span = std::min(ctx->proven_span, ctx->window_span);
+            ctx->span_ceiling = std::min(ctx->span_ceiling, ctx->window_span * 2);     // (this scan does not grow to that size again)
+            ctx->calib_ovf = ctx->counters_host->ko_overflows;
             ctx->calib_left = 0;
         }
         else if (act && want < 0 && ctx->window_span > 4096) {
@@ -657,7 +661,7 @@ static void adapt_window(fgpu_ctx* ctx) {
             ctx->window_span = std::min<uint64_t>(ctx->window_span * 2, usual);
             if (ctx->window_span > ctx->proven_span) ctx->calib_left = std::max(ctx->calib_left, 2);
         }
-        else if (f * 16 < p && ctx->window_span < ctx->max_span) ctx->window_span *= 2;   // thin coverage per window: see FGPU_MAX_SPAN
+        else if (f * 16 < p && ctx->window_span < std::min<uint64_t>(ctx->max_span, ctx->span_ceiling)) ctx->window_span *= 2;   // thin coverage per window: see FGPU_MAX_SPAN
     }
     if (dbg_span) fprintf(stderr, "[span] batch: followers %llu of %llu pieces -> span %llu, looks %d, vote %d\n", (unsigned long long)f, (unsigned long long)p,
                           (unsigned long long)ctx->window_span, ctx->calib_left, ctx->adapt_vote);
@@ -805,6 +809,8 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->calib_f = ctx->calib_p = 0;
     ctx->adapt_followers = ctx->adapt_pieces = ctx->adapt_overflows = 0;
     ctx->adapt_vote = 0;
+    ctx->calib_ovf = 0;
+    ctx->span_ceiling = ~0ULL;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     memset(&ctx->carried, 0, sizeof(ctx->carried));

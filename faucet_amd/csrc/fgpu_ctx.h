@@ -274,6 +274,8 @@ struct fgpu_ctx {
 
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // FGPU_DEBUG_HOST=1: where the host thread of a scan spends its time (see fgpu_scan_end)
+    uint64_t calib_ovf = 0;            // ko_overflows as of the last look (a window whose large clusters outgrew the large-cluster walks' tables)
+    uint64_t span_ceiling = ~0ULL;     // a size at which that happened in this scan: the windows do not grow to it again
     int adapt_vote = 0;                // what the last batch's counters asked for without getting it yet (-1 smaller, +1 larger)
     uint64_t proven_span = 0;          // largest window size a batch of this context was walked at without most pieces queueing
     uint64_t adapt_overflows = 0;

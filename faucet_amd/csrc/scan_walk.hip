@@ -2346,6 +2346,9 @@ __global__ void __launch_bounds__(64) k_ovw_commit(Planes pl, FdParams fp, JTabl
         if (v[6]) { atomicAdd(&cnt->walk_parallel, v[6]); atomicAdd(&cnt->ovw[0], v[6]); }
         if (v[7]) { atomicAdd(&cnt->ovw[1], v[7]); atomicAdd(&cnt->ovw[2], 1ULL); }
         if (blockIdx.x == 0 && settled < 0 && kt.state[3]) atomicAdd(&cnt->ovw[3], 1ULL);   // a window left to the key-ordered walk
+        // ... because its large clusters outgrew the optimistic walk's tables: a sign of far too large a window, like the key-ordered walk's own
+        // overflow (the window-size controller reads ko_overflows; the pieces of these walks do not show as followers)
+        if (blockIdx.x == 0 && settled < 0 && kt.state[3] && ot.state[1]) atomicAdd(&cnt->ko_overflows, 1ULL);
     }
 }
 
@@ -3189,16 +3192,33 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         if (ctx->calib_left > 0 && !ctx->prm.walk_window_span) {
             FGPU_HIP(hipMemcpyAsync(ctx->fb_host, &ctx->counters->followers, 8, hipMemcpyDeviceToHost, walk_stream));
             FGPU_HIP(hipMemcpyAsync(ctx->fb_host + 1, &ctx->counters->walked_pieces, 8, hipMemcpyDeviceToHost, walk_stream));
+            FGPU_HIP(hipMemcpyAsync(ctx->fb_host + 2, &ctx->counters->ko_overflows, 8, hipMemcpyDeviceToHost, walk_stream));
             FGPU_HIP(hipStreamSynchronize(walk_stream));
             const uint64_t f = ctx->fb_host[0] - ctx->calib_f, p = ctx->fb_host[1] - ctx->calib_p;
+            if (ctx->fb_host[2] > ctx->calib_ovf && span_now > 4096) {
+                // the window's large clusters outgrew the tables of the large-cluster walks (their pieces do not queue, so the share of
+                // followers says nothing about them) and were walked by one thread each: far too large a window for this data -- a quarter,
+                // and the next windows are looked at as well (round 4: read pairs inside repeats at 600x, a 36 MB file whose windows grew to
+                // 2^23 positions within its three batches: pass 2 2.0 s, 0.8 s with windows of 2^20)
+                ctx->calib_ovf = ctx->fb_host[2];
+                ctx->calib_f = ctx->fb_host[0];
+                ctx->calib_p = ctx->fb_host[1];
+                span_now = std::max<uint64_t>(4096, span_now / 4);
+                ctx->proven_span = std::min(ctx->proven_span, span_now);
+                ctx->calib_left = std::max(ctx->calib_left, 4);
+                ctx->span_ceiling = std::min(ctx->span_ceiling, span_now * 2);     // (this scan does not grow to that size again)
+                static const bool dbg_span_o = getenv("FGPU_DEBUG_SPAN") != nullptr;
+                if (dbg_span_o) fprintf(stderr, "[span] look: the large-cluster walks' tables overflowed -> span %llu, looks left %d\n", (unsigned long long)span_now, ctx->calib_left);
+            } else
             if (p >= 64) {
                 ctx->calib_f = ctx->fb_host[0];
                 ctx->calib_p = ctx->fb_host[1];
                 bool shrunk = false;
                 if (f * 2 > p && span_now > 4096) { span_now /= 2; shrunk = true; }
-                else if (f * 3 < p && span_now < std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN))
-                    span_now = std::min<uint64_t>(span_now * 4, std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN));
-                else if (f * 16 < p && span_now < ctx->max_span) span_now = std::min<uint64_t>(span_now * 4, ctx->max_span);
+                else if (f * 3 < p && span_now < std::min<uint64_t>(std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN), ctx->span_ceiling))
+                    span_now = std::min<uint64_t>(span_now * 4, std::min<uint64_t>(std::min<uint64_t>(ctx->max_span, FGPU_USUAL_SPAN), ctx->span_ceiling));
+                else if (f * 16 < p && span_now < std::min<uint64_t>(ctx->max_span, ctx->span_ceiling))
+                    span_now = std::min<uint64_t>(span_now * 4, std::min<uint64_t>(ctx->max_span, ctx->span_ceiling));
                 else ctx->calib_left = 1;          // settled
                 ctx->calib_left--;
                 // waiting for a window keeps the host from feeding the pure stage of the next batch: worth it while windows are small
