@@ -3069,7 +3069,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                                                ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
         OvwTables ot;
         memset(&ot, 0, sizeof(ot));
-        constexpr int kEvLog2 = 21, kFiltLog2 = 22, kMarkLog2 = 20;
+        constexpr int kEvLog2 = 23, kFiltLog2 = 24, kMarkLog2 = 22;
         const uint32_t filt_words = 1u << (kFiltLog2 - 5);
         const uint32_t list_cap = (uint32_t)std::min<uint64_t>(ctx->wmax, 1u << 20);
         uint32_t* ovw_filt = nullptr;
