@@ -110,6 +110,7 @@ int handle_arguments(int argc, char** argv, Options& o) {
     else if (o.from_bloom) printf("Starting from after bloom load based on bloom file.\n");
     else printf("Starting at the beginning: will load bloom and find junctions from the read set.\n");
     if (o.just_load) printf("Only loading bloom, dumping and termination.\n");
+    printf(o.node_graph ? "Using node graph.\n" : "Using contig graph.\n");          // src/Faucet.cpp:146-149 (a switch of the stage this build stops before)
     printf("Read load file name: %s\n", o.read_load_file.c_str());
     printf("Read scan file name: %s\n", o.read_scan_file.c_str());
     printf("k: %d \n", o.k);
@@ -120,6 +121,9 @@ int handle_arguments(int argc, char** argv, Options& o) {
     printf("Max spacer dist: %d\n", o.max_spacer_dist);
     printf(o.two_hash ? "Using 2 hash functions.\n" : "Using space-optimal hash settings.\n");
     printf("Paired ends: %d\n", (int)o.paired_ends);
+    // src/Faucet.cpp:177-181 prints sizeof(Junction / ContigNode / Contig / int / long) of ITS build: the reference's values on x86-64 Linux,
+    // so that what a caller greps or diffs in the log stays where it is
+    printf("Size of junction: 14\nSize of contigNode: 48\nSize of contig: 104\nSize of int: 4\nSize of long: 8\n");
     return 0;
 }
 
@@ -793,14 +797,28 @@ int main(int argc, char** argv) {
             for (const auto& kv : container) order.push_back(kv.second);
         }
         clk.mark("  dump order");
+        // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596) first counts the junctions that are solid at thresholds 0..4
+        // (Junction::isSolid, utils/Junction.cpp:38-46: more than one of the four extensions with that much coverage)
+        for (int thr = 0; thr < 5; thr++) {
+            long solid = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                int paths = 0;
+                for (int e = 0; e < 4; e++) paths += recs[i].cov[e] >= thr ? 1 : 0;
+                solid += paths > 1 ? 1 : 0;
+            }
+            printf("There are %ld junctions with solidity at least %d.\n", solid, thr);
+        }
         printf("Writing to junction file\n");
         if (int rc = write_junctions(o.file_prefix + ".junctions", keys.data(), recs.data(), order, o.k)) return rc;
         printf("Done writing to junction file\n");
         clk.mark("junction download + dump");
         if (!o.no_cleaning) {   // src/Faucet.cpp:297-300
             if (int rc = short_pf.dump(o.file_prefix + ".short_pair_filter")) return rc;
-            if (o.paired_ends)
+            printf("bloom dumped \n");                                   // (Bloom::dump's line, utils/Bloom.cpp:571-578: once per filter written)
+            if (o.paired_ends) {
                 if (int rc = long_pf.dump(o.file_prefix + ".long_pair_filter")) return rc;
+                printf("bloom dumped \n");
+            }
         }
         printf("Weight of short pair filter: %f\n", short_pf.weight());
         if (o.paired_ends) printf("Weight of long pair filter: %f\n", long_pf.weight());

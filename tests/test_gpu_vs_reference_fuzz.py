@@ -18,6 +18,19 @@ LINES = ("Distinct junctions:", "Number of kmers that we j-checked:", "Number of
          "Number of skipped kmers:", "Reads without errors:", "Empty count:", "Reads processed:", "Unambiguous reads:", "Weights after load:")
 
 
+def stdout_lines(text):
+    """stdout without the progress lines and with the numbers of wall-clock lines blanked"""
+    out = []
+    for ln in text.replace("\r", "\n").splitlines():
+        ln = ln.rstrip()
+        if not ln or ln.startswith("reads consumed") or ln.startswith("reads scanned"):
+            continue
+        if re.search(r"Time|time|seconds", ln):
+            ln = re.sub(r"[0-9.]+", "#", ln)
+        out.append(ln)
+    return out
+
+
 @pytest.mark.parametrize("seed", range(100, 112))
 def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
     from tests.test_oracle_vs_reference_fuzz import random_run
@@ -42,6 +55,11 @@ def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
         got = [ln.strip() for ln in rg.stdout.splitlines() if ln.startswith(line)]
         assert want == got, (line, want, got)
     assert re.search(r"Distinct junctions: \d+", rg.stdout)
+    # ... and the log as a whole: what the command line prints is, line for line, what the reference prints up to the point where its
+    # contig-graph stage begins (wall-clock numbers and the progress lines aside; the output prefix differs by construction)
+    a = [ln.replace(str(dr), "<prefix>") for ln in stdout_lines(rr.stdout)]
+    b = [ln.replace(str(dg), "<prefix>") for ln in stdout_lines(rg.stdout)]
+    assert b and b[-1].startswith("Number of junctions:") and a[:len(b)] == b, [x for x in zip(a, b) if x[0] != x[1]][:5]
 
 
 def _same_files(da, db, crashed):
