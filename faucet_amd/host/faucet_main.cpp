@@ -489,13 +489,17 @@ long read_junctions(const std::string& path, int k, JunctionTable& map) {
     return n_lines;
 }
 
-int load_pair_filter(PairFilter& pf, const std::string& path) {   // Bloom::load (utils/Bloom.cpp:580-587), with the size checked
+int load_pair_filter(PairFilter& pf, const std::string& path) {   // Bloom::load (utils/Bloom.cpp:580-587): what fits is taken, like -bloom_file
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); return 2; }
+    printf("loading bloom filter from file, nelem %llu \n", (unsigned long long)pf.bits.size());
     const size_t got = fread(pf.bits.data(), 1, pf.bits.size(), f);
     const bool more = fgetc(f) != EOF;
     fclose(f);
-    if (got != pf.bits.size() || more) { fprintf(stderr, "%s is not %llu bytes\n", path.c_str(), (unsigned long long)pf.bits.size()); return 2; }
+    if (got != pf.bits.size() || more)
+        fprintf(stderr, "note: %s is not of the %llu bytes this run's filter has: its head is taken, what it does not cover stays empty (as in the reference)\n",
+                path.c_str(), (unsigned long long)pf.bits.size());
+    printf("bloom loaded\n");
     return 0;
 }
 
@@ -528,7 +532,13 @@ int main(int argc, char** argv) {
     if (o.from_bloom) {
         if (o.two_hash) fgpu_size_two_hash(o.estimated_kmers, o.fp_rate, &bits, &tai, &n_hash);
         else fgpu_size_optimal(o.estimated_kmers, o.fp_rate, &bits, &tai, &n_hash);
-        printf("Bits per kmer: %d \n", bits);
+        printf("Bits per kmer: %d \n", bits);                       // create_bloom_filter_2_hash / _optimal, utils/Bloom.cpp:204-247
+        if (o.two_hash) {
+            printf("Estimated items: %llu \n", (unsigned long long)o.estimated_kmers);
+            printf("Estimated bloom size: %llu .\n", (unsigned long long)(o.estimated_kmers * (uint64_t)bits));
+        }
+        printf("BF memory: %f MB\n", (float)((o.estimated_kmers * (uint64_t)bits) / 8ULL / 1024ULL) / 1024);
+        printf("Number of hash functions: %d \n", n_hash);
     } else {
         int32_t iters = 0;
         double p1 = fgpu_solve_p1(o.estimated_kmers, o.singletons, o.fp_rate, &iters);

@@ -533,13 +533,13 @@ def test_cli_restarts_from_junction_files_like_the_reference(tmp_path):
             continue
         assert line in r.stdout, line
     assert not (tmp_path / "again.junctions").exists()
-    # without -bloom_file the reference refuses (exit code 1); a truncated pair filter is an error here (the reference would half-read it)
+    # without -bloom_file the reference refuses (exit code 1); a truncated pair filter is half-read as the reference half-reads it
     r = subprocess.run([exe, "-read_load_file", "u", "-read_scan_file", "u", "-file_prefix", "x", "-junctions_file", str(tmp_path / "pe")] + meta["args"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Cannot start from junctions without a bloom file." in r.stderr
-    (tmp_path / "pe.long_pair_filter").write_bytes(b"\0" * 100)
+    (tmp_path / "pe.long_pair_filter").write_bytes(b"\0" * 100)           # (taken the way Bloom::load takes it since round 4: what fits, the rest empty)
     r = subprocess.run(base + ["-junctions_file", str(tmp_path / "pe")] + meta["args"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 2
+    assert r.returncode == 3 and "is not of the" in r.stderr
 
 
 @pytest.mark.parametrize("force_lazy_fail", [False, True])

@@ -84,7 +84,10 @@ def restart_modes_differences(seed, tmp):
     args = [a for a in args if a != "--two_hash"]
     io = ["-read_load_file", path, "-read_scan_file", path]
     notes = []
-    for mode in ("just_load", "bloom_file", "bloom_file_two_hash", "node_graph"):
+    modes = ["just_load", "bloom_file", "bloom_file_two_hash", "node_graph"]
+    if "--paired_ends" in args and "--no_cleaning" not in args:
+        modes.append("junctions_file")       # (needs all three files of a run with cleaning; the reference loads both pair filters whatever the flags)
+    for mode in modes:
         d = {tag: str(tmp / f"{mode}_{tag}") for tag in ("ref", "gpu")}
         for v in d.values():
             os.mkdir(v)
@@ -92,12 +95,18 @@ def restart_modes_differences(seed, tmp):
             extra = ["--just_load_bloom"]
         elif mode.startswith("bloom_file"):
             extra = ["-bloom_file", str(tmp / "just_load_ref" / "out.bloom")] + (["--two_hash"] if mode.endswith("two_hash") else [])
+        elif mode == "junctions_file":
+            extra = ["-bloom_file", str(tmp / "just_load_ref" / "out.bloom"), "-junctions_file", str(tmp / "node_graph_ref" / "out")]
         else:
             extra = ["--node_graph"]
         r = {tag: subprocess.run(["stdbuf", "-o0", exe] + io + ["-file_prefix", os.path.join(d[tag], "out")] + args + extra,
                                  capture_output=True, text=True, errors="replace", timeout=600) for tag, exe in (("ref", REF_BIN), ("gpu", EXE))}
         diff = _same_files(d["gpu"], d["ref"], r["ref"].returncode < 0)
-        if diff or r["gpu"].returncode not in (0, 3) or not os.listdir(d["gpu"]):
+        a = [ln.replace(d["ref"], "<prefix>") for ln in stdout_lines(r["ref"].stdout)]
+        b = [ln.replace(d["gpu"], "<prefix>") for ln in stdout_lines(r["gpu"].stdout)]
+        if a[:len(b)] != b:                  # the log, line for line, up to where the reference's contig-graph stage begins
+            diff.append(("stdout", [x for x in zip(a, b) if x[0] != x[1]][:3]))
+        if diff or r["gpu"].returncode not in (0, 3) or (mode != "junctions_file" and not os.listdir(d["gpu"])):
             notes.append((mode, diff, r["gpu"].returncode, r["ref"].returncode, r["gpu"].stderr[-200:]))
     return notes
 
