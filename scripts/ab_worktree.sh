@@ -1,5 +1,7 @@
 #!/bin/bash
 # ON THE GPU BOX: the tree against a second build of an earlier commit kept under ab_old/ (git worktree, not tracked), same box, alternating.
+#   in the build container first:  git worktree add -f ab_old <commit> && echo ab_old/ >> .git/info/exclude && (cd ab_old && python -m faucet_amd.build && make -C oracle)
+#   afterwards:                    git worktree remove --force ab_old
 #   full-size legs included: configs 2, 5, 4 and the CLI legs from one bench run each
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 show() {
