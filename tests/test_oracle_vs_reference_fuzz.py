@@ -71,6 +71,8 @@ def random_run(seed, tmp_path):
         args += ["-j", str(int(rng.integers(0, 3)))]
     if rng.integers(0, 3) == 0:
         args += ["-max_spacer_dist", str(int(rng.choice([5, 20, 60])))]
+    if os.environ.get("FUZZ_J"):                 # (scripts: larger j than the draws above take)
+        args = [a for i, a in enumerate(args) if a != "-j" and (i == 0 or args[i - 1] != "-j")] + ["-j", os.environ["FUZZ_J"]]
     if os.environ.get("FUZZ_MORE_FLAGS"):        # (drawn behind everything else, so that the seeds of the suite keep their runs)
         if rng.integers(0, 3) == 0:
             args.append("--two_hash")            # sizes a filter restarted from a .bloom file; from reads it must not change anything
