@@ -84,6 +84,7 @@ SIGNATURES = {
     "fgpu_bitmap_or": (C.c_int, [_vp, _vp, _vp, _u64]),
     "fgpu_host_alloc": (_vp, [_u64]),
     "fgpu_host_free": (None, [_vp]),
+    "fgpu_text_reserve": (C.c_int, [_vp, _u64]),
     "fgpu_text_split": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, C.c_int, _P(Reads), _P(_u64)]),
     "fgpu_scan_begin": (C.c_int, [_vp]),
     "fgpu_scan_batch": (C.c_int, [_vp, _P(Reads)]),

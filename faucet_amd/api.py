@@ -303,6 +303,10 @@ class Context:
     def synchronize(self):
         self._c(self.lib.fgpu_synchronize(self.h))
 
+    def text_reserve(self, max_chunk_bytes: int):
+        """the largest chunk text_split will be handed: its buffers are sized for it once instead of growing with the first chunks"""
+        self._c(self.lib.fgpu_text_reserve(self.h, int(max_chunk_bytes)))
+
     def text_split(self, text: bytes, fastq: bool, final_chunk: bool):
         """Record splitting of raw FASTA/FASTQ text on the device (the reference's getline loops).  Returns (ReadBatch that
         points into the device copy of the text and is valid until the next text_split, bytes consumed)."""

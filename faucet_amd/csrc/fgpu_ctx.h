@@ -328,6 +328,7 @@ struct fgpu_ctx {
     // fgpu_text_split: the text and the batch that points into it, two sets used in turn, on a stream of their own
     TextSet text[2];
     uint64_t text_calls = 0;
+    uint64_t text_reserve = 0;          // fgpu_text_reserve: the largest chunk of text the caller will hand to fgpu_text_split
     hipStream_t tstream = nullptr;
     hipEvent_t ev_text_mark[2] = {nullptr, nullptr};   // main stream, at the beginning of each call
     hipEvent_t ev_text_done = nullptr;                 // text stream, at the end of each call (the main stream waits for it)

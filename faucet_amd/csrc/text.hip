@@ -88,6 +88,12 @@ int fgpu_text_streams(fgpu_ctx* ctx) {
     return FGPU_OK;
 }
 
+int fgpu_text_reserve(fgpu_ctx* ctx, uint64_t max_chunk_bytes) {
+    if (!ctx) return FGPU_ERR_ARG;
+    ctx->text_reserve = max_chunk_bytes;          // a hint: the next fgpu_text_split sizes its buffers for it (larger chunks still work)
+    return FGPU_OK;
+}
+
 extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
                                fgpu_reads* out, uint64_t* consumed) {
     if (!ctx || !out || !consumed || (nbytes && !text)) return FGPU_ERR_ARG;
@@ -114,18 +120,23 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
         ~OnStream() { c->launch_stream = saved; }
     } on_stream(ctx);
     hipStream_t st = ctx->tstream;
+    // The buffers of a set are sized for the largest chunk the caller has announced (fgpu_text_reserve), not for this one: a caller that
+    // starts with small chunks and doubles them (the command line: 1/4, 1/4, 1/2, 1 of -chunk_mb) made every buffer of both sets be freed
+    // and allocated again three times, each a synchronisation of the device -- 20 ms of a 77 ms pass over a 1 GB file.
+    const uint64_t cap = std::max<uint64_t>(nbytes, ctx->text_reserve);
+    const uint64_t cap_words = (cap + 63) / 64;
     const unsigned char* d_text;
     if (text_on_device) {
         d_text = (const unsigned char*)text;
     } else {
-        if ((rc = fgpu_ensure(ctx, &ts.buf, nbytes + 64))) return rc;
+        if ((rc = fgpu_ensure(ctx, &ts.buf, cap + 64))) return rc;
         FGPU_HIP(hipMemcpyAsync(ts.buf.p, text, nbytes, hipMemcpyHostToDevice, st));
         d_text = (const unsigned char*)ts.buf.p;
     }
     const uint64_t n_words = (nbytes + 63) / 64;
     const uint32_t P = fastq ? 4u : 2u;
-    if ((rc = fgpu_ensure(ctx, &ts.nl, n_words * 8))) return rc;
-    if ((rc = fgpu_ensure(ctx, &ts.rank, (2 * n_words + 2) * 4))) return rc;
+    if ((rc = fgpu_ensure(ctx, &ts.nl, cap_words * 8))) return rc;
+    if ((rc = fgpu_ensure(ctx, &ts.rank, (2 * cap_words + 2) * 4))) return rc;
     uint64_t* nl = (uint64_t*)ts.nl.p;
     uint32_t* count = (uint32_t*)ts.rank.p;
     uint32_t* rank = count + n_words + 1;
@@ -134,7 +145,14 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), st));
     FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, n_words * 64 / 2 + 2, rocprim::plus<uint64_t>(), st));
     if (tmp2 > tmp_bytes) tmp_bytes = tmp2;   // the second scan (at most one record per 2 bytes) reuses the scratch
-    if ((rc = fgpu_ensure(ctx, &ts.tmp, tmp_bytes + 16))) return rc;
+    size_t tmp_cap = tmp_bytes;
+    if (cap_words > n_words) {                // (the scratch the largest announced chunk will ask for)
+        size_t a = 0, b = 0;
+        FGPU_HIP(rocprim::exclusive_scan(nullptr, a, count, rank, 0u, cap_words, rocprim::plus<uint32_t>(), st));
+        FGPU_HIP(rocprim::exclusive_scan(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, cap_words * 64 / 2 + 2, rocprim::plus<uint64_t>(), st));
+        tmp_cap = std::max(tmp_cap, std::max(a, b));
+    }
+    if ((rc = fgpu_ensure(ctx, &ts.tmp, tmp_cap + 16))) return rc;
     FGPU_HIP(rocprim::exclusive_scan(ts.tmp.p, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), st));
     uint32_t last[2];
     unsigned char last_byte = 0;
@@ -148,7 +166,7 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     const uint64_t n_rec = final_chunk ? (n_lines + P - 1) / P : n_newlines / P;
     if (n_rec == 0) return FGPU_OK;   // not even one complete record: the caller reads more
     if (n_rec >= 0xFFFFFFFFULL) { ctx->err = "more than 2^32 records in one chunk of text"; return FGPU_ERR_CAPACITY; }
-    if ((rc = fgpu_ensure(ctx, &ts.rec, (4 * n_rec + 4) * 8))) return rc;
+    if ((rc = fgpu_ensure(ctx, &ts.rec, (4 * std::max<uint64_t>(n_rec, n_rec * cap / nbytes + 16) + 4) * 8))) return rc;   // (records of a chunk of the reserved size, at this chunk's density)
     uint64_t* starts = (uint64_t*)ts.rec.p;
     uint64_t* ends = starts + n_rec;         // becomes the lengths
     uint64_t* offsets = ends + n_rec + 1;    // n_rec + 1 entries

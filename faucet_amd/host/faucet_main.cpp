@@ -212,6 +212,10 @@ public:
             char* text = sl.base + kPad - tail_;
             const uint64_t n = tail_ + sl.got;
             uint64_t used = 0;
+            if (!reserved_) {     // the chunks start small and double: the library sizes its buffers for the largest once (fgpu_text_reserve)
+                fgpu_text_reserve(ctx, chunk_ + (1u << 20));
+                reserved_ = true;
+            }
             const int rc = fgpu_text_split(ctx, text, n, 0, fastq_ ? 1 : 0, sl.eof ? 1 : 0, out, &used);
             split_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_split).count();
             if (rc != FGPU_OK) return -rc;
@@ -235,6 +239,7 @@ public:
     }
 private:
     static constexpr uint64_t kPad = kTextPad;
+    bool reserved_ = false;
     struct Slot {
         char* base = nullptr;
         size_t got = 0;

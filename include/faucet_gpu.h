@@ -210,6 +210,9 @@ int fgpu_bitmap_or(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t n
  * link speed and asynchronously.  NULL when it cannot be had; plain malloc'ed memory works too, only slower. */
 void* fgpu_host_alloc(uint64_t bytes);
 void  fgpu_host_free(void* p);
+/* Announces the largest chunk of text (bytes) the caller will hand to fgpu_text_split, so that the first, smaller chunks of a pass do not each
+ * make the library free and re-allocate its working buffers (every re-allocation synchronises the device).  A hint: larger chunks still work. */
+int fgpu_text_reserve(fgpu_ctx* ctx, uint64_t max_chunk_bytes);
 int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
                     fgpu_reads* out, uint64_t* consumed);
 

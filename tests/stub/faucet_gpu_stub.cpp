@@ -99,6 +99,7 @@ void* fgpu_host_alloc(uint64_t bytes) { return malloc(bytes ? bytes : 1); }
 void fgpu_host_free(void* p) { free(p); }
 
 // the reference's reading loop over a chunk of text (utils/Bloom.cpp:280-282,340; src/ReadScanner.cpp:306-308,349)
+int fgpu_text_reserve(fgpu_ctx* c, uint64_t) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_text_split(fgpu_ctx* c, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk, fgpu_reads* out,
                     uint64_t* consumed) {
     if (!c || !out || !consumed || text_on_device) return FGPU_ERR_ARG;

@@ -883,6 +883,7 @@ def _getline_records(text: bytes, fastq: bool):
 def _load_split(ctx, text, fastq, chunk):
     """stream `text` through fgpu_text_split in chunks of `chunk` bytes, carrying the unconsumed tail, into a load pass"""
     ctx.load_begin()
+    ctx.text_reserve(min(chunk, 1 << 20) + 4096 if chunk % 2 else 0)      # (with and without the hint of the largest chunk: same results)
     carry, pos, n_reads = b"", 0, 0
     while True:
         nxt = text[pos:pos + chunk]
