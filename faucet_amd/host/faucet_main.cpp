@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -179,6 +180,26 @@ public:
         if (fd_ < 0) return;
         struct stat st;
         regular_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode);
+        if (regular_ && st.st_size > 0 && !getenv("FGPU_CLI_NO_MMAP")) {
+            // a regular file is copied out of its mapping: memcpy from the page cache runs at 2-4 times the rate of pread by as many threads
+            // (scripts/micro/read_rate.cpp on the GPU box's host: 4 threads 80 against 34 GB/s), and reading was what pass 1 waited for
+            // The mapping belongs to the process, not to the pass: taking a 1 GB mapping down costs 45 ms (a quarter of a million page table
+            // entries), and both passes usually read the same file -- the second finds the pages mapped already.  Released at exit.
+            struct Mapped { dev_t dev; ino_t ino; off_t size; const char* p; };
+            static std::vector<Mapped> mapped;
+            static std::mutex mapped_m;
+            std::lock_guard<std::mutex> g(mapped_m);
+            for (const Mapped& mp : mapped)
+                if (mp.dev == st.st_dev && mp.ino == st.st_ino && mp.size == st.st_size) map_ = mp.p;
+            if (!map_) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd_, 0);
+                if (m != MAP_FAILED) {
+                    map_ = (const char*)m;
+                    mapped.push_back(Mapped{st.st_dev, st.st_ino, st.st_size, map_});
+                }
+            }
+            if (map_) map_size_ = (uint64_t)st.st_size;
+        }
         for (int i = 0; i < 2; i++) slot_[i].base = pinned_slot(i, kPad + chunk_);
         reader_ = std::thread(&TextSource::read_ahead, this);
     }
@@ -278,7 +299,13 @@ private:
     // `want` bytes from the input, fewer only at its end.  A regular file is read by kReaders threads at once (one thread copies out of
     // the page cache at 7-8 GB/s, which was 2.4 times the time the device needs for the same text); anything else (a pipe, a process
     // substitution) is read in order by this thread alone.
-    static size_t read_fully(int fd, char* dst, size_t want, off_t at, bool positioned) {
+    size_t read_fully(int fd, char* dst, size_t want, off_t at, bool positioned) const {
+        if (positioned && map_) {                 // (the file as it was when it was mapped: what lies beyond that size is not looked for)
+            if ((uint64_t)at >= map_size_) return 0;
+            const size_t n = (size_t)std::min<uint64_t>(want, map_size_ - (uint64_t)at);
+            memcpy(dst, map_ + at, n);
+            return n;
+        }
         size_t got = 0;
         while (got < want) {
             const ssize_t r = positioned ? pread(fd, dst + got, want - got, at + (off_t)got) : read(fd, dst + got, want - got);
@@ -313,6 +340,8 @@ private:
     }
     static constexpr unsigned kReaders = 4;
     double wait_ms_ = 0, split_ms_ = 0, read_ms_ = 0;
+    const char* map_ = nullptr;       // a regular file, mapped (read_fully copies out of it)
+    uint64_t map_size_ = 0;
     int fd_;
     bool regular_ = false;
     uint64_t offset_ = 0;
