@@ -407,7 +407,7 @@ def config3_cli_leg(device):
         size = os.path.getsize(path)
         del text
         cmd = [exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", os.path.join(d, "out")] + fx["args"]
-        best, phases = None, None
+        best, phases, notes = None, None, []
         for _ in range(2):
             t0 = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FGPU_CLI_TIMES="1"))
@@ -417,6 +417,7 @@ def config3_cli_leg(device):
             if best is None or dt < best:
                 best = dt
                 phases = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[cli\] (pass [12][^\d]*?)\s+([0-9.]+) ms", r.stderr)}
+                notes = [ln.strip()[6:].strip() for ln in r.stderr.splitlines() if "walked optimistically" in ln or "long pair filter on the device" in ln]
         m = re.search(r"Distinct junctions: (\d+)", r.stdout)
 
         def sha(pth):
@@ -428,7 +429,7 @@ def config3_cli_leg(device):
 
         same = {ext: sha(os.path.join(d, "out." + ext)) == fx[ext + "_sha256"] for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter")}
         p12 = [v for n, v in (phases or {}).items() if n.startswith("pass 1")] + [v for n, v in (phases or {}).items() if n.startswith("pass 2")]
-        return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "kmers": kmers, "input_bytes": size, "pass_ms": phases,
+        return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "kmers": kmers, "input_bytes": size, "pass_ms": phases, "walks": notes,
                 # SURVEY 8d's definition of the metric: N / (t_load + t_scan), each pass from its first input byte to its outputs final in host
                 # memory -- the CLI's own clock around the two passes (file reading included), without HIP start-up, file dumps and process exit
                 "load_scan_value": kmers / (sum(p12) / 1e3) if len(p12) == 2 else None,

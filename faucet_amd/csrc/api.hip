@@ -597,6 +597,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->adapt_vote = 0;
     ctx->calib_ovf = 0;
     ctx->span_ceiling = ~0ULL;
+    ctx->repeats_seen_before = false;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     ctx->scan_batch_seq = 0;
@@ -811,6 +812,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->adapt_vote = 0;
     ctx->calib_ovf = 0;
     ctx->span_ceiling = ~0ULL;
+    ctx->repeats_seen_before = false;
     ctx->walked_pieces = 0;
     ctx->scan_batch_index = 0;
     memset(&ctx->carried, 0, sizeof(ctx->carried));

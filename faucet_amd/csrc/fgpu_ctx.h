@@ -274,6 +274,7 @@ struct fgpu_ctx {
 
     uint64_t adapt_followers = 0, adapt_pieces = 0;   // window-span controller state
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // FGPU_DEBUG_HOST=1: where the host thread of a scan spends its time (see fgpu_scan_end)
+    bool repeats_seen_before = false;  // this scan's counters have shown repeats (kept while a lagging snapshot shows too few pieces to judge)
     uint64_t calib_ovf = 0;            // ko_overflows as of the last look (a window whose large clusters outgrew the large-cluster walks' tables)
     uint64_t span_ceiling = ~0ULL;     // a size at which that happened in this scan: the windows do not grow to it again
     int adapt_vote = 0;                // what the last batch's counters asked for without getting it yet (-1 smaller, +1 larger)

@@ -3024,7 +3024,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // step for the lower bar (walk stage 52.6 -> 62.6 ms; scripts/ovw_thresholds.sh, gpurun_out/r04_ovw_thresholds2.txt).
         static const int ko_avg_env = getenv("FGPU_WALK_KO_AVG") ? std::min(255, std::max(0, atoi(getenv("FGPU_WALK_KO_AVG")))) : -1;
         static const int ko_avg_min_env = getenv("FGPU_WALK_KO_AVG_MIN") ? std::min(255, std::max(1, atoi(getenv("FGPU_WALK_KO_AVG_MIN")))) : -1;
-        const bool repeats_seen = ctx->counters_host->walk_parallel * 50 > ctx->counters_host->walked_pieces;
+        const bool repeats_seen = ctx->counters_host->walk_parallel * 50 > ctx->counters_host->walked_pieces ||
+                                  (ctx->walk_ko_always && ctx->counters_host->walked_pieces < (1ULL << 17) && ctx->delta_next >= 2 && ctx->repeats_seen_before);   // (same lag: keep what the scan had found)
+        if (repeats_seen) ctx->repeats_seen_before = true;
         const uint32_t ko_total = std::min<uint32_t>(ctx->walk_ko_weight, 0xFFFFu);
         const uint32_t ko_avg = ko_avg_env >= 0 ? (uint32_t)ko_avg_env : repeats_seen ? 8u : 12u;
         const uint32_t ko_total_rep = ko_avg_min_env > 0 ? (uint32_t)ko_avg_min_env : repeats_seen ? 16u : std::min<uint32_t>(255u, 3 * ko_total / 8);
@@ -3065,8 +3067,15 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // (a caller that expects repeats gets it for the scan's first two batches; after that the scan's own counters decide: on ordinary data the
         // few large clusters cost less with the key-ordered walk alone than with a dozen launches more per window -- config 2 with the CLI's
         // settings: walk stage 52.6 ms with the rounds always issued, scripts/ovw_config2.sh)
-        const bool ovw_on = ovw_rounds > 0 && ((ctx->walk_ko_always && ctx->delta_next < 2) ||
-                                               ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
+        // (the counters are the host's snapshot of the previous pure stage's end: when the walk lags two batches behind at that moment --
+        // it happens, by the timing of the machine -- they do not show a single large cluster yet.  A caller that expects repeats therefore
+        // keeps the rounds until the counters have SEEN enough pieces to say otherwise: round 4 met runs of config 3's shape in which the
+        // third batch went without them and pass 2 took 310-360 instead of 160 ms)
+        const bool ovw_seen_enough = ctx->counters_host->walked_pieces >= (1ULL << 17);
+        static const bool dbg_ovw_gap = getenv("FGPU_DEBUG_OVW_GAP") != nullptr;   // measurement aid: the rounds withheld from a scan's third and fourth batch
+        const bool ovw_on = ovw_rounds > 0 && !(dbg_ovw_gap && (ctx->delta_next == 2 || ctx->delta_next == 3)) &&
+                            ((ctx->walk_ko_always && (ctx->delta_next < 2 || !ovw_seen_enough)) ||
+                             ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
         OvwTables ot;
         memset(&ot, 0, sizeof(ot));
         constexpr int kEvLog2 = 23, kFiltLog2 = 24, kMarkLog2 = 22;
