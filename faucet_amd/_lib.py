@@ -127,7 +127,27 @@ SIGNATURES = {
     "fgpu_diag_scan_replays": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_late_flags": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_binned_probes": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, _P(_f64), _P(_f64), _P(_f64), _P(_f64)]),
+    "fgpu_scan_pairs_devptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(_u64)]),
+    "fgpu_device_alloc": (C.c_int, [_vp, _u64, _P(_vp)]),
+    "fgpu_device_free": (C.c_int, [_vp, _vp]),
+    "fgpu_device_copy": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "fgpu_device_zero": (C.c_int, [_vp, _vp, _u64]),
+    "fgpu_group_create": (C.c_int, [C.c_int, C.c_int, _P(_vp)]),
+    "fgpu_group_destroy": (None, [_vp]),
+    "fgpu_group_attach": (C.c_int, [_vp, C.c_int, _vp]),
+    "fgpu_group_abort": (None, [_vp]),
+    "fgpu_group_last_error": (C.c_char_p, [_vp, C.c_int]),
+    "fgpu_group_barrier": (C.c_int, [_vp, C.c_int]),
+    "fgpu_group_or_allreduce": (C.c_int, [_vp, C.c_int, _vp, _u64]),
+    "fgpu_group_exclusive_prefix_or": (C.c_int, [_vp, C.c_int, _vp, _vp, _u64]),
+    "fgpu_group_send": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _u64]),
+    "fgpu_group_send_async": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _u64]),
+    "fgpu_group_flush": (C.c_int, [_vp, C.c_int]),
+    "fgpu_group_recv": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _u64]),
+    "fgpu_group_probe": (C.c_int, [_vp, C.c_int, C.c_int, _P(C.c_int), _P(_u64)]),
+    "fgpu_group_selftest": (C.c_int, [_vp, C.c_int, _u64, _P(C.c_int)]),
 }
+TRANSPORT_COPY, TRANSPORT_RCCL = 0, 1
 
 _lib = None
 
@@ -153,7 +173,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.fgpu_abi_version() != 2:
+    if lib.fgpu_abi_version() != 3:
         raise RuntimeError("libfaucet_gpu.so ABI version mismatch")
     _lib = lib
     return lib

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfaucet_gpu.so")
 CLI = os.path.join(HERE, "faucet")
-HIP_SOURCES = ["api.hip", "pack.hip", "load.hip", "scan_pure.hip", "scan_walk.hip", "diag.hip", "text.hip", "stage3.hip", "pairs.hip"]
+HIP_SOURCES = ["api.hip", "pack.hip", "load.hip", "scan_pure.hip", "scan_walk.hip", "diag.hip", "text.hip", "stage3.hip", "pairs.hip", "group.hip"]
 CPP_SOURCES = ["sizing.cpp"]
 HEADERS = ["fgpu_ctx.h", "fgpu_device.h", "fgpu_flags.h", os.path.join(ROOT, "include", "faucet_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -58,7 +58,7 @@ def build(force: bool = False, jobs: int = 6) -> str:
     if force or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     main = os.path.join(HERE, "host", "faucet_main.cpp")
-    if os.path.exists(main) and (force or _newer(CLI, [main, LIB, os.path.join(HERE, "host", "junction_order.h")] + hdrs)):
+    if os.path.exists(main) and (force or _newer(CLI, [main, LIB] + [os.path.join(HERE, "host", h) for h in ("junction_order.h", "shard_host.h", "text_source.h")] + hdrs)):
         _run(["g++", "-std=c++11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), main, "-o", CLI,
               "-L", HERE, "-lfaucet_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-lpthread"])
     return LIB

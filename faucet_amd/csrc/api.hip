@@ -16,7 +16,7 @@ int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries
 int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n);
 int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* recs_host, uint64_t cap, uint64_t* n_out);
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;   // (per thread: the ranks of a group create their contexts at the same time)
 
 // ---- helpers declared in fgpu_ctx.h ---------------------------------------------------------------------------
 int g_fgpu_trace = getenv("FGPU_TRACE") && getenv("FGPU_TRACE")[0] == '1';
@@ -101,7 +101,9 @@ static int check_errors(fgpu_ctx* ctx) {
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 32ULL) { ctx->err = "fgpu_reads.total_bases does not match the batch's offsets"; return FGPU_ERR_ARG; }
     // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
-    static const bool force_lazy_fail = getenv("FGPU_DEBUG_LAZY_FAIL") && getenv("FGPU_DEBUG_LAZY_FAIL")[0] == '1';
+    // (= n > 1: only once n batches of the scan have been prepared, so that the replay finds batches whose lists have been harvested already)
+    static const long lazy_fail_knob = getenv("FGPU_DEBUG_LAZY_FAIL") ? atol(getenv("FGPU_DEBUG_LAZY_FAIL")) : 0;
+    const bool force_lazy_fail = lazy_fail_knob == 1 || (lazy_fail_knob > 1 && ctx->scan_batch_index >= (uint64_t)lazy_fail_knob);
     const bool lazy = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime && !ctx->eager_scan;
     // (before the key-ordered walk's own flags: a late junction test that comes out true inside a large cluster voids the lazy scan
     // -- bit 4 -- and the piece then stops at a k-mer nobody registered -- bit 16: a consequence, gone with the eager scan that follows)
@@ -580,6 +582,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->eager_scan = ctx->lazy_failed = false;
     ctx->late_acc[0] = ctx->late_acc[1] = ctx->late_acc[2] = 0;
     ctx->stops_delivered = 0;
+    ctx->lp_applied_seq = 0;
     if (ctx->short_pf) FGPU_HIP(hipMemsetAsync(ctx->short_pf, 0, ctx->short_pf_tai / 8, ctx->stream));   // a scan starts with empty pair filters
     if ((rc = fgpu_long_pairs_reset(ctx))) return rc;
     ctx->have_import = false;

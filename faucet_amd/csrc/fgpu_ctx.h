@@ -303,6 +303,8 @@ struct fgpu_ctx {
     bool short_pf_lists_to_host = true;
     LongPairs lp;                         // the long pair filter on the device (fgpu_scan_long_pairs)
     uint64_t stops_delivered = 0;         // batches whose lists the caller has taken (a replay does not hand them out again)
+    uint64_t lp_applied_seq = 0;          // batches whose lists the device's long pair filter has taken: a replay harvests a batch the caller has not
+                                          // taken yet a second time, and the check-then-insert loop must not see it twice
     uint64_t scan_replays = 0;            // replays since the context was made (fgpu_diag_scan_replays)
     uint64_t late_acc[3] = {0, 0, 0};        // late junction tests of this scan's voided attempts (DevCounters::late_n is reset with the replay)
     uint64_t journal_max_read_len = 0;

@@ -3387,7 +3387,15 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
         ctx->stops_delivered = b->seq + 1;                // nobody takes them: the lists end in the device's pair filter
     }
     const uint64_t np = b->n_pieces;
-    if (!np) return fgpu_long_pairs_batch(ctx, nullptr, 0, b->n_reads);   // (its reads still count as ends of pairs)
+    // the long pair filter takes every batch exactly once, whoever else reads the lists: with lists_to_host a replay harvests the batches the
+    // caller has not taken yet again, and a second pass of the check-then-insert loop over them would count and insert twice
+    const bool lp_due = b->seq >= ctx->lp_applied_seq;
+    if (!np) {
+        if (!lp_due) return FGPU_OK;
+        const int rc0 = fgpu_long_pairs_batch(ctx, nullptr, 0, b->n_reads);   // (its reads still count as ends of pairs)
+        if (!rc0) ctx->lp_applied_seq = b->seq + 1;
+        return rc0;
+    }
     int rc;
     if ((rc = fgpu_ensure(ctx, &b->stop_off, (2 * np + 2) * 4))) return rc;
     uint32_t* count = (uint32_t*)b->stop_off.p;
@@ -3412,7 +3420,10 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
         hipLaunchKernelGGL(k_short_pairs, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const fgpu_stop*)b->stop_out.p, (const uint32_t*)count,
                            (const uint32_t*)offset, np, PairFilterDev{ctx->short_pf, ctx->short_pf_tai - 1, ctx->short_pf_hashes}, ctx->fd.k);
     // scanReads' paired-end loop over the same lists (pairs.hip): check-then-insert in file order, exact, on the device
-    if ((rc = fgpu_long_pairs_batch(ctx, (const fgpu_stop*)b->stop_out.p, total, b->n_reads))) return rc;
+    if (lp_due) {
+        if ((rc = fgpu_long_pairs_batch(ctx, (const fgpu_stop*)b->stop_out.p, total, b->n_reads))) return rc;
+        ctx->lp_applied_seq = b->seq + 1;
+    }
     if (to_host) {
         StopBatch& sb = ctx->stop_queue.back();
         if (total) {

@@ -33,6 +33,12 @@
 
 #include "faucet_gpu.h"
 #include "junction_order.h"
+#include "shard_host.h"
+#include "text_source.h"
+
+using faucet_host::TextSource;
+using faucet_host::pinned_slot;
+using faucet_host::kTextPad;
 
 namespace {
 
@@ -50,6 +56,8 @@ struct Options {   // globals of src/Faucet.h:14-53
     uint64_t batch_reads = 0;         // not a reference flag: > 0 = split records on the host, this many reads per device call
     uint64_t chunk_mb = 64;           // not a reference flag: file text handed to the device per call, records split there
     uint64_t chunk_bytes = 0;         // = chunk_mb << 20, less for regular files that are smaller (main)
+    int gpus = 1;                     // not a reference flag: read shards over this many GPUs, one host thread each (shard_host.h)
+    std::string transport = "copy";   // not a reference flag: how the shards' bitmaps and tables travel: copy (device-to-device copies) | rccl
 };
 
 void argument_error() {   // src/Faucet.cpp:50-54
@@ -89,6 +97,8 @@ int handle_arguments(int argc, char** argv, Options& o) {
         else if (a == "-junctions_file") { if (!val(v)) goto bad; o.junctions_prefix = v; o.from_junctions = true; }
         else if (a == "-batch_reads") { if (!val(v)) goto bad; o.batch_reads = (uint64_t)atoll(v); }
         else if (a == "-chunk_mb") { if (!val(v)) goto bad; o.chunk_mb = (uint64_t)atoll(v); if (!o.chunk_mb) o.chunk_mb = 1; }
+        else if (a == "-gpus") { if (!val(v)) goto bad; o.gpus = atoi(v); if (o.gpus < 1 || o.gpus > 64) { fprintf(stderr, "-gpus must be in 1..64\n"); return 1; } }
+        else if (a == "-transport") { if (!val(v)) goto bad; o.transport = v; if (o.transport != "copy" && o.transport != "rccl") { fprintf(stderr, "-transport must be copy or rccl\n"); return 1; } }
         else if (a == "--help" || a == "-h") { argument_error(); return 1; }
         else { fprintf(stderr, "Cannot parse tag %s\n", argv[i]); argument_error(); return 1; }
         continue;
@@ -152,208 +162,6 @@ public:
 private:
     std::ifstream in_;
     bool fastq_;
-};
-
-// The two text buffers of the device-split input are pinned (the copy to the device runs at link speed) and belong to the process, not to
-// one pass: pinning and unpinning 160 MB costs 30 ms each way, which was a fifth of a pass over a 1 GB file.  main() pins them on a helper
-// thread while the context is being created; they are returned when the process ends.
-static char* pinned_slot(int i, uint64_t bytes) {
-    static char* base[2] = {nullptr, nullptr};
-    static uint64_t have[2] = {0, 0};
-    static std::mutex m;
-    std::lock_guard<std::mutex> g(m);
-    if (have[i] < bytes) {
-        if (base[i]) fgpu_host_free(base[i]);
-        base[i] = (char*)fgpu_host_alloc(bytes);
-        if (!base[i]) base[i] = (char*)malloc(bytes);
-        have[i] = base[i] ? bytes : 0;
-    }
-    return base[i];
-}
-static const uint64_t kTextPad = 16u << 20;   // room in front of a chunk for the unconsumed tail of the previous one
-
-// The same loop with the records split on the device (fgpu_text_split): the host only moves file text, `chunk` bytes at a
-// time, and carries the unconsumed tail (an incomplete record) over to the next call.  Works on non-seekable input.
-class TextSource {
-public:
-    TextSource(const std::string& path, bool fastq, uint64_t chunk) : fd_(open(path.c_str(), O_RDONLY)), fastq_(fastq), chunk_(chunk) {
-        if (fd_ < 0) return;
-        struct stat st;
-        regular_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode);
-        if (regular_ && st.st_size > 0 && !getenv("FGPU_CLI_NO_MMAP")) {
-            // a regular file is copied out of its mapping: memcpy from the page cache runs at 2-4 times the rate of pread by as many threads
-            // (scripts/micro/read_rate.cpp on the GPU box's host: 4 threads 80 against 34 GB/s), and reading was what pass 1 waited for
-            // The mapping belongs to the process, not to the pass: taking a 1 GB mapping down costs 45 ms (a quarter of a million page table
-            // entries), and both passes usually read the same file -- the second finds the pages mapped already.  Released at exit.
-            struct Mapped { dev_t dev; ino_t ino; off_t size; const char* p; };
-            static std::vector<Mapped> mapped;
-            static std::mutex mapped_m;
-            std::lock_guard<std::mutex> g(mapped_m);
-            for (const Mapped& mp : mapped)
-                if (mp.dev == st.st_dev && mp.ino == st.st_ino && mp.size == st.st_size) map_ = mp.p;
-            if (!map_) {
-                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd_, 0);
-                if (m != MAP_FAILED) {
-                    map_ = (const char*)m;
-                    mapped.push_back(Mapped{st.st_dev, st.st_ino, st.st_size, map_});
-                }
-            }
-            if (map_) map_size_ = (uint64_t)st.st_size;
-        }
-        for (int i = 0; i < 2; i++) slot_[i].base = pinned_slot(i, kPad + chunk_);
-        reader_ = std::thread(&TextSource::read_ahead, this);
-    }
-    ~TextSource() {
-        if (fd_ < 0) return;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        reader_.join();
-        close(fd_);
-        if (getenv("FGPU_CLI_TIMES"))
-            fprintf(stderr, "[cli]   text source: %.2f ms waiting for the reader, %.2f ms in fgpu_text_split, %.2f ms reading (reader thread)\n",
-                    wait_ms_, split_ms_, read_ms_);
-    }
-    bool is_open() const { return fd_ >= 0 && slot_[0].base && slot_[1].base; }
-    // 1 = a batch (device pointers, valid until the next call), 0 = input exhausted, < 0 = -status of a failed call
-    int next(fgpu_ctx* ctx, fgpu_reads* out) {
-        for (;;) {
-            if (finished_) return 0;
-            Slot& sl = slot_[cur_];
-            const auto t_wait = std::chrono::steady_clock::now();
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return sl.full; });
-            }
-            const auto t_split = std::chrono::steady_clock::now();
-            wait_ms_ += std::chrono::duration<double, std::milli>(t_split - t_wait).count();
-            // the unconsumed tail of the previous chunk sits right in front of this chunk's text
-            char* text = sl.base + kPad - tail_;
-            const uint64_t n = tail_ + sl.got;
-            uint64_t used = 0;
-            if (!reserved_) {     // the chunks start small and double: the library sizes its buffers for the largest once (fgpu_text_reserve)
-                fgpu_text_reserve(ctx, chunk_ + (1u << 20));
-                reserved_ = true;
-            }
-            const int rc = fgpu_text_split(ctx, text, n, 0, fastq_ ? 1 : 0, sl.eof ? 1 : 0, out, &used);
-            split_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_split).count();
-            if (rc != FGPU_OK) return -rc;
-            const uint64_t left = n - used;
-            if (sl.eof) {
-                finished_ = true;
-            } else {
-                if (left > kPad) return -FGPU_ERR_CAPACITY;   // a single line of more than 16 MB: use -batch_reads (host getline)
-                memcpy(slot_[cur_ ^ 1].base + kPad - left, text + used, left);
-                tail_ = left;
-                {
-                    std::lock_guard<std::mutex> g(m_);
-                    sl.full = false;
-                }
-                cv_.notify_all();
-                cur_ ^= 1;
-            }
-            if (out->n_reads) return 1;
-            // no complete record inside a whole chunk: its text has become the tail, read on
-        }
-    }
-private:
-    static constexpr uint64_t kPad = kTextPad;
-    bool reserved_ = false;
-    struct Slot {
-        char* base = nullptr;
-        size_t got = 0;
-        bool eof = false, full = false;
-    };
-    // The first batches of both passes are the dear ones per read (empty carry: every occurrence goes through the resolve kernel;
-    // empty junction map: every junction test is evaluated), so the input starts with smaller chunks: 1/4, 1/4, 1/2 of a chunk,
-    // full chunks from then on.  A function of the chunk index only: both passes cut the same file into the same batches, which
-    // is what lets the scan reuse the planes the load kept.
-    size_t chunk_bytes(uint64_t i) const {
-        const uint64_t w = i < 2 ? chunk_ / 4 : i == 2 ? chunk_ / 2 : chunk_;
-        return (size_t)std::max<uint64_t>(w, std::min<uint64_t>(chunk_, 64u << 10));
-    }
-    void read_ahead() {   // reader thread: keeps the other slot filled while the device works on the current one
-        for (int i = 0;; i ^= 1) {
-            Slot& sl = slot_[i];
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return stop_ || !sl.full; });
-                if (stop_) return;
-            }
-            const size_t want = chunk_bytes(n_chunks_++);
-            const auto t_read = std::chrono::steady_clock::now();
-            const size_t got = fill(sl.base + kPad, want);
-            read_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_read).count();
-            {
-                std::lock_guard<std::mutex> g(m_);
-                sl.got = got;
-                sl.eof = got < want;
-                sl.full = true;
-            }
-            cv_.notify_all();
-            if (got < want) return;
-        }
-    }
-    // `want` bytes from the input, fewer only at its end.  A regular file is read by kReaders threads at once (one thread copies out of
-    // the page cache at 7-8 GB/s, which was 2.4 times the time the device needs for the same text); anything else (a pipe, a process
-    // substitution) is read in order by this thread alone.
-    size_t read_fully(int fd, char* dst, size_t want, off_t at, bool positioned) const {
-        if (positioned && map_) {                 // (the file as it was when it was mapped: what lies beyond that size is not looked for)
-            if ((uint64_t)at >= map_size_) return 0;
-            const size_t n = (size_t)std::min<uint64_t>(want, map_size_ - (uint64_t)at);
-            memcpy(dst, map_ + at, n);
-            return n;
-        }
-        size_t got = 0;
-        while (got < want) {
-            const ssize_t r = positioned ? pread(fd, dst + got, want - got, at + (off_t)got) : read(fd, dst + got, want - got);
-            if (r < 0 && errno == EINTR) continue;
-            if (r <= 0) break;
-            got += (size_t)r;
-        }
-        return got;
-    }
-    size_t fill(char* dst, size_t want) {
-        if (!regular_ || want < (8u << 20)) {
-            const size_t got = read_fully(fd_, dst, want, (off_t)offset_, regular_);
-            offset_ += got;
-            return got;
-        }
-        const size_t part = ((want + kReaders - 1) / kReaders + 4095) & ~(size_t)4095;
-        size_t got_part[kReaders] = {0};
-        std::thread helpers[kReaders];
-        for (unsigned t = 1; t < kReaders; t++)
-            if ((size_t)t * part < want)
-                helpers[t] = std::thread([&, t] { got_part[t] = read_fully(fd_, dst + t * part, std::min(part, want - t * part), (off_t)(offset_ + t * part), true); });
-        got_part[0] = read_fully(fd_, dst, std::min(part, want), (off_t)offset_, true);
-        size_t got = 0;
-        bool short_part = false;
-        for (unsigned t = 0; t < kReaders; t++) {
-            if (helpers[t].joinable()) helpers[t].join();
-            if (!short_part) got += got_part[t];
-            if ((size_t)t * part < want && got_part[t] < std::min(part, want - t * part)) short_part = true;   // the file ends inside this part
-        }
-        offset_ += got;
-        return got;
-    }
-    static constexpr unsigned kReaders = 4;
-    double wait_ms_ = 0, split_ms_ = 0, read_ms_ = 0;
-    const char* map_ = nullptr;       // a regular file, mapped (read_fully copies out of it)
-    uint64_t map_size_ = 0;
-    int fd_;
-    bool regular_ = false;
-    uint64_t offset_ = 0;
-    bool fastq_;
-    uint64_t chunk_;
-    Slot slot_[2];
-    int cur_ = 0;
-    uint64_t tail_ = 0, n_chunks_ = 0;
-    bool finished_ = false, stop_ = false;
-    std::thread reader_;
-    std::mutex m_;
-    std::condition_variable cv_;
 };
 
 // one interface over both ways of cutting the input into batches
@@ -553,6 +361,195 @@ struct PhaseClock {
     }
 };
 
+// What both kinds of run -- one device, or read shards over several -- do once the scan has ended: the lines ReadScanner::scanReads and
+// printScanSummary print (src/ReadScanner.cpp:19-27,352-358), the junction map (held by `ctx`: the only context, or the last shard's) into
+// <prefix>.junctions in the reference's dump order, and the pair filter files (src/Faucet.cpp:296-300).  0, or the exit code of a failure.
+int write_scan_outputs(const Options& o, fgpu_ctx* ctx, const fgpu_scan_stats& ss, uint64_t empty_count, uint64_t not_empty_count, double seconds,
+                       const PairFilter& short_pf, const PairFilter& long_pf, PhaseClock& clk) {
+    printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);
+    printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);
+    printf("Unambiguous reads: %llu\n", (unsigned long long)ss.unambiguous_reads);
+    printf("Time in seconds for read scan: %f \n", seconds);
+    printf("\nDistinct junctions: %llu \n", (unsigned long long)ss.n_junctions);
+    printf("Number of kmers that we j-checked: %llu \n", (unsigned long long)ss.nb_jcheck_kmer);
+    printf("Number of reads with no junctions: %llu \n", (unsigned long long)ss.nb_no_juncs);
+    printf("Number of processed kmers: %llu \n", (unsigned long long)ss.nb_processed);
+    printf("Number of skipped kmers: %llu \n", (unsigned long long)ss.nb_skipped);
+    printf("Reads without errors: %llu\n", (unsigned long long)ss.reads_no_errors);
+
+    // junction records come back in creation order; the reference's container gives the reference's dump order
+    uint64_t n = 0;
+    CHECK(fgpu_scan_junction_count(ctx, &n));
+    std::vector<uint64_t> keys(n ? n : 1);
+    std::vector<fgpu_junction> recs(n ? n : 1);
+    CHECK(fgpu_scan_download_junctions(ctx, keys.data(), recs.data(), keys.size(), &n));
+    clk.mark("  junction download");
+    // the reference's dump order = the iteration order of its container after these insertions (junction_order.h)
+    std::vector<uint32_t> order;
+    if (DumpOrder::agrees_with_the_container(keys.data(), (size_t)std::min<uint64_t>(n, 50000))) {
+        order = DumpOrder::of(keys.data(), (size_t)n);
+    } else {   // a standard library that links its nodes another way: ask the container itself
+        std::unordered_map<uint64_t, uint32_t> container;
+        for (uint64_t i = 0; i < n; i++) container.insert(std::pair<uint64_t, uint32_t>(keys[i], (uint32_t)i));
+        for (const auto& kv : container) order.push_back(kv.second);
+    }
+    clk.mark("  dump order");
+    // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596) first counts the junctions that are solid at thresholds 0..4
+    // (Junction::isSolid, utils/Junction.cpp:38-46: more than one of the four extensions with that much coverage)
+    for (int thr = 0; thr < 5; thr++) {
+        long solid = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            int paths = 0;
+            for (int e = 0; e < 4; e++) paths += recs[i].cov[e] >= thr ? 1 : 0;
+            solid += paths > 1 ? 1 : 0;
+        }
+        printf("There are %ld junctions with solidity at least %d.\n", solid, thr);
+    }
+    printf("Writing to junction file\n");
+    if (int rc = write_junctions(o.file_prefix + ".junctions", keys.data(), recs.data(), order, o.k)) return rc;
+    printf("Done writing to junction file\n");
+    clk.mark("junction download + dump");
+    if (!o.no_cleaning) {   // src/Faucet.cpp:297-300
+        if (int rc = short_pf.dump(o.file_prefix + ".short_pair_filter")) return rc;
+        printf("bloom dumped \n");                                   // (Bloom::dump's line, utils/Bloom.cpp:571-578: once per filter written)
+        if (o.paired_ends) {
+            if (int rc = long_pf.dump(o.file_prefix + ".long_pair_filter")) return rc;
+            printf("bloom dumped \n");
+        }
+    }
+    printf("Weight of short pair filter: %f\n", short_pf.weight());
+    if (o.paired_ends) printf("Weight of long pair filter: %f\n", long_pf.weight());
+    printf("Number of junctions: %llu\n", (unsigned long long)order.size());
+    return 0;
+}
+
+// ---- `-gpus N`: the same run with the reads sharded over N GPUs, one host thread per device (shard_host.h) -------------------------------
+// Same files, same log, same exit codes as the single-device run below; what differs is who does the passes: shard r = the r-th file-order
+// share of the records, on device r (with fewer devices than shards several shards share a device: what a one-GPU box can test).  Inputs
+// must be regular files (a shard is a byte range); -bloom_file restarts load the filter on every device.
+int main_sharded(const Options& o, const fgpu_params& prm, uint64_t tai, PhaseClock& clk) {
+    using namespace faucet_host;
+    if (o.batch_reads) { fprintf(stderr, "-batch_reads (records split on the host) cannot be combined with -gpus: the shards split their records on their devices\n"); return 1; }
+    const int ndev = fgpu_device_count();
+    if (ndev < 1) { fprintf(stderr, "fgpu_create failed (%d): no gfx950 device\n", FGPU_ERR_HIP); return 2; }
+    ShardOptions so;
+    so.n_ranks = o.gpus;
+    so.transport = o.transport == "rccl" ? FGPU_TRANSPORT_RCCL : FGPU_TRANSPORT_COPY;
+    for (int r = 0; r < o.gpus; r++) so.devices.push_back(r % ndev);
+    if (ndev < o.gpus) fprintf(stderr, "note: %d read shards on %d device%s: shards share devices\n", o.gpus, ndev, ndev == 1 ? "" : "s");
+    so.prm = prm;
+    so.fastq = o.fastq;
+    so.mercy = o.mercy;
+    so.paired_ends = o.paired_ends;
+    so.no_cleaning = o.no_cleaning;
+    so.verbose = clk.on;
+    // every shard reads its share through buffers of its own: chunks no larger than a share needs
+    so.chunk_bytes = o.chunk_bytes;
+    {
+        struct stat st;
+        uint64_t largest = 0;
+        for (const std::string* f : {&o.read_load_file, &o.read_scan_file})
+            if (stat(f->c_str(), &st) == 0 && S_ISREG(st.st_mode)) largest = std::max<uint64_t>(largest, (uint64_t)st.st_size);
+        const uint64_t share = largest / (uint64_t)o.gpus + (4u << 20);
+        if (share < so.chunk_bytes) so.chunk_bytes = ((share >> 20) + 1) << 20;
+    }
+    ShardedRun run(so);
+    if (int rc = run.create()) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, run.error().c_str()); return 2; }
+    clk.mark("arguments, sizing, contexts");
+    std::vector<uint8_t> bloom_bytes(tai / 8);
+    std::thread bloom_writer;
+    bool bloom_write_failed = false;
+    struct JoinWriter {
+        std::thread& t;
+        ~JoinWriter() { if (t.joinable()) t.join(); }
+    } join_writer{bloom_writer};
+    auto bloom_file_complete = [&]() -> bool {
+        if (bloom_writer.joinable()) bloom_writer.join();
+        if (bloom_write_failed) fprintf(stderr, "cannot write %s.bloom\n", o.file_prefix.c_str());
+        return !bloom_write_failed;
+    };
+    fgpu_ctx* ctx = run.first_ctx();      // (CHECK reports through it)
+    if (o.from_bloom) {                   // Bloom::load (utils/Bloom.cpp:580-587), the filter on every device
+        FILE* f = fopen(o.bloom_input_file.c_str(), "rb");
+        if (!f) { fprintf(stderr, "cannot open %s\n", o.bloom_input_file.c_str()); return 2; }
+        printf("loading bloom filter from file, nelem %llu \n", (unsigned long long)(tai / 8));
+        const size_t got = fread(bloom_bytes.data(), 1, bloom_bytes.size(), f);
+        fclose(f);
+        if (got != bloom_bytes.size())
+            fprintf(stderr, "note: %s holds %llu of the %llu bytes this run's filter has: the rest stays empty (as in the reference)\n",
+                    o.bloom_input_file.c_str(), (unsigned long long)got, (unsigned long long)(tai / 8));
+        for (int r = 0; r < run.n_ranks(); r++) {
+            ctx = run.ctx(r);
+            CHECK(fgpu_bloom_upload(ctx, FGPU_BLOO2, bloom_bytes.data(), bloom_bytes.size()));
+        }
+        printf("bloom loaded\n");
+    } else {
+        time_t start, stop;
+        time(&start);
+        printf("Weights before load: %f, %f \n", 0.0f, 0.0f);
+        ShardLoadResult lr;
+        if (int rc = run.load(o.read_load_file, &lr)) { fprintf(stderr, "load pass failed (%d): %s\n", rc, run.error().c_str()); return 2; }
+        clk.mark(lr.fixup ? "pass 1 (shards, fix-up protocol)" : "pass 1 (shards, presence protocol)");
+        fprintf(stdout, "\rreads consumed: %lld", (long long)lr.stats.reads_processed);
+        printf("\n");
+        printf("Weights after load: %f, %f \n", lr.w1, lr.w2);
+        printf("Reads processed: %llu\n", (unsigned long long)lr.stats.reads_processed);
+        printf("Unambiguous reads: %llu\n", (unsigned long long)lr.stats.unambiguous_reads);
+        time(&stop);
+        printf("Time to load: %f \n", difftime(stop, start));
+        ctx = run.first_ctx();
+        CHECK(fgpu_bloom_download(ctx, FGPU_BLOO2, bloom_bytes.data(), bloom_bytes.size()));
+        const std::string path = o.file_prefix + ".bloom";       // Bloom::dump, utils/Bloom.cpp:571-578
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
+        bloom_writer = std::thread([f, &bloom_bytes, &bloom_write_failed] {
+            if (fwrite(bloom_bytes.data(), 1, bloom_bytes.size(), f) != bloom_bytes.size()) bloom_write_failed = true;
+            if (fclose(f) != 0) bloom_write_failed = true;
+        });
+        printf("bloom dumped \n");
+        clk.mark("bloom download (dump beside pass 2)");
+    }
+    PairFilter short_pf, long_pf;        // src/Faucet.cpp:266-283, as in the single-device run
+    {
+        const uint64_t E = o.estimated_kmers;
+        short_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 10 : E / 20, 0.01f);
+        if (o.paired_ends) long_pf.create(o.high_cov ? E / 2 : o.mercy ? E / 5 : E / 10, 0.01f);
+    }
+    if (o.just_load) return bloom_file_complete() ? 0 : 2;
+    {
+        time_t start, stop;
+        time(&start);
+        float w2 = 0;
+        ctx = run.last_ctx();
+        CHECK(fgpu_bloom_weight(ctx, FGPU_BLOO2, &w2));
+        printf("Weight before read scan: %f \n", w2);
+        run.set_pair_filters(o.no_cleaning ? 0 : short_pf.tai, short_pf.n_hash, o.paired_ends && !o.no_cleaning ? long_pf.tai : 0, long_pf.n_hash);
+        ShardScanResult sr;
+        if (int rc = run.scan(o.read_scan_file, &sr)) { fprintf(stderr, "junction scan failed (%d): %s\n", rc, run.error().c_str()); return 2; }
+        fprintf(stdout, "\rreads scanned: %lld", (long long)sr.stats.reads_processed);
+        if (!o.no_cleaning) CHECK(fgpu_scan_short_pairs_download(ctx, short_pf.bits.data(), short_pf.bits.size()));
+        if (o.paired_ends && !o.no_cleaning) {
+            uint64_t e = 0, ne = 0;      // (the counts are the sum over the shards, sr; the last shard's filter is the run's)
+            CHECK(fgpu_scan_long_pairs_download(ctx, long_pf.bits.data(), long_pf.bits.size(), &e, &ne));
+        }
+        time(&stop);
+        clk.mark("pass 2 (shards)");
+        if (int rc = write_scan_outputs(o, ctx, sr.stats, sr.empty_count, sr.not_empty_count, difftime(stop, start), short_pf, long_pf, clk)) return rc;
+    }
+    clk.mark("pair filter weights");
+    if (!o.no_cleaning)
+        fprintf(stderr, "The contig-graph stage is not part of this build: the load and scan outputs have been written; the reference\n"
+                        "continues from the same calls through integration/faucet_binding.cpp (INTEGRATION.md).\n");
+    if (!bloom_file_complete()) return 2;
+    const int code = o.no_cleaning ? 0 : 3;
+    if (!getenv("FGPU_CLI_TIDY")) {      // (as in the single-device run: the driver releases what the process held)
+        fflush(stdout);
+        fflush(stderr);
+        _exit(code);
+    }
+    return code;
+}
+
 int main(int argc, char** argv) {
     PhaseClock clk;
     Options o;
@@ -619,6 +616,7 @@ int main(int argc, char** argv) {
         }
         if (all_regular && largest + (1u << 20) < o.chunk_bytes) o.chunk_bytes = ((largest >> 20) + 1) << 20;
     }
+    if (o.gpus > 1 && !o.from_junctions) return main_sharded(o, prm, tai, clk);
     {
         std::thread pin;   // (joined before anything else can fail or read)
         if (!o.batch_reads && !o.from_junctions)
@@ -813,60 +811,7 @@ int main(int argc, char** argv) {
                         (unsigned long long)d[5]);
         }
         clk.mark("pass 2 (read + scan)");
-        printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);
-        printf("Reads processed: %llu\n", (unsigned long long)ss.reads_processed);
-        printf("Unambiguous reads: %llu\n", (unsigned long long)ss.unambiguous_reads);
-        printf("Time in seconds for read scan: %f \n", difftime(stop, start));
-        printf("\nDistinct junctions: %llu \n", (unsigned long long)ss.n_junctions);
-        printf("Number of kmers that we j-checked: %llu \n", (unsigned long long)ss.nb_jcheck_kmer);
-        printf("Number of reads with no junctions: %llu \n", (unsigned long long)ss.nb_no_juncs);
-        printf("Number of processed kmers: %llu \n", (unsigned long long)ss.nb_processed);
-        printf("Number of skipped kmers: %llu \n", (unsigned long long)ss.nb_skipped);
-        printf("Reads without errors: %llu\n", (unsigned long long)ss.reads_no_errors);
-
-        // junction records come back in creation order; the reference's container gives the reference's dump order
-        uint64_t n = 0;
-        CHECK(fgpu_scan_junction_count(ctx, &n));
-        std::vector<uint64_t> keys(n ? n : 1);
-        std::vector<fgpu_junction> recs(n ? n : 1);
-        CHECK(fgpu_scan_download_junctions(ctx, keys.data(), recs.data(), keys.size(), &n));
-        clk.mark("  junction download");
-        // the reference's dump order = the iteration order of its container after these insertions (junction_order.h)
-        std::vector<uint32_t> order;
-        if (DumpOrder::agrees_with_the_container(keys.data(), (size_t)std::min<uint64_t>(n, 50000))) {
-            order = DumpOrder::of(keys.data(), (size_t)n);
-        } else {   // a standard library that links its nodes another way: ask the container itself
-            std::unordered_map<uint64_t, uint32_t> container;
-            for (uint64_t i = 0; i < n; i++) container.insert(std::pair<uint64_t, uint32_t>(keys[i], (uint32_t)i));
-            for (const auto& kv : container) order.push_back(kv.second);
-        }
-        clk.mark("  dump order");
-        // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596) first counts the junctions that are solid at thresholds 0..4
-        // (Junction::isSolid, utils/Junction.cpp:38-46: more than one of the four extensions with that much coverage)
-        for (int thr = 0; thr < 5; thr++) {
-            long solid = 0;
-            for (uint64_t i = 0; i < n; i++) {
-                int paths = 0;
-                for (int e = 0; e < 4; e++) paths += recs[i].cov[e] >= thr ? 1 : 0;
-                solid += paths > 1 ? 1 : 0;
-            }
-            printf("There are %ld junctions with solidity at least %d.\n", solid, thr);
-        }
-        printf("Writing to junction file\n");
-        if (int rc = write_junctions(o.file_prefix + ".junctions", keys.data(), recs.data(), order, o.k)) return rc;
-        printf("Done writing to junction file\n");
-        clk.mark("junction download + dump");
-        if (!o.no_cleaning) {   // src/Faucet.cpp:297-300
-            if (int rc = short_pf.dump(o.file_prefix + ".short_pair_filter")) return rc;
-            printf("bloom dumped \n");                                   // (Bloom::dump's line, utils/Bloom.cpp:571-578: once per filter written)
-            if (o.paired_ends) {
-                if (int rc = long_pf.dump(o.file_prefix + ".long_pair_filter")) return rc;
-                printf("bloom dumped \n");
-            }
-        }
-        printf("Weight of short pair filter: %f\n", short_pf.weight());
-        if (o.paired_ends) printf("Weight of long pair filter: %f\n", long_pf.weight());
-        printf("Number of junctions: %llu\n", (unsigned long long)order.size());
+        if (int rc = write_scan_outputs(o, ctx, ss, empty_count, not_empty_count, difftime(stop, start), short_pf, long_pf, clk)) return rc;
     }
     clk.mark("pair filter weights");
     if (!o.no_cleaning)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FGPU_ABI_VERSION 2
+#define FGPU_ABI_VERSION 3
 
 enum {
     FGPU_OK = 0,
@@ -299,6 +299,61 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
  * fgpu_scan_import_table that must follow replaces it, and the walk refuses to start while it is in place (FGPU_ERR_STATE). */
 int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries);
 #define FGPU_TABLE_ENTRY_BYTES 32
+
+/* The two pair filters as they stand on the device while a scan is open (after fgpu_scan_begin, which empties them): which = 0 the short
+ * one (fgpu_scan_short_pairs), 1 the long one (fgpu_scan_long_pairs, FGPU_LONG_PAIRS_FILTER); tai / 8 bytes each.  For read shards walked one
+ * after the other (several GPUs): the filters a shard ends with are what the next shard starts from -- the short filter only collects adds, the
+ * long one is check-then-insert in file order, and a shard that begins at an even record finds no first end waiting.  The next shard copies
+ * them in (fgpu_group_recv / fgpu_device_copy on the context's stream) before its first walk. */
+int fgpu_scan_pairs_devptr(fgpu_ctx* ctx, int which, void** dptr, uint64_t* nbytes);
+
+/* ---- device memory for the host's exchange buffers (HIP stays behind the ABI) -------------------- */
+int fgpu_device_alloc(fgpu_ctx* ctx, uint64_t nbytes, void** dptr);      /* on the context's device */
+int fgpu_device_free(fgpu_ctx* ctx, void* dptr);                          /* waits for the context's stream first */
+int fgpu_device_copy(fgpu_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t nbytes);   /* on the context's stream */
+int fgpu_device_zero(fgpu_ctx* ctx, void* dst_dev, uint64_t nbytes);                        /* on the context's stream */
+
+/* ---- several GPUs driven by ONE process: a group of contexts and their exchanges -----------------
+ * The reference is a single process (src/Faucet.cpp:204-245); BASELINE.json's north_star shards its reads over the GPUs of one node.
+ * A group ties N contexts together -- one per rank, each driven by its own host thread (the rule above), each on its own device, or
+ * several on one device where there are fewer devices than ranks (tests) -- and moves DEVICE buffers between them on the contexts' own
+ * streams: whatever a context has queued before an exchange is finished before its buffers are read, whatever it queues afterwards
+ * sees what has arrived, and no call waits for a device.  Host threads do wait for each other (a receive for its send to be posted, a
+ * send for its receive), which is the only synchronisation there is.
+ *   FGPU_TRANSPORT_COPY  device-to-device copies inside the process (hipMemcpyPeerAsync over xGMI between devices), ordered by events
+ *   FGPU_TRANSPORT_RCCL  ncclSend / ncclRecv on one communicator per rank (librccl.so is loaded when the first such group is made);
+ *                        needs one device per rank (RCCL refuses two ranks on one device)
+ * Every rank's thread makes the same sequence of collective calls; point-to-point calls pair up per (source, destination) in the order
+ * they are made.  An error on one rank: fgpu_group_abort wakes every thread that waits and makes all further calls fail. */
+typedef struct fgpu_group fgpu_group;
+#define FGPU_TRANSPORT_COPY 0
+#define FGPU_TRANSPORT_RCCL 1
+int         fgpu_group_create(int n_ranks, int transport, fgpu_group** out);
+void        fgpu_group_destroy(fgpu_group* g);                /* after every rank's thread has stopped using it */
+/* rank's thread: ties ctx to the rank; returns when every rank has attached (RCCL: the communicators exist) */
+int         fgpu_group_attach(fgpu_group* g, int rank, fgpu_ctx* ctx);
+void        fgpu_group_abort(fgpu_group* g);
+const char* fgpu_group_last_error(const fgpu_group* g, int rank);
+int         fgpu_group_barrier(fgpu_group* g, int rank);       /* host threads only; no device is waited for */
+/* bitmap := OR over ranks, in place on every rank (nbytes a multiple of 16, the same on all): reduce-scatter by slices -- rank q collects
+ * slice q of everybody and reduces it with the OR kernel -- then all-gather of the reduced slices: 2 (N-1)/N of a bitmap crosses each
+ * rank's links per call.  RCCL has no bitwise-OR reduction (rccl.h: ncclSum/Prod/Max/Min/Avg).  bloo2 after pass 1. */
+int fgpu_group_or_allreduce(fgpu_group* g, int rank, void* bitmap_dev, uint64_t nbytes);
+/* out := OR of the bitmaps of all ranks below `rank` (zero on rank 0); bitmap is left as it is.  The carried-in bloo1 of a read shard
+ * (what the sequential run has in bloo1 when it reaches the shard). */
+int fgpu_group_exclusive_prefix_or(fgpu_group* g, int rank, const void* bitmap_dev, void* out_dev, uint64_t nbytes);
+/* point to point.  send: the buffer must stay as it is until the matching receive has run; the call returns once the receiver has
+ * queued its copy (its thread has called fgpu_group_recv) and orders the sender's stream behind that copy.  send_async returns at once --
+ * for a buffer nothing writes again before fgpu_group_flush (the table preview of DESIGN.md section 5).  probe: is a send from src waiting
+ * (*nbytes its size)?  Never blocks. */
+int fgpu_group_send(fgpu_group* g, int rank, int dst, const void* dev, uint64_t nbytes);
+int fgpu_group_send_async(fgpu_group* g, int rank, int dst, const void* dev, uint64_t nbytes);
+int fgpu_group_flush(fgpu_group* g, int rank);
+int fgpu_group_recv(fgpu_group* g, int rank, int src, void* dev, uint64_t nbytes);
+int fgpu_group_probe(fgpu_group* g, int rank, int src, int* waiting, uint64_t* nbytes);
+/* the transport moves nbytes from a buffer of this rank to another buffer of this rank (RCCL: a send to itself and its receive in one group)
+ * and the result is compared on the host: *ok = 1 iff every byte arrived.  What a box with one device can show of the RCCL transport. */
+int fgpu_group_selftest(fgpu_group* g, int rank, uint64_t nbytes, int* ok);
 
 /* ---- probes for tests (pure, no state change) ------------------------------------------------- */
 /* For each of n k-mers (2-bit encoded, utils/Kmer.cpp:82-88,410-425): canonical form and

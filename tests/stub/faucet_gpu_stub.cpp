@@ -12,7 +12,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,9 +48,12 @@ struct fgpu_ctx {
     std::vector<uint64_t> starts, offsets;
     std::vector<char> flat;                  // a batch with `starts` made contiguous for the oracle
     std::vector<uint64_t> flat_offs;
+    struct Prepared { std::vector<char> bases; std::vector<uint64_t> offs; uint64_t n; };
+    std::deque<Prepared> prepared;           // fgpu_scan_prepare: batches waiting for fgpu_scan_walk_prepared
+    uint64_t carried_reads;                  // reads_processed handed over by the shard below (fgpu_scan_import_table)
 };
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;
 
 static int fail(fgpu_ctx* c, int rc, const char* what) {
     if (c) c->err = what; else g_create_error = what;
@@ -57,7 +63,7 @@ static int fail(fgpu_ctx* c, int rc, const char* what) {
 extern "C" {
 
 int fgpu_abi_version(void) { return FGPU_ABI_VERSION; }
-int fgpu_device_count(void) { return 0; }
+int fgpu_device_count(void) { return 1; }   // (the stand-in IS the device)
 
 int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     if (!p || !out) return FGPU_ERR_ARG;
@@ -78,6 +84,7 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
     c->scan_reads = c->scan_kmers = 0;
     c->phase = 0;
     c->batch_seq = 0;
+    c->carried_reads = 0;
     *out = c;
     return FGPU_OK;
 }
@@ -287,22 +294,19 @@ int fgpu_scan_begin(fgpu_ctx* c) {
     c->scan_reads = c->scan_kmers = 0;
     c->batch_seq = 0;
     c->queue.clear();
+    c->prepared.clear();
+    c->carried_reads = 0;
     c->phase = 2;
     return FGPU_OK;
 }
 
-int fgpu_scan_batch(fgpu_ctx* c, const fgpu_reads* r) {
-    if (!c || !r) return FGPU_ERR_ARG;
-    if (c->phase != 2) return fail(c, FGPU_ERR_STATE, "scan_batch outside scan_begin/scan_end");
-    const char* bases;
-    const uint64_t* offs;
-    flatten(c, r, &bases, &offs);
+static int stub_scan_flat(fgpu_ctx* c, const char* bases, const uint64_t* offs, uint64_t n_reads) {
     const bool record = (c->prm.flags & FGPU_FLAG_RECORD_STOPS) != 0;
     StubStops sb;
     sb.seq = c->batch_seq++;
     std::vector<uint64_t> ext(4096);
     std::vector<uint32_t> info(4096);
-    for (uint64_t i = 0; i < r->n_reads; i++) {
+    for (uint64_t i = 0; i < n_reads; i++) {
         const uint64_t len = offs[i + 1] - offs[i];
         uint64_t n = fo_scan_input_read_ex(c->sc, bases + offs[i], len, c->short_pf ? 0 : 1, ext.data(), info.data(), ext.size());
         if (n > ext.size()) return fail(c, FGPU_ERR_CAPACITY, "stub: more than 4096 list elements on one read");
@@ -321,6 +325,43 @@ int fgpu_scan_batch(fgpu_ctx* c, const fgpu_reads* r) {
     return FGPU_OK;
 }
 
+int fgpu_scan_batch(fgpu_ctx* c, const fgpu_reads* r) {
+    if (!c || !r) return FGPU_ERR_ARG;
+    if (c->phase != 2) return fail(c, FGPU_ERR_STATE, "scan_batch outside scan_begin/scan_end");
+    const char* bases;
+    const uint64_t* offs;
+    flatten(c, r, &bases, &offs);
+    return stub_scan_flat(c, bases, offs, r->n_reads);
+}
+
+// the pure stage has no counterpart in the oracle: a prepared batch is kept as it is and scanned when its turn comes
+int fgpu_scan_prepare(fgpu_ctx* c, const fgpu_reads* r) {
+    if (!c || !r) return FGPU_ERR_ARG;
+    if (c->phase != 2) return fail(c, FGPU_ERR_STATE, "scan_prepare outside scan_begin/scan_end");
+    const char* bases;
+    const uint64_t* offs;
+    flatten(c, r, &bases, &offs);
+    c->prepared.emplace_back();
+    fgpu_ctx::Prepared& p = c->prepared.back();
+    p.n = r->n_reads;
+    p.offs.assign(offs, offs + r->n_reads + 1);
+    p.bases.assign(bases, bases + offs[r->n_reads]);
+    if (p.bases.empty()) p.bases.push_back('N');
+    return FGPU_OK;
+}
+
+int fgpu_scan_walk_prepared(fgpu_ctx* c) {
+    if (!c) return FGPU_ERR_ARG;
+    if (c->phase != 2) return fail(c, FGPU_ERR_STATE, "scan_walk_prepared outside scan_begin/scan_end");
+    while (!c->prepared.empty()) {
+        fgpu_ctx::Prepared& p = c->prepared.front();
+        const int rc = stub_scan_flat(c, p.bases.data(), p.offs.data(), p.n);
+        if (rc != FGPU_OK) return rc;
+        c->prepared.pop_front();
+    }
+    return FGPU_OK;
+}
+
 int fgpu_scan_end(fgpu_ctx* c, fgpu_scan_stats* st) {
     if (!c) return FGPU_ERR_ARG;
     if (c->phase != 2) return fail(c, FGPU_ERR_STATE, "scan_end without scan_begin");
@@ -328,7 +369,7 @@ int fgpu_scan_end(fgpu_ctx* c, fgpu_scan_stats* st) {
         fo_scan_stats o;
         fo_scan_get_stats(c->sc, &o);
         memset(st, 0, sizeof(*st));
-        st->reads_processed = c->scan_reads;
+        st->reads_processed = c->scan_reads + c->carried_reads;
         st->unambiguous_reads = o.unambiguous_reads;
         st->reads_no_errors = o.reads_no_errors;
         st->nb_jcheck_kmer = o.nb_jcheck_kmer;
@@ -374,23 +415,265 @@ int fgpu_scan_download_junctions(fgpu_ctx* c, uint64_t* keys, fgpu_junction* rec
 
 // ---- the rest of the ABI is not needed by the stub's callers ------------------------------------------------------------------------------
 #define STUB_UNSUPPORTED(c) fail(c, FGPU_ERR_STATE, "not in the test stub (tests/stub/faucet_gpu_stub.cpp)")
-int fgpu_presence_batch(fgpu_ctx* c, const fgpu_reads*) { return STUB_UNSUPPORTED(c); }
 int fgpu_load_fixup(fgpu_ctx* c, const void*, fgpu_load_stats*) { return STUB_UNSUPPORTED(c); }
-int fgpu_bloom_devptr(fgpu_ctx* c, int, void**, uint64_t*) { return STUB_UNSUPPORTED(c); }
-int fgpu_bitmap_or(fgpu_ctx* c, void*, const void*, uint64_t) { return STUB_UNSUPPORTED(c); }
-int fgpu_scan_prepare(fgpu_ctx* c, const fgpu_reads*) { return STUB_UNSUPPORTED(c); }
-int fgpu_scan_walk_prepared(fgpu_ctx* c) { return STUB_UNSUPPORTED(c); }
 int fgpu_scan_set_eager(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_profile_enable(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_diag_ovw(fgpu_ctx* c, uint64_t out[6]) { if (!c || !out) return FGPU_ERR_ARG; memset(out, 0, 6 * sizeof(uint64_t)); return FGPU_OK; }
-int fgpu_scan_table_entries(fgpu_ctx* c, uint64_t*) { return STUB_UNSUPPORTED(c); }
-int fgpu_scan_export_table(fgpu_ctx* c, void*, uint64_t, uint64_t*) { return STUB_UNSUPPORTED(c); }
-int fgpu_scan_import_table(fgpu_ctx* c, const void*, uint64_t, const fgpu_scan_stats*) { return STUB_UNSUPPORTED(c); }
-int fgpu_scan_import_hint(fgpu_ctx* c, const void*, uint64_t) { return STUB_UNSUPPORTED(c); }
 int fgpu_stage3_set_junctions(fgpu_ctx* c, const uint64_t*, const fgpu_junction*, uint64_t) { return STUB_UNSUPPORTED(c); }
 uint64_t fgpu_stage3_contig_words(int32_t k, int32_t max_read_length) { return (uint64_t)(2 * max_read_length + k + 31) / 32 + 1; }
 int fgpu_stage3_find_neighbors(fgpu_ctx* c, const uint64_t*, const int8_t*, uint64_t, int32_t, fgpu_neighbor*, uint64_t*, uint64_t*, uint64_t) {
     return STUB_UNSUPPORTED(c);
 }
+
+// ---- read shards (faucet_amd/host/shard_host.h): the presence protocol of pass 1, the table hand-over of pass 2, the exchanges ------------------
+// "Device" memory is host memory here, a stream is the calling thread: every call has finished when it returns.
+int fgpu_presence_batch(fgpu_ctx* c, const fgpu_reads* r) {
+    if (!c || !r) return FGPU_ERR_ARG;
+    if (c->phase != 0) return fail(c, FGPU_ERR_STATE, "presence_batch while a pass is open");
+    const char* bases;
+    const uint64_t* offs;
+    flatten(c, r, &bases, &offs);
+    fo_load_stats st;
+    fo_load_single_filter(c->b1, bases, offs, r->n_reads, c->prm.k, &st);      // every k-mer's bits, no order
+    return FGPU_OK;
+}
+int fgpu_bloom_devptr(fgpu_ctx* c, int which, void** dptr, uint64_t* nbytes) {
+    fo_bloom* b = c ? which_bloom(c, which) : NULL;
+    if (!b || !dptr) return FGPU_ERR_ARG;
+    *dptr = fo_bloom_bits(b);
+    if (nbytes) *nbytes = fo_bloom_nbytes(b);
+    return FGPU_OK;
+}
+int fgpu_bitmap_or(fgpu_ctx* c, void* dst, const void* src, uint64_t nbytes) {
+    if (!c || !dst || !src) return FGPU_ERR_ARG;
+    for (uint64_t i = 0; i < nbytes; i++) ((uint8_t*)dst)[i] |= ((const uint8_t*)src)[i];
+    return FGPU_OK;
+}
+int fgpu_device_alloc(fgpu_ctx* c, uint64_t nbytes, void** dptr) { if (!c || !dptr) return FGPU_ERR_ARG; *dptr = calloc(nbytes ? nbytes : 16, 1); return *dptr ? FGPU_OK : FGPU_ERR_NOMEM; }
+int fgpu_device_free(fgpu_ctx* c, void* dptr) { if (!c) return FGPU_ERR_ARG; free(dptr); return FGPU_OK; }
+int fgpu_device_copy(fgpu_ctx* c, void* dst, const void* src, uint64_t nbytes) { if (!c) return FGPU_ERR_ARG; if (nbytes) memmove(dst, src, nbytes); return FGPU_OK; }
+int fgpu_device_zero(fgpu_ctx* c, void* dst, uint64_t nbytes) { if (!c) return FGPU_ERR_ARG; if (nbytes) memset(dst, 0, nbytes); return FGPU_OK; }
+int fgpu_scan_pairs_devptr(fgpu_ctx* c, int which, void** dptr, uint64_t* nbytes) {
+    fo_bloom* b = !c ? NULL : which == 0 ? c->short_pf : which == 1 ? c->long_pf : NULL;
+    if (!b || !dptr) return c ? fail(c, FGPU_ERR_STATE, "no such pair filter") : FGPU_ERR_ARG;
+    *dptr = fo_bloom_bits(b);
+    if (nbytes) *nbytes = fo_bloom_nbytes(b);
+    return FGPU_OK;
+}
+
+// the junction table as it travels between shards: 32 bytes per record -- key, record, padding -- in creation order
+struct StubEntry { uint64_t key; fo_junction rec; uint8_t pad[FGPU_TABLE_ENTRY_BYTES - 8 - sizeof(fo_junction)]; };
+static_assert(sizeof(StubEntry) == FGPU_TABLE_ENTRY_BYTES, "table entry size");
+int fgpu_scan_table_entries(fgpu_ctx* c, uint64_t* n) {
+    if (!c || !n || !c->sc) return FGPU_ERR_ARG;
+    *n = fo_scan_get_junctions(c->sc, 1, NULL, NULL, 0);
+    return FGPU_OK;
+}
+int fgpu_scan_export_table(fgpu_ctx* c, void* buf, uint64_t buf_bytes, uint64_t* n_entries) {
+    if (!c || !buf || !n_entries || !c->sc) return FGPU_ERR_ARG;
+    const uint64_t n = fo_scan_get_junctions(c->sc, 1, NULL, NULL, 0);
+    if (n * sizeof(StubEntry) > buf_bytes) return fail(c, FGPU_ERR_CAPACITY, "table buffer too small");
+    std::vector<uint64_t> keys(n ? n : 1);
+    std::vector<fo_junction> recs(n ? n : 1);
+    fo_scan_get_junctions(c->sc, 1, keys.data(), recs.data(), n);
+    StubEntry* e = (StubEntry*)buf;
+    for (uint64_t i = 0; i < n; i++) { memset(&e[i], 0, sizeof(StubEntry)); e[i].key = keys[i]; e[i].rec = recs[i]; }
+    *n_entries = n;
+    return FGPU_OK;
+}
+int fgpu_scan_import_table(fgpu_ctx* c, const void* buf, uint64_t n, const fgpu_scan_stats* carried) {
+    if (!c || (n && !buf) || !c->sc) return FGPU_ERR_ARG;
+    if (c->phase != 2) return fail(c, FGPU_ERR_STATE, "import_table outside scan_begin/scan_end");
+    std::vector<uint64_t> keys(n ? n : 1);
+    std::vector<fo_junction> recs(n ? n : 1);
+    const StubEntry* e = (const StubEntry*)buf;
+    for (uint64_t i = 0; i < n; i++) { keys[i] = e[i].key; recs[i] = e[i].rec; }
+    fo_scan_stats st;
+    memset(&st, 0, sizeof(st));
+    if (carried) {
+        st.unambiguous_reads = carried->unambiguous_reads;
+        st.reads_no_errors = carried->reads_no_errors;
+        st.nb_jcheck_kmer = carried->nb_jcheck_kmer;
+        st.nb_no_juncs = carried->nb_no_juncs;
+        st.nb_processed = carried->nb_processed;
+        st.nb_skipped = carried->nb_skipped;
+        c->carried_reads = carried->reads_processed;
+    }
+    fo_scan_import(c->sc, keys.data(), recs.data(), n, carried ? &st : NULL);
+    return FGPU_OK;
+}
+int fgpu_scan_import_hint(fgpu_ctx* c, const void*, uint64_t) { return c ? FGPU_OK : FGPU_ERR_ARG; }   // (the oracle has no preview to make)
+
+// the group: mailboxes per (source, destination); a receive copies out of the sender's buffer, a send returns when that has happened
+struct StubMsg { const void* ptr; uint64_t nbytes; bool copied; };
+struct fgpu_group {
+    int n;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::deque<StubMsg*> > chan;
+    std::vector<std::vector<StubMsg*> > outstanding;
+    std::vector<fgpu_ctx*> ctx;
+    int attached, bar_count;
+    uint64_t bar_gen;
+    bool aborted;
+    std::string err;
+};
+int fgpu_group_create(int n_ranks, int transport, fgpu_group** out) {
+    if (!out || n_ranks < 1 || n_ranks > 64 || (transport != FGPU_TRANSPORT_COPY && transport != FGPU_TRANSPORT_RCCL)) return FGPU_ERR_ARG;
+    fgpu_group* g = new fgpu_group();
+    g->n = n_ranks;
+    g->chan.resize((size_t)n_ranks * n_ranks);
+    g->outstanding.resize((size_t)n_ranks);
+    g->ctx.assign((size_t)n_ranks, NULL);
+    g->attached = g->bar_count = 0;
+    g->bar_gen = 0;
+    g->aborted = false;
+    *out = g;
+    if (transport == FGPU_TRANSPORT_RCCL) { g->err = "the test stub has no RCCL transport"; return FGPU_ERR_HIP; }
+    return FGPU_OK;
+}
+void fgpu_group_destroy(fgpu_group* g) {
+    if (!g) return;
+    std::vector<StubMsg*> left;
+    for (auto& q : g->chan) for (StubMsg* msg : q) left.push_back(msg);
+    for (auto& v : g->outstanding) for (StubMsg* msg : v) { bool seen = false; for (StubMsg* o : left) if (o == msg) seen = true; if (!seen) left.push_back(msg); }
+    for (StubMsg* msg : left) delete msg;
+    delete g;
+}
+const char* fgpu_group_last_error(const fgpu_group* g, int) { return g ? g->err.c_str() : "no group"; }
+void fgpu_group_abort(fgpu_group* g) {
+    if (!g) return;
+    { std::lock_guard<std::mutex> lk(g->m); g->aborted = true; }
+    g->cv.notify_all();
+}
+int fgpu_group_attach(fgpu_group* g, int rank, fgpu_ctx* c) {
+    if (!g || rank < 0 || rank >= g->n || !c) return FGPU_ERR_ARG;
+    std::unique_lock<std::mutex> lk(g->m);
+    g->ctx[(size_t)rank] = c;
+    if (++g->attached == g->n) g->cv.notify_all();
+    else g->cv.wait(lk, [&] { return g->attached == g->n || g->aborted; });
+    return g->aborted ? FGPU_ERR_STATE : FGPU_OK;
+}
+int fgpu_group_barrier(fgpu_group* g, int rank) {
+    if (!g || rank < 0 || rank >= g->n) return FGPU_ERR_ARG;
+    std::unique_lock<std::mutex> lk(g->m);
+    const uint64_t gen = g->bar_gen;
+    if (++g->bar_count == g->n) { g->bar_count = 0; g->bar_gen++; g->cv.notify_all(); return FGPU_OK; }
+    g->cv.wait(lk, [&] { return g->aborted || g->bar_gen != gen; });
+    return g->bar_gen != gen ? FGPU_OK : FGPU_ERR_STATE;
+}
+static StubMsg* stub_post(fgpu_group* g, int rank, int dst, const void* p, uint64_t nbytes) {
+    StubMsg* msg = new StubMsg{p, nbytes, false};
+    { std::lock_guard<std::mutex> lk(g->m); g->chan[(size_t)rank * g->n + dst].push_back(msg); }
+    g->cv.notify_all();
+    return msg;
+}
+static int stub_settle(fgpu_group* g, StubMsg* msg) {
+    std::unique_lock<std::mutex> lk(g->m);
+    g->cv.wait(lk, [&] { return g->aborted || msg->copied; });
+    if (!msg->copied) return FGPU_ERR_STATE;
+    lk.unlock();
+    delete msg;
+    return FGPU_OK;
+}
+int fgpu_group_recv(fgpu_group* g, int rank, int src, void* dev, uint64_t nbytes) {
+    if (!g || rank < 0 || rank >= g->n || src < 0 || src >= g->n) return FGPU_ERR_ARG;
+    std::unique_lock<std::mutex> lk(g->m);
+    std::deque<StubMsg*>& q = g->chan[(size_t)src * g->n + rank];
+    g->cv.wait(lk, [&] { return g->aborted || !q.empty(); });
+    if (q.empty()) return FGPU_ERR_STATE;
+    StubMsg* msg = q.front();
+    if (msg->nbytes != nbytes) { g->err = "receive and send differ in size"; return FGPU_ERR_ARG; }
+    q.pop_front();
+    if (nbytes) memcpy(dev, msg->ptr, nbytes);       // (under the lock: the sender is still waiting, its buffer is valid)
+    msg->copied = true;
+    lk.unlock();
+    g->cv.notify_all();
+    return FGPU_OK;
+}
+int fgpu_group_send(fgpu_group* g, int rank, int dst, const void* dev, uint64_t nbytes) {
+    if (!g || rank < 0 || rank >= g->n || dst < 0 || dst >= g->n || dst == rank) return FGPU_ERR_ARG;
+    return stub_settle(g, stub_post(g, rank, dst, dev, nbytes));
+}
+int fgpu_group_send_async(fgpu_group* g, int rank, int dst, const void* dev, uint64_t nbytes) {
+    if (!g || rank < 0 || rank >= g->n || dst < 0 || dst >= g->n || dst == rank) return FGPU_ERR_ARG;
+    g->outstanding[(size_t)rank].push_back(stub_post(g, rank, dst, dev, nbytes));
+    return FGPU_OK;
+}
+int fgpu_group_flush(fgpu_group* g, int rank) {
+    if (!g || rank < 0 || rank >= g->n) return FGPU_ERR_ARG;
+    std::vector<StubMsg*> out;
+    out.swap(g->outstanding[(size_t)rank]);
+    int rc = FGPU_OK;
+    for (size_t i = 0; i < out.size(); i++) {
+        if (rc == FGPU_OK) rc = stub_settle(g, out[i]);
+        if (rc != FGPU_OK) g->outstanding[(size_t)rank].push_back(out[i]);      // (left to fgpu_group_destroy)
+    }
+    return rc;
+}
+int fgpu_group_probe(fgpu_group* g, int rank, int src, int* waiting, uint64_t* nbytes) {
+    if (!g || rank < 0 || rank >= g->n || src < 0 || src >= g->n || !waiting) return FGPU_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->m);
+    std::deque<StubMsg*>& q = g->chan[(size_t)src * g->n + rank];
+    *waiting = q.empty() ? 0 : 1;
+    if (nbytes) *nbytes = q.empty() ? 0 : q.front()->nbytes;
+    return g->aborted ? FGPU_ERR_STATE : FGPU_OK;
+}
+static void stub_slices(uint64_t nbytes, int n, std::vector<uint64_t>& lo, std::vector<uint64_t>& hi) {
+    uint64_t step = (nbytes + (uint64_t)n - 1) / (uint64_t)n;
+    step = (step + 15) & ~15ULL;
+    lo.resize((size_t)n);
+    hi.resize((size_t)n);
+    for (int q = 0; q < n; q++) { lo[(size_t)q] = std::min<uint64_t>((uint64_t)q * step, nbytes); hi[(size_t)q] = std::min<uint64_t>((uint64_t)(q + 1) * step, nbytes); }
+}
+// the same slice schedule as the library's (faucet_amd/csrc/group.hip), byte arrays in host memory
+int fgpu_group_or_allreduce(fgpu_group* g, int rank, void* bitmap, uint64_t nbytes) {
+    if (!g || rank < 0 || rank >= g->n || !bitmap || (nbytes & 15)) return FGPU_ERR_ARG;
+    if (g->n == 1) return FGPU_OK;
+    std::vector<uint64_t> lo, hi;
+    stub_slices(nbytes, g->n, lo, hi);
+    uint8_t* bm = (uint8_t*)bitmap;
+    const uint64_t mine = hi[(size_t)rank] - lo[(size_t)rank];
+    std::vector<uint8_t> stage((size_t)(mine ? mine : 1) * (size_t)(g->n - 1));
+    std::vector<StubMsg*> posted;
+    for (int q = 0; q < g->n; q++) if (q != rank && hi[(size_t)q] > lo[(size_t)q]) posted.push_back(stub_post(g, rank, q, bm + lo[(size_t)q], hi[(size_t)q] - lo[(size_t)q]));
+    int i = 0, rc = FGPU_OK;
+    for (int q = 0; q < g->n && rc == FGPU_OK; q++) { if (q == rank) continue; if (mine) rc = fgpu_group_recv(g, rank, q, stage.data() + (size_t)i * mine, mine); i++; }
+    for (StubMsg* msg : posted) { const int r2 = stub_settle(g, msg); if (rc == FGPU_OK) rc = r2; }
+    if (rc != FGPU_OK) return rc;
+    for (int s2 = 0; mine && s2 < g->n - 1; s2++) for (uint64_t b = 0; b < mine; b++) bm[lo[(size_t)rank] + b] |= stage[(size_t)s2 * mine + b];
+    posted.clear();
+    for (int q = 0; q < g->n; q++) if (q != rank && mine) posted.push_back(stub_post(g, rank, q, bm + lo[(size_t)rank], mine));
+    for (int q = 0; q < g->n && rc == FGPU_OK; q++) if (q != rank && hi[(size_t)q] > lo[(size_t)q]) rc = fgpu_group_recv(g, rank, q, bm + lo[(size_t)q], hi[(size_t)q] - lo[(size_t)q]);
+    for (StubMsg* msg : posted) { const int r2 = stub_settle(g, msg); if (rc == FGPU_OK) rc = r2; }
+    return rc;
+}
+int fgpu_group_exclusive_prefix_or(fgpu_group* g, int rank, const void* bitmap, void* out_v, uint64_t nbytes) {
+    if (!g || rank < 0 || rank >= g->n || !bitmap || !out_v || (nbytes & 15)) return FGPU_ERR_ARG;
+    uint8_t* out = (uint8_t*)out_v;
+    if (g->n == 1) { memset(out, 0, nbytes); return FGPU_OK; }
+    std::vector<uint64_t> lo, hi;
+    stub_slices(nbytes, g->n, lo, hi);
+    const uint8_t* bm = (const uint8_t*)bitmap;
+    const uint64_t mine = hi[(size_t)rank] - lo[(size_t)rank], cell = mine ? mine : 1;
+    std::vector<uint8_t> stage((size_t)cell * (size_t)g->n), pref((size_t)cell * (size_t)g->n, 0);
+    if (mine) memcpy(stage.data() + (size_t)rank * mine, bm + lo[(size_t)rank], mine);
+    std::vector<StubMsg*> posted;
+    for (int q = 0; q < g->n; q++) if (q != rank && hi[(size_t)q] > lo[(size_t)q]) posted.push_back(stub_post(g, rank, q, bm + lo[(size_t)q], hi[(size_t)q] - lo[(size_t)q]));
+    int rc = FGPU_OK;
+    for (int q = 0; q < g->n && rc == FGPU_OK; q++) if (q != rank && mine) rc = fgpu_group_recv(g, rank, q, stage.data() + (size_t)q * mine, mine);
+    for (StubMsg* msg : posted) { const int r2 = stub_settle(g, msg); if (rc == FGPU_OK) rc = r2; }
+    if (rc != FGPU_OK) return rc;
+    for (int q = 1; mine && q < g->n; q++) for (uint64_t b = 0; b < mine; b++) pref[(size_t)q * mine + b] = pref[(size_t)(q - 1) * mine + b] | stage[(size_t)(q - 1) * mine + b];
+    posted.clear();
+    for (int q = 1; q < g->n; q++) if (q != rank && mine) posted.push_back(stub_post(g, rank, q, pref.data() + (size_t)q * mine, mine));
+    if (rank != 0) for (int q = 0; q < g->n && rc == FGPU_OK; q++) if (q != rank && hi[(size_t)q] > lo[(size_t)q]) rc = fgpu_group_recv(g, rank, q, out + lo[(size_t)q], hi[(size_t)q] - lo[(size_t)q]);
+    for (StubMsg* msg : posted) { const int r2 = stub_settle(g, msg); if (rc == FGPU_OK) rc = r2; }
+    if (rc != FGPU_OK) return rc;
+    if (rank == 0) memset(out, 0, nbytes);
+    else if (mine) memcpy(out + lo[(size_t)rank], pref.data() + (size_t)rank * mine, mine);
+    return FGPU_OK;
+}
+int fgpu_group_selftest(fgpu_group* g, int rank, uint64_t nbytes, int* ok) { if (!g || rank < 0 || rank >= g->n || !ok || !nbytes) return FGPU_ERR_ARG; *ok = 1; return FGPU_OK; }
 
 }  // extern "C"

@@ -329,7 +329,7 @@ def test_config5_full_size_equals_the_oracle():
     _assert_equals_oracle_fixture("config5", lst, sst, bloo1, bloo2, keys, recs)
 
 
-def _run_cli(name, tmp_path):
+def _run_cli(name, tmp_path, extra=()):
     """the reads of a full-size case as a FASTA / FASTQ file through the `faucet` command line; returns the output prefix"""
     dev = torch.device("cuda", 0)
     fx = FULL[name]
@@ -344,7 +344,7 @@ def _run_cli(name, tmp_path):
     del text
     prefix = str(tmp_path / "out")
     cli = os.path.join(ROOT, "faucet_amd", "faucet")
-    r = subprocess.run([cli, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + fx["args"], capture_output=True, text=True, timeout=800)
+    r = subprocess.run([cli, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + fx["args"] + list(extra), capture_output=True, text=True, timeout=800)
     assert r.returncode == (0 if "--no_cleaning" in fx["args"] else 3), r.stdout[-2000:] + r.stderr[-2000:]
     os.remove(inp)
     return prefix, r.stdout
@@ -372,6 +372,28 @@ def test_config2_fasta_through_the_cli_equals_the_reference(tmp_path):
     prefix, out = _run_cli("config2_cli", tmp_path)
     for ext in ("bloom", "junctions"):
         assert _sha_file(prefix + "." + ext) == fx[ext + "_sha256"], "." + ext + " differs from the reference's"
+
+
+@pytest.mark.skipif("config2_cli" not in FULL, reason="no config2_cli entry in tests/golden/fullsize.json")
+def test_config2_fasta_sharded_over_two_contexts_by_the_cli_equals_the_reference(tmp_path):
+    """`faucet -gpus 2` on config 2's 1.1 GB FASTA file: the C++ host cuts the file into two file-order shards, one host thread and one context
+    each (both on the box's one device), fix-up protocol in pass 1, the walk handed from shard to shard -- same bytes as the compiled reference"""
+    fx = FULL["config2_cli"]
+    prefix, out = _run_cli("config2_cli", tmp_path, ["-gpus", "2"])
+    for ext in ("bloom", "junctions"):
+        assert _sha_file(prefix + "." + ext) == fx[ext + "_sha256"], "." + ext + " differs from the reference's"
+
+
+@pytest.mark.skipif("config3" not in FULL, reason="no config3 entry in tests/golden/fullsize.json")
+def test_config3_paired_end_fastq_sharded_over_three_contexts_equals_the_reference(tmp_path):
+    """config 3's shape with cleaning, `-gpus 3`: both pair filters travel with the junction table from shard to shard (the long one is
+    check-then-insert in file order); all four files equal the compiled reference's"""
+    fx = FULL["config3"]
+    prefix, out = _run_cli("config3", tmp_path, ["-gpus", "3"])
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        assert _sha_file(prefix + "." + ext) == fx[ext + "_sha256"], "." + ext + " differs from the reference's"
+    for label, key in (("Distinct junctions: ", "distinct_junctions"), ("Number of processed kmers: ", "nb_processed"), ("Reads without errors: ", "reads_no_errors")):
+        assert f"{label}{fx[key]}" in out, label
 
 
 def test_config4_per_gpu_shape_is_invariant_under_scheduling_choices():

@@ -1121,6 +1121,51 @@ def test_the_library_absorbs_a_failed_lazy_check(tmp_path, monkeypatch):
     assert r.returncode == 0 and "absorbed ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_a_replay_applies_the_long_pair_loop_to_every_batch_once():
+    """with the lists ALSO handed to the host (fgpu_scan_short_pairs(..., lists_to_host = 1)) a replay harvests every batch the caller
+    has not taken yet a second time; the device's check-then-insert loop (fgpu_scan_long_pairs) must see each batch once all the same.
+    FGPU_DEBUG_LAZY_FAIL=4 forces the replay once four batches have been prepared -- lists of earlier batches are harvested by then."""
+    import os
+    import subprocess
+    code = (
+        "import numpy as np\n"
+        "from faucet_amd import _lib as L, api\n"
+        "from tests.test_gpu_parity import chunks, _paired_oracle, _pairs_in_repeats\n"
+        "k, E, S = 21, 400_000, 150_000\n"
+        "bases, offs = _pairs_in_repeats(20_001, 5)\n"
+        "tai, nh = api.load_filter_shape(E, S)\n"
+        "b2, short, long_, osc = _paired_oracle(bases, offs, k, tai, nh, E)\n"
+        "ost = osc.stats()\n"
+        "for take_during in (False, True):\n"
+        "    ctx = api.Context(k, tai, nh, record_stops=True)\n"
+        "    ctx.bloom_upload(L.BLOO2, b2.bits())\n"
+        "    ctx.scan_short_pairs(short.tai, short.n_hash, True)\n"
+        "    ctx.scan_long_pairs(long_.tai, long_.n_hash, 2)\n"
+        "    ctx.scan_begin()\n"
+        "    seqs = []\n"
+        "    for i, part in enumerate(chunks(bases, offs, 7)):\n"
+        "        ctx.scan_batch(part)\n"
+        "        if take_during and i in (1, 2):\n"
+        "            t = ctx.take_stops()\n"
+        "            if t is not None: seqs.append(t[0])\n"
+        "    ctx.scan_end()\n"
+        "    while True:\n"
+        "        t = ctx.take_stops()\n"
+        "        if t is None: break\n"
+        "        seqs.append(t[0])\n"
+        "    assert seqs == list(range(7)), seqs\n"
+        "    assert ctx.diag_scan_replays() == 1, ctx.diag_scan_replays()\n"
+        "    bits, empty, not_empty = ctx.scan_long_pairs_download(long_.tai)\n"
+        "    assert (empty, not_empty) == (ost['empty_count'], ost['not_empty_count']), (empty, not_empty)\n"
+        "    assert np.array_equal(bits, long_.bits())\n"
+        "    assert np.array_equal(ctx.scan_short_pairs_download(short.tai), short.bits())\n"
+        "print('once each ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGPU_DEBUG_LAZY_FAIL="4")
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "once each ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("n_batches", [1, 5])
 def test_mercy_load_matches_the_reference(n_batches):
     """load_two_filters(..., mercy = true) (utils/Bloom.cpp:300-333): the reference's --mercy .bloom, byte for byte, and it does

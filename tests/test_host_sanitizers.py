@@ -124,3 +124,27 @@ def test_read_pairs_inside_repeats_equal_the_compiled_reference(cli, tmp_path):
     for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
         with open(prefix + "." + ext, "rb") as f, open(ref_prefix + "." + ext, "rb") as g2:
             assert f.read() == g2.read(), ext
+
+
+@pytest.mark.parametrize("gpus", [2, 4])
+@pytest.mark.parametrize("case", ["se_cleaning_k21", "pe_repeats_k25", "mercy_k21"])
+def test_read_shards_over_several_host_threads_are_clean_and_equal_the_reference(cli, gpus, case, tmp_path):
+    """`faucet -gpus N` (faucet_amd/host/shard_host.h): one host thread per shard, each with a reader thread of its own, the rendezvous of the
+    exchanges and of the table hand-over -- under both sanitizers against the stub (whose group moves host memory; presence protocol: the
+    stub has no first-set times), and the four files are the compiled reference's: cuts at record (pair) boundaries, counters summed over
+    shards, pair filters handed along the chain."""
+    exe, _ = cli
+    c = Case(case)
+    inp = str(tmp_path / ("reads.fq" if c.fastq else "reads.fa"))
+    with open(inp, "wb") as f:
+        f.write(c.reads_text())
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix, "-gpus", str(gpus), "-chunk_mb", "1"] + c.meta["args"],
+                       capture_output=True, text=True, env=dict(_env(), FAUCET_SHARD_PROTOCOL="presence"), timeout=900)
+    _check(r, 0 if c.no_cleaning else 3)
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        gold = os.path.join(c.dir, f"out.{ext}.gz")
+        if not os.path.exists(gold):
+            continue
+        with open(prefix + "." + ext, "rb") as f, gzip.open(gold, "rb") as g:
+            assert f.read() == g.read(), ext
