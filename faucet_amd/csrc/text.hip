@@ -97,7 +97,8 @@ int fgpu_text_reserve(fgpu_ctx* ctx, uint64_t max_chunk_bytes) {
 extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes, int text_on_device, int fastq, int final_chunk,
                                fgpu_reads* out, uint64_t* consumed) {
     if (!ctx || !out || !consumed || (nbytes && !text)) return FGPU_ERR_ARG;
-    if (ctx->phase == 2 && !ctx->prepared.empty()) { ctx->err = "fgpu_text_split while prepared batches still point into the previous text"; return FGPU_ERR_STATE; }
+    // (prepared scan batches -- fgpu_scan_prepare, read shards -- do not point into the text any more: a batch is packed into its own code and
+    // plane buffers inside the call that takes it, and that call ends with a synchronisation of the main stream, the piece count)
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     memset(out, 0, sizeof(*out));
     out->on_device = 1;

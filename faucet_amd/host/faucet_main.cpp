@@ -430,6 +430,12 @@ int write_scan_outputs(const Options& o, fgpu_ctx* ctx, const fgpu_scan_stats& s
 int main_sharded(const Options& o, const fgpu_params& prm, uint64_t tai, PhaseClock& clk) {
     using namespace faucet_host;
     if (o.batch_reads) { fprintf(stderr, "-batch_reads (records split on the host) cannot be combined with -gpus: the shards split their records on their devices\n"); return 1; }
+    for (const std::string* f : {&o.read_load_file, &o.read_scan_file}) {      // (before any device is touched)
+        struct stat st;
+        if (o.from_bloom && f == &o.read_load_file) continue;
+        if (stat(f->c_str(), &st) != 0) { fprintf(stderr, "cannot open %s\n", f->c_str()); return 2; }
+        if (!S_ISREG(st.st_mode)) { fprintf(stderr, "%s is not a regular file: with -gpus the read shards are byte ranges of their input (pipes need -gpus 1)\n", f->c_str()); return 2; }
+    }
     const int ndev = fgpu_device_count();
     if (ndev < 1) { fprintf(stderr, "fgpu_create failed (%d): no gfx950 device\n", FGPU_ERR_HIP); return 2; }
     ShardOptions so;

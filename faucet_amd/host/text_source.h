@@ -255,9 +255,10 @@ private:
 // `group` records stay together (2 for --paired_ends: reads 2p and 2p + 1 of the scan are a pair, src/ReadScanner.cpp:303-350).
 // Returns n + 1 offsets, cuts[0] = 0, cuts[n] = size; shards may be empty.  false: not a regular file, or it cannot be read.
 inline bool record_cuts(const std::string& path, int lines_per_record, int group, int n, std::vector<uint64_t>* cuts) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;      // (looked at before it is opened: opening a FIFO would wait for its writer)
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
-    struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
     const uint64_t size = (uint64_t)st.st_size;
     cuts->assign((size_t)n + 1, size);
