@@ -23,21 +23,35 @@
 #include "../utils/Kmer.h"
 #include "../utils/JuncPairs.h"
 #include "faucet_gpu.h"
+#include "shard_host.h"     // faucet_amd/host: the two passes over several GPUs from this one process (one host thread per device)
 
 extern int j;               // src/Faucet.h:15
 extern int maxSpacerDist;   // src/Faucet.h:48
 
-static fgpu_ctx* g_ctx;
+static fgpu_ctx* g_ctx;     // the context Stage 3 asks (with several GPUs: the last shard's, which holds the junction map; every shard holds bloo2)
+static faucet_host::ShardedRun* g_run;   // several GPUs: the read shards' contexts and their exchanges
 // what the run will ask of the scan, known before pass 1 (the context is made there): set from main() right after handle_arguments,
 // e.g. `gpu_configure(!no_cleaning, paired_ends);`.  With cleaning on the scan has to keep scanInputRead's lists (FGPU_FLAG_RECORD_STOPS:
 // both pair filters are filled from them on the device); with --paired_ends the lists are kept in any case (the pair counts).
 static bool g_want_pairs = false, g_paired_ends = false;
-void gpu_configure(bool cleaning, bool paired_ends) { g_want_pairs = cleaning; g_paired_ends = paired_ends; }
+// n_gpus: read shards over that many GPUs (faucet_amd/host/shard_host.h; the reads must then come from regular files).  0 = what the
+// environment says (FAUCET_GPUS, FAUCET_TRANSPORT=copy|rccl), else one -- the reference has no such flag; a maintainer adds one to
+// handle_arguments (src/Faucet.cpp:57-182) and passes it here.
+static int g_gpus = 1, g_transport = FGPU_TRANSPORT_COPY;
+void gpu_configure(bool cleaning, bool paired_ends, int n_gpus = 0) {
+    g_want_pairs = cleaning;
+    g_paired_ends = paired_ends;
+    if (n_gpus <= 0) { const char* e = getenv("FAUCET_GPUS"); n_gpus = e ? atoi(e) : 1; }
+    g_gpus = n_gpus < 1 ? 1 : n_gpus > 64 ? 64 : n_gpus;
+    const char* t = getenv("FAUCET_TRANSPORT");
+    g_transport = t && !strcmp(t, "rccl") ? FGPU_TRANSPORT_RCCL : FGPU_TRANSPORT_COPY;
+}
 
 static void gpu_die(const char* what, int rc) {
-    fprintf(stderr, "%s failed (%d): %s\n", what, rc, fgpu_last_error(g_ctx));
+    fprintf(stderr, "%s failed (%d): %s\n", what, rc, g_run && !g_run->error().empty() ? g_run->error().c_str() : fgpu_last_error(g_ctx));
     // fgpu_create leaves a thread of the library setting up the scan's streams; fgpu_destroy joins it, so that exit() does not tear the HIP
     // runtime down under it
+    if (g_run) { delete g_run; g_run = NULL; g_ctx = NULL; }
     if (g_ctx) { fgpu_destroy(g_ctx); g_ctx = NULL; }
     exit(2);
 }
@@ -84,6 +98,31 @@ void gpu_load_two_filters(Bloom* bloo1, Bloom* bloo2, std::string reads_filename
     p.n_hash = bloo1->getNumHash();
     p.tai = bloo1->tai;
     p.flags = (mercy ? FGPU_FLAG_MERCY : 0) | ((g_want_pairs || g_paired_ends) ? (FGPU_FLAG_RECORD_STOPS | FGPU_FLAG_KEY_ORDER_FROM_START) : 0);
+    if (g_gpus > 1) {
+        // read shards: shard r = the r-th file-order share of the records, on device r (fewer devices than shards: they share), one host thread each
+        faucet_host::ShardOptions so;
+        const int ndev = fgpu_device_count();
+        if (ndev < 1) { fprintf(stderr, "fgpu_create failed: no gfx950 device\n"); exit(2); }
+        so.n_ranks = g_gpus;
+        so.transport = g_transport;
+        for (int r = 0; r < g_gpus; r++) so.devices.push_back(r % ndev);
+        so.prm = p;
+        so.fastq = fastq;
+        so.mercy = mercy;
+        so.paired_ends = g_paired_ends;
+        so.no_cleaning = !g_want_pairs;
+        so.chunk_bytes = 32u << 20;
+        g_run = new faucet_host::ShardedRun(so);
+        int rc = g_run->create();
+        if (rc != FGPU_OK) gpu_die("creating the read shards' contexts", rc);
+        faucet_host::ShardLoadResult lr;
+        if ((rc = g_run->load(reads_filename, &lr)) != FGPU_OK) gpu_die("sharded load pass", rc);
+        g_ctx = g_run->last_ctx();     // its bloo1 is the run's (carried-in bits of the lower shards included), as every shard's bloo2 is
+        GPU_CHECK(fgpu_bloom_download(g_ctx, FGPU_BLOO1, bloo1->blooma, bloo1->tai / 8));
+        GPU_CHECK(fgpu_bloom_download(g_ctx, FGPU_BLOO2, bloo2->blooma, bloo2->tai / 8));
+        printf("Reads processed: %llu\nUnambiguous reads: %llu\n", (unsigned long long)lr.stats.reads_processed, (unsigned long long)lr.stats.unambiguous_reads);
+        return;
+    }
     int rc = fgpu_create(&p, &g_ctx);
     if (rc != FGPU_OK) { fprintf(stderr, "fgpu_create failed (%d): %s\n", rc, fgpu_last_error(NULL)); exit(2); }
     GPU_CHECK(fgpu_load_begin(g_ctx, 0));
@@ -134,7 +173,25 @@ static void gpu_print_scan_summary(const fgpu_scan_stats& st) {
 // replaces buildJunctionMapFromReads() (src/Faucet.cpp:240-246) for single-end input.  With cleaning on (short_pair_filter != NULL, the
 // Bloom made at src/Faucet.cpp:266-283) scan_forward's addPair calls (src/ReadScanner.cpp:208-225) happen on the device and the filter's
 // bytes come back at the end; gpu_configure(true, false) must have been called before pass 1 (FGPU_FLAG_RECORD_STOPS).
+// several GPUs: the same scan over the read shards; the last shard ends with the run's junction map, pair filters and counters
+static void gpu_scan_sharded(JunctionMap* junctionMap, const std::string& read_scan_file, Bloom* short_pair_filter, Bloom* long_pair_filter, bool paired) {
+    g_run->set_pair_filters(short_pair_filter ? short_pair_filter->tai : 0, short_pair_filter ? short_pair_filter->getNumHash() : 0,
+                            long_pair_filter ? long_pair_filter->tai : 0, long_pair_filter ? long_pair_filter->getNumHash() : 0);
+    faucet_host::ShardScanResult sr;
+    const int rc = g_run->scan(read_scan_file, &sr);
+    if (rc != FGPU_OK) gpu_die("sharded junction scan", rc);
+    if (short_pair_filter) GPU_CHECK(fgpu_scan_short_pairs_download(g_ctx, short_pair_filter->blooma, short_pair_filter->tai / 8));
+    if (long_pair_filter) {
+        uint64_t e = 0, ne = 0;        // (this shard's counts; the run's are the sum over the shards, sr)
+        GPU_CHECK(fgpu_scan_long_pairs_download(g_ctx, long_pair_filter->blooma, long_pair_filter->tai / 8, &e, &ne));
+    }
+    gpu_fill_junction_map(junctionMap);
+    if (paired) printf("Empty count: %d, not empty count: %d\n", (int)sr.empty_count, (int)sr.not_empty_count);
+    gpu_print_scan_summary(sr.stats);
+}
+
 void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, Bloom* short_pair_filter = NULL) {
+    if (g_run) return gpu_scan_sharded(junctionMap, read_scan_file, short_pair_filter, NULL, false);
     fgpu_scan_stats st;
     if (short_pair_filter) GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 0));
     const int rc = gpu_scan_pass(read_scan_file, fastq, &st);
@@ -155,6 +212,7 @@ void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, 
 void gpu_scan_paired(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, Bloom* short_pair_filter, Bloom* long_pair_filter,
                      bool no_cleaning) {
     const bool filters = !no_cleaning && long_pair_filter;
+    if (g_run) return gpu_scan_sharded(junctionMap, read_scan_file, no_cleaning ? NULL : short_pair_filter, filters ? long_pair_filter : NULL, true);
     if (short_pair_filter && !no_cleaning)
         GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 0));
     if (filters) GPU_CHECK(fgpu_scan_long_pairs(g_ctx, long_pair_filter->tai, long_pair_filter->getNumHash(), FGPU_LONG_PAIRS_FILTER));

@@ -48,7 +48,7 @@
 
 extern bool no_cleaning, paired_ends;      // src/Faucet.h:46-47, defined in Faucet.o
 
-void gpu_configure(bool cleaning, bool paired_ends);
+void gpu_configure(bool cleaning, bool paired_ends, int n_gpus);
 void gpu_load_two_filters(Bloom* bloo1, Bloom* bloo2, std::string reads_filename, bool fastq, bool mercy);
 void gpu_scan(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, Bloom* short_pair_filter);
 void gpu_scan_paired(JunctionMap* junctionMap, std::string read_scan_file, bool fastq, Bloom* short_pair_filter, Bloom* long_pair_filter,
@@ -58,7 +58,7 @@ extern "C" {
 
 void __wrap__Z16load_two_filtersP5BloomS0_NSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEEbb(Bloom* bloo1, Bloom* bloo2, std::string reads_filename,
                                                                                                   bool fastq, bool mercy) {
-    gpu_configure(!no_cleaning, paired_ends);
+    gpu_configure(!no_cleaning, paired_ends, 0);       // (0: the number of GPUs from $FAUCET_GPUS -- the reference has no flag for it)
     gpu_load_two_filters(bloo1, bloo2, reads_filename, fastq, mercy);
 }
 

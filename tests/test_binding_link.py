@@ -40,7 +40,7 @@ def normalised(path):
     return re.sub(rb"0x[0-9a-f]+", lambda m: seen.setdefault(m.group(0), b"n%d" % len(seen)), data)
 
 
-def run_both(linked, case, tmp_path, extra=()):
+def run_both(linked, case, tmp_path, extra=(), env_bound=None):
     c = Case(case)
     inp = str(tmp_path / ("reads.fq" if c.fastq else "reads.fa"))
     with open(inp, "wb") as f:
@@ -50,7 +50,7 @@ def run_both(linked, case, tmp_path, extra=()):
         d = tmp_path / tag
         d.mkdir()
         r = subprocess.run([exe, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", str(d / "out")] + c.meta["args"] + list(extra),
-                           capture_output=True, text=True, timeout=600)
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env_bound or {})) if tag == "bound" else None)
         outs[tag] = (r, d)
     return c, outs
 
@@ -70,3 +70,18 @@ def test_reference_with_the_binding_linked_in_ends_like_the_pure_reference(linke
         want = [ln for ln in rp.stdout.splitlines() if ln.startswith(line)]
         got = [ln for ln in rb.stdout.splitlines() if ln.startswith(line)]
         assert want and want == got, line
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+@pytest.mark.parametrize("case", ["se_cleaning_k21", "pe_repeats_k25", "mercy_k21"])
+def test_the_linked_binding_over_read_shards_ends_like_the_pure_reference(linked, case, gpus, tmp_path):
+    """the same link with FAUCET_GPUS=N: the binding runs both passes over N read shards (faucet_amd/host/shard_host.h: one host thread per
+    shard, exchanges through the C ABI's group -- here the stub's), hands the reference its Bloom objects, junction map and pair filters, and
+    the reference's own Stage 3 ends as it does on its own passes"""
+    c, outs = run_both(linked, case, tmp_path, env_bound={"FAUCET_GPUS": str(gpus), "FAUCET_SHARD_PROTOCOL": "presence"})
+    (rp, dp), (rb, db) = outs["pure"], outs["bound"]
+    assert rb.returncode == rp.returncode, (rp.returncode, rb.returncode, rb.stdout[-1500:], rb.stderr[-1500:])
+    files = sorted(os.listdir(dp))
+    assert files == sorted(os.listdir(db))
+    for f in files:
+        assert normalised(str(dp / f)) == normalised(str(db / f)), f

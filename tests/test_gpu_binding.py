@@ -47,3 +47,23 @@ def test_reference_stage3_runs_on_the_gpu_passes_and_ends_like_the_pure_referenc
         assert got[f] == d, f
     for line in want["summary"]:
         assert line in r.stdout.splitlines(), line
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/faucet_ref_gpu was not built (it needs the reference tree: make -C oracle ref_gpu)")
+@pytest.mark.parametrize("gpus", [2, 3])
+@pytest.mark.parametrize("case", sorted(WANT))
+def test_reference_stage3_on_gpu_passes_over_read_shards(case, gpus, tmp_path):
+    """FAUCET_GPUS=N: the linked binding runs both passes over N read shards (one host thread and one context per shard; on this box all on
+    device 0) -- the reference's Stage 3 ends with the pure reference's files all the same"""
+    c = Case(case)
+    inp = str(tmp_path / ("reads.fq" if c.fastq else "reads.fa"))
+    with open(inp, "wb") as f:
+        f.write(c.reads_text())
+    r = subprocess.run([EXE, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", str(tmp_path / "out")] + c.meta["args"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, FAUCET_GPUS=str(gpus)))
+    want = WANT[case]
+    assert r.returncode == want["exit"], (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    got = {f: hashlib.sha256(normalised(str(tmp_path / f))).hexdigest() for f in sorted(os.listdir(tmp_path)) if f.startswith("out.")}
+    assert sorted(got) == sorted(want["files"]), (sorted(got), sorted(want["files"]))
+    for f, d in want["files"].items():
+        assert got[f] == d, f
