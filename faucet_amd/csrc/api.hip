@@ -334,7 +334,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
     if (ctx->lp.flips_host) hipHostFree(ctx->lp.flips_host);
-    void* ptrs[] = {ctx->lp.bits, ctx->lp.first, ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
+    void* ptrs[] = {ctx->lp.bits, ctx->lp.first, ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->rec, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
                     ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->cl_roots, ctx->counters,
                     ctx->wdesc};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -373,7 +373,20 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     if (ctx->phase != 0) { ctx->err = "load_begin while another pass is open"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     if (int rc = fgpu_bloom_download_wait(ctx)) return rc;   // a download still in flight reads the filters this pass rewrites
-    if (!ctx->first) {
+    // Where the pass keeps its state (load.hip, Filt): the interleaved pair + first[], or -- FGPU_LOAD_LAYOUT=records: measured in round 5, a
+    // faster marking kernel on filters of 2^32 bits and more but no faster pass, not the default -- 256-byte records.  Records need 8 bytes per
+    // filter bit: where they cannot be had the pass falls back to the pair layout (4.25 bytes per bit).
+    static const char* layout_env = getenv("FGPU_LOAD_LAYOUT");
+    bool want_rec = layout_env && layout_env[0] == 'r';
+    if (want_rec && !ctx->rec) {
+        if (hipMalloc(&ctx->rec, ctx->prm.tai / 32 * 256) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->rec = nullptr;
+            want_rec = false;
+        }
+    }
+    ctx->rec_layout = want_rec;
+    if (!ctx->rec_layout && !ctx->first) {
         hipError_t e = hipMalloc(&ctx->first, ctx->prm.tai * 4);
         if (e != hipSuccess) {
             ctx->err = std::string("hipMalloc of the first-set-time array (4 bytes per Bloom bit) failed: ") + hipGetErrorString(e);
@@ -381,7 +394,7 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
             return FGPU_ERR_NOMEM;
         }
     }
-    if (!ctx->pair) {   // working copy of both filters, interleaved word by word, for the duration of a load pass
+    if (!ctx->rec_layout && !ctx->pair) {   // working copy of both filters, interleaved word by word, for the duration of a load pass
         hipError_t e = hipMalloc(&ctx->pair, ctx->bloom_bytes * 2);
         if (e != hipSuccess) {
             ctx->err = std::string("hipMalloc of the interleaved filter pair failed: ") + hipGetErrorString(e);
@@ -412,7 +425,7 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
         unsigned n = 1, d = 1;
         if (sscanf(sweep_env, "%u/%u", &n, &d) == 2 && d > 0) { ctx->sweep_num = n; ctx->sweep_den = d; }
     }
-    FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));
+    if (!ctx->rec_layout) FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));   // (records: k_rec_init, fgpu_load_pair_begin)
     fgpu_resident_reset(ctx, true);
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->bloo2, 0, ctx->bloom_bytes, ctx->stream));

@@ -206,6 +206,8 @@ struct fgpu_ctx {
     uint32_t* bloo2 = nullptr;
     uint32_t* first = nullptr;       // first-set time per Bloom bit, 4*tai bytes (allocated at load_begin)
     uint2* pair = nullptr;           // {bloo1 word, bloo2 word} interleaved: the working copy of both filters during a load pass
+    uint32_t* rec = nullptr;         // the same state as 256-byte records {bloo1 word, bloo2 word, ..., 32 first-set times} (load.hip, Filt<1>):
+    bool rec_layout = false;         // filters of 2^32 bits and more; `pair` and `first` are not used (nor allocated) then
     uint64_t bloom_bytes = 0;
     int phase = 0;                   // 0 idle, 1 loading, 2 scanning
     std::vector<ResidentBatch*> resident;  // load batches kept for the scan, in load order (buffers recycled across passes)

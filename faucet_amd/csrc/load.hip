@@ -67,8 +67,31 @@ __device__ __forceinline__ void block_add(unsigned long long* dst, unsigned long
 #endif
 constexpr int MISS_PLANES = 4;   // planes of "bit i was missing from the carry" kept for k_load_resolve (hash functions beyond are re-tested)
 
+// Where the working state of a load pass lives.  Two layouts, one algorithm:
+//   REC = 0  `base` = pair[]: {bloo1 word, bloo2 word} interleaved, 8 bytes per 32 filter bits; the first-set times in their own array first[]
+//            (4 bytes per filter bit).  Filters up to 2^31 bits: the 8-byte words of config 2 (128 MiB) stay in the Infinity Cache.
+//   REC = 1  `base` = 256-byte RECORDS, one per 32 filter bits, aligned: word 0 bloo1, word 1 bloo2, words 16..47 the first-set times of the
+//            record's 32 bits (two further lines of the same 256 bytes), the rest unused: FGPU_LOAD_LAYOUT=records (round 5; measured, NOT the
+//            default).  The marking kernel is bound by the atomicMin of the times it posts (1.9 per k-mer on configs 4 and 5), and an atomic
+//            into the 256-byte block whose first line the kernel has just loaded costs half of one into a separate 32 GiB array -- same three
+//            loads, same three atomics per new k-mer, other addresses (scripts/micro/mark_model3.hip: 2^33 bits, 63 % new k-mers 21.8 -> 15.8 ms
+//            per 1.34e8 k-mers; blocks of 192 or 160 bytes 17.6 / 18.5: the alignment counts; 2^29 bits 7.6 -> 13.0 ms).  On config 4's reads
+//            the kernel gains 14 % (231 -> 203 ms per 25 M reads), config 5's 15 %, and the pass gives it back: a sweep that brings the carry up
+//            to date streams the records (20.5 ms against 8.9), a pass begins by writing 48 GiB of them (29 ms) -- profiles/r05_load_layouts.txt,
+//            DESIGN.md section 10.  64 GiB instead of 34 at 2^33 bits.
+template <int REC>
+struct Filt {
+    uint32_t* base;
+    uint32_t* first;
+    __device__ __forceinline__ uint32_t* word(uint64_t h) const { return base + (REC ? ((h >> 5) << 6) : ((h >> 5) << 1)); }   // -> {bloo1, bloo2}
+    __device__ __forceinline__ uint2 load(uint64_t h) const { return *(const uint2*)word(h); }
+    __device__ __forceinline__ uint32_t* time(uint64_t h) const { return REC ? base + ((h >> 5) << 6) + 16 + (h & 31) : first + FD_FIRST(h); }
+};
+constexpr uint64_t REC_WORDS = 64;      // 32-bit words per record
+
+template <int REC>
 __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad,
-                                                   uint64_t T, uint64_t n_words, FdParams fp, uint2* pair, uint32_t* first, uint32_t tb,
+                                                   uint64_t T, uint64_t n_words, FdParams fp, Filt<REC> f, uint32_t tb,
                                                    uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_ok = 0, n_hit = 0, n_pend = 0;
     const uint64_t total = n_words * 64;
@@ -85,7 +108,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
             uint32_t missing = 0, b2_missing = 0;
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
-                const uint2 v = pair[h >> 5];
+                const uint2 v = f.load(h);
                 if (!((v.x >> (h & 31)) & 1u)) missing |= 1u << i;
                 if (!((v.y >> (h & 31)) & 1u)) b2_missing |= 1u << i;
                 h = (h + hB) & fp.tai_mask;
@@ -96,7 +119,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 if (b2_missing) {   // a stale 0 only costs a redundant atomic; bits are never cleared
                     h = hA;
                     for (int i = 0; i < fp.n_hash; i++) {
-                        if (b2_missing & (1u << i)) atomicOr(&pair[h >> 5].y, 1u << (h & 31));
+                        if (b2_missing & (1u << i)) atomicOr(f.word(h) + 1, 1u << (h & 31));
                         h = (h + hB) & fp.tai_mask;
                     }
                 }
@@ -108,7 +131,7 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
                 for (int i = 0; i < fp.n_hash; i++) {
                     // the next carry is derived afterwards: from first[] by a sweep (k_carry_from_first) or by re-hashing the
                     // occurrences that were not contained (k_carry_set)
-                    if (missing & (1u << i)) atomicMin(&first[FD_FIRST(h)], tb + (uint32_t)p);
+                    if (missing & (1u << i)) atomicMin(f.time(h), tb + (uint32_t)p);
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -134,8 +157,9 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
     block_add(&cnt->mark_pending, n_pend);
 }
 
+template <int REC>
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
-                                                      uint2* pair, const uint32_t* __restrict__ first, uint32_t tb,
+                                                      Filt<REC> f, uint32_t tb,
                                                       const uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
@@ -154,8 +178,8 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
             pass = true;
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
-                bool in_carry = i < MISS_PLANES ? !((missing >> i) & 1u) : ((pair[h >> 5].x >> (h & 31)) & 1u) != 0;
-                if (!in_carry && !(first[FD_FIRST(h)] < tb + (uint32_t)p)) { pass = false; break; }
+                bool in_carry = i < MISS_PLANES ? !((missing >> i) & 1u) : ((f.load(h).x >> (h & 31)) & 1u) != 0;
+                if (!in_carry && !(*f.time(h) < tb + (uint32_t)p)) { pass = false; break; }
                 h = (h + hB) & fp.tai_mask;
             }
             if (pass) {   // rare: every bit was set earlier in this very batch
@@ -163,7 +187,7 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
                 h = hA;
                 for (int i = 0; i < fp.n_hash; i++) {
                     const uint32_t bit = 1u << (h & 31);
-                    if (!(pair[h >> 5].y & bit)) atomicOr(&pair[h >> 5].y, bit);   // a stale 0 only costs a redundant atomic
+                    if (!(f.word(h)[1] & bit)) atomicOr(f.word(h) + 1, bit);   // a stale 0 only costs a redundant atomic
                     h = (h + hB) & fp.tai_mask;
                 }
             }
@@ -187,9 +211,9 @@ struct PendPool {
     int excl[64];
 };
 
-template <int S>
-__global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restrict__ codes, uint64_t n_words, FdParams fp, uint2* pair,
-                                                         const uint32_t* __restrict__ first, uint32_t tb, const uint64_t* __restrict__ pending,
+template <int S, int REC>
+__global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restrict__ codes, uint64_t n_words, FdParams fp, Filt<REC> f,
+                                                         uint32_t tb, const uint64_t* __restrict__ pending,
                                                          uint64_t plane_stride, unsigned long long* sure, DevCounters* cnt) {
     // Plain LDS objects indexed directly, so that the accesses are ds_read / ds_write: those execute in order for a wave, which is
     // what makes a word written by one lane visible to the lane that reads it next.  (Declared volatile, or reached through a
@@ -275,7 +299,7 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
             seen[q] = 0;
             if (missing[q]) {
                 const uint64_t h = (hA[q] + (uint64_t)__builtin_ctz(missing[q]) * hB[q]) & fp.tai_mask;
-                seen[q] = first[FD_FIRST(h)];
+                seen[q] = *f.time(h);
             }
         }
 #pragma unroll
@@ -290,7 +314,7 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
                     uint64_t hh = hA[q];
                     for (int i = 0; i < fp.n_hash; i++) {
                         const uint32_t b = 1u << (hh & 31);
-                        if (!(pair[hh >> 5].y & b)) atomicOr(&pair[hh >> 5].y, b);
+                        if (!(f.word(hh)[1] & b)) atomicOr(f.word(hh) + 1, b);
                         hh = (hh + hB[q]) & fp.tai_mask;
                     }
                     atomicOr(&sure[item_p[q] >> 6], 1ULL << (item_p[q] & 63));
@@ -307,13 +331,13 @@ __global__ void __launch_bounds__(256) k_load_resolve_sm(const uint64_t* __restr
 // evolves exactly as without mercy, and which occurrences were "contained" is the sure plane the two kernels above have
 // just written; what is left is a small sequential state machine per unambiguous segment plus a few TIME-AWARE membership
 // tests: bloo1 as it stood when occurrence t was processed = bits of the carried-in state or first set at a time <= t.
-__device__ __forceinline__ bool bloo1_contains_at(const uint2* __restrict__ pair, const uint32_t* __restrict__ first, uint64_t canon,
-                                                  uint32_t t, const FdParams& fp) {
+template <int REC>
+__device__ __forceinline__ bool bloo1_contains_at(const Filt<REC>& f, uint64_t canon, uint32_t t, const FdParams& fp) {
     uint64_t hA, hB;
     fd_hash_pair(canon, fp.tai_mask, hA, hB);
     uint64_t h = hA;
     for (int i = 0; i < fp.n_hash; i++) {
-        if (!((pair[h >> 5].x >> (h & 31)) & 1u) && !(first[h] <= t)) return false;
+        if (!((f.load(h).x >> (h & 31)) & 1u) && !(*f.time(h) <= t)) return false;
         h = (h + hB) & fp.tai_mask;
     }
     return true;
@@ -321,22 +345,23 @@ __device__ __forceinline__ bool bloo1_contains_at(const uint2* __restrict__ pair
 
 // isJunction(readKmer, bloo1, dir) as load_two_filters calls it: the cursor faces BACKWARD there, so the "real extension" is
 // the reverse complement of the window before, whatever dir says; dir only picks the strand the four candidates extend.
-__device__ __forceinline__ bool mercy_is_junction(const uint64_t* __restrict__ codes, const uint2* __restrict__ pair,
-                                                  const uint32_t* __restrict__ first, uint32_t tb, uint64_t pos, bool dir_forward, const FdParams& fp) {
+template <int REC>
+__device__ __forceinline__ bool mercy_is_junction(const uint64_t* __restrict__ codes, const Filt<REC>& f, uint32_t tb, uint64_t pos, bool dir_forward,
+                                                  const FdParams& fp) {
     const uint64_t km = fd_kmer_at(codes, pos, fp.k), rc = fd_revcomp(km, fp.k);
     const uint64_t real_ext = ((rc << 2) | (uint64_t)(fd_base_at(codes, pos - 1) ^ 2)) & fp.kmask;
     const uint64_t from = dir_forward ? km : rc;
     for (int nt = 0; nt < 4; nt++) {
         const uint64_t e = ((from << 2) | (uint64_t)nt) & fp.kmask;
-        if (e != real_ext && bloo1_contains_at(pair, first, fd_canon(e, fp.k), tb + (uint32_t)pos, fp)) return true;
+        if (e != real_ext && bloo1_contains_at(f, fd_canon(e, fp.k), tb + (uint32_t)pos, fp)) return true;
     }
     return false;
 }
 
 // one thread per 64-position word: the unambiguous segments (length >= k) that START in it
+template <int REC>
 __global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t n_words,
-                                                    FdParams fp, uint2* pair, const uint32_t* __restrict__ first, uint32_t tb,
-                                                    const uint64_t* __restrict__ sure) {
+                                                    FdParams fp, Filt<REC> f, uint32_t tb, const uint64_t* __restrict__ sure) {
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t good = ~bad[w];
         const uint64_t prev_good = w ? (~bad[w - 1]) >> 63 : 0;
@@ -362,14 +387,14 @@ __global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__
                 if (contained) {
                     have_last = true;
                     if (hv_lo >= 0) {               // came from low to high (:311-318)
-                        if (!mercy_is_junction(codes, pair, first, tb, pos, false, fp)) {
+                        if (!mercy_is_junction(codes, f, tb, pos, false, fp)) {
                             for (uint64_t q = p + (uint64_t)hv_lo; q < pos; q++) {
                                 uint64_t hA, hB;
                                 fd_hash_pair(fd_canon(fd_kmer_at(codes, q, fp.k), fp.k), fp.tai_mask, hA, hB);
                                 uint64_t h = hA;
                                 for (int b = 0; b < fp.n_hash; b++) {
                                     const uint32_t bit = 1u << (h & 31);
-                                    if (!(pair[h >> 5].y & bit)) atomicOr(&pair[h >> 5].y, bit);
+                                    if (!(f.word(h)[1] & bit)) atomicOr(f.word(h) + 1, bit);
                                     h = (h + hB) & fp.tai_mask;
                                 }
                             }
@@ -377,7 +402,7 @@ __global__ void __launch_bounds__(256) k_load_mercy(const uint64_t* __restrict__
                         hv_lo = -1;
                     }
                 } else if (have_last && hv_lo < 0) {   // came from high to low (:322-326); later low k-mers just join the run
-                    if (!mercy_is_junction(codes, pair, first, tb, pos, true, fp)) hv_lo = (int64_t)i;
+                    if (!mercy_is_junction(codes, f, tb, pos, true, fp)) hv_lo = (int64_t)i;
                 }
             }
         }
@@ -398,6 +423,35 @@ __global__ void __launch_bounds__(256) k_pair_split(const uint2* __restrict__ pa
         b[i] = v.y;
     }
 }
+// the record layout's counterparts: a record starts as {carried-in bloo1 word, empty bloo2 word, ..., 32 times "never"}; lanes = the record's
+// 64 words (the unused ones are written too: whole lines, no read-modify-write); at the end the two filter words go back to the .bloom arrays
+__global__ void __launch_bounds__(256) k_rec_init(uint32_t* __restrict__ rec, const uint32_t* __restrict__ a, uint64_t n32) {
+    const uint64_t total = n32 * REC_WORDS;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = (uint32_t)(i & (REC_WORDS - 1));
+        if (w >= 48) continue;                             // the fourth line of a record is never read
+        rec[i] = w == 0 ? a[i >> 6] : w == 1 ? 0u : 0xFFFFFFFFu;
+    }
+}
+__global__ void __launch_bounds__(256) k_rec_split(const uint32_t* __restrict__ rec, uint32_t* __restrict__ a, uint32_t* __restrict__ b, uint64_t n32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 v = *(const uint2*)(rec + i * REC_WORDS);
+        a[i] = v.x;
+        b[i] = v.y;
+    }
+}
+// the sweep: 32 lanes per record read its 32 times (two coalesced lines), a ballot gives the record's "set since the last sweep" word
+__global__ void __launch_bounds__(256) k_carry_from_rec(uint32_t* __restrict__ rec, uint64_t n32) {
+    const uint64_t total = n32 * 32;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i >> 5;
+        const uint32_t t = rec[r * REC_WORDS + 16 + (i & 31)];
+        const uint64_t m = __ballot(t != 0xFFFFFFFFu);
+        const uint32_t mine = (uint32_t)(fd_lane() < 32 ? m : m >> 32);
+        if ((fd_lane() & 31) == 0 && mine) rec[r * REC_WORDS] |= mine;
+    }
+}
+
 // carry := carry | bits set during the batch.  A bit is set iff its first-set time is no longer "never": one streaming
 // pass over first[] (4 bytes per Bloom bit, lanes = consecutive bits, one ballot per 64 bits) replaces one atomicOr per
 // newly set bit in the mark kernel.
@@ -427,8 +481,9 @@ __global__ void __launch_bounds__(256) k_carry_from_first(uint2* __restrict__ pa
 // carry |= bits of every occurrence that was NOT contained when met (those are exactly the occurrences that set bits in
 // bloo1).  The alternative to the sweep when the filter is large: its cost follows the number of new k-mers of the batch
 // (3 test-then-set accesses each), not the size of first[] (32 GiB per sweep for config 4's 2^33-bit filters).
+template <int REC>
 __global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
-                                                   uint64_t n_words, FdParams fp, uint2* pair, const uint64_t* __restrict__ sure) {
+                                                   uint64_t n_words, FdParams fp, Filt<REC> f, const uint64_t* __restrict__ sure) {
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         if (!(p < T && fd_window_ok(bad, p, fp.k)) || ((sure[p >> 6] >> (p & 63)) & 1ULL)) continue;
@@ -437,7 +492,7 @@ __global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ 
         uint64_t h = hA;
         for (int i = 0; i < fp.n_hash; i++) {
             const uint32_t bit = 1u << (h & 31);
-            if (!(pair[h >> 5].x & bit)) atomicOr(&pair[h >> 5].x, bit);
+            if (!(f.word(h)[0] & bit)) atomicOr(f.word(h), bit);
             h = (h + hB) & fp.tai_mask;
         }
     }
@@ -445,9 +500,10 @@ __global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ 
 
 // multi-GPU, fgpu_load_fixup: the occurrences the shard's own pass kept out of bloo2, looked at again with the lower ranks' bits.
 // bit set before t  <=>  in the prefix (set by a lower rank: all of those come earlier in file order) or first set locally before t.
+template <int REC>
 __global__ void __launch_bounds__(256) k_load_fixup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
                                                     uint64_t n_words, FdParams fp, const uint32_t* __restrict__ prefix,
-                                                    const uint32_t* __restrict__ first, uint32_t tb, uint32_t* bloo2,
+                                                    Filt<REC> f, uint32_t tb, uint32_t* bloo2,
                                                     unsigned long long* sure, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
@@ -459,7 +515,7 @@ __global__ void __launch_bounds__(256) k_load_fixup(const uint64_t* __restrict__
             pass = true;
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
-                if (!((prefix[h >> 5] >> (h & 31)) & 1u) && !(first[h] < tb + (uint32_t)p)) { pass = false; break; }
+                if (!((prefix[h >> 5] >> (h & 31)) & 1u) && !(*f.time(h) < tb + (uint32_t)p)) { pass = false; break; }
                 h = (h + hB) & fp.tai_mask;
             }
             if (pass) {
@@ -600,7 +656,8 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
 // carry |= bits set since the last sweep; closes the epoch (times start at 0 again: every bit with a time is now in the carry)
 int fgpu_load_sweep(fgpu_ctx* ctx) {
     if (ctx->epoch_positions == 0) return FGPU_OK;
-    FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
+    if (ctx->rec_layout) FGPU_LAUNCH("carry_update", k_carry_from_rec, 8192, 256, ctx->rec, ctx->prm.tai / 32);
+    else FGPU_LAUNCH("carry_update", k_carry_from_first, 4096, 256, ctx->pair, (const uint4*)ctx->first, ctx->prm.tai);
     ctx->swept_positions += ctx->epoch_positions;
     ctx->epoch_positions = 0;
     return FGPU_OK;
@@ -631,32 +688,45 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     const uint32_t tb = ctx->shard_times ? (uint32_t)ctx->pass_positions : ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
     ctx->cur_tb = tb;
     ctx->pass_positions += span;
-    FGPU_LAUNCH("load_mark", k_load_mark, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                ctx->pair, ctx->first, tb, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
     static const int resolve_sm = getenv("FGPU_RESOLVE_SM") ? atoi(getenv("FGPU_RESOLVE_SM")) : 4096;
-    if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm)
-    {
-        static const int slots = getenv("FGPU_RESOLVE_SM_SLOTS") ? atoi(getenv("FGPU_RESOLVE_SM_SLOTS")) : 1;
-        const unsigned rgrid = (unsigned)std::min<uint64_t>((bb.n_words + 255) / 256, (uint64_t)std::max(resolve_sm, 64));
-#define FGPU_RESOLVE_SM(SLOTS)                                                                                                      \
-    FGPU_LAUNCH("load_resolve", k_load_resolve_sm<SLOTS>, rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, ctx->pair, \
-                (const uint32_t*)ctx->first, tb, (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters)
-        if (slots <= 1) FGPU_RESOLVE_SM(1);
-        else if (slots == 2) FGPU_RESOLVE_SM(2);
-        else FGPU_RESOLVE_SM(4);
-#undef FGPU_RESOLVE_SM
-    }
-    else
-    FGPU_LAUNCH("load_resolve", k_load_resolve, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, ctx->pair,
-                (const uint32_t*)ctx->first, tb, (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);
-    if (ctx->prm.flags & FGPU_FLAG_MERCY)
-        FGPU_LAUNCH("load_mercy", k_load_mercy, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.n_words,
-                    ctx->fd, ctx->pair, (const uint32_t*)ctx->first, tb, (const uint64_t*)bb.sure.p);
-    // carry := carry | bits set during this batch -- or later: the carry may lag behind (see fgpu_load_sweep)
-    if (ctx->carry_by_set) {
-        FGPU_LAUNCH("carry_update", k_carry_set, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd,
-                    ctx->pair, (const uint64_t*)bb.sure.p);
+    static const int slots = getenv("FGPU_RESOLVE_SM_SLOTS") ? atoi(getenv("FGPU_RESOLVE_SM_SLOTS")) : 1;
+    const unsigned rgrid = (unsigned)std::min<uint64_t>((bb.n_words + 255) / 256, (uint64_t)std::max(resolve_sm, 64));
+    const bool mercy = (ctx->prm.flags & FGPU_FLAG_MERCY) != 0;
+#define FGPU_LOAD_BATCH(REC, F)                                                                                                                       \
+    do {                                                                                                                                              \
+        FGPU_LAUNCH("load_mark", k_load_mark<REC>, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd, F,  \
+                    tb, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);                                                  \
+        if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm) {                                                                                             \
+            if (slots <= 1)                                                                                                                            \
+                FGPU_LAUNCH("load_resolve", (k_load_resolve_sm<1, REC>), rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, F, tb,          \
+                            (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters);                               \
+            else if (slots == 2)                                                                                                                       \
+                FGPU_LAUNCH("load_resolve", (k_load_resolve_sm<2, REC>), rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, F, tb,          \
+                            (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters);                               \
+            else                                                                                                                                       \
+                FGPU_LAUNCH("load_resolve", (k_load_resolve_sm<4, REC>), rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, F, tb,          \
+                            (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters);                               \
+        } else {                                                                                                                                       \
+            FGPU_LAUNCH("load_resolve", k_load_resolve<REC>, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, F, tb,                 \
+                        (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);                                             \
+        }                                                                                                                                              \
+        if (mercy)                                                                                                                                     \
+            FGPU_LAUNCH("load_mercy", k_load_mercy<REC>, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p,      \
+                        bb.n_words, ctx->fd, F, tb, (const uint64_t*)bb.sure.p);                                                                       \
+        if (ctx->carry_by_set)                                                                                                                         \
+            FGPU_LAUNCH("carry_update", k_carry_set<REC>, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words,         \
+                        ctx->fd, F, (const uint64_t*)bb.sure.p);                                                                                       \
+    } while (0)
+    if (ctx->rec_layout) {
+        const Filt<1> f = {ctx->rec, nullptr};
+        FGPU_LOAD_BATCH(1, f);
     } else {
+        const Filt<0> f = {(uint32_t*)ctx->pair, ctx->first};
+        FGPU_LOAD_BATCH(0, f);
+    }
+#undef FGPU_LOAD_BATCH
+    // carry := carry | bits set during this batch -- or later: the carry may lag behind (see fgpu_load_sweep)
+    if (!ctx->carry_by_set) {
         ctx->epoch_positions += span;
         if (ctx->epoch_positions * ctx->sweep_den >= ctx->swept_positions * ctx->sweep_num && (rc = fgpu_load_sweep(ctx))) return rc;
     }
@@ -665,11 +735,13 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
 
 // interleave the carried-in bloo1 with an empty bloo2 at the start of a load pass, split them again at its end
 int fgpu_load_pair_begin(fgpu_ctx* ctx) {
-    FGPU_LAUNCH("pair_join", k_pair_join, 2048, 256, ctx->pair, (const uint32_t*)ctx->bloo1, (const uint32_t*)nullptr, ctx->bloom_bytes / 4);
+    if (ctx->rec_layout) FGPU_LAUNCH("pair_join", k_rec_init, 8192, 256, ctx->rec, (const uint32_t*)ctx->bloo1, ctx->bloom_bytes / 4);
+    else FGPU_LAUNCH("pair_join", k_pair_join, 2048, 256, ctx->pair, (const uint32_t*)ctx->bloo1, (const uint32_t*)nullptr, ctx->bloom_bytes / 4);
     return FGPU_OK;
 }
 int fgpu_load_pair_end(fgpu_ctx* ctx) {
-    FGPU_LAUNCH("pair_split", k_pair_split, 2048, 256, (const uint2*)ctx->pair, ctx->bloo1, ctx->bloo2, ctx->bloom_bytes / 4);
+    if (ctx->rec_layout) FGPU_LAUNCH("pair_split", k_rec_split, 4096, 256, (const uint32_t*)ctx->rec, ctx->bloo1, ctx->bloo2, ctx->bloom_bytes / 4);
+    else FGPU_LAUNCH("pair_split", k_pair_split, 2048, 256, (const uint2*)ctx->pair, ctx->bloo1, ctx->bloo2, ctx->bloom_bytes / 4);
     return FGPU_OK;
 }
 
@@ -677,8 +749,15 @@ int fgpu_stage_fixup(fgpu_ctx* ctx, const uint32_t* prefix) {
     for (uint64_t i = 0; i < ctx->resident_count; i++) {
         ResidentBatch& r = *ctx->resident[i];
         if (!r.T) continue;
-        FGPU_LAUNCH("load_fixup", k_load_fixup, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
-                    r.n_words, ctx->fd, prefix, (const uint32_t*)ctx->first, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        if (ctx->rec_layout) {
+            const Filt<1> f = {ctx->rec, nullptr};
+            FGPU_LAUNCH("load_fixup", k_load_fixup<1>, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
+                        r.n_words, ctx->fd, prefix, f, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        } else {
+            const Filt<0> f = {(uint32_t*)ctx->pair, ctx->first};
+            FGPU_LAUNCH("load_fixup", k_load_fixup<0>, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
+                        r.n_words, ctx->fd, prefix, f, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        }
     }
     return FGPU_OK;
 }

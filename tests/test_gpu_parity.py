@@ -1166,6 +1166,29 @@ def test_a_replay_applies_the_long_pair_loop_to_every_batch_once():
     assert r.returncode == 0 and "once each ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("case", ["c1_k21", "ragged_k31", "mercy_k21", "twohash_k31_L150", "pe_repeats_k25"])
+def test_load_pass_with_256_byte_records_gives_the_reference_filter(case, tmp_path):
+    """FGPU_LOAD_LAYOUT=records (load.hip, Filt<1>; round 5, measured and not the default): the pass keeps {bloo1 word, bloo2 word, 32 first-set
+    times} in one aligned 256-byte record per 32 filter bits instead of the interleaved pair + first[] -- same algorithm, other addresses; the
+    reference's files come out, --mercy (times of every bit) and several batches with their sweeps included, and with -gpus 2 the fix-up
+    protocol reads its times from the records"""
+    import os
+    import subprocess
+    c = Case(case)
+    reads = tmp_path / ("reads.fq" if c.fastq else "reads.fa")
+    reads.write_bytes(c.reads_text())
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "faucet_amd", "faucet")
+    for extra in (["-batch_reads", "97"], ["-gpus", "2"]):
+        prefix = tmp_path / ("out" + extra[0])
+        r = subprocess.run([exe, "-read_load_file", str(reads), "-read_scan_file", str(reads), "-file_prefix", str(prefix)] + extra + c.meta["args"],
+                           capture_output=True, text=True, env=dict(os.environ, FGPU_LOAD_LAYOUT="records"), timeout=600)
+        assert r.returncode == (0 if c.no_cleaning else 3), r.stderr[-2000:]
+        assert np.array_equal(np.fromfile(str(prefix) + ".bloom", dtype=np.uint8), c.bloom())
+        assert open(str(prefix) + ".junctions").read().split("\n")[:-1] == c.junction_lines()
+        w = c.counters["weights_after_load"]
+        assert f"Weights after load: {w[0]:.6f}, {w[1]:.6f}" in r.stdout.replace("\r", "\n")
+
+
 @pytest.mark.parametrize("n_batches", [1, 5])
 def test_mercy_load_matches_the_reference(n_batches):
     """load_two_filters(..., mercy = true) (utils/Bloom.cpp:300-333): the reference's --mercy .bloom, byte for byte, and it does
