@@ -24,7 +24,7 @@ int g_fgpu_trace = getenv("FGPU_TRACE") && getenv("FGPU_TRACE")[0] == '1';
 int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes) {
     if (b->bytes >= bytes && b->p) return FGPU_OK;
     if (b->p) {
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
         FGPU_HIP(hipFree(b->p));
         b->p = nullptr;
         b->bytes = 0;
@@ -40,6 +40,15 @@ int fgpu_ensure(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes) {
     }
     b->bytes = want;
     return FGPU_OK;
+}
+
+int fgpu_ensure_b(fgpu_ctx* ctx, DevBuf* b, uint64_t bytes) {
+    if (b->bytes >= bytes && b->p) return FGPU_OK;
+    const double s = ctx->ensure_scale > 1.0 ? ctx->ensure_scale : 1.0;
+    const uint64_t want = (uint64_t)((double)bytes * s);
+    if (fgpu_ensure(ctx, b, want) == FGPU_OK) return FGPU_OK;
+    (void)hipGetLastError();                 // no room for the largest batch: what this one needs
+    return fgpu_ensure(ctx, b, bytes);
 }
 
 int fgpu_prof_begin(fgpu_ctx* ctx, const char* name) {
@@ -80,8 +89,8 @@ int fgpu_bg_join(fgpu_ctx* ctx) {
 int fgpu_prof_collect(fgpu_ctx* ctx) {
     if (ctx->pending_events.empty()) return FGPU_OK;
     if (int rc = fgpu_bg_join(ctx)) return rc;
-    FGPU_HIP(hipStreamSynchronize(ctx->wstream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->wstream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     for (PendingEvent& pe : ctx->pending_events) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
@@ -124,18 +133,18 @@ static int check_errors(fgpu_ctx* ctx) {
 // everything issued so far, on both streams, has completed
 static int sync_all(fgpu_ctx* ctx) {
     if (int rc = fgpu_bg_join(ctx)) return rc;
-    FGPU_HIP(hipStreamSynchronize(ctx->wstream));
-    FGPU_HIP(hipStreamSynchronize(ctx->cstream));   // the side stream's last resets (nothing waits for them but the next window of their parity)
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->wstream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->cstream));   // the side stream's last resets (nothing waits for them but the next window of their parity)
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
 static int pull_counters(fgpu_ctx* ctx) {
     if (int rc = fgpu_bg_join(ctx)) return rc;
-    FGPU_HIP(hipStreamSynchronize(ctx->wstream));
-    FGPU_HIP(hipStreamSynchronize(ctx->cstream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->wstream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->cstream));
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     // A late junction test that came out true at an unregistered k-mer leaves the lazy scan standing only because k_delta_collect has looked
     // for that k-mer on the window's other pieces.  Every walk and every sweep issued so far has completed here, so each
     // noted position must have been passed over by its window's sweep -- [2] == [0]; if one was not, the scan is treated as void and scanned
@@ -334,6 +343,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
     for (PendingEvent& pe : ctx->pending_events) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (DevBuf* b : ctx->owned) if (b->p) hipFree(b->p);
     if (ctx->lp.flips_host) hipHostFree(ctx->lp.flips_host);
+    if (ctx->lp.ev_open) hipEventDestroy(ctx->lp.ev_open);
     void* ptrs[] = {ctx->lp.bits, ctx->lp.first, ctx->short_pf, ctx->bloo1, ctx->bloo2, ctx->first, ctx->pair, ctx->rec, ctx->jkeys, ctx->jrecs, ctx->jstamps, ctx->jfilter, ctx->wkeys,
                     ctx->wbits, ctx->uf_parent, ctx->cl_count, ctx->cl_offset, ctx->cl_fill, ctx->cl_fail, ctx->ko_hk, ctx->ko_occ, ctx->ko_piece, ctx->cl_members, ctx->cl_roots, ctx->counters,
                     ctx->wdesc};
@@ -433,6 +443,9 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     if (rc) return rc;
     FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
     memset(&ctx->load_stats, 0, sizeof(ctx->load_stats));
+    ctx->host_waits = 0;
+    ctx->host_wait_ms = 0;
+    ctx->wait_sites.clear();
     ctx->phase = 1;
     return FGPU_OK;
 }
@@ -510,7 +523,7 @@ int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nb
     if (!ctx || !host_out || !bloom_ptr(ctx, which) || nbytes != ctx->bloom_bytes) return FGPU_ERR_ARG;
     if (ctx->phase == 1) { ctx->err = "bloom_download inside a load pass: the filters are interleaved until load_end"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipMemcpyAsync(host_out, bloom_ptr(ctx, which), nbytes, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
@@ -518,7 +531,7 @@ int fgpu_bloom_download_wait(fgpu_ctx* ctx) {
     if (!ctx) return FGPU_ERR_ARG;
     if (!ctx->copy_pending) return FGPU_OK;
     ctx->copy_pending = false;
-    FGPU_HIP(hipStreamSynchronize(ctx->copy_stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->copy_stream));
     return FGPU_OK;
 }
 
@@ -544,7 +557,7 @@ int fgpu_bloom_upload(fgpu_ctx* ctx, int which, const uint8_t* host_in, uint64_t
     if (int rc = fgpu_bloom_download_wait(ctx)) return rc;
     if (which == FGPU_BLOO2) fgpu_resident_reset(ctx, false);   // the kept "routed to bloo2" planes speak about the filter this replaces
     FGPU_HIP(hipMemcpyAsync(bloom_ptr(ctx, which), host_in, nbytes, hipMemcpyHostToDevice, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
@@ -555,7 +568,7 @@ int fgpu_bloom_weight(fgpu_ctx* ctx, int which, float* weight) {
     int rc = fgpu_util_popcount(ctx, bloom_ptr(ctx, which), ctx->bloom_bytes, &ctx->counters->pad);
     if (rc) return rc;
     FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->pad, &ctx->counters->pad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     *weight = (float)(long)ctx->counters_host->pad / (float)ctx->prm.tai;   // Bloom::weight: (float)weight/(float)tai
     return FGPU_OK;
 }
@@ -596,6 +609,9 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->late_acc[0] = ctx->late_acc[1] = ctx->late_acc[2] = 0;
     ctx->stops_delivered = 0;
     ctx->lp_applied_seq = 0;
+    ctx->host_waits = 0;
+    ctx->host_wait_ms = 0;
+    ctx->wait_sites.clear();
     if (ctx->short_pf) FGPU_HIP(hipMemsetAsync(ctx->short_pf, 0, ctx->short_pf_tai / 8, ctx->stream));   // a scan starts with empty pair filters
     if ((rc = fgpu_long_pairs_reset(ctx))) return rc;
     ctx->have_import = false;
@@ -718,7 +734,7 @@ static int scan_pure_into(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) 
     ctx->cur = b;
     const double t_a = fgpu_host_now();
     if (b->walk_pending) {   // the walk stream may still be reading this batch's planes
-        FGPU_HIP(hipEventSynchronize(b->walk_done));
+        FGPU_HIP(fgpu_sync_event(ctx, b->walk_done));
         b->walk_pending = false;
     }
     const double t_b = fgpu_host_now();
@@ -771,7 +787,7 @@ static int journal_add(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
     if (!ctx->journal_pool.empty()) { j = ctx->journal_pool.back(); ctx->journal_pool.pop_back(); }
     else j = new JournalBatch();
     int rc;
-    if ((rc = fgpu_ensure(ctx, &j->codes, cb)) || (rc = fgpu_ensure(ctx, &j->bad, bbytes)) || (ob && (rc = fgpu_ensure(ctx, &j->offs, ob)))) {
+    if ((rc = fgpu_ensure_b(ctx, &j->codes, cb)) || (rc = fgpu_ensure_b(ctx, &j->bad, bbytes)) || (ob && (rc = fgpu_ensure_b(ctx, &j->offs, ob)))) {
         ctx->journal_pool.push_back(j);
         return rc;
     }
@@ -809,7 +825,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     }
     FGPU_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(DevCounters), ctx->stream));
     FGPU_HIP(hipMemcpyAsync(&ctx->counters->max_read_len, &ctx->journal_max_read_len, 8, hipMemcpyHostToDevice, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     const uint64_t reads_processed = ctx->scan_stats.reads_processed;
     memset(&ctx->scan_stats, 0, sizeof(ctx->scan_stats));
     ctx->scan_stats.reads_processed = reads_processed;
@@ -834,7 +850,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     memset(&ctx->carried, 0, sizeof(ctx->carried));
     if (ctx->have_import) {   // the table the previous shard handed over comes first again
         if ((rc = fgpu_scan_reserve(ctx, ctx->import_n)) || (rc = fgpu_scan_import_impl(ctx, ctx->import_copy.p, ctx->import_n))) { ctx->in_replay = false; return rc; }
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
         ctx->scan_imported = ctx->import_n;
         if (ctx->import_has_carried) {
             ctx->carried = ctx->import_carried;
@@ -846,7 +862,7 @@ static int scan_replay(fgpu_ctx* ctx) {
         BatchBufs* b = acquire_batch(ctx);
         if (b->stops_pending && (rc = fgpu_scan_harvest(ctx, b))) break;   // lists of the replayed batch these buffers held two batches ago
         if (b->walk_pending) {
-            FGPU_HIP(hipEventSynchronize(b->walk_done));
+            FGPU_HIP(fgpu_sync_event(ctx, b->walk_done));
             b->walk_pending = false;
         }
         b->seq = j->seq;
@@ -855,7 +871,7 @@ static int scan_replay(fgpu_ctx* ctx) {
         b->d_offs = (const uint64_t*)j->offs.p;
         if (b->T) {
             const uint64_t cb = 2 * (b->n_words + FGPU_PADW) * 8, bbytes = (b->n_words + FGPU_PADW) * 8;
-            if ((rc = fgpu_ensure(ctx, &b->codes, cb)) || (rc = fgpu_ensure(ctx, &b->bad, bbytes))) break;
+            if ((rc = fgpu_ensure_b(ctx, &b->codes, cb)) || (rc = fgpu_ensure_b(ctx, &b->bad, bbytes))) break;
             FGPU_HIP(hipMemcpyAsync(b->codes.p, j->codes.p, cb, hipMemcpyDeviceToDevice, ctx->stream));
             FGPU_HIP(hipMemcpyAsync(b->bad.p, j->bad.p, bbytes, hipMemcpyDeviceToDevice, ctx->stream));
         }
@@ -984,7 +1000,7 @@ int fgpu_scan_short_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t l
     if (ctx->phase != 0) { ctx->err = "fgpu_scan_short_pairs while a pass is open"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     if (ctx->short_pf) {
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
         FGPU_HIP(hipFree(ctx->short_pf));
         ctx->short_pf = nullptr;
         ctx->short_pf_tai = 0;
@@ -1007,7 +1023,7 @@ int fgpu_scan_short_pairs_download(fgpu_ctx* ctx, uint8_t* out, uint64_t n_bytes
     if (n_bytes != ctx->short_pf_tai / 8) { ctx->err = "fgpu_scan_short_pairs_download: the filter has tai / 8 bytes"; return FGPU_ERR_ARG; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     FGPU_HIP(hipMemcpyAsync(out, ctx->short_pf, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
@@ -1044,6 +1060,18 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
     if (!ctx) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "scan_end without scan_begin"; return FGPU_ERR_STATE; }
     static const bool dbg_host = getenv("FGPU_DEBUG_HOST") != nullptr;
+    static const bool dbg_waits = getenv("FGPU_DEBUG_WAITS") != nullptr;
+    struct TellWaits {      // (at the very end of the call: the last walks and harvests are waited for inside it)
+        fgpu_ctx* c;
+        bool on;
+        ~TellWaits() {
+            if (!on) return;
+            for (const WaitSite& w : c->wait_sites) {
+                const char* f = strrchr(w.file, '/');
+                fprintf(stderr, "[waits] %-14s:%-5d %6llu times %9.2f ms\n", f ? f + 1 : w.file, w.line, (unsigned long long)w.n, w.ms);
+            }
+        }
+    } tell_waits{ctx, dbg_waits};
     if (dbg_host) {
         fprintf(stderr, "[host] scan: wait for the buffers' last walk %.2f ms, pack issue %.2f, pure stage issue (first half) %.2f, wait for the piece count %.2f, "
                         "pure stage issue (second half) %.2f, walk issue %.2f\n", ctx->host_ms[0], ctx->host_ms[1], ctx->host_ms[2], ctx->host_ms[3], ctx->host_ms[4], ctx->host_ms[5]);
@@ -1055,6 +1083,7 @@ int fgpu_scan_end(fgpu_ctx* ctx, fgpu_scan_stats* stats) {
         if (!rc) rc = pull_counters(ctx);
     }
     while (!rc && !ctx->to_harvest.empty()) rc = fgpu_scan_harvest(ctx, ctx->to_harvest.front());   // every walk has finished
+    if (!rc) rc = fgpu_long_pairs_close(ctx);              // the last batch of lists: its rounds' outcome, a first end left without a mate
     ctx->phase = 0;
     ctx->journal_on = false;
     if (!rc && !ctx->prm.walk_window_span && ctx->scan_windows > 8) ctx->settled_span = ctx->window_span;
@@ -1131,7 +1160,7 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     }
     // the import runs on the main stream, the ordered walk on the walk stream behind events recorded BEFORE this call
     // (end of each prepared batch's pure stage): without this wait the walk would start on a half-imported table
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     ctx->scan_imported += n_entries;
     if (carried) ctx->carried = *carried;
     // creation stamps of this shard must sort after everything imported
@@ -1150,7 +1179,7 @@ int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries
     if (rc) return rc;
     if ((rc = fgpu_scan_reserve(ctx, n_entries))) return rc;
     if ((rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries))) return rc;
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     ctx->hint_in_table = true;
     return FGPU_OK;
 }
@@ -1168,7 +1197,7 @@ int fgpu_probe_hash(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, uint6
     FGPU_HIP(hipMemcpyAsync(canon_out, d + n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(hA_out, d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(hB_out, d + 3 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
@@ -1182,7 +1211,7 @@ int fgpu_probe_contains(fgpu_ctx* ctx, int which, const uint64_t* canon_host, ui
     FGPU_HIP(hipMemcpyAsync(d, canon_host, n * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = fgpu_util_probe_contains(ctx, bloom_ptr(ctx, which), d, n, (unsigned char*)(d + n)))) return rc;
     FGPU_HIP(hipMemcpyAsync(out, d + n, n, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
@@ -1197,12 +1226,19 @@ static int probe_stage3(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, i
     FGPU_HIP(hipMemcpyAsync(d, kmers_host, n * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = fgpu_util_probe_stage3(ctx, d, n, mode, (signed char*)(d + n)))) return rc;
     FGPU_HIP(hipMemcpyAsync(out, d + n, n, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 int fgpu_probe_jcheck(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 0, out); }
 int fgpu_probe_valid_extension(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 1, out); }
 int fgpu_probe_bloom_junction(fgpu_ctx* ctx, const uint64_t* kmers_host, uint64_t n, int8_t* out) { return probe_stage3(ctx, kmers_host, n, 2, out); }
+
+int fgpu_diag_host_waits(fgpu_ctx* ctx, uint64_t* waits, double* ms) {
+    if (!ctx || !waits) return FGPU_ERR_ARG;
+    *waits = ctx->host_waits;
+    if (ms) *ms = ctx->host_wait_ms;
+    return FGPU_OK;
+}
 
 int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays) {
     if (!ctx || !replays) return FGPU_ERR_ARG;

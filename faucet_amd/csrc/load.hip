@@ -637,7 +637,7 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
     }
     if (ctx->resident_count == ctx->resident.size()) ctx->resident.push_back(new ResidentBatch());
     ResidentBatch& r = *ctx->resident[ctx->resident_count];
-    if (fgpu_ensure(ctx, &r.codes, cb) || fgpu_ensure(ctx, &r.bad, pb) || fgpu_ensure(ctx, &r.sure, pb)) {
+    if (fgpu_ensure_b(ctx, &r.codes, cb) || fgpu_ensure_b(ctx, &r.bad, pb) || fgpu_ensure_b(ctx, &r.sure, pb)) {
         (void)hipGetLastError();
         ctx->resident_open = false;   // out of memory: do without
         return FGPU_OK;
@@ -667,9 +667,9 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     BatchBufs& bb = *ctx->cur;
     if (bb.T == 0) return FGPU_OK;
     const uint64_t plane_stride = bb.n_words + FGPU_PADW;   // plane 0: pending; planes 1..MISS_PLANES: bit i missing from the carry
-    int rc = fgpu_ensure(ctx, &bb.pending, (MISS_PLANES + 1) * plane_stride * 8);
+    int rc = fgpu_ensure_b(ctx, &bb.pending, (MISS_PLANES + 1) * plane_stride * 8);
     if (rc) return rc;
-    if ((rc = fgpu_ensure(ctx, &bb.sure, (bb.n_words + FGPU_PADW) * 8))) return rc;
+    if ((rc = fgpu_ensure_b(ctx, &bb.sure, (bb.n_words + FGPU_PADW) * 8))) return rc;
     const unsigned grid = fgpu_grid(bb.n_words * 64, 256);
     if ((rc = fgpu_util_count_segments(ctx, ctx->fd.k))) return rc;
     // Times are positions within the current EPOCH = the batches since the last sweep of first[] (k_carry_from_first).  A bit

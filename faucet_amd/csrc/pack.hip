@@ -244,18 +244,23 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
         d_starts = reads->starts;
         if (reads->offsets == ctx->split_offsets && n == ctx->split_n) {   // cut by fgpu_text_split just now: the total came with it
             total = ctx->split_total;
+            // ... and so did the size of its chunk: the buffers of this batch that have to grow are made for the largest chunk announced
+            ctx->ensure_scale = ctx->text_reserve > ctx->text_last_bytes && ctx->text_last_bytes
+                                    ? std::min(8.0, (double)ctx->text_reserve / (double)ctx->text_last_bytes) : 1.0;
         } else if (reads->total_bases) {   // the caller's word for it; k_pack_fix compares it with the offsets (error flag 32)
+            ctx->ensure_scale = 1.0;
             total = reads->total_bases;
         } else {
             uint64_t ends[2];
             FGPU_HIP(hipMemcpyAsync(&ends[0], reads->offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
             FGPU_HIP(hipMemcpyAsync(&ends[1], reads->offsets + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-            FGPU_HIP(hipStreamSynchronize(ctx->stream));
+            FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
             total = ends[1] - ends[0];
         }
         d_bases = (const unsigned char*)reads->bases;
         d_offs = reads->offsets;
     } else {
+        ctx->ensure_scale = 1.0;
         total = reads->offsets[n] - reads->offsets[0];
         // Host buffers go through one of two staging sets on the text stream: the copy of this batch runs beside the kernels of the batch
         // before it, and the host waits for the copy only (so the caller may reuse its buffers) -- on the main stream the device idled
@@ -264,7 +269,7 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
         int rc = fgpu_text_streams(ctx);
         if (rc) return rc;
         if (ctx->host_set >= 0) {   // the call that packed the previous host batch failed half-way: nothing is known about its set
-            FGPU_HIP(hipStreamSynchronize(ctx->stream));
+            FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
             ctx->host_stage_used[0] = ctx->host_stage_used[1] = false;
             ctx->host_set = -1;
         }
@@ -281,7 +286,7 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
         FGPU_HIP(hipMemcpyAsync(so.p, reads->offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->tstream));
         FGPU_HIP(hipEventRecord(ctx->ev_text_done, ctx->tstream));
         FGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_text_done, 0));
-        FGPU_HIP(hipStreamSynchronize(ctx->tstream));
+        FGPU_HIP(fgpu_sync_stream(ctx, ctx->tstream));
         d_bases = (const unsigned char*)sb.p - reads->offsets[0];
         d_offs = (const uint64_t*)so.p;
     }
@@ -297,15 +302,15 @@ int fgpu_stage_pack(fgpu_ctx* ctx, const fgpu_reads* reads) {
     bb.d_offs = d_offs;
     int rc;
     if (n == 0) {   // nothing to pack; later stages see an empty stream
-        if ((rc = fgpu_ensure(ctx, &bb.codes, 64))) return rc;
-        if ((rc = fgpu_ensure(ctx, &bb.bad, 64))) return rc;
+        if ((rc = fgpu_ensure_b(ctx, &bb.codes, 64))) return rc;
+        if ((rc = fgpu_ensure_b(ctx, &bb.bad, 64))) return rc;
         FGPU_HIP(hipMemsetAsync(bb.bad.p, 0xFF, 64, ctx->stream));
         FGPU_HIP(hipMemsetAsync(bb.codes.p, 0, 64, ctx->stream));
         return FGPU_OK;
     }
-    if ((rc = fgpu_ensure(ctx, &bb.codes, (2 * (bb.n_words + FGPU_PADW)) * 8))) return rc;
-    if ((rc = fgpu_ensure(ctx, &bb.bad, (bb.n_words + FGPU_PADW) * 8))) return rc;
-    if ((rc = fgpu_ensure(ctx, &bb.readflag, n + 16))) return rc;
+    if ((rc = fgpu_ensure_b(ctx, &bb.codes, (2 * (bb.n_words + FGPU_PADW)) * 8))) return rc;
+    if ((rc = fgpu_ensure_b(ctx, &bb.bad, (bb.n_words + FGPU_PADW) * 8))) return rc;
+    if ((rc = fgpu_ensure_b(ctx, &bb.readflag, n + 16))) return rc;
     FGPU_HIP(hipMemsetAsync(bb.readflag.p, 0, n, ctx->stream));
     // four trips of 64 x 32 positions per wave: the bisection that opens a wave's run is paid once per 8192 positions
     FGPU_LAUNCH("pack", k_pack, fgpu_grid((bb.n_words + FGPU_PADW) / 2 + 1, 256), 256, d_bases, d_offs, d_starts, n, T, bb.n_words, (uint64_t*)bb.codes.p,

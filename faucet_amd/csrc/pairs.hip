@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(256) k_lp_post(LpLists L, LpFilter F, uint8_t*
 }
 
 // settled: the inserters' bits go into the filter (the carry of the next batch) and their times out of first[]
-__global__ void __launch_bounds__(256) k_lp_commit(LpLists L, LpFilter F, const uint8_t* __restrict__ state, unsigned long long* __restrict__ diag) {
+__global__ void __launch_bounds__(256) k_lp_commit(LpLists L, LpFilter F, const uint8_t* __restrict__ state, unsigned long long* __restrict__ diag,
+                                                   const uint32_t* __restrict__ last_flips) {
+    if (last_flips && *last_flips != 0) return;      // the rounds issued ahead did not settle: the host issues more, then commits (lp_close)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool ins = e < L.n_elems && state[e] == LP_INSERT;
     if (ins) {
@@ -209,11 +211,85 @@ __global__ void __launch_bounds__(256) k_lp_commit(LpLists L, LpFilter F, const 
 
 }  // namespace
 
+// The rounds of one batch are issued AHEAD -- kAhead of them, each a no-op once an earlier one has settled -- with the commit behind them, and the
+// host looks at the outcome when the next batch of lists arrives (or the scan ends): no wait of the host per batch (round 5; there was one per
+// group of four rounds and one per odd batch).  lp_close is that look: how many rounds the batch took, more rounds and the commit if kAhead did
+// not settle it (not seen so far: 4 at most on config 3's shape), and the list of a first end that waits for its mate.
+constexpr int kAhead = 8;
+
+static int lp_rounds(fgpu_ctx* ctx, const LpLists& L, const LpFilter& F, uint8_t* state, uint8_t* state_new, uint32_t* d_flips, int n, unsigned blocks) {
+    FGPU_HIP(hipMemsetAsync(d_flips, 0, 4 * n, ctx->stream));
+    for (int g = 0; g < n; g++) {
+        FGPU_LAUNCH("long_pairs", k_lp_eval, blocks, 256, L, F, (const uint8_t*)state, state_new, g ? (const uint32_t*)(d_flips + g - 1) : (const uint32_t*)nullptr, d_flips + g);
+        FGPU_LAUNCH("long_pairs", k_lp_withdraw, blocks, 256, L, F, (const uint8_t*)state, (const uint32_t*)(d_flips + g));
+        FGPU_LAUNCH("long_pairs", k_lp_post, blocks, 256, L, F, state, (const uint8_t*)state_new, (const uint32_t*)(d_flips + g));
+    }
+    return FGPU_OK;
+}
+
+// the outcome of the batch whose rounds are in flight; everything it queued must have run (the callers have synchronised the stream, or do here)
+int fgpu_long_pairs_close(fgpu_ctx* ctx) {
+    LongPairs& lp = ctx->lp;
+    if (!lp.open) return FGPU_OK;
+    lp.open = false;
+    if (hipEventQuery(lp.ev_open) != hipSuccess) FGPU_HIP(fgpu_sync_event(ctx, lp.ev_open));
+    const uint32_t n_elems = lp.open_elems, n_vreads = lp.open_vreads;
+    uint64_t *canon = (uint64_t*)lp.canon.p, *h0 = (uint64_t*)lp.h0.p, *h1 = (uint64_t*)lp.h1.p;
+    if (lp.open_filter) {
+        uint8_t *state = (uint8_t*)lp.state.p, *state_new = state + n_elems;
+        const LpLists L = {canon, h0, h1, (uint32_t*)lp.vread.p, (uint32_t*)lp.rs.p, n_elems, n_vreads};
+        const LpFilter F = {lp.bits, lp.first, lp.tai ? lp.tai - 1 : 0, lp.n_hash};
+        unsigned long long* d_diag = (unsigned long long*)lp.dev.p;
+        uint32_t* d_flips = (uint32_t*)((unsigned long long*)lp.dev.p + 8);
+        const unsigned blocks = fgpu_blocks(std::max<uint64_t>(n_elems, 1), 256);
+        int used = kAhead;
+        for (int g = 0; g < kAhead; g++)
+            if (lp.flips_host[g] == 0) { used = g + 1; break; }
+        uint64_t rounds = (uint64_t)used;
+        if (lp.flips_host[kAhead - 1] != 0) {          // not settled by the rounds issued ahead: the old way, a look per group, then the commit
+            constexpr int kGroup = 4;
+            for (;;) {
+                if (int rc = lp_rounds(ctx, L, F, state, state_new, d_flips, kGroup, blocks)) return rc;
+                FGPU_HIP(hipMemcpyAsync(lp.flips_host, d_flips, 4 * kGroup, hipMemcpyDeviceToHost, ctx->stream));
+                FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
+                int u = kGroup;
+                for (int g = 0; g < kGroup; g++)
+                    if (lp.flips_host[g] == 0) { u = g + 1; break; }
+                rounds += (uint64_t)u;
+                if (lp.flips_host[u - 1] == 0) break;
+                if (rounds > (uint64_t)n_elems + kAhead + kGroup) { ctx->err = "long pair filter: the rounds did not settle (internal error)"; return FGPU_ERR_STATE; }
+            }
+            FGPU_LAUNCH("long_pairs", k_lp_commit, blocks, 256, L, F, (const uint8_t*)state, d_diag, (const uint32_t*)nullptr);
+        }
+        lp.rounds += rounds;
+        lp.max_rounds = std::max<uint64_t>(lp.max_rounds, rounds);
+    }
+    // a first end at the end of the batch waits for its mate: its list is kept (canonical forms and hashes)
+    uint32_t new_kept = 0;
+    if (lp.open_odd) {
+        const uint32_t last_start = lp.flips_host[kAhead];
+        new_kept = n_elems - last_start;
+        if (new_kept) {
+            DevBuf& nk = lp.kept_set[lp.kept_cur ^ 1];
+            if (int rc = fgpu_ensure_b(ctx, &nk, 24ULL * new_kept)) return rc;
+            uint64_t* kp = (uint64_t*)nk.p;
+            FGPU_HIP(hipMemcpyAsync(kp, canon + last_start, 8ULL * new_kept, hipMemcpyDeviceToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(kp + new_kept, h0 + last_start, 8ULL * new_kept, hipMemcpyDeviceToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(kp + 2 * new_kept, h1 + last_start, 8ULL * new_kept, hipMemcpyDeviceToDevice, ctx->stream));
+            lp.kept_cur ^= 1;
+        }
+    }
+    lp.pending_first = lp.open_odd;
+    lp.n_kept = new_kept;
+    return FGPU_OK;
+}
+
 // Applies scanReads' paired-end loop to the lists of one harvested batch (device array of n_stops stops, sorted by read; n_reads reads).
 // Called by fgpu_scan_harvest, in scan order, on the main stream.
 int fgpu_long_pairs_batch(fgpu_ctx* ctx, const fgpu_stop* d_stops, uint64_t n_stops, uint64_t n_reads) {
     LongPairs& lp = ctx->lp;
     if (!lp.mode || !n_reads) return FGPU_OK;
+    if (int rc = fgpu_long_pairs_close(ctx)) return rc;     // the batch before: its waiting first end, its rounds
     const uint64_t n_elems64 = lp.n_kept + n_stops, n_vreads64 = n_reads + (lp.pending_first ? 1 : 0);
     if (n_elems64 >= 0xFFFFFFF0ULL || n_vreads64 >= 0xFFFFFFF0ULL) { ctx->err = "long pair filter: more than 2^32 list elements in one batch"; return FGPU_ERR_CAPACITY; }
     const uint32_t n_elems = (uint32_t)n_elems64, n_vreads = (uint32_t)n_vreads64, n_pairs = n_vreads / 2, n_kept = (uint32_t)lp.n_kept;
@@ -226,9 +302,9 @@ int fgpu_long_pairs_batch(fgpu_ctx* ctx, const fgpu_stop* d_stops, uint64_t n_st
         return FGPU_OK;
     }
     int rc;
-    if ((rc = fgpu_ensure(ctx, &lp.canon, 8ULL * n_elems)) || (rc = fgpu_ensure(ctx, &lp.h0, 8ULL * n_elems)) || (rc = fgpu_ensure(ctx, &lp.h1, 8ULL * n_elems)) ||
-        (rc = fgpu_ensure(ctx, &lp.vread, 4ULL * n_elems)) || (rc = fgpu_ensure(ctx, &lp.rs, 4ULL * (n_vreads + 2))) ||
-        (rc = fgpu_ensure(ctx, &lp.state, 2ULL * n_elems)))
+    if ((rc = fgpu_ensure_b(ctx, &lp.canon, 8ULL * n_elems)) || (rc = fgpu_ensure_b(ctx, &lp.h0, 8ULL * n_elems)) || (rc = fgpu_ensure_b(ctx, &lp.h1, 8ULL * n_elems)) ||
+        (rc = fgpu_ensure_b(ctx, &lp.vread, 4ULL * n_elems)) || (rc = fgpu_ensure_b(ctx, &lp.rs, 4ULL * (n_vreads + 2))) ||
+        (rc = fgpu_ensure_b(ctx, &lp.state, 2ULL * n_elems)))
         return rc;
     uint64_t *canon = (uint64_t*)lp.canon.p, *h0 = (uint64_t*)lp.h0.p, *h1 = (uint64_t*)lp.h1.p;
     uint32_t *vread = (uint32_t*)lp.vread.p, *rs = (uint32_t*)lp.rs.p;
@@ -245,52 +321,29 @@ int fgpu_long_pairs_batch(fgpu_ctx* ctx, const fgpu_stop* d_stops, uint64_t n_st
                 lp.pending_first ? 1u : 0u, ctx->fd.k, mask, canon, h0, h1, vread);
     FGPU_LAUNCH("long_pairs", k_lp_read_starts, fgpu_blocks(n_vreads + 1, 256), 256, (const uint32_t*)vread, n_elems, n_vreads, rs);
     unsigned long long* d_diag = (unsigned long long*)lp.dev.p;          // [0..2] diagnostics, [3] empty, [4] not empty
-    uint32_t* d_flips = (uint32_t*)((unsigned long long*)lp.dev.p + 8);  // one counter per round of a group
+    uint32_t* d_flips = (uint32_t*)((unsigned long long*)lp.dev.p + 8);  // one counter per round issued ahead
     if (n_pairs) FGPU_LAUNCH("long_pairs", k_lp_count, fgpu_blocks(n_pairs, 256), 256, (const uint32_t*)rs, n_pairs, d_diag + 3);
     const LpLists L = {canon, h0, h1, vread, rs, n_elems, n_vreads};
-    if (lp.mode == FGPU_LONG_PAIRS_FILTER && n_pairs) {
+    const bool filter = lp.mode == FGPU_LONG_PAIRS_FILTER && n_pairs;
+    if (filter) {
         const LpFilter F = {lp.bits, lp.first, mask, lp.n_hash};
         FGPU_LAUNCH("long_pairs", k_lp_init, blocks, 256, L, F, state, state_new, d_diag);
-        constexpr int kGroup = 4;    // rounds issued between two looks at the flip counters (a settled group's later rounds return at once)
-        for (uint64_t round = 0;; round += kGroup) {
-            FGPU_HIP(hipMemsetAsync(d_flips, 0, 4 * kGroup, ctx->stream));
-            for (int g = 0; g < kGroup; g++) {
-                FGPU_LAUNCH("long_pairs", k_lp_eval, blocks, 256, L, F, (const uint8_t*)state, state_new, g ? (const uint32_t*)(d_flips + g - 1) : (const uint32_t*)nullptr, d_flips + g);
-                FGPU_LAUNCH("long_pairs", k_lp_withdraw, blocks, 256, L, F, (const uint8_t*)state, (const uint32_t*)(d_flips + g));
-                FGPU_LAUNCH("long_pairs", k_lp_post, blocks, 256, L, F, state, (const uint8_t*)state_new, (const uint32_t*)(d_flips + g));
-            }
-            FGPU_HIP(hipMemcpyAsync(lp.flips_host, d_flips, 4 * kGroup, hipMemcpyDeviceToHost, ctx->stream));
-            FGPU_HIP(hipStreamSynchronize(ctx->stream));
-            int used = kGroup;
-            for (int g = 0; g < kGroup; g++)
-                if (lp.flips_host[g] == 0) { used = g + 1; break; }
-            lp.rounds += (uint64_t)used;
-            lp.max_rounds = std::max<uint64_t>(lp.max_rounds, round + (uint64_t)used);
-            if (lp.flips_host[used - 1] == 0) break;
-            if (round > (uint64_t)n_elems + kGroup) { ctx->err = "long pair filter: the rounds did not settle (internal error)"; return FGPU_ERR_STATE; }
-        }
-        FGPU_LAUNCH("long_pairs", k_lp_commit, blocks, 256, L, F, (const uint8_t*)state, d_diag);
+        if ((rc = lp_rounds(ctx, L, F, state, state_new, d_flips, kAhead, blocks))) return rc;
+        FGPU_LAUNCH("long_pairs", k_lp_commit, blocks, 256, L, F, (const uint8_t*)state, d_diag, (const uint32_t*)(d_flips + kAhead - 1));
+        FGPU_HIP(hipMemcpyAsync(lp.flips_host, d_flips, 4 * kAhead, hipMemcpyDeviceToHost, ctx->stream));
     }
-    // a first end at the end of the batch waits for its mate: its list is kept (canonical forms and hashes)
-    uint32_t new_kept = 0;
-    if (odd) {
-        uint32_t last_start = 0;
-        FGPU_HIP(hipMemcpyAsync(lp.flips_host, rs + (n_vreads - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
-        last_start = lp.flips_host[0];
-        new_kept = n_elems - last_start;
-        if (new_kept) {
-            DevBuf& nk = lp.kept_set[lp.kept_cur ^ 1];
-            if ((rc = fgpu_ensure(ctx, &nk, 24ULL * new_kept))) return rc;
-            uint64_t* kp = (uint64_t*)nk.p;
-            FGPU_HIP(hipMemcpyAsync(kp, canon + last_start, 8ULL * new_kept, hipMemcpyDeviceToDevice, ctx->stream));
-            FGPU_HIP(hipMemcpyAsync(kp + new_kept, h0 + last_start, 8ULL * new_kept, hipMemcpyDeviceToDevice, ctx->stream));
-            FGPU_HIP(hipMemcpyAsync(kp + 2 * new_kept, h1 + last_start, 8ULL * new_kept, hipMemcpyDeviceToDevice, ctx->stream));
-            lp.kept_cur ^= 1;
-        }
+    if (odd) FGPU_HIP(hipMemcpyAsync(lp.flips_host + kAhead, rs + (n_vreads - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!filter && !odd) {           // nothing to look at later
+        lp.pending_first = false;
+        lp.n_kept = 0;
+        return FGPU_OK;
     }
-    lp.pending_first = odd;
-    lp.n_kept = new_kept;
+    FGPU_HIP(hipEventRecord(lp.ev_open, ctx->stream));
+    lp.open = true;
+    lp.open_elems = n_elems;
+    lp.open_vreads = n_vreads;
+    lp.open_odd = odd;
+    lp.open_filter = filter;
     return FGPU_OK;
 }
 
@@ -298,6 +351,7 @@ int fgpu_long_pairs_batch(fgpu_ctx* ctx, const fgpu_stop* d_stops, uint64_t n_st
 int fgpu_long_pairs_reset(fgpu_ctx* ctx) {
     LongPairs& lp = ctx->lp;
     if (!lp.mode) return FGPU_OK;
+    lp.open = false;                 // (a scan that was abandoned with a batch in flight: its outcome is of no interest any more)
     if (lp.bits) FGPU_HIP(hipMemsetAsync(lp.bits, 0, lp.tai / 8, ctx->stream));
     if (lp.first) FGPU_HIP(hipMemsetAsync(lp.first, 0xFF, lp.tai * 4, ctx->stream));
     FGPU_HIP(hipMemsetAsync(lp.dev.p, 0, 128, ctx->stream));
@@ -315,7 +369,7 @@ int fgpu_scan_long_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t mo
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     LongPairs& lp = ctx->lp;
     if (lp.bits || lp.first) {
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
         if (lp.bits) FGPU_HIP(hipFree(lp.bits));
         if (lp.first) FGPU_HIP(hipFree(lp.first));
         lp.bits = lp.first = nullptr;
@@ -341,6 +395,7 @@ int fgpu_scan_long_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t mo
     int rc = fgpu_ensure(ctx, &lp.dev, 256);
     if (rc) return rc;
     if (!lp.flips_host) FGPU_HIP(hipHostMalloc((void**)&lp.flips_host, 64));
+    if (!lp.ev_open) FGPU_HIP(hipEventCreateWithFlags(&lp.ev_open, hipEventDisableTiming));
     lp.mode = mode;
     return fgpu_long_pairs_reset(ctx);
 }
@@ -352,10 +407,11 @@ int fgpu_scan_long_pairs_download(fgpu_ctx* ctx, uint8_t* out, uint64_t n_bytes,
     if (ctx->phase != 0) { ctx->err = "fgpu_scan_long_pairs_download while a pass is open"; return FGPU_ERR_STATE; }
     if (out && (lp.mode != FGPU_LONG_PAIRS_FILTER || n_bytes != lp.tai / 8)) { ctx->err = "fgpu_scan_long_pairs_download: the filter has tai / 8 bytes"; return FGPU_ERR_ARG; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (int rc = fgpu_long_pairs_close(ctx)) return rc;       // the last batch's rounds (fgpu_scan_end has closed it already)
     unsigned long long c[5] = {0, 0, 0, 0, 0};
     FGPU_HIP(hipMemcpyAsync(c, lp.dev.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
     if (out) FGPU_HIP(hipMemcpyAsync(out, lp.bits, n_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     if (empty_count) *empty_count = c[3] + lp.empty_host;
     if (not_empty_count) *not_empty_count = c[4];
     return FGPU_OK;
@@ -368,8 +424,9 @@ int fgpu_diag_long_pairs(fgpu_ctx* ctx, uint64_t out[6]) {
     if (!lp.mode) return FGPU_OK;
     unsigned long long c[3] = {0, 0, 0};
     FGPU_HIP(hipSetDevice(ctx->prm.device));
+    if (int rc = fgpu_long_pairs_close(ctx)) return rc;
     FGPU_HIP(hipMemcpyAsync(c, lp.dev.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));   // (behind the batches queued on the context's stream)
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     out[0] = c[0] + c[1];   // items: first-end k-mers of read pairs with two non-empty lists
     out[1] = c[1];          // of those, paired against the filter as their batch found it
     out[2] = c[2];          // addPair calls

@@ -558,8 +558,8 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     int rc;
     DevBuf* planes[] = {&bb.valid, &bb.pm, &bb.ps, &bb.ff, &bb.fb, &bb.cf0, &bb.cf1, &bb.cb0, &bb.cb1, &bb.inF, &bb.inB, &bb.lk, &bb.nF, &bb.nB, &bb.need};
     for (DevBuf* b : planes)
-        if ((rc = fgpu_ensure(ctx, b, wb))) return rc;
-    if ((rc = fgpu_ensure(ctx, &bb.ps_prefix, (bb.n_words + FGPU_PADW + bb.n_words / SCAN_BLOCK + 2) * 4))) return rc;
+        if ((rc = fgpu_ensure_b(ctx, b, wb))) return rc;
+    if ((rc = fgpu_ensure_b(ctx, &bb.ps_prefix, (bb.n_words + FGPU_PADW + bb.n_words / SCAN_BLOCK + 2) * 4))) return rc;
     const double t_a = fgpu_host_now();
     // valid/pm/ps need zeroed padding (funnel reads run one word past the end); pm is built with atomicOr
     FGPU_HIP(hipMemsetAsync(bb.valid.p, 0, wb, ctx->stream));
@@ -576,7 +576,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     ctx->scan_batch_index++;
     if (kept && (kept->T != bb.T || kept->n_words != bb.n_words)) kept = nullptr;
     if (kept) {
-        if ((rc = fgpu_ensure(ctx, &bb.same, 64))) return rc;
+        if ((rc = fgpu_ensure_b(ctx, &bb.same, 64))) return rc;
         FGPU_HIP(hipMemsetAsync(bb.same.p, 0x01, 4, ctx->stream));
         const uint64_t ncw = 2 * bb.n_words;   // 32 bases per code word
         FGPU_LAUNCH("scan_same", k_scan_same, fgpu_grid(ncw, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)kept->codes.p, ncw,
@@ -598,7 +598,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     FGPU_LAUNCH("prefix_apply", k_prefix_apply, fgpu_blocks(nw1, 256), 256, prefix, (const uint32_t*)block_sums, nw1);
     FGPU_HIP(hipMemcpyAsync(ctx->counters_host, ctx->counters, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->stream));
     const double t_b = fgpu_host_now();
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     const double t_c = fgpu_host_now();
     ctx->host_ms[2] += t_b - t_a;
     ctx->host_ms[3] += t_c - t_b;
@@ -607,12 +607,12 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces) {
     ctx->scan_pieces_seen = ctx->counters_host->pieces;
     *n_pieces = np;
     bb.n_pieces = np;
-    if ((rc = fgpu_ensure(ctx, &bb.pieces, (np + 1) * sizeof(uint2)))) return rc;
+    if ((rc = fgpu_ensure_b(ctx, &bb.pieces, (np + 1) * sizeof(uint2)))) return rc;
     if (np) {
         FGPU_LAUNCH("piece_list", k_scan_piece_list, wgrid, 256, (const uint64_t*)bb.ps.p, (const uint64_t*)bb.pm.p,
                     (const uint32_t*)prefix, bb.n_words, (uint2*)bb.pieces.p);
         if (ctx->record_stops) {   // the offsets are the caller's and only valid during this call
-            if ((rc = fgpu_ensure(ctx, &bb.piece_read, np * 4))) return rc;
+            if ((rc = fgpu_ensure_b(ctx, &bb.piece_read, np * 4))) return rc;
             FGPU_LAUNCH("piece_read", k_scan_piece_read, fgpu_blocks(np, 256), 256, (const uint2*)bb.pieces.p, np, bb.d_offs, bb.n_reads,
                         (uint32_t*)bb.piece_read.p);
         }

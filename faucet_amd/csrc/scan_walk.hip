@@ -2774,11 +2774,11 @@ int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n);
 // travel through the export format of the multi-GPU hand-over (k_export / k_import), so nothing about a junction changes.
 int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap) {
     if (new_cap <= ctx->jcap) return FGPU_OK;
-    if (ctx->wstream) FGPU_HIP(hipStreamSynchronize(ctx->wstream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->wstream) FGPU_HIP(fgpu_sync_stream(ctx, ctx->wstream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->n_junctions, &ctx->counters->n_junctions, 8, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->error_flags, &ctx->counters->error_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     if (ctx->counters_host->error_flags & 1ULL) return FGPU_OK;   // already overflowed: the scan is void, the caller reports it
     const uint64_t n_max = ctx->counters_host->n_junctions + ctx->scan_imported;
     int rc;
@@ -2801,7 +2801,7 @@ int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap) {
     FGPU_HIP(hipMemsetAsync(ctx->jrecs, 0, ctx->jcap * 32, ctx->stream));
     FGPU_HIP(hipMemsetAsync(ctx->jfilter, 0, ctx->jcap * 2 / 8, ctx->stream));
     if ((rc = fgpu_scan_import_impl(ctx, ctx->dl_entries.p, n))) return rc;
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));   // the walk stream starts on the new table
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));   // the walk stream starts on the new table
     ctx->scan_grown++;
     return FGPU_OK;
 }
@@ -2846,7 +2846,7 @@ int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     const bool eager = (ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) || ctx->eager_runtime || ctx->eager_scan;   // evaluate testForJunction everywhere
     FGPU_HIP(hipMemsetAsync(bb.need.p, eager ? 0xFF : 0, wb, ctx->stream));
     if (!bb.n_pieces) return FGPU_OK;
-    if (int rc = fgpu_ensure(ctx, &bb.kh, (bb.n_words + FGPU_PADW) * 64 * 4)) return rc;
+    if (int rc = fgpu_ensure_b(ctx, &bb.kh, (bb.n_words + FGPU_PADW) * 64 * 4)) return rc;
 
     static const int need_tight = getenv("FGPU_NEED_TIGHT") ? atoi(getenv("FGPU_NEED_TIGHT")) : 2;   // measurement aid, see k_need_prewalk
     JTable jt = make_jt(ctx);
@@ -2882,13 +2882,13 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
               (uint64_t*)bb.lk.p, (const uint64_t*)bb.need.p, nullptr, nullptr, (const uint32_t*)bb.kh.p, nullptr};
     {   // in-map planes of the walk = the pure stage's snapshot planes nF / nB (see k_walk_register); creation plane of this batch
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
-        if (int rc = fgpu_ensure(ctx, &bb.cr, wb)) return rc;
+        if (int rc = fgpu_ensure_b(ctx, &bb.cr, wb)) return rc;
         pl.cr = (unsigned long long*)bb.cr.p;
     }
     if (ctx->record_stops) {
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
         int rc;
-        if ((rc = fgpu_ensure(ctx, &bb.sF, wb)) || (rc = fgpu_ensure(ctx, &bb.sB, wb))) return rc;
+        if ((rc = fgpu_ensure_b(ctx, &bb.sF, wb)) || (rc = fgpu_ensure_b(ctx, &bb.sB, wb))) return rc;
         pl.sF = (unsigned long long*)bb.sF.p;
         pl.sB = (unsigned long long*)bb.sB.p;
     }
@@ -2938,7 +2938,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     DeltaList& mine_list = ctx->delta_ring[ctx->delta_next % FGPU_DELTA_RING];
     {
         int rc;
-        if ((rc = fgpu_ensure(ctx, &mine_list.list, (bb.n_words + FGPU_PADW) * 64 * 4)) || (rc = fgpu_ensure(ctx, &mine_list.count, 64))) return rc;
+        if ((rc = fgpu_ensure_b(ctx, &mine_list.list, (bb.n_words + FGPU_PADW) * 64 * 4)) || (rc = fgpu_ensure(ctx, &mine_list.count, 64))) return rc;
         FGPU_HIP(hipMemsetAsync(mine_list.count.p, 0, 8, walk_stream));
     }
     // thousands of tiny launches: by default one event pair around the whole stage
@@ -3202,7 +3202,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             FGPU_HIP(hipMemcpyAsync(ctx->fb_host, &ctx->counters->followers, 8, hipMemcpyDeviceToHost, walk_stream));
             FGPU_HIP(hipMemcpyAsync(ctx->fb_host + 1, &ctx->counters->walked_pieces, 8, hipMemcpyDeviceToHost, walk_stream));
             FGPU_HIP(hipMemcpyAsync(ctx->fb_host + 2, &ctx->counters->ko_overflows, 8, hipMemcpyDeviceToHost, walk_stream));
-            FGPU_HIP(hipStreamSynchronize(walk_stream));
+            FGPU_HIP(fgpu_sync_stream(ctx, walk_stream));
             const uint64_t f = ctx->fb_host[0] - ctx->calib_f, p = ctx->fb_host[1] - ctx->calib_p;
             if (ctx->fb_host[2] > ctx->calib_ovf && span_now > 4096) {
                 // the window's large clusters outgrew the tables of the large-cluster walks (their pieces do not queue, so the share of
@@ -3366,15 +3366,34 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
     for (size_t i = 0; i < ctx->to_harvest.size(); i++)
         if (ctx->to_harvest[i] == b) { ctx->to_harvest.erase(ctx->to_harvest.begin() + i); break; }
     if (!b->stops_pending) return FGPU_OK;
+    // ONE wait of the host per harvested batch (round 5; there were three: for the walk's event, for the error flags, for the lists' total):
+    // the main stream waits for the walk by itself, and what the host has to see -- the flags of the walk (a walk that went wrong must not hand
+    // out lists), how many elements the lists hold -- comes back with one synchronisation.
     if (b->walk_pending) {
-        FGPU_HIP(hipEventSynchronize(b->walk_done));
+        FGPU_HIP(hipStreamWaitEvent(ctx->stream, b->walk_done, 0));
         b->walk_pending = false;
     }
-    if (ctx->journal_on && !ctx->in_replay) {   // lists of a walk that went wrong must not leave the library: look before handing out
-        FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->error_flags, &ctx->counters->error_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->counters_host->error_flags & 4ULL) { ctx->lazy_failed = true; ctx->to_harvest.insert(ctx->to_harvest.begin(), b); return FGPU_INTERNAL_REPLAY; }
+    const bool check = ctx->journal_on && !ctx->in_replay;
+    const uint64_t np_count = b->n_pieces;
+    uint32_t* count_c = nullptr;
+    uint32_t* offset_c = nullptr;
+    if (np_count) {
+        if (int rc0 = fgpu_ensure_b(ctx, &b->stop_off, (2 * np_count + 2) * 4)) return rc0;
+        count_c = (uint32_t*)b->stop_off.p;
+        offset_c = count_c + np_count + 1;
+        hipLaunchKernelGGL(k_stop_count, dim3(fgpu_blocks(np_count, 256)), dim3(256), 0, ctx->stream, (const uint2*)b->pieces.p, np_count,
+                           (const unsigned long long*)b->sF.p, (const unsigned long long*)b->sB.p, count_c);
+        size_t tmp_bytes = 0;
+        FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count_c, offset_c, 0u, np_count, rocprim::plus<uint32_t>(), ctx->stream));
+        DevBuf& tmp = ctx->probe_buf;
+        if (int rc0 = fgpu_ensure_b(ctx, &tmp, tmp_bytes + 16)) return rc0;
+        FGPU_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, count_c, offset_c, 0u, np_count, rocprim::plus<uint32_t>(), ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(&ctx->fb_host[4], count_c + np_count - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(&ctx->fb_host[5], offset_c + np_count - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (check) FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->error_flags, &ctx->counters->error_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (np_count || check) FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
+    if (check && (ctx->counters_host->error_flags & 4ULL)) { ctx->lazy_failed = true; ctx->to_harvest.insert(ctx->to_harvest.begin(), b); return FGPU_INTERNAL_REPLAY; }
     b->stops_pending = false;
     if (b->seq < ctx->stops_delivered) return FGPU_OK;   // scanned again by a replay: the caller has this batch's lists already
     // the lists come to the host unless their consumers on the device said otherwise (fgpu_scan_short_pairs' lists_to_host; a scan that only
@@ -3397,22 +3416,10 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
         return rc0;
     }
     int rc;
-    if ((rc = fgpu_ensure(ctx, &b->stop_off, (2 * np + 2) * 4))) return rc;
-    uint32_t* count = (uint32_t*)b->stop_off.p;
-    uint32_t* offset = count + np + 1;
-    hipLaunchKernelGGL(k_stop_count, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const uint2*)b->pieces.p, np,
-                       (const unsigned long long*)b->sF.p, (const unsigned long long*)b->sB.p, count);
-    size_t tmp_bytes = 0;
-    FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, offset, 0u, np, rocprim::plus<uint32_t>(), ctx->stream));
-    DevBuf& tmp = ctx->probe_buf;
-    if ((rc = fgpu_ensure(ctx, &tmp, tmp_bytes + 16))) return rc;
-    FGPU_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, count, offset, 0u, np, rocprim::plus<uint32_t>(), ctx->stream));
-    uint32_t last[2];
-    FGPU_HIP(hipMemcpyAsync(&last[0], count + np - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipMemcpyAsync(&last[1], offset + np - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t total = (uint64_t)last[0] + last[1];
-    if ((rc = fgpu_ensure(ctx, &b->stop_out, total * sizeof(fgpu_stop)))) return rc;
+    uint32_t* count = count_c;
+    uint32_t* offset = offset_c;
+    const uint64_t total = (uint64_t)(uint32_t)ctx->fb_host[4] + (uint64_t)(uint32_t)ctx->fb_host[5];
+    if ((rc = fgpu_ensure_b(ctx, &b->stop_out, total * sizeof(fgpu_stop)))) return rc;
     hipLaunchKernelGGL(k_stop_fill, dim3(fgpu_blocks(np, 256)), dim3(256), 0, ctx->stream, (const uint2*)b->pieces.p, np,
                        (const unsigned long long*)b->sF.p, (const unsigned long long*)b->sB.p, (const uint32_t*)offset,
                        (const uint32_t*)b->piece_read.p, (const uint64_t*)b->codes.p, ctx->fd, (fgpu_stop*)b->stop_out.p);
@@ -3440,7 +3447,7 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b) {
                 sb.cap = cap;
             }
             FGPU_HIP(hipMemcpyAsync(sb.data, b->stop_out.p, total * sizeof(fgpu_stop), hipMemcpyDeviceToHost, ctx->stream));
-            FGPU_HIP(hipStreamSynchronize(ctx->stream));
+            FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
         }
         sb.n = total;
     }
@@ -3455,7 +3462,7 @@ int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries
     FGPU_LAUNCH("export", k_export, (unsigned)std::min<uint64_t>(fgpu_blocks(ctx->jcap, 256), 4096), 256, make_jt(ctx), ctx->fd, (ExportEntry*)dev_entries,
                 d_stamps, d_n);
     FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->pad, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     *n_entries = ctx->counters_host->pad;
     return FGPU_OK;
 }
@@ -3470,7 +3477,7 @@ int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n) {
 int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* recs_host, uint64_t cap, uint64_t* n_out) {
     uint64_t n_max = ctx->scan_stats.n_junctions;
     FGPU_HIP(hipMemcpyAsync(&ctx->counters_host->n_junctions, &ctx->counters->n_junctions, 8, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     n_max = ctx->counters_host->n_junctions + ctx->scan_imported;
     *n_out = n_max;
     if (!n_max || !keys_host || !recs_host) return FGPU_OK;
@@ -3499,6 +3506,6 @@ int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* r
     // page-locked destinations (fgpu_host_alloc) receive this at link speed; pageable ones through the runtime's staging
     FGPU_HIP(hipMemcpyAsync(keys_host, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(recs_host, d_recs, n * sizeof(fgpu_junction), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }

@@ -214,7 +214,7 @@ extern "C" int fgpu_stage3_set_junctions(fgpu_ctx* ctx, const uint64_t* keys_hos
     }
     unsigned int repeated = 0;
     FGPU_HIP(hipMemcpyAsync(&repeated, ctx->s3_in.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     if (repeated) { ctx->err = "fgpu_stage3_set_junctions: a k-mer occurs more than once"; return FGPU_ERR_ARG; }
     ctx->s3_count = n;
     ctx->s3_ready = true;
@@ -261,7 +261,7 @@ extern "C" int fgpu_stage3_find_neighbors(fgpu_ctx* ctx, const uint64_t* start_k
     FGPU_HIP(hipMemcpyAsync(out, d_out, n * sizeof(fgpu_neighbor), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(&probes, d_probes, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (stride) FGPU_HIP(hipMemcpyAsync(contigs_out, d_contigs, n * stride * 8, hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     if (n_probes) *n_probes = probes;
     return FGPU_OK;
 }

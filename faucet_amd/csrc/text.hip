@@ -104,6 +104,7 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     out->on_device = 1;
     *consumed = 0;
     ctx->split_offsets = nullptr;
+    ctx->text_last_bytes = nbytes;
     if (nbytes == 0) return FGPU_OK;
     int rc;
     if ((rc = fgpu_text_streams(ctx))) return rc;
@@ -160,7 +161,7 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     FGPU_HIP(hipMemcpyAsync(&last[0], count + n_words - 1, 4, hipMemcpyDeviceToHost, st));
     FGPU_HIP(hipMemcpyAsync(&last[1], rank + n_words - 1, 4, hipMemcpyDeviceToHost, st));
     FGPU_HIP(hipMemcpyAsync(&last_byte, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, st));
-    FGPU_HIP(hipStreamSynchronize(st));
+    FGPU_HIP(fgpu_sync_stream(ctx, st));
     const uint64_t n_newlines = (uint64_t)last[0] + last[1];
     // lines as getline counts them: every '\n' ends one; at the end of the file a non-empty unterminated tail is one more
     const uint64_t n_lines = n_newlines + ((final_chunk && last_byte != '\n') ? 1 : 0);
@@ -184,7 +185,7 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     FGPU_HIP(hipMemcpyAsync(&total, offsets + n_rec, 8, hipMemcpyDeviceToHost, st));   // saves the batch call its own look at the offsets
     FGPU_HIP(hipEventRecord(ctx->ev_text_done, st));
     FGPU_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_text_done, 0));
-    FGPU_HIP(hipStreamSynchronize(st));
+    FGPU_HIP(fgpu_sync_stream(ctx, st));
     *consumed = used;
     out->bases = (const char*)d_text;
     out->offsets = offsets;

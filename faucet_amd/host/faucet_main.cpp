@@ -801,6 +801,12 @@ int main(int argc, char** argv) {
         time(&stop);
         if (clk.on) fprintf(stderr, "[cli]   %.2f ms in fgpu_scan_batch calls, %.2f ms in fgpu_scan_end (the last walks, the last lists, the pair filters' last batches)\n",
                             clk.scan_ms, clk.take_ms);
+        if (clk.on) {
+            uint64_t waits = 0;
+            double wait_ms = 0;
+            if (fgpu_diag_host_waits(ctx, &waits, &wait_ms) == FGPU_OK)
+                fprintf(stderr, "[cli]   pass 2: the host waited for the device %llu times, %.2f ms in all\n", (unsigned long long)waits, wait_ms);
+        }
         if (clk.on && o.paired_ends && !o.no_cleaning) {
             uint64_t d[6] = {0, 0, 0, 0, 0, 0};
             if (fgpu_diag_long_pairs(ctx, d) == FGPU_OK)

@@ -444,6 +444,10 @@ int fgpu_diag_binned_probes(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_prob
  * [2] would raise a distance, [3] crosses positions whose junction tests the preview left out */
 int fgpu_diag_walk_probe(fgpu_ctx* ctx, uint64_t out[4]);
 int fgpu_diag_scan_replays(fgpu_ctx* ctx, uint64_t* replays);
+/* How often the host thread has waited for the device (hipStreamSynchronize / hipEventSynchronize inside the library) since the current or last pass
+ * began (fgpu_load_begin / fgpu_scan_begin), and for how long in all (ms, may be NULL).  Every wait is also a chance for a busy host to schedule the
+ * thread late: what a pass costs beside other tenants of the box grows with this count, not with the device's work. */
+int fgpu_diag_host_waits(fgpu_ctx* ctx, uint64_t* waits, double* ms);
 /* after fgpu_scan_end: [0] junction tests the walk had to run itself (the preview had left the position out) that came out TRUE at a
  * k-mer no piece of the window had registered -- the walk goes on and the window is checked afterwards --, [1] of those, the ones whose
  * k-mer was then found on another piece of the same window: only these void a lazy scan (the library scans its journal again, see above),

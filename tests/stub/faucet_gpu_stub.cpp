@@ -418,6 +418,7 @@ int fgpu_scan_download_junctions(fgpu_ctx* c, uint64_t* keys, fgpu_junction* rec
 int fgpu_load_fixup(fgpu_ctx* c, const void*, fgpu_load_stats*) { return STUB_UNSUPPORTED(c); }
 int fgpu_scan_set_eager(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_profile_enable(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
+int fgpu_diag_host_waits(fgpu_ctx* c, uint64_t* waits, double* ms) { if (!c || !waits) return FGPU_ERR_ARG; *waits = 0; if (ms) *ms = 0; return FGPU_OK; }
 int fgpu_diag_ovw(fgpu_ctx* c, uint64_t out[6]) { if (!c || !out) return FGPU_ERR_ARG; memset(out, 0, 6 * sizeof(uint64_t)); return FGPU_OK; }
 int fgpu_stage3_set_junctions(fgpu_ctx* c, const uint64_t*, const fgpu_junction*, uint64_t) { return STUB_UNSUPPORTED(c); }
 uint64_t fgpu_stage3_contig_words(int32_t k, int32_t max_read_length) { return (uint64_t)(2 * max_read_length + k + 31) / 32 + 1; }

@@ -1186,7 +1186,7 @@ def test_load_pass_with_256_byte_records_gives_the_reference_filter(case, tmp_pa
         assert np.array_equal(np.fromfile(str(prefix) + ".bloom", dtype=np.uint8), c.bloom())
         assert open(str(prefix) + ".junctions").read().split("\n")[:-1] == c.junction_lines()
         w = c.counters["weights_after_load"]
-        assert f"Weights after load: {w[0]:.6f}, {w[1]:.6f}" in r.stdout.replace("\r", "\n")
+        assert f"Weights after load: {w[0]}, {w[1]}" in r.stdout.replace("\r", "\n")
 
 
 @pytest.mark.parametrize("n_batches", [1, 5])
