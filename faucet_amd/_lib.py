@@ -126,6 +126,8 @@ SIGNATURES = {
     "fgpu_diag_load_split": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
     "fgpu_diag_scan_replays": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_host_waits": (C.c_int, [_vp, _P(_u64), _P(_f64)]),
+    "fgpu_diag_load_tables": (C.c_int, [_vp, _u64, _P(_f64), _P(_f64), _P(_f64)]),
+    "fgpu_diag_pair_placements": (C.c_int, [_vp, C.c_int, _u64, _P(_f64)]),
     "fgpu_diag_late_flags": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_diag_binned_probes": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, _P(_f64), _P(_f64), _P(_f64), _P(_f64)]),
     "fgpu_scan_pairs_devptr": (C.c_int, [_vp, C.c_int, _P(_vp), _P(_u64)]),

@@ -304,6 +304,9 @@ int fgpu_create(const fgpu_params* p, fgpu_ctx** out) {
         });
     }
     lap("main stream");
+    // FGPU_DEBUG_ALLOC_FIRST=1 (measurement, scripts/kinds_probe.py): the first-set times -- the context's largest allocation, 4 bytes per filter
+    // bit -- are asked for before anything else of the context instead of at the first fgpu_load_begin
+    if (!rc && getenv("FGPU_DEBUG_ALLOC_FIRST") && hipMalloc(&ctx->first, p->tai * 4) != hipSuccess) { (void)hipGetLastError(); ctx->first = nullptr; }
     if (!rc && (e = hipMalloc(&ctx->bloo1, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo1", e);
     if (!rc && (e = hipMalloc(&ctx->bloo2, ctx->bloom_bytes)) != hipSuccess) fail("hipMalloc bloo2", e);
     if (!rc && (e = hipMalloc(&ctx->counters, sizeof(DevCounters))) != hipSuccess) fail("hipMalloc counters", e);
@@ -411,6 +414,7 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
             ctx->pair = nullptr;
             return FGPU_ERR_NOMEM;
         }
+        if (int rc = fgpu_place_pair(ctx)) return rc;     // large filters: where the pair lies relative to first[] decides the marking kernel's speed (diag.hip)
     }
     // The carry of the following batches: brought up to date by sweeps of first[] (4 bytes per filter bit, streaming) that close epochs of
     // batches -- after batches 0, 1, 3, 7 ... the carry may lag, see fgpu_stage_load -- or, in between, by re-hashing a batch's new

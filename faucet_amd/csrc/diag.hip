@@ -4,6 +4,7 @@
 //     array of the load pass and the junction presence filter see).  A random access moves one 64-byte sector at
 //     least, so accesses/s x 64 B is the "random-64 B-gather" rate the roofline fractions are put next to.
 // Nothing of the product path calls these; bench.py reports them beside the k-mer rates.
+#include <functional>
 #include <vector>
 
 #include "fgpu_ctx.h"
@@ -433,6 +434,195 @@ extern "C" int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint
     FGPU_HIP(e);
     *access_per_s = (double)(rounds * 8) * iters / (ms * 1e-3);
     return FGPU_OK;
+}
+
+// the marking kernel's access pattern on given tables, nothing else of the kernel: per item three random 8-byte loads of filter words and -- six
+// items in ten -- three atomicMin into the times of the same bit positions
+template <int NH>
+__global__ void __launch_bounds__(256) k_diag_mark_pattern(const uint2* __restrict__ pair, uint32_t* __restrict__ first, uint64_t bit_mask, uint64_t n, uint64_t salt,
+                                                           uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = diag_rand(i ^ salt);
+        const uint64_t hA = r & bit_mask, hB = diag_rand(r) | 1;
+        uint64_t h = hA;
+        uint2 v[NH];
+#pragma unroll
+        for (int q = 0; q < NH; q++) { v[q] = pair[h >> 5]; h = (h + hB) & bit_mask; }
+#pragma unroll
+        for (int q = 0; q < NH; q++) acc += v[q].x ^ v[q].y;
+        if (diag_rand(r + 7) % 10 < 6) {
+            h = hA;
+#pragma unroll
+            for (int q = 0; q < NH; q++) { atomicMin(&first[h], 0xFFFFFFF0u + (uint32_t)(i & 7)); h = (h + hB) & bit_mask; }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+static void launch_mark_pattern(int nh, hipStream_t st, const void* pair, uint32_t* first, uint64_t bit_mask, uint64_t n, uint64_t salt, uint32_t* sink) {
+    const dim3 g(fgpu_grid(n, 256)), b(256);
+    if (nh <= 2) hipLaunchKernelGGL(k_diag_mark_pattern<2>, g, b, 0, st, (const uint2*)pair, first, bit_mask, n, salt, sink);
+    else if (nh == 3) hipLaunchKernelGGL(k_diag_mark_pattern<3>, g, b, 0, st, (const uint2*)pair, first, bit_mask, n, salt, sink);
+    else hipLaunchKernelGGL(k_diag_mark_pattern<4>, g, b, 0, st, (const uint2*)pair, first, bit_mask, n, salt, sink);
+}
+
+// The same two access patterns on the context's OWN tables of a load pass (scripts/kinds_probe.py, VERDICT r4 item 4: the marking kernel on 2^33-bit
+// filters runs at one of a few speeds that stay with an allocation): random 4-byte loads from the interleaved filter pair, random atomicMin into the
+// first-set times.  Between passes only: both tables are rewritten by the next fgpu_load_begin.
+extern "C" int fgpu_diag_load_tables(fgpu_ctx* ctx, uint64_t n_access, double* pair_loads_per_s, double* first_atomics_per_s, double* mixed_items_per_s) {
+    if (!ctx || !pair_loads_per_s || !first_atomics_per_s || n_access < 8) return FGPU_ERR_ARG;
+    if (ctx->phase != 0 || !ctx->pair || !ctx->first) { ctx->err = "fgpu_diag_load_tables: between passes, after a load pass in the pair layout"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    uint32_t* sink = nullptr;
+    hipEvent_t e[4];
+    FGPU_HIP(hipMalloc(&sink, 64));
+    for (hipEvent_t& x : e) hipEventCreate(&x);
+    const uint64_t rounds = n_access / 8;
+    const unsigned grid = fgpu_grid(rounds, 256);
+    for (int i = -1; i < 1; i++) {          // (one warm-up, one timed)
+        if (i == 0) hipEventRecord(e[0], ctx->stream);
+        hipLaunchKernelGGL(k_diag_random<0>, dim3(grid), dim3(256), 0, ctx->stream, (uint32_t*)ctx->pair, ctx->bloom_bytes * 2 / 4 - 1, rounds, 77ULL + (uint64_t)i, sink);
+    }
+    hipEventRecord(e[1], ctx->stream);
+    hipLaunchKernelGGL(k_diag_random<1>, dim3(grid), dim3(256), 0, ctx->stream, ctx->first, ctx->prm.tai - 1, rounds, 99ULL, sink);
+    hipLaunchKernelGGL(k_diag_random<1>, dim3(grid), dim3(256), 0, ctx->stream, ctx->first, ctx->prm.tai - 1, rounds, 101ULL, sink);
+    hipEventRecord(e[2], ctx->stream);
+    const uint64_t items = n_access / 4;
+    launch_mark_pattern(ctx->fd.n_hash, ctx->stream, ctx->pair, ctx->first, ctx->prm.tai - 1, items, 5ULL, sink);
+    hipEventRecord(e[3], ctx->stream);
+    const hipError_t err = hipEventSynchronize(e[3]);
+    float ms_l = 0, ms_a = 0, ms_m = 0;
+    hipEventElapsedTime(&ms_l, e[0], e[1]);
+    hipEventElapsedTime(&ms_a, e[1], e[2]);
+    hipEventElapsedTime(&ms_m, e[2], e[3]);
+    if (mixed_items_per_s) *mixed_items_per_s = (double)items / (ms_m * 1e-3);
+    for (hipEvent_t& x : e) hipEventDestroy(x);
+    hipFree(sink);
+    FGPU_HIP(err);
+    *pair_loads_per_s = (double)(rounds * 8) / (ms_l * 1e-3);
+    *first_atomics_per_s = (double)(rounds * 16) / (ms_a * 1e-3);
+    return FGPU_OK;
+}
+
+// ---- where the filter pair lies (round 5) ---------------------------------------------------------------------------------------
+// On 2^33-bit filters the marking kernel ran at one of two speeds, 236 or 275 ms per 25 M reads of config 4, fixed for the life of a context and
+// changing from context to context.  Counters of a fast and a slow context agree in every COUNT (read requests, atomics, DRAM reads and writes, TLB
+// requests and misses, L2 hits) and differ in how long a request stays outstanding at the memory side (TCC_EA0_RDREQ_LEVEL / _RDREQ 2 475 -> 2 810
+// cycles, _ATOMIC_LEVEL / _ATOMIC 1 257 -> 1 404: profiles/r05_load_mark_kinds.txt).  Random loads from the pair alone and random atomicMin into
+// first[] alone run at the same rates in both; the two TOGETHER, as the kernel mixes them, do not (6.9e9 against 6.3e9 items/s) -- and the same
+// first[] with ANOTHER allocation of the pair is fast again: what decides is where the 2 GiB of filter words lie relative to the 32 GiB of times.
+// The driver's placement cannot be asked for, so it is measured: after the two allocations of a pass's first fgpu_load_begin the mixed pattern is
+// timed on them (2^24 items, ~2.5 ms); if the two patterns do not overlap (rate below 1.04 x the rate their separate rates add up to), further
+// allocations of the pair are tried -- held meanwhile, so that they differ -- until one does (16 at most), and the rest are returned.
+// Filters of 2^32 bits and more only (below, the pair lives in the Infinity Cache).  FGPU_PAIR_PLACE=0 switches it off, =1 on for every size (tests),
+// FGPU_DEBUG_PLACE=1 tells what it measured.
+int fgpu_place_pair(fgpu_ctx* ctx) {
+    static const char* env = getenv("FGPU_PAIR_PLACE");
+    static const bool tell = getenv("FGPU_DEBUG_PLACE") != nullptr;
+    if (env ? env[0] == '0' : ctx->prm.tai < (1ULL << 32)) return FGPU_OK;
+    if (!ctx->pair || !ctx->first) return FGPU_OK;
+    const int nh = std::min(std::max(ctx->fd.n_hash, 2), 4);
+    const uint64_t n_items = 1ULL << 24, mask = ctx->prm.tai - 1, pair_bytes = ctx->bloom_bytes * 2;
+    uint32_t* sink = nullptr;
+    FGPU_HIP(hipMalloc(&sink, 64));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto timed = [&](const std::function<void(uint64_t)>& launch, double* ms_out) -> int {
+        launch(1);                                     // (warm-up: the pages' translations)
+        hipEventRecord(e0, ctx->stream);
+        launch(2);
+        hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) { ctx->err = "placing the filter pair: a probe failed"; return FGPU_ERR_HIP; }
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        *ms_out = ms;
+        return FGPU_OK;
+    };
+    auto mixed = [&](void* pair, double* rate) -> int {
+        double ms = 0;
+        const int rc = timed([&](uint64_t salt) { launch_mark_pattern(nh, ctx->stream, pair, ctx->first, mask, n_items, salt, sink); }, &ms);
+        *rate = (double)n_items / (ms * 1e-3);
+        return rc;
+    };
+    int rc = FGPU_OK;
+    double ms_l = 0, ms_a = 0, r0 = 0;
+    const uint64_t rounds = (1ULL << 25) / 8;
+    rc = timed([&](uint64_t salt) { hipLaunchKernelGGL(k_diag_random<0>, dim3(fgpu_grid(rounds, 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->pair, pair_bytes / 4 - 1, rounds, salt, sink); }, &ms_l);
+    if (!rc) rc = timed([&](uint64_t salt) { hipLaunchKernelGGL(k_diag_random<1>, dim3(fgpu_grid(rounds, 256)), dim3(256), 0, ctx->stream, ctx->first, mask, rounds, salt, sink); }, &ms_a);
+    if (!rc) rc = mixed(ctx->pair, &r0);
+    std::vector<void*> held;
+    if (!rc) {
+        const double loads = (double)(rounds * 8) / (ms_l * 1e-3), atomics = (double)(rounds * 8) / (ms_a * 1e-3);
+        const double serial = 1.0 / ((double)nh / loads + 0.6 * (double)nh / atomics);     // items/s if the two patterns did not overlap at all
+        const double want = 1.04 * serial;
+        void* best = ctx->pair;
+        double best_rate = r0;
+        int tried = 0;
+        while (best_rate < want && tried < 16) {
+            void* cand = nullptr;
+            if (hipMalloc(&cand, pair_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            held.push_back(cand);
+            tried++;
+            double r = 0;
+            if ((rc = mixed(cand, &r))) break;
+            if (r > best_rate) { best = cand; best_rate = r; }
+        }
+        if (tell)
+            fprintf(stderr, "[place] filter pair: loads %.3g/s, atomics %.3g/s, together %.3g items/s as allocated (no overlap: %.3g); %d other allocations tried, kept %s at %.3g\n",
+                    loads, atomics, r0, serial, tried, best == (void*)ctx->pair ? "the first" : "another", best_rate);
+        if (best != (void*)ctx->pair) {
+            held.push_back(ctx->pair);
+            ctx->pair = (uint2*)best;
+        }
+        for (void* p : held) if (p != (void*)ctx->pair) hipFree(p);
+        held.clear();
+    }
+    for (void* p : held) if (p != (void*)ctx->pair) hipFree(p);
+    hipFree(sink);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+// Does the speed of the mixed pattern depend on where the PAIR array lies (2 x the filter: cheap to allocate again) while the first-set times stay where
+// they are?  k candidate allocations held at once (so that they differ), each probed with the context's first[]; items per second each.
+extern "C" int fgpu_diag_pair_placements(fgpu_ctx* ctx, int k, uint64_t n_items, double* items_per_s) {
+    if (!ctx || k < 1 || k > 16 || !items_per_s || n_items < 64) return FGPU_ERR_ARG;
+    if (ctx->phase != 0 || !ctx->first) { ctx->err = "fgpu_diag_pair_placements: between passes, after a load pass in the pair layout"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    std::vector<void*> cand((size_t)k, nullptr), spacers;
+    uint32_t* sink = nullptr;
+    FGPU_HIP(hipMalloc(&sink, 64));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    int rc = FGPU_OK;
+    for (int i = 0; i < k && rc == FGPU_OK; i++) {
+        // (from the eighth candidate on a spacer of growing size goes in front: 64 MiB, 128 MiB ... -- another offset, not just the next block)
+        if (i >= 8) {
+            void* spacer = nullptr;
+            if (hipMalloc(&spacer, (64ULL << 20) << (i - 8)) == hipSuccess) spacers.push_back(spacer); else (void)hipGetLastError();
+        }
+        if (hipMalloc(&cand[(size_t)i], ctx->bloom_bytes * 2) != hipSuccess) { (void)hipGetLastError(); cand[(size_t)i] = nullptr; ctx->err = "diag: out of device memory"; rc = FGPU_ERR_NOMEM; break; }
+        hipMemsetAsync(cand[(size_t)i], 0, ctx->bloom_bytes * 2, ctx->stream);
+        for (int rep = 0; rep < 2; rep++) {
+            if (rep == 1) hipEventRecord(e0, ctx->stream);
+            launch_mark_pattern(ctx->fd.n_hash, ctx->stream, cand[(size_t)i], ctx->first, ctx->prm.tai - 1, n_items, 11ULL + (uint64_t)rep, sink);
+        }
+        hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) { ctx->err = "diag: probe failed"; rc = FGPU_ERR_HIP; break; }
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        items_per_s[i] = (double)n_items / (ms * 1e-3);
+    }
+    for (void* p : cand) if (p) hipFree(p);
+    for (void* p : spacers) hipFree(p);
+    hipFree(sink);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
 }
 
 // what the runtime reports for the memory system of the context's device (printed beside the measured ceilings)

@@ -466,6 +466,7 @@ int fgpu_scan_harvest(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_long_pairs_batch(fgpu_ctx* ctx, const fgpu_stop* d_stops, uint64_t n_stops, uint64_t n_reads);
 int fgpu_long_pairs_reset(fgpu_ctx* ctx);
 int fgpu_long_pairs_close(fgpu_ctx* ctx);
+int fgpu_place_pair(fgpu_ctx* ctx);
 int fgpu_scan_reset(fgpu_ctx* ctx);
 int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap);
 int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records);

@@ -433,6 +433,13 @@ int fgpu_diag_binned_chain(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_items
 int fgpu_diag_ko_trace(fgpu_ctx* ctx, uint64_t* out, uint64_t cap_records, uint64_t* n);
 int fgpu_diag_ko_stamps(fgpu_ctx* ctx, uint64_t* out, uint64_t cap_words, uint64_t* n_pieces);   /* per-step stamps of one piece in 16 (-DFGPU_KO_TRACE) */
 int fgpu_diag_random_access(fgpu_ctx* ctx, uint64_t table_bytes, uint64_t n_access, int mode, int iters, double* access_per_s);
+/* The two access patterns of the marking kernel on the context's own tables of the last load pass (pair layout): random loads from the interleaved
+ * filter words, random atomicMin into the first-set times; accesses per second; and both together as the kernel mixes them (three loads per item, three
+ * atomics for six items in ten; items per second, may be NULL).  Between passes (the tables are rewritten by the next load). */
+int fgpu_diag_load_tables(fgpu_ctx* ctx, uint64_t n_access, double* pair_loads_per_s, double* first_atomics_per_s, double* mixed_items_per_s);
+/* The mixed pattern with k other allocations of the filter pair (held at once, then freed) against the context's first-set times: does the pair's place
+ * decide the marking kernel's speed?  items_per_s[k].  Measurement (scripts/kinds_probe.py). */
+int fgpu_diag_pair_placements(fgpu_ctx* ctx, int k, uint64_t n_items, double* items_per_s);
 /* NS1's query-side blocking, measured: n_probes single-bit probes at pseudo-random positions of a table of table_bytes (power of two, <= 512 MiB),
  * once directly (one random load each, what the path's kernels do) and once binned by slice of slice_bytes (LDS-staged buckets per 4096 probes,
  * one queue per slice, slices probed by the workgroups of the XCD whose L2 then holds them).  Rates in probes/s; the binned one covers both of
