@@ -288,8 +288,9 @@ def reference_bit_counts(k, read_len, err, coverage, bits_per_kmer_ratio, seed=7
 
 
 # ---------------------------------------------------------------------------------------------- main
-def cli_leg(reads, args, kmers, want_junctions):
-    """writes the reads as FASTA (fixed-width headers), runs faucet_amd/faucet on it twice, reports the faster run"""
+def cli_leg(reads, args, kmers, want_junctions, variants=()):
+    """writes the reads as FASTA (fixed-width headers), runs faucet_amd/faucet on it twice, reports the faster run; `variants`: (key, extra
+    arguments) pairs run on the same file afterwards (the C++ host over read shards: `-gpus N`), reported under their key"""
     import re
     import shutil
     import tempfile
@@ -325,7 +326,26 @@ def cli_leg(reads, args, kmers, want_junctions):
                 raise RuntimeError("faucet exited with %d: %s" % (r.returncode, r.stderr[-300:]))
             best = dt if best is None else min(best, dt)
         m = re.search(r"Distinct junctions: (\d+)", r.stdout)
-        return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "input_bytes": size,
+        import hashlib
+        digest = lambda ext: hashlib.sha256(open(os.path.join(d, "out." + ext), "rb").read()).hexdigest()   # noqa: E731
+        want_files = {ext: digest(ext) for ext in ("bloom", "junctions")}
+        extra = {}
+        for key, more in variants:
+            vb = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                rv = subprocess.run(cmd[:-2] + ["-file_prefix", os.path.join(d, key)] + list(more), capture_output=True, text=True)
+                dtv = time.perf_counter() - t0
+                if rv.returncode != 0:
+                    extra[key] = {"error": "faucet exited with %d: %s" % (rv.returncode, rv.stderr[-300:])}
+                    break
+                vb = dtv if vb is None else min(vb, dtv)
+            else:
+                same = {ext: hashlib.sha256(open(os.path.join(d, key + "." + ext), "rb").read()).hexdigest() == want_files[ext] for ext in want_files}
+                extra[key] = {"arguments": list(more), "seconds": vb, "value": kmers / vb, "unit": "k-mers/s", "files_equal_the_single_device_runs": same,
+                              "note": "the same file through the C++ host that shards the reads (faucet_amd/host/shard_host.h): one host thread and one context per "
+                                      "shard, ALL on this box's one device -- a functional record of the N-GPU command line, not a scaling number"}
+        return {"seconds": best, "value": kmers / best, "unit": "k-mers/s", "input_bytes": size, **extra,
                 "output_bytes": os.path.getsize(os.path.join(d, "out.bloom")) + os.path.getsize(os.path.join(d, "out.junctions")),
                 "junctions_equal_the_steps": bool(m) and int(m.group(1)) == int(want_junctions),
                 "parent_cpu_seconds_during_the_runs": parent_cpu, "load_average": list(os.getloadavg()),
@@ -365,9 +385,17 @@ def full_size_leg(name, device, batch_reads):
         same = {k2: int(sst[k2]) == int(v) for k2, v in fx["counters"].items() if k2 in sst}
         same["to_bloo2"] = int(lst["to_bloo2"]) == int(fx["to_bloo2"])
         same["junction_records"] = len(keys) == int(fx["counters"]["n_junctions"])
-        kt = sorted(ctx.kernel_times().items(), key=lambda kv: -kv[1][1])[:6]
+        all_kt = ctx.kernel_times()
+        kt = sorted(all_kt.items(), key=lambda kv: -kv[1][1])[:6]
+        lm = all_kt.get("load_mark")
+        roof = None
+        if lm and lm[0]:
+            avg_ms = lm[1] / lm[0]
+            achieved = 64.0 * nh * (kmers / lm[0]) / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "load_mark", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "avg_launch_ms": avg_ms, "launches": lm[0], "algorithmic_bytes_per_kmer": 64.0 * nh, "kmers_per_launch": kmers / lm[0]}
         steps.append({"seconds": dt, "value": kmers / dt, "counters_equal_the_oracles": all(same.values()),
-                      "differing": sorted(k2 for k2, v in same.items() if not v), "kernel_ms": {n: round(ms, 1) for n, (cnt, ms) in kt},
+                      "differing": sorted(k2 for k2, v in same.items() if not v), "kernel_ms": {n: round(ms, 1) for n, (cnt, ms) in kt}, "roofline_load_mark": roof,
                       "junction_tests_run_by_the_walk": int(sst["flags_filled"]), "late_junction_tests": ctx.diag_late_flags(),
                       "scan_replays_so_far": ctx.diag_scan_replays()})
     out = {"seconds": steps[1]["seconds"], "value": steps[1]["value"], "unit": "k-mers/s", "kmers": kmers, "junctions": int(len(keys)),
@@ -671,6 +699,9 @@ def main():
                     "valid_reused_rank0": int(sst["valid_reused"]), "flags_filled_in_walk_rank0": int(sst["flags_filled"]), "nb_processed_rank0": int(sst["nb_processed"]),
                     "nb_skipped_rank0": int(sst["nb_skipped"]), "nb_jcheck_kmer_rank0": int(sst["nb_jcheck_kmer"])},
         "kernel_ms_per_step_rank0": {n: round(ms / max(prof_steps, 1), 3) for n, (c, ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])},
+        "ms_per_step_with_events": 1e3 * prof_elapsed / prof_steps if prof_steps else None,
+        "timing_method": "value / ms_per_step: K steps WITHOUT HIP events around the kernels (since round 4; rounds 1-3 timed with them: +1.5 %); "
+                         "ms_per_step_with_events: the bracketed steps behind them; N > 1 defaults to strong scaling on config 4 (rounds 1-3: weak)",
         "profiled_steps": {"steps": prof_steps, "ms_per_step": 1e3 * prof_elapsed / prof_steps if prof_steps else None,
                            "note": "separate steps of the same context with HIP events around every kernel, right behind the timed ones: where "
                                    "kernel_ms_per_step_rank0, roofline and device_time_share come from"},
@@ -851,7 +882,7 @@ def main():
     # included -- beside `value`, never as `value`; the junction count must be the step's.
     if world == 1 and not args.host_input and not args.no_host_leg and not force_sharded and not strong:
         try:
-            res["cli_file_to_files"] = cli_leg(reads, args, kmers_local, res["outputs"]["junctions"])
+            res["cli_file_to_files"] = cli_leg(reads, args, kmers_local, res["outputs"]["junctions"], variants=(("gpus2_one_device", ["-gpus", "2"]),))
         except Exception as e:   # noqa: BLE001  (a missing /tmp or binary must not cost the bench line)
             res["cli_file_to_files"] = {"error": repr(e)[:300]}
     # ---- the slowest configuration in the driver's line: BASELINE config 3's shape through the CLI, file to files
@@ -871,6 +902,13 @@ def main():
                 res["full_size"][name] = full_size_leg(name, device, br)
             except Exception as e:   # noqa: BLE001
                 res["full_size"][name] = {"error": repr(e)[:300]}
+        # the same kernel on the LARGE filters, where it is furthest from the roofline: config 4's second step
+        try:
+            rl = res["full_size"]["config4"]["second_step"]["roofline_load_mark"]
+            if rl:
+                res["roofline_large"] = dict(rl, workload="BASELINE config 4 whole on one GPU (2 x 1 GiB filters), second step of the context", traffic=None)
+        except (KeyError, TypeError):
+            pass
     emit(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

@@ -187,6 +187,9 @@ __global__ void __launch_bounds__(256) k_pack_fix(const unsigned char* __restric
     const uint64_t off0 = offs[0];
     const uint64_t L = offs[i + 1] - offs[i];
     const uint64_t S = (offs[i] - off0) + i;
+    // the buffers were sized from the caller's total_bases: a read that ends beyond it is left alone -- the mismatch is the error reported above
+    // (flag 32), never a write past the code and mask arrays
+    if (S + L > total + n_reads) return;
     const uint64_t rbeg = starts ? starts[i] : offs[i];
     uint64_t s = 0;
     while (s < L) {
