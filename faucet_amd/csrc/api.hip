@@ -498,7 +498,7 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     ctx->load_stats.unambiguous_reads = ctx->counters_host->segments;
     if (stats) *stats = ctx->load_stats;
     ctx->fixup_ready = ctx->shard_times && ctx->pass_empty_carry && ctx->resident_count == ctx->pass_batches &&
-                       !(ctx->prm.flags & FGPU_FLAG_MERCY);
+                       !(ctx->prm.flags & FGPU_FLAG_MERCY) && ctx->fd.n_hash <= 4;
     return FGPU_OK;
 }
 
@@ -506,7 +506,7 @@ int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stat
     if (!ctx || !prefix_dev) return FGPU_ERR_ARG;
     if (ctx->phase != 0) { ctx->err = "load_fixup while a pass is open"; return FGPU_ERR_STATE; }
     if (!ctx->fixup_ready) {
-        ctx->err = "load_fixup needs a finished load pass begun with FGPU_LOAD_SHARD_TIMES and an empty carry, every batch kept resident, no --mercy";
+        ctx->err = "load_fixup needs a finished load pass begun with FGPU_LOAD_SHARD_TIMES and an empty carry, every batch kept resident, no --mercy, at most 4 hash functions";
         return FGPU_ERR_STATE;
     }
     FGPU_HIP(hipSetDevice(ctx->prm.device));

@@ -41,6 +41,7 @@ struct BatchBufs {
     DevBuf readflag;               // 1 byte per read: has interior non-ACGT characters
     DevBuf pending;                // pass 1: occurrences that need the first-set-time test
     DevBuf sure;                   // pass 1: occurrences routed to bloo2 (kept for the scan as ResidentBatch::sure)
+    DevBuf fail;                   // pass 1 of a read shard: planes of "bit i of the occurrence was not set before it" (fgpu_load_fixup)
     DevBuf same;                   // pass 2: one word, non-zero iff this batch equals the load batch of the same index
     // pass 2 planes (1 bit per stream position, LSB first)
     DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
@@ -72,6 +73,7 @@ struct BatchBufs {
 // by construction, so getValidReads' probe of them is known to answer "present" without touching the filter.
 struct ResidentBatch {
     DevBuf codes, bad, sure;
+    DevBuf fail;                 // read shards: the resolve kernel's "bit i was not set before the occurrence" planes (fgpu_load_fixup)
     uint64_t T = 0, n_words = 0;
     uint32_t tb = 0;             // time base of the batch's first-set times (FGPU_LOAD_SHARD_TIMES: position within the pass)
 };
@@ -206,7 +208,7 @@ struct fgpu_ctx {
     uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
     uint64_t epoch_positions = 0;    // stream positions loaded since the last sweep of first[] (time base of the next batch)
     uint64_t swept_positions = 0;    // stream positions the carry covers
-    bool shard_times = false;        // FGPU_LOAD_SHARD_TIMES: times count from the start of the pass (fgpu_load_fixup compares them later)
+    bool shard_times = false;        // FGPU_LOAD_SHARD_TIMES: the pass of a read shard keeps what fgpu_load_fixup needs (the fail planes of its occurrences)
     bool fixup_ready = false;        // the last load pass ran that way with an empty carry and every batch resident
     uint64_t pass_positions = 0;     // stream positions of the pass so far
     uint32_t cur_tb = 0;             // time base of the batch being loaded

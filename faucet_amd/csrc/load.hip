@@ -160,12 +160,20 @@ __global__ void __launch_bounds__(256) k_load_mark(const uint64_t* __restrict__ 
 template <int REC>
 __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict__ codes, uint64_t T, uint64_t n_words, FdParams fp,
                                                       Filt<REC> f, uint32_t tb,
-                                                      const uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt) {
+                                                      const uint64_t* __restrict__ pending, uint64_t plane_stride, uint64_t* __restrict__ sure, DevCounters* cnt,
+                                                      uint64_t* __restrict__ fail) {
+    // fail != nullptr (read shards, fgpu_load_fixup): MISS_PLANES planes of "bit i of this occurrence was NOT set before it" -- every missing bit
+    // is looked at then, not only up to the first that fails; needs n_hash <= MISS_PLANES
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t pw = pending[p >> 6];   // wave-uniform: the 64 lanes of a wave cover one word
-        if (!pw) continue;
+        if (!pw) {
+            if (fail && fd_lane() == 0)
+                for (int i = 0; i < MISS_PLANES; i++) fail[i * plane_stride + (p >> 6)] = 0;
+            continue;
+        }
+        uint32_t failed = 0;
         bool pass = false;
         if ((pw >> (p & 63)) & 1ULL) {
             uint32_t missing = 0;                // what k_load_mark saw (the carry does not change between the two kernels)
@@ -179,7 +187,11 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
             uint64_t h = hA;
             for (int i = 0; i < fp.n_hash; i++) {
                 bool in_carry = i < MISS_PLANES ? !((missing >> i) & 1u) : ((f.load(h).x >> (h & 31)) & 1u) != 0;
-                if (!in_carry && !(*f.time(h) < tb + (uint32_t)p)) { pass = false; break; }
+                if (!in_carry && !(*f.time(h) < tb + (uint32_t)p)) {
+                    pass = false;
+                    failed |= 1u << i;
+                    if (!fail) break;
+                }
                 h = (h + hB) & fp.tai_mask;
             }
             if (pass) {   // rare: every bit was set earlier in this very batch
@@ -194,6 +206,15 @@ __global__ void __launch_bounds__(256) k_load_resolve(const uint64_t* __restrict
         }
         const uint64_t sm = __ballot(pass);
         if (fd_lane() == 0 && sm) sure[p >> 6] |= sm;
+        if (fail) {
+            uint64_t fm[MISS_PLANES];
+#pragma unroll
+            for (int i = 0; i < MISS_PLANES; i++) fm[i] = __ballot((failed >> i) & 1u);
+            if (fd_lane() == 0) {
+#pragma unroll
+                for (int i = 0; i < MISS_PLANES; i++) fail[i * plane_stride + (p >> 6)] = fm[i];
+            }
+        }
     }
     block_add(&cnt->to_bloo2, n_pass);
 }
@@ -498,29 +519,37 @@ __global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ 
     }
 }
 
-// multi-GPU, fgpu_load_fixup: the occurrences the shard's own pass kept out of bloo2, looked at again with the lower ranks' bits.
-// bit set before t  <=>  in the prefix (set by a lower rank: all of those come earlier in file order) or first set locally before t.
-template <int REC>
+// Read shards, fgpu_load_fixup: the occurrences the shard's own pass kept out of bloo2, looked at again with the lower shards' bits.
+// An occurrence goes to bloo2 iff every one of its bits was set before it: by a lower shard (all of those come earlier in file order: the
+// bit is in `prefix`) or earlier in this shard.  Which of its bits were NOT set earlier in this shard the own pass has written down when it
+// resolved the occurrence (the `fail` planes of k_load_resolve) -- so the question left is whether those bits are all in the prefix.  No
+// first-set time is read here: a shard may hold any number of positions (rounds 2-4 compared 32-bit times that counted through the whole
+// shard: at most 2^32 positions, i.e. config 4 from 8 GPUs on).
 __global__ void __launch_bounds__(256) k_load_fixup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
                                                     uint64_t n_words, FdParams fp, const uint32_t* __restrict__ prefix,
-                                                    Filt<REC> f, uint32_t tb, uint32_t* bloo2,
+                                                    const uint64_t* __restrict__ fail, uint64_t plane_stride, uint32_t* bloo2,
                                                     unsigned long long* sure, DevCounters* cnt) {
     unsigned long long n_pass = 0;
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
         bool pass = false;
         if (p < T && fd_window_ok(bad, p, fp.k) && !((sure[p >> 6] >> (p & 63)) & 1ULL)) {
-            uint64_t hA, hB;
-            fd_hash_pair(fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, hA, hB);
-            pass = true;
-            uint64_t h = hA;
-            for (int i = 0; i < fp.n_hash; i++) {
-                if (!((prefix[h >> 5] >> (h & 31)) & 1u) && !(*f.time(h) < tb + (uint32_t)p)) { pass = false; break; }
-                h = (h + hB) & fp.tai_mask;
-            }
-            if (pass) {
-                n_pass++;
-                fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+            uint32_t failed = 0;
+#pragma unroll
+            for (int i = 0; i < MISS_PLANES; i++) failed |= (uint32_t)((fail[i * plane_stride + (p >> 6)] >> (p & 63)) & 1ULL) << i;
+            if (failed) {                               // (an occurrence outside bloo2 has at least one)
+                uint64_t hA, hB;
+                fd_hash_pair(fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, hA, hB);
+                pass = true;
+                uint64_t h = hA;
+                for (int i = 0; i < fp.n_hash && pass; i++) {
+                    if (((failed >> i) & 1u) && !((prefix[h >> 5] >> (h & 31)) & 1u)) pass = false;
+                    h = (h + hB) & fp.tai_mask;
+                }
+                if (pass) {
+                    n_pass++;
+                    fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
+                }
             }
         }
         const uint64_t sm = __ballot(pass);   // lanes = the 64 positions of one plane word
@@ -631,13 +660,14 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
     if (!ctx->resident_open) return FGPU_OK;
     BatchBufs& bb = *ctx->cur;
     const uint64_t cb = 2 * (bb.n_words + FGPU_PADW) * 8, pb = (bb.n_words + FGPU_PADW) * 8;
-    if (ctx->resident_bytes + cb + 2 * pb > ctx->resident_budget) {
+    if (ctx->resident_bytes + cb + 2 * pb + (ctx->shard_times ? MISS_PLANES * pb : 0) > ctx->resident_budget) {
         ctx->resident_open = false;   // batches pair by index: once one is missing, later ones would not line up
         return FGPU_OK;
     }
     if (ctx->resident_count == ctx->resident.size()) ctx->resident.push_back(new ResidentBatch());
     ResidentBatch& r = *ctx->resident[ctx->resident_count];
-    if (fgpu_ensure_b(ctx, &r.codes, cb) || fgpu_ensure_b(ctx, &r.bad, pb) || fgpu_ensure_b(ctx, &r.sure, pb)) {
+    const uint64_t fb = ctx->shard_times ? MISS_PLANES * pb : 0;      // read shards: which bits of an occurrence were not set before it (fgpu_load_fixup)
+    if (fgpu_ensure_b(ctx, &r.codes, cb) || fgpu_ensure_b(ctx, &r.bad, pb) || fgpu_ensure_b(ctx, &r.sure, pb) || (fb && fgpu_ensure_b(ctx, &r.fail, fb))) {
         (void)hipGetLastError();
         ctx->resident_open = false;   // out of memory: do without
         return FGPU_OK;
@@ -648,8 +678,9 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
     FGPU_HIP(hipMemcpyAsync(r.codes.p, bb.codes.p, cb, hipMemcpyDeviceToDevice, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(r.bad.p, bb.bad.p, pb, hipMemcpyDeviceToDevice, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(r.sure.p, bb.sure.p, pb, hipMemcpyDeviceToDevice, ctx->stream));
+    if (fb) FGPU_HIP(hipMemcpyAsync(r.fail.p, bb.fail.p, fb, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->resident_count++;
-    ctx->resident_bytes += cb + 2 * pb;
+    ctx->resident_bytes += cb + 2 * pb + fb;
     return FGPU_OK;
 }
 
@@ -679,13 +710,11 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     // holds a few coverages of the genome nearly every k-mer that will ever be in it already is: sweeps are made when an epoch
     // has grown to sweep_num/sweep_den of what the carry already covers (after batches 0, 1, 3, 7 ... of equal batches).
     const uint64_t span = bb.n_words * 64;
-    if (!ctx->carry_by_set && !ctx->shard_times && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
-    if (ctx->shard_times && ctx->pass_positions + span >= 0xFFFFFFF0ULL) {
-        ctx->err = "FGPU_LOAD_SHARD_TIMES: the pass exceeds 2^32 stream positions";
-        return FGPU_ERR_CAPACITY;
-    }
-    // shard times: one time base for the whole pass (sweeps still bring the carry up to date; they just do not restart the clock)
-    const uint32_t tb = ctx->shard_times ? (uint32_t)ctx->pass_positions : ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
+    if (!ctx->carry_by_set && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
+    const uint32_t tb = ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
+    // read shards (FGPU_LOAD_SHARD_TIMES): the resolve kernel also writes down WHICH bits of an occurrence were not set before it
+    const bool keep_fail = ctx->shard_times && ctx->fd.n_hash <= MISS_PLANES;
+    if (keep_fail && (rc = fgpu_ensure_b(ctx, &bb.fail, MISS_PLANES * plane_stride * 8))) return rc;
     ctx->cur_tb = tb;
     ctx->pass_positions += span;
     static const int resolve_sm = getenv("FGPU_RESOLVE_SM") ? atoi(getenv("FGPU_RESOLVE_SM")) : 4096;
@@ -696,7 +725,7 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     do {                                                                                                                                              \
         FGPU_LAUNCH("load_mark", k_load_mark<REC>, grid, 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p, bb.T, bb.n_words, ctx->fd, F,  \
                     tb, (uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);                                                  \
-        if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm) {                                                                                             \
+        if (ctx->fd.n_hash <= MISS_PLANES && resolve_sm && !keep_fail) {                                                                              \
             if (slots <= 1)                                                                                                                            \
                 FGPU_LAUNCH("load_resolve", (k_load_resolve_sm<1, REC>), rgrid, 256, (const uint64_t*)bb.codes.p, bb.n_words, ctx->fd, F, tb,          \
                             (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters);                               \
@@ -708,7 +737,8 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
                             (const uint64_t*)bb.pending.p, plane_stride, (unsigned long long*)bb.sure.p, ctx->counters);                               \
         } else {                                                                                                                                       \
             FGPU_LAUNCH("load_resolve", k_load_resolve<REC>, grid, 256, (const uint64_t*)bb.codes.p, bb.T, bb.n_words, ctx->fd, F, tb,                 \
-                        (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters);                                             \
+                        (const uint64_t*)bb.pending.p, plane_stride, (uint64_t*)bb.sure.p, ctx->counters,                                              \
+                        keep_fail ? (uint64_t*)bb.fail.p : (uint64_t*)nullptr);                                                                        \
         }                                                                                                                                              \
         if (mercy)                                                                                                                                     \
             FGPU_LAUNCH("load_mercy", k_load_mercy<REC>, fgpu_grid(bb.n_words, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.bad.p,      \
@@ -749,15 +779,8 @@ int fgpu_stage_fixup(fgpu_ctx* ctx, const uint32_t* prefix) {
     for (uint64_t i = 0; i < ctx->resident_count; i++) {
         ResidentBatch& r = *ctx->resident[i];
         if (!r.T) continue;
-        if (ctx->rec_layout) {
-            const Filt<1> f = {ctx->rec, nullptr};
-            FGPU_LAUNCH("load_fixup", k_load_fixup<1>, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
-                        r.n_words, ctx->fd, prefix, f, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
-        } else {
-            const Filt<0> f = {(uint32_t*)ctx->pair, ctx->first};
-            FGPU_LAUNCH("load_fixup", k_load_fixup<0>, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
-                        r.n_words, ctx->fd, prefix, f, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
-        }
+        FGPU_LAUNCH("load_fixup", k_load_fixup, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T, r.n_words,
+                    ctx->fd, prefix, (const uint64_t*)r.fail.p, r.n_words + FGPU_PADW, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
     }
     return FGPU_OK;
 }

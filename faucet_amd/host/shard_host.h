@@ -8,7 +8,7 @@
 // one PROCESS per GPU over torch.distributed; DESIGN.md section 5 says why each step is exact.
 //
 //   shard r = the r-th file-order share of the records (text_source.h, record_cuts), read and driven by thread r on device r
-//   pass 1   fix-up protocol (shards whose positions fit 32-bit first-set times): every rank loads its shard alone
+//   pass 1   fix-up protocol (a shard that stays in HBM, at most 4 hash functions): every rank loads its shard alone
 //            (FGPU_LOAD_SHARD_TIMES) -> exclusive prefix-OR of the shards' bloo1 over ranks -> fgpu_load_fixup against that prefix on
 //            ranks > 0 -> OR-allreduce of bloo2;  presence protocol (otherwise, and with --mercy): presence bitmap of the shard ->
 //            exclusive prefix-OR = the carried-in bloo1 -> ordered load on it -> OR-allreduce of bloo2
@@ -126,12 +126,12 @@ public:
         }
         uint64_t largest = 0;
         for (int r = 0; r < o_.n_ranks; r++) largest = std::max(largest, cuts[(size_t)r + 1] - cuts[(size_t)r]);
-        // the fix-up protocol dates every occurrence of a shard with a 32-bit time (a stream position <= its byte in the file) and keeps the
-        // shard's batches in HBM (4 bits per base, an eighth of the device); --mercy leaves no fix-up state (fgpu_load_end)
-        bool fixup = !o_.mercy && largest < 0xFFF00000ULL - (1ULL << 24);
+        // the fix-up protocol keeps the shard's batches in HBM (8 bits per base with the fail planes; the library gives them an eighth of the
+        // device) and covers four hash functions; --mercy leaves no fix-up state (fgpu_load_end)
+        bool fixup = !o_.mercy && o_.prm.n_hash <= 4 && largest < (24ULL << 30);
         if (const char* e = getenv("FAUCET_SHARD_PROTOCOL")) {
             if (!strcmp(e, "presence")) fixup = false;
-            else if (!strcmp(e, "fixup") && !fixup) { error_ = "FAUCET_SHARD_PROTOCOL=fixup: a shard is too large for 32-bit first-set times, or --mercy is on"; return FGPU_ERR_ARG; }
+            else if (!strcmp(e, "fixup") && !fixup) { error_ = "FAUCET_SHARD_PROTOCOL=fixup: a shard is too large to stay in HBM, more than 4 hash functions, or --mercy is on"; return FGPU_ERR_ARG; }
         }
         std::vector<fgpu_load_stats> st((size_t)o_.n_ranks);
         float w1 = 0, w2 = 0;

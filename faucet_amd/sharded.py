@@ -602,12 +602,14 @@ class GpuShard:
         return self.ctx.load_end()
 
     def fixup_possible(self, batches):
-        """the fix-up protocol needs first-set times that count through the whole shard (32 bits) and every batch kept in HBM"""
+        """the fix-up protocol needs every batch of the shard kept in HBM with its fail planes (round 5: no 2^32-position limit any more)"""
         pos = [getattr(b, "n_positions", None) for b in batches]
         if any(p is None for p in pos) or getattr(self.ctx, "mercy", False):    # --mercy: fgpu_load_end leaves no fix-up state
             return False
+        if getattr(self.ctx, "n_hash", 0) > 4:           # the fail planes cover four hash functions
+            return False
         free, total = torch.cuda.mem_get_info(self.device)
-        return sum(pos) + 64 * len(pos) < 0xFFF00000 and sum(pos) // 2 + (64 << 20) < total // 8
+        return sum(pos) + (64 << 20) < total // 8        # 8 bits per position kept in HBM (codes, bad, sure, four fail planes): an eighth of the device
 
     def or_tensor(self, dst, src):
         self.ctx.bitmap_or(dst.data_ptr(), src.data_ptr(), dst.numel())

@@ -163,8 +163,10 @@ void     fgpu_size_two_hash(uint64_t estimated, float fp, int32_t* bits_per_item
  * multi-GPU shards start from the prefix-OR of the lower ranks' k-mer presence bitmaps). */
 int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry);
 #define FGPU_LOAD_KEEP_CARRY   1   /* bloo1's current content is the carried-in state */
-#define FGPU_LOAD_SHARD_TIMES  2   /* first-set times count from the start of the pass, not of an epoch, so that fgpu_load_fixup can
-                                    * compare them afterwards; a pass is then limited to 2^32 - 16 stream positions (FGPU_ERR_CAPACITY) */
+#define FGPU_LOAD_SHARD_TIMES  2   /* the pass of a read shard that fgpu_load_fixup will complete: besides routing each occurrence it writes down which
+                                    * of the occurrence's bits were NOT set before it within the shard (n_hash <= 4 planes of one bit per position,
+                                    * kept in HBM with the batch).  Any number of positions (rounds 2-4 kept 32-bit times that counted through the
+                                    * whole shard instead: at most 2^32 positions per shard; the name is theirs). */
 /* Consume one batch, in file order.  Exact: occurrence t goes to bloo2 iff all its bits were set
  * by occurrences < t, t following the reference's processing order. */
 int fgpu_load_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
@@ -172,12 +174,12 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats);
 /* OR the bits of every k-mer of the batch into bloo1 with no ordering (presence bitmap; used by
  * multi-GPU shards before the prefix-OR exchange).  Same unit counters as load_batch. */
 int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
-/* Multi-GPU shards without the presence pass.  After a load pass of THIS shard alone (begun with
- * FGPU_LOAD_SHARD_TIMES and an empty carry, all batches kept resident) and the exchange of the shards' bloo1, `prefix_dev` = OR of the
- * bloo1 of all lower ranks (device pointer, tai/8 bytes) is what the sequential run has in bloo1 when it reaches this shard.  Every
- * occurrence the local pass kept out of bloo2 is looked at again: it goes to bloo2 iff each of its bits is in the prefix or was set
- * locally before it (first-set times of the pass).  Adds those occurrences to bloo2, to the planes the scan reuses and to
- * stats->to_bloo2; bloo1 |= prefix.  FGPU_ERR_STATE when the pass was not begun that way or a batch was not kept. */
+/* Read shards without the presence pass.  After a load pass of THIS shard alone (begun with FGPU_LOAD_SHARD_TIMES and an
+ * empty carry, all batches kept resident, no --mercy, at most 4 hash functions) and the exchange of the shards' bloo1, `prefix_dev` = OR of the bloo1
+ * of all lower shards (device pointer, tai/8 bytes) is what the sequential run has in bloo1 when it reaches this shard.  Every occurrence the local
+ * pass kept out of bloo2 is looked at again: it goes to bloo2 iff each of the bits the local pass found NOT set before it is in the prefix.  Adds
+ * those occurrences to bloo2, to the planes the scan reuses and to stats->to_bloo2; bloo1 |= prefix.  FGPU_ERR_STATE when the pass was not
+ * begun that way or a batch was not kept. */
 int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stats);
 
 /* filters: raw bit arrays, tai/8 bytes, exactly the .bloom file body (utils/Bloom.cpp:571-587) */
