@@ -28,7 +28,7 @@ class Params(C.Structure):
                 ("max_batch_bases", C.c_uint64), ("stream", C.c_void_p), ("walk_window_span", C.c_uint64)]
 
 
-LOAD_KEEP_CARRY, LOAD_SHARD_TIMES = 1, 2
+LOAD_KEEP_CARRY, LOAD_SHARD_TIMES, LOAD_SHARD_PLANES = 1, 2, 4
 
 
 class Reads(C.Structure):

@@ -165,8 +165,9 @@ class Context:
         _check(rc, self.h)
 
     # pass 1
-    def load_begin(self, keep_carry=False, shard_times=False):
-        self._c(self.lib.fgpu_load_begin(self.h, (L.LOAD_KEEP_CARRY if keep_carry else 0) | (L.LOAD_SHARD_TIMES if shard_times else 0)))
+    def load_begin(self, keep_carry=False, shard_times=False, shard_planes=False):
+        self._c(self.lib.fgpu_load_begin(self.h, (L.LOAD_KEEP_CARRY if keep_carry else 0) | (L.LOAD_SHARD_TIMES if shard_times else 0) |
+                                         (L.LOAD_SHARD_PLANES if shard_planes else 0)))
 
     def load_fixup(self, prefix_dev_ptr) -> dict:
         """multi-GPU: re-evaluate what this shard's own pass kept out of bloo2 against the OR of the lower ranks' bloo1"""

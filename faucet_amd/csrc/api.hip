@@ -428,6 +428,7 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
     ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai == (1ULL << 31);
     ctx->shard_times = (keep_carry & FGPU_LOAD_SHARD_TIMES) != 0;
+    ctx->shard_planes = (keep_carry & FGPU_LOAD_SHARD_PLANES) != 0 && !ctx->shard_times;
     ctx->fixup_ready = false;
     ctx->pass_positions = ctx->pass_batches = 0;
     ctx->pass_empty_carry = !(keep_carry & FGPU_LOAD_KEEP_CARRY);
@@ -497,8 +498,8 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     ctx->load_mark_pending = ctx->counters_host->mark_pending;
     ctx->load_stats.unambiguous_reads = ctx->counters_host->segments;
     if (stats) *stats = ctx->load_stats;
-    ctx->fixup_ready = ctx->shard_times && ctx->pass_empty_carry && ctx->resident_count == ctx->pass_batches &&
-                       !(ctx->prm.flags & FGPU_FLAG_MERCY) && ctx->fd.n_hash <= 4;
+    ctx->fixup_ready = (ctx->shard_times || (ctx->shard_planes && ctx->fd.n_hash <= 4)) && ctx->pass_empty_carry &&
+                       ctx->resident_count == ctx->pass_batches && !(ctx->prm.flags & FGPU_FLAG_MERCY);
     return FGPU_OK;
 }
 
@@ -506,7 +507,7 @@ int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stat
     if (!ctx || !prefix_dev) return FGPU_ERR_ARG;
     if (ctx->phase != 0) { ctx->err = "load_fixup while a pass is open"; return FGPU_ERR_STATE; }
     if (!ctx->fixup_ready) {
-        ctx->err = "load_fixup needs a finished load pass begun with FGPU_LOAD_SHARD_TIMES and an empty carry, every batch kept resident, no --mercy, at most 4 hash functions";
+        ctx->err = "load_fixup needs a finished load pass begun with FGPU_LOAD_SHARD_TIMES and an empty carry (or FGPU_LOAD_SHARD_PLANES and at most 4 hash functions), every batch kept resident, no --mercy";
         return FGPU_ERR_STATE;
     }
     FGPU_HIP(hipSetDevice(ctx->prm.device));

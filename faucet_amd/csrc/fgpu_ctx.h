@@ -208,7 +208,8 @@ struct fgpu_ctx {
     uint32_t* bloo1 = nullptr;       // carried-in bitmap ("carry_old"), tai/8 bytes
     uint64_t epoch_positions = 0;    // stream positions loaded since the last sweep of first[] (time base of the next batch)
     uint64_t swept_positions = 0;    // stream positions the carry covers
-    bool shard_times = false;        // FGPU_LOAD_SHARD_TIMES: the pass of a read shard keeps what fgpu_load_fixup needs (the fail planes of its occurrences)
+    bool shard_times = false;        // FGPU_LOAD_SHARD_TIMES: times count from the start of the pass (fgpu_load_fixup compares them later; < 2^32 positions)
+    bool shard_planes = false;       // FGPU_LOAD_SHARD_PLANES: the pass keeps, per occurrence, which bits were not set before it (fgpu_load_fixup; any size)
     bool fixup_ready = false;        // the last load pass ran that way with an empty carry and every batch resident
     uint64_t pass_positions = 0;     // stream positions of the pass so far
     uint32_t cur_tb = 0;             // time base of the batch being loaded

@@ -522,9 +522,9 @@ __global__ void __launch_bounds__(256) k_carry_set(const uint64_t* __restrict__ 
 // Read shards, fgpu_load_fixup: the occurrences the shard's own pass kept out of bloo2, looked at again with the lower shards' bits.
 // An occurrence goes to bloo2 iff every one of its bits was set before it: by a lower shard (all of those come earlier in file order: the
 // bit is in `prefix`) or earlier in this shard.  Which of its bits were NOT set earlier in this shard the own pass has written down when it
-// resolved the occurrence (the `fail` planes of k_load_resolve) -- so the question left is whether those bits are all in the prefix.  No
-// first-set time is read here: a shard may hold any number of positions (rounds 2-4 compared 32-bit times that counted through the whole
-// shard: at most 2^32 positions, i.e. config 4 from 8 GPUs on).
+// resolved the occurrence (the `fail` planes of k_load_resolve, FGPU_LOAD_SHARD_PLANES) -- so the question left is whether those bits are all in
+// the prefix.  No first-set time is read here: a shard may hold any number of positions (k_load_fixup_times below compares 32-bit times that
+// count through the whole shard: at most 2^32 positions, i.e. config 4 from 8 GPUs on -- and costs the own pass nothing, so it stays for those).
 __global__ void __launch_bounds__(256) k_load_fixup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
                                                     uint64_t n_words, FdParams fp, const uint32_t* __restrict__ prefix,
                                                     const uint64_t* __restrict__ fail, uint64_t plane_stride, uint32_t* bloo2,
@@ -550,6 +550,37 @@ __global__ void __launch_bounds__(256) k_load_fixup(const uint64_t* __restrict__
                     n_pass++;
                     fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
                 }
+            }
+        }
+        const uint64_t sm = __ballot(pass);   // lanes = the 64 positions of one plane word
+        if (fd_lane() == 0 && sm) sure[p >> 6] |= sm;
+    }
+    block_add(&cnt->to_bloo2, n_pass);
+}
+
+// The same question answered from first-set times, for shards of fewer than 2^32 positions (FGPU_LOAD_SHARD_TIMES: the own pass dated every
+// occurrence on one clock for the whole shard and resolved with the dense kernel, which costs it nothing; rounds 2-4's form): bit set before t
+// <=> in the prefix or first set locally before t.
+template <int REC>
+__global__ void __launch_bounds__(256) k_load_fixup_times(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ bad, uint64_t T,
+                                                          uint64_t n_words, FdParams fp, const uint32_t* __restrict__ prefix,
+                                                          Filt<REC> f, uint32_t tb, uint32_t* bloo2, unsigned long long* sure, DevCounters* cnt) {
+    unsigned long long n_pass = 0;
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool pass = false;
+        if (p < T && fd_window_ok(bad, p, fp.k) && !((sure[p >> 6] >> (p & 63)) & 1ULL)) {
+            uint64_t hA, hB;
+            fd_hash_pair(fd_canon(fd_kmer_at(codes, p, fp.k), fp.k), fp.tai_mask, hA, hB);
+            pass = true;
+            uint64_t h = hA;
+            for (int i = 0; i < fp.n_hash; i++) {
+                if (!((prefix[h >> 5] >> (h & 31)) & 1u) && !(*f.time(h) < tb + (uint32_t)p)) { pass = false; break; }
+                h = (h + hB) & fp.tai_mask;
+            }
+            if (pass) {
+                n_pass++;
+                fd_bloom_set(bloo2, hA, hB, fp.tai_mask, fp.n_hash);
             }
         }
         const uint64_t sm = __ballot(pass);   // lanes = the 64 positions of one plane word
@@ -660,13 +691,13 @@ static int fgpu_resident_keep(fgpu_ctx* ctx) {
     if (!ctx->resident_open) return FGPU_OK;
     BatchBufs& bb = *ctx->cur;
     const uint64_t cb = 2 * (bb.n_words + FGPU_PADW) * 8, pb = (bb.n_words + FGPU_PADW) * 8;
-    if (ctx->resident_bytes + cb + 2 * pb + (ctx->shard_times ? MISS_PLANES * pb : 0) > ctx->resident_budget) {
+    if (ctx->resident_bytes + cb + 2 * pb + (ctx->shard_planes ? MISS_PLANES * pb : 0) > ctx->resident_budget) {
         ctx->resident_open = false;   // batches pair by index: once one is missing, later ones would not line up
         return FGPU_OK;
     }
     if (ctx->resident_count == ctx->resident.size()) ctx->resident.push_back(new ResidentBatch());
     ResidentBatch& r = *ctx->resident[ctx->resident_count];
-    const uint64_t fb = ctx->shard_times ? MISS_PLANES * pb : 0;      // read shards: which bits of an occurrence were not set before it (fgpu_load_fixup)
+    const uint64_t fb = ctx->shard_planes ? MISS_PLANES * pb : 0;     // read shards: which bits of an occurrence were not set before it (fgpu_load_fixup)
     if (fgpu_ensure_b(ctx, &r.codes, cb) || fgpu_ensure_b(ctx, &r.bad, pb) || fgpu_ensure_b(ctx, &r.sure, pb) || (fb && fgpu_ensure_b(ctx, &r.fail, fb))) {
         (void)hipGetLastError();
         ctx->resident_open = false;   // out of memory: do without
@@ -710,10 +741,15 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     // holds a few coverages of the genome nearly every k-mer that will ever be in it already is: sweeps are made when an epoch
     // has grown to sweep_num/sweep_den of what the carry already covers (after batches 0, 1, 3, 7 ... of equal batches).
     const uint64_t span = bb.n_words * 64;
-    if (!ctx->carry_by_set && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
-    const uint32_t tb = ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
-    // read shards (FGPU_LOAD_SHARD_TIMES): the resolve kernel also writes down WHICH bits of an occurrence were not set before it
-    const bool keep_fail = ctx->shard_times && ctx->fd.n_hash <= MISS_PLANES;
+    if (!ctx->carry_by_set && !ctx->shard_times && ctx->epoch_positions + span >= 0xFFFFFFF0ULL && (rc = fgpu_load_sweep(ctx))) return rc;
+    if (ctx->shard_times && ctx->pass_positions + span >= 0xFFFFFFF0ULL) {
+        ctx->err = "FGPU_LOAD_SHARD_TIMES: the pass exceeds 2^32 stream positions (FGPU_LOAD_SHARD_PLANES has no such limit)";
+        return FGPU_ERR_CAPACITY;
+    }
+    // FGPU_LOAD_SHARD_TIMES: one clock for the whole pass (sweeps still bring the carry up to date; they just do not restart it)
+    const uint32_t tb = ctx->shard_times ? (uint32_t)ctx->pass_positions : ctx->carry_by_set ? 0u : (uint32_t)ctx->epoch_positions;
+    // FGPU_LOAD_SHARD_PLANES: the resolve kernel also writes down WHICH bits of an occurrence were not set before it
+    const bool keep_fail = ctx->shard_planes && ctx->fd.n_hash <= MISS_PLANES;
     if (keep_fail && (rc = fgpu_ensure_b(ctx, &bb.fail, MISS_PLANES * plane_stride * 8))) return rc;
     ctx->cur_tb = tb;
     ctx->pass_positions += span;
@@ -779,8 +815,18 @@ int fgpu_stage_fixup(fgpu_ctx* ctx, const uint32_t* prefix) {
     for (uint64_t i = 0; i < ctx->resident_count; i++) {
         ResidentBatch& r = *ctx->resident[i];
         if (!r.T) continue;
-        FGPU_LAUNCH("load_fixup", k_load_fixup, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T, r.n_words,
-                    ctx->fd, prefix, (const uint64_t*)r.fail.p, r.n_words + FGPU_PADW, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        if (ctx->shard_planes) {
+            FGPU_LAUNCH("load_fixup", k_load_fixup, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T, r.n_words,
+                        ctx->fd, prefix, (const uint64_t*)r.fail.p, r.n_words + FGPU_PADW, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        } else if (ctx->rec_layout) {
+            const Filt<1> f = {ctx->rec, nullptr};
+            FGPU_LAUNCH("load_fixup", k_load_fixup_times<1>, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
+                        r.n_words, ctx->fd, prefix, f, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        } else {
+            const Filt<0> f = {(uint32_t*)ctx->pair, ctx->first};
+            FGPU_LAUNCH("load_fixup", k_load_fixup_times<0>, fgpu_grid(r.n_words * 64, 256), 256, (const uint64_t*)r.codes.p, (const uint64_t*)r.bad.p, r.T,
+                        r.n_words, ctx->fd, prefix, f, r.tb, ctx->bloo2, (unsigned long long*)r.sure.p, ctx->counters);
+        }
     }
     return FGPU_OK;
 }

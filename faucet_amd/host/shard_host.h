@@ -128,7 +128,9 @@ public:
         for (int r = 0; r < o_.n_ranks; r++) largest = std::max(largest, cuts[(size_t)r + 1] - cuts[(size_t)r]);
         // the fix-up protocol keeps the shard's batches in HBM (8 bits per base with the fail planes; the library gives them an eighth of the
         // device) and covers four hash functions; --mercy leaves no fix-up state (fgpu_load_end)
-        bool fixup = !o_.mercy && o_.prm.n_hash <= 4 && largest < (24ULL << 30);
+        const char* force_planes = getenv("FAUCET_SHARD_PLANES");
+        const bool short_shards = largest < 0xFFF00000ULL - (1ULL << 24) && !(force_planes && force_planes[0] == '1');   // a shard's positions (<= its bytes) fit one 32-bit clock
+        bool fixup = !o_.mercy && (short_shards || o_.prm.n_hash <= 4) && largest < (24ULL << 30);
         if (const char* e = getenv("FAUCET_SHARD_PROTOCOL")) {
             if (!strcmp(e, "presence")) fixup = false;
             else if (!strcmp(e, "fixup") && !fixup) { error_ = "FAUCET_SHARD_PROTOCOL=fixup: a shard is too large to stay in HBM, more than 4 hash functions, or --mercy is on"; return FGPU_ERR_ARG; }
@@ -143,7 +145,7 @@ public:
             RANK_CHECK(fgpu_device_alloc(c, nbytes, &prefix));
             struct FreePrefix { fgpu_ctx* c; void* p; ~FreePrefix() { fgpu_device_free(c, p); } } free_prefix{c, prefix};
             if (fixup) {
-                RANK_CHECK(fgpu_load_begin(c, FGPU_LOAD_SHARD_TIMES));
+                RANK_CHECK(fgpu_load_begin(c, short_shards ? FGPU_LOAD_SHARD_TIMES : FGPU_LOAD_SHARD_PLANES));
                 RANK_TRY(for_each_batch(r, path, cuts, [&](const fgpu_reads* b) { return fgpu_load_batch(c, b); }, nullptr));
                 RANK_CHECK(fgpu_load_end(c, &st[(size_t)r]));
                 const double t1 = now_ms();

@@ -596,7 +596,10 @@ class GpuShard:
         self.ctx.bitmap_or(ptr, src.data_ptr(), nbytes)
 
     def load(self, batches, keep_carry, shard_times=False):
-        self.ctx.load_begin(keep_carry=keep_carry, shard_times=shard_times)
+        # the fix-up protocol's own pass: on one clock where the shard's positions fit 32 bits (costs nothing), else with the fail planes
+        pos = [getattr(b, "n_positions", None) for b in batches]
+        short = all(p is not None for p in pos) and sum(pos) + 64 * len(pos) < 0xFFF00000 and os.environ.get("FAUCET_SHARD_PLANES", "0") != "1"
+        self.ctx.load_begin(keep_carry=keep_carry, shard_times=shard_times and short, shard_planes=shard_times and not short)
         for b in batches:
             self.ctx.load_batch(b)
         return self.ctx.load_end()
@@ -606,7 +609,8 @@ class GpuShard:
         pos = [getattr(b, "n_positions", None) for b in batches]
         if any(p is None for p in pos) or getattr(self.ctx, "mercy", False):    # --mercy: fgpu_load_end leaves no fix-up state
             return False
-        if getattr(self.ctx, "n_hash", 0) > 4:           # the fail planes cover four hash functions
+        short = sum(pos) + 64 * len(pos) < 0xFFF00000    # one 32-bit clock for the shard; beyond: fail planes, which cover four hash functions
+        if not short and getattr(self.ctx, "n_hash", 0) > 4:
             return False
         free, total = torch.cuda.mem_get_info(self.device)
         return sum(pos) + (64 << 20) < total // 8        # 8 bits per position kept in HBM (codes, bad, sure, four fail planes): an eighth of the device

@@ -163,10 +163,13 @@ void     fgpu_size_two_hash(uint64_t estimated, float fp, int32_t* bits_per_item
  * multi-GPU shards start from the prefix-OR of the lower ranks' k-mer presence bitmaps). */
 int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry);
 #define FGPU_LOAD_KEEP_CARRY   1   /* bloo1's current content is the carried-in state */
-#define FGPU_LOAD_SHARD_TIMES  2   /* the pass of a read shard that fgpu_load_fixup will complete: besides routing each occurrence it writes down which
-                                    * of the occurrence's bits were NOT set before it within the shard (n_hash <= 4 planes of one bit per position,
-                                    * kept in HBM with the batch).  Any number of positions (rounds 2-4 kept 32-bit times that counted through the
-                                    * whole shard instead: at most 2^32 positions per shard; the name is theirs). */
+#define FGPU_LOAD_SHARD_TIMES  2   /* the pass of a read shard that fgpu_load_fixup will complete, for shards of fewer than 2^32 - 16 stream positions
+                                    * (FGPU_ERR_CAPACITY beyond): first-set times count from the start of the pass, not of an epoch, and the fix-up
+                                    * compares them.  Costs the pass nothing. */
+#define FGPU_LOAD_SHARD_PLANES 4   /* the same for shards of ANY size (round 5): while it resolves its occurrences the pass writes down which of an
+                                    * occurrence's bits were NOT set before it within the shard (n_hash <= 4 planes of one bit per position, kept in HBM
+                                    * with the batch), and the fix-up asks the lower shards' bits for exactly those.  The resolve kernel then looks at every
+                                    * missing bit instead of stopping at the first that fails (+10 % on the pass). */
 /* Consume one batch, in file order.  Exact: occurrence t goes to bloo2 iff all its bits were set
  * by occurrences < t, t following the reference's processing order. */
 int fgpu_load_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
@@ -174,10 +177,11 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats);
 /* OR the bits of every k-mer of the batch into bloo1 with no ordering (presence bitmap; used by
  * multi-GPU shards before the prefix-OR exchange).  Same unit counters as load_batch. */
 int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
-/* Read shards without the presence pass.  After a load pass of THIS shard alone (begun with FGPU_LOAD_SHARD_TIMES and an
- * empty carry, all batches kept resident, no --mercy, at most 4 hash functions) and the exchange of the shards' bloo1, `prefix_dev` = OR of the bloo1
+/* Read shards without the presence pass.  After a load pass of THIS shard alone (begun with FGPU_LOAD_SHARD_TIMES, or with
+ * FGPU_LOAD_SHARD_PLANES and at most 4 hash functions; an empty carry, all batches kept resident, no --mercy) and the exchange of the shards' bloo1, `prefix_dev` = OR of the bloo1
  * of all lower shards (device pointer, tai/8 bytes) is what the sequential run has in bloo1 when it reaches this shard.  Every occurrence the local
- * pass kept out of bloo2 is looked at again: it goes to bloo2 iff each of the bits the local pass found NOT set before it is in the prefix.  Adds
+ * pass kept out of bloo2 is looked at again: it goes to bloo2 iff each of its bits is in the prefix or was set locally before it (by the pass's
+ * times, or by the planes it wrote down).  Adds
  * those occurrences to bloo2, to the planes the scan reuses and to stats->to_bloo2; bloo1 |= prefix.  FGPU_ERR_STATE when the pass was not
  * begun that way or a batch was not kept. */
 int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stats);

@@ -103,7 +103,8 @@ def test_integration_binding_compiles_against_the_reference_headers():
         pytest.skip("reference tree not mounted here")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-include", "vector", "-include", "cmath", "-I", os.path.join(ref, "src"),
-                        "-I", os.path.join(ref, "utils"), "-I", os.path.join(root, "include"), os.path.join(root, "integration", "faucet_binding.cpp")],
+                        "-I", os.path.join(ref, "utils"), "-I", os.path.join(root, "include"), "-I", os.path.join(root, "faucet_amd", "host"),
+                        os.path.join(root, "integration", "faucet_binding.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
 

@@ -480,13 +480,16 @@ def test_config4_full_size_equals_the_oracle(config4):
 
 
 @needs_config4
-@pytest.mark.parametrize("protocol", ["presence", "fixup"])
-def test_config4_as_eight_shards_in_file_order_equals_the_oracle_after_every_rank(config4, protocol):
+@pytest.mark.parametrize("protocol", ["presence", "fixup", "fixup_planes"])
+def test_config4_as_eight_shards_in_file_order_equals_the_oracle_after_every_rank(config4, protocol, monkeypatch):
     """The same reads as the 8 contiguous shards of the 8-GPU layout through the sharded pipeline's own steps (faucet_amd/sharded.py,
     run_in_turn: one process, the ranks' contexts made in turn so that 8 x 32 GiB of first-set times never coexist; the exclusive prefix-OR
     and the OR of bloo2 as slice-wise ORs on the device; the junction table handed from rank to rank, the hint from rank 0).  After EVERY
     rank the filters, the junction map and the counters are the sequential run's at that shard boundary = the oracle's checkpoint."""
     from faucet_amd import sharded
+    if protocol == "fixup_planes":        # the fix-up's own pass with the fail planes (what shards beyond 2^32 positions take) instead of the shard-long clock
+        monkeypatch.setenv("FAUCET_SHARD_PLANES", "1")
+        protocol = "fixup"
     reads, tai, nh, fx = config4
     c = fx["params"]
     dev = reads.device

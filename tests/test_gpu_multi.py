@@ -58,7 +58,7 @@ def test_sharded_cli_writes_the_reference_files(case, gpus, tmp_path):
         assert f"Empty count: {cn['empty_count']}, not empty count: {cn['not_empty_count']}" in r.stdout
 
 
-@pytest.mark.parametrize("protocol", ["presence", "fixup"])
+@pytest.mark.parametrize("protocol", ["presence", "fixup", "fixup_planes"])
 @pytest.mark.parametrize("extra", [[], ["-chunk_mb", "1"]], ids=["one_chunk", "chunks_1MB"])
 def test_both_pass1_protocols_and_small_chunks(protocol, extra, tmp_path):
     """the fix-up protocol (own load, exclusive prefix-OR of bloo1, fgpu_load_fixup) and the presence protocol (presence bitmaps, prefix-OR,
@@ -67,9 +67,12 @@ def test_both_pass1_protocols_and_small_chunks(protocol, extra, tmp_path):
         c = Case(case)
         where = tmp_path / case
         where.mkdir()
-        prefix, r = _run(c, where, 3, extra, env={"FAUCET_SHARD_PROTOCOL": protocol, "FGPU_CLI_TIMES": "1"}, tag=protocol)
+        env = {"FAUCET_SHARD_PROTOCOL": protocol.split("_")[0], "FGPU_CLI_TIMES": "1"}
+        if protocol == "fixup_planes":          # the fix-up's own pass with the fail planes (FGPU_LOAD_SHARD_PLANES: any shard size) instead of one clock
+            env["FAUCET_SHARD_PLANES"] = "1"
+        prefix, r = _run(c, where, 3, extra, env=env, tag=protocol)
         assert r.returncode == (0 if c.no_cleaning else 3), r.stdout[-2000:] + r.stderr[-3000:]
-        assert ("fix-up protocol" if protocol == "fixup" else "presence protocol") in r.stderr
+        assert ("fix-up protocol" if protocol.startswith("fixup") else "presence protocol") in r.stderr
         _same_files(c, prefix)
 
 

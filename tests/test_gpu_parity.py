@@ -1440,11 +1440,13 @@ def test_a_batch_that_outgrows_the_junction_table_fails_promptly():
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["shard_times", "shard_planes"])
 @pytest.mark.parametrize("n_shards,batches_per_shard,ratio", [(2, 1, None), (3, 4, None), (4, 3, "0/1"), (3, 5, "1000000/1")])
-def test_shard_fixup_protocol_is_exact(n_shards, batches_per_shard, ratio, monkeypatch):
+def test_shard_fixup_protocol_is_exact(n_shards, batches_per_shard, ratio, mode, monkeypatch):
     """Multi-GPU pass 1 without the presence pass (fgpu_load_fixup), emulated with one context per shard on this device: every shard
-    loads its reads alone with first-set times that count through the shard, then re-evaluates what it kept out of bloo2 against the OR
-    of the lower shards' bloo1.  The OR of the shards' bloo2 is the oracle's bloo2, the last shard's bloo1 the oracle's bloo1, the
+    loads its reads alone -- with first-set times that count through the shard (FGPU_LOAD_SHARD_TIMES: shards below 2^32 positions), or writing
+    down which bits of an occurrence were not set before it (FGPU_LOAD_SHARD_PLANES, round 5: any shard size) -- then re-evaluates what it kept
+    out of bloo2 against the OR of the lower shards' bloo1.  The OR of the shards' bloo2 is the oracle's bloo2, the last shard's bloo1 the oracle's bloo1, the
     to_bloo2 counts add up, and the scan of every shard reuses the fixed-up planes (valid_reused == to_bloo2 of the shard)."""
     import torch
     if ratio:
@@ -1461,7 +1463,7 @@ def test_shard_fixup_protocol_is_exact(n_shards, batches_per_shard, ratio, monke
         shards.append([api.ReadBatch(bases, offs[x:y + 1].copy()) for x, y in zip(sub[:-1], sub[1:])])
         ctxs.append(api.Context(k, tai, nh))
     for ctx, sh in zip(ctxs, shards):
-        ctx.load_begin(shard_times=True)
+        ctx.load_begin(**{mode: True})
         for b in sh:
             ctx.load_batch(b)
         stats.append(ctx.load_end())
@@ -1487,7 +1489,7 @@ def test_shard_fixup_protocol_is_exact(n_shards, batches_per_shard, ratio, monke
     for ctx, sh, st in zip(ctxs, shards, stats):
         ctx.bloom_upload(L.BLOO2, merged)                       # (an upload forgets the planes ...
     ctx = ctxs[-1]
-    ctx.load_begin(shard_times=True)                            # ... so load the last shard again and fix it up: the planes are kept)
+    ctx.load_begin(**{mode: True})                              # ... so load the last shard again and fix it up: the planes are kept)
     for b in shards[-1]:
         ctx.load_batch(b)
     ctx.load_end()
@@ -1511,7 +1513,8 @@ def test_load_fixup_refuses_passes_it_cannot_speak_for():
     import torch
     prefix = torch.zeros(tai // 8, dtype=torch.uint8, device="cuda")
     for kw, begin in (({}, {}), ({"keep_resident": False}, {"shard_times": True}), ({"mercy": True}, {"shard_times": True}),
-                      ({}, {"shard_times": True, "keep_carry": True})):
+                      ({}, {"shard_times": True, "keep_carry": True}), ({"keep_resident": False}, {"shard_planes": True}),
+                      ({"mercy": True}, {"shard_planes": True}), ({}, {"shard_planes": True, "keep_carry": True})):
         ctx = api.Context(k, tai, nh, **kw)
         ctx.load_begin(**begin)
         ctx.load_batch(api.ReadBatch(bases, offs))
