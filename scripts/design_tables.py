@@ -19,6 +19,9 @@ if d.get("host_input"):
     print(f"| 2, reads handed over as host buffers (PCIe inside the step; never `value`) | {d['host_input']['ms_per_step'] / 1e3:.4f} | {d['host_input']['value']:.3g} | `host_input` |")
 if cli:
     print(f"| 2 as a 1.1 GB FASTA file through the `faucet` process, start-up and output files included | {cli['seconds']:.3f} | {cli['value']:.3g} | `cli_file_to_files` |")
+    g2 = cli.get("gpus2_one_device")
+    if g2 and "seconds" in g2:
+        print(f"| the same file through `faucet -gpus 2` (the C++ host over two read shards, BOTH on this box's one device: a functional record, not a scaling number; files equal: {all(g2['files_equal_the_single_device_runs'].values())}) | {g2['seconds']:.3f} | {g2['value']:.3g} | `cli_file_to_files.gpus2_one_device` |")
 if c3:
     p = c3.get("pass_ms") or {}
     p1 = [v for n, v in p.items() if n.startswith("pass 1")]
@@ -35,6 +38,9 @@ print()
 print("per kernel per step (ms, `kernel_ms_per_step_rank0`, from the bracketed steps): " + ", ".join(f"`{n}` {v:.1f}" for n, v in list(k.items())[:11]))
 print(f"roofline ({r['kernel']}): {r['avg_launch_ms']:.3f} ms per launch of {r['kmers_per_launch']:.3g} k-mers, frac {r['frac']:.3f} (sectors needed), "
       f"{r['frac_measured_traffic']:.3f} (counters), {r['frac_reference_accesses']:.3f} (reference's separate arrays)")
+rl = d.get("roofline_large")
+if rl:
+    print(f"roofline_large ({rl['kernel']} on config 4's 2 x 1 GiB filters): {rl['avg_launch_ms']:.2f} ms per launch of {rl['kmers_per_launch']:.3g} k-mers, frac {rl['frac']:.3f} (sectors needed)")
 pa = d.get("pipeline_ab64", {})
 pm = d.get("pipeline_measured", {})
 if pa:
