@@ -45,7 +45,8 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c3["load_scan_value"] > 1e9
     # round 4: the headline steps run without HIP events; kernel times and the roofline's launch time come from separate bracketed steps
     ps = d["profiled_steps"]
-    assert ps["steps"] >= 1 and ps["ms_per_step"] >= 0.99 * d["ms_per_step"]
+    # (the bracketed steps cost ~1.5 % more by an A/B on one box; run to run on the pool either group of steps may come out a few per cent ahead)
+    assert ps["steps"] >= 1 and ps["ms_per_step"] >= 0.95 * d["ms_per_step"]
     assert abs(d["roofline"]["avg_launch_ms"] * d["roofline"]["launches"] / ps["steps"] - d["kernel_ms_per_step_rank0"]["load_mark"]) < 0.01
     for name in ("config5", "config4"):
         assert d["full_size"][name]["counters_equal_the_oracles"] is True and d["full_size"][name]["value"] > 4e9
