@@ -32,7 +32,7 @@ def stdout_lines(text):
 
 
 @pytest.mark.parametrize("seed", range(100, 112))
-def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
+def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path, cli_extra=()):
     from tests.test_oracle_vs_reference_fuzz import random_run
     path, fastq, args = random_run(seed, tmp_path)
     outs = {}
@@ -40,8 +40,8 @@ def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
         d = tmp_path / tag
         d.mkdir()
         # (unbuffered stdout: the reference may crash in its contig-graph stage, after the files and the counters this test is about)
-        r = subprocess.run(["stdbuf", "-o0", exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", str(d / "out")] + args,
-                           capture_output=True, text=True, errors="replace", timeout=600)
+        r = subprocess.run(["stdbuf", "-o0", exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", str(d / "out")] + args +
+                           (list(cli_extra) if tag == "gpu" else []), capture_output=True, text=True, errors="replace", timeout=600)
         outs[tag] = (r, d)
     (rr, dr), (rg, dg) = outs["ref"], outs["gpu"]
     assert rg.returncode == (0 if "--no_cleaning" in args else 3), rg.stderr[-2000:]      # (the reference goes on into its contig graph and may crash there)
@@ -60,6 +60,15 @@ def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path):
     a = [ln.replace(str(dr), "<prefix>") for ln in stdout_lines(rr.stdout)]
     b = [ln.replace(str(dg), "<prefix>") for ln in stdout_lines(rg.stdout)]
     assert b and b[-1].startswith("Number of junctions:") and a[:len(b)] == b, [x for x in zip(a, b) if x[0] != x[1]][:5]
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+@pytest.mark.parametrize("seed", range(300, 306))
+def test_cli_over_read_shards_equals_the_compiled_reference_on_a_random_run(seed, gpus, tmp_path):
+    """the same with `-gpus N` (the C++ host over N read shards, faucet_amd/host/shard_host.h; all shards on the box's one device): random k, read
+    length, FASTA / FASTQ, single / paired ends, cleaning, --mercy (presence protocol), reads with N, truncated reads, empty records -- the cuts fall
+    wherever the bytes put them; every file and every line of the log as the compiled reference writes them"""
+    test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path, cli_extra=["-gpus", str(gpus)])
 
 
 def _same_files(da, db, crashed):
