@@ -971,16 +971,25 @@ int fgpu_scan_walk_prepared(fgpu_ctx* ctx) {
     FGPU_HIP(hipSetDevice(ctx->prm.device));
     int rc = FGPU_OK;
     if (ctx->lazy_failed) return scan_replay(ctx);      // (walks the prepared batches as well)
+    // The batches were prepared before their turn: their snapshot planes speak of a table that has since been replaced (the preview by the real
+    // table) and walked on, so they are made again by the walk stream right before every batch's walk.  FGPU_PREPARED_REFRESH=overlap
+    // (round 5, measured, not the default): batch i + 1's on the main stream WHILE batch i is walked, what batch i creates meanwhile reaching
+    // batch i + 1 through the created-key lists as in a streaming scan -- exact (the sharded tests pass with it), and no faster: the 23 ms of
+    // plane-making leave the chain, 11 ms of contention and 10 ms of registering three batches' created keys per window enter it (first hop of
+    // config 4 on 8 shards 66.2 against 65.4 ms, profiles/r05_hop_refresh_ab.txt).
+    static const bool serial_refresh = !(getenv("FGPU_PREPARED_REFRESH") && getenv("FGPU_PREPARED_REFRESH")[0] == 'o');
+    if (!serial_refresh && !ctx->prepared.empty()) rc = fgpu_scan_refresh_planes(ctx, ctx->prepared[0]);
     for (size_t i = 0; i < ctx->prepared.size() && !rc; i++) {
         BatchBufs* b = ctx->prepared[i];
         if (i > 0) {   // feedback for the window controller and for the size of the junction table between batches
-            if ((rc = pull_counters(ctx))) break;
+            if ((rc = pull_counters(ctx))) break;                  // (the walk of batch i - 1 has finished; so have the planes of batch i)
             if (ctx->lazy_failed) { ctx->cur = &ctx->bb_default; return scan_replay(ctx); }
             if (!ctx->prm.walk_window_span) adapt_window(ctx);
             if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported))) break;
         }
+        if (!serial_refresh && i + 1 < ctx->prepared.size() && (rc = fgpu_scan_refresh_planes(ctx, ctx->prepared[i + 1]))) break;
         ctx->cur = b;
-        ctx->refresh_snapshot = true;
+        ctx->refresh_snapshot = serial_refresh;
         rc = fgpu_stage_scan_walk(ctx, b->n_pieces);
         ctx->refresh_snapshot = false;
         ctx->walked_pieces += b->n_pieces;

@@ -457,6 +457,7 @@ void fgpu_resident_reset(fgpu_ctx* ctx, bool keep_going);
 int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_stage_scan_need(fgpu_ctx* ctx);
+int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx);
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);
 int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out);

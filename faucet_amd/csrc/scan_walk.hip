@@ -2859,6 +2859,19 @@ int fgpu_stage_scan_need(fgpu_ctx* ctx) {
     return FGPU_OK;
 }
 
+// Read shards, FGPU_PREPARED_REFRESH=overlap (fgpu_scan_walk_prepared; measured in round 5, not the default): the snapshot planes of a batch that
+// was prepared before its turn, made again on the MAIN stream against the table as it stands, so that batch i + 1's are made while batch i is
+// walked.  The batch's walk waits for pure_done, recorded here.
+int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b) {
+    if (!b->n_pieces || !b->T) return FGPU_OK;
+    JTable jt = make_jt(ctx);
+    ctx->launch_stream = ctx->stream;
+    FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(b->n_words * 64, 256), 256, (const uint64_t*)b->codes.p, (const uint64_t*)b->pm.p, b->n_words,
+                ctx->fd, jt, (uint64_t*)b->nF.p, (uint64_t*)b->nB.p, (uint32_t*)b->kh.p, (uint64_t)0);
+    if (b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
+    return FGPU_OK;
+}
+
 int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx) {
     static const int drop = getenv("FGPU_DEBUG_NEED_DROP") ? atoi(getenv("FGPU_DEBUG_NEED_DROP")) : 0;
     BatchBufs& bb = *ctx->cur;
