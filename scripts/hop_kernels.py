@@ -16,6 +16,7 @@ from faucet_amd import api, sharded  # noqa: E402
 from faucet_amd import synth_det as sd  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+HOP = int(sys.argv[2]) if len(sys.argv) > 2 else 1        # which rank's hop is looked at: the table it is handed = the sequential scan of shards 0 .. HOP - 1
 fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fullsize.json")))["config4"]
 c = fx["params"]
 dev = torch.device("cuda", 0)
@@ -78,11 +79,21 @@ def show(i):
         hint[0] = (buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n)
 
 
-stats0 = timed("rank 0: streaming scan of its shard", lambda: b.scan_stream(batches0, after_batch=show))
+stats0 = timed("rank 0: streaming scan of its shard", lambda: b.scan_stream(batches0, after_batch=show) if HOP == 1 else None)
+if HOP > 1:       # the table a later rank is handed: shards 0 .. HOP - 1 scanned one after the other by this one context (the same map, the same counters)
+    for x in batches0:
+        ctx.scan_batch(x)
+        show(len(batches0))
+    for r in range(1, HOP):
+        del batches0, reads0
+        reads0, batches0 = batches_of(r)
+        for x in batches0:
+            ctx.scan_batch(x)
+    stats0 = ctx.scan_end()
 n0, buf0 = b.export_table()
 table0 = buf0[:max(n0, 1) * L.TABLE_ENTRY_BYTES].clone()
 del reads0, batches0
-reads1, batches1 = batches_of(1)
+reads1, batches1 = batches_of(HOP)
 b.clear_filters()
 b.load(batches1, keep_carry=False, shard_times=True)
 b.load_fixup(prefix)
@@ -91,7 +102,7 @@ ctx.synchronize()
 for rep in range(2):
     b.scan_begin()
     b.import_hint(hint[0][0], hint[0][1])
-    timed("rank 1: pure stage on the preview", lambda: [b.scan_prepare(x) for x in batches1])
+    timed(f"rank {HOP}: pure stage on the preview", lambda: [b.scan_prepare(x) for x in batches1])
     carried = {n: int(stats0[n]) for n in sharded._STAT_NAMES}
-    timed(f"rank 1: import of {n0} records + walk of the prepared shard (the hop)", lambda: b.walk_shard(batches1, table0, n0, carried))
-    timed("rank 1: export", lambda: b.export_table())
+    timed(f"rank {HOP}: import of {n0} records + walk of the prepared shard (the hop)", lambda: b.walk_shard(batches1, table0, n0, carried))
+    timed(f"rank {HOP}: export", lambda: b.export_table())
