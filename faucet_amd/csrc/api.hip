@@ -713,8 +713,16 @@ static BatchBufs* acquire_batch(fgpu_ctx* ctx) {
     BatchBufs* b;
     // (at most FGPU_DELTA_RING: a batch registers the created-key lists of the FGPU_DELTA_RING - 1 batches before it)
     static const size_t depth = getenv("FGPU_SCAN_BUFFERS") ? (size_t)std::min(FGPU_DELTA_RING, std::max(2, atoi(getenv("FGPU_SCAN_BUFFERS")))) : 2;
-    if (ctx->pool.size() >= depth) { b = ctx->pool.front(); ctx->pool.erase(ctx->pool.begin()); }
-    else {
+    // The buffers handed out are the ones used `depth` batches ago -- NOT the oldest of the pool: a context that has walked a prepared shard
+    // keeps dozens of buffers, and a streaming scan that took them first in, first out let its pure stage run as far ahead of the walk as the
+    // pool is deep (nothing left to wait for), beyond what the created-key lists cover: keys missing from the snapshot planes, a wrong map
+    // (seen at config 4's size, 50 M reads streamed after a 60 M-read prepared shard: 9 887 records too many).  The streaming scan pushes every
+    // batch's buffers back at the end of the pool, so the one used `depth` batches ago sits `depth` from the end.
+    if (ctx->pool.size() >= depth) {
+        const size_t at = ctx->pool.size() - depth;
+        b = ctx->pool[at];
+        ctx->pool.erase(ctx->pool.begin() + at);
+    } else {
         b = new BatchBufs();
         ctx->all_batches.push_back(b);
         hipEventCreateWithFlags(&b->pure_done, hipEventDisableTiming);

@@ -2455,6 +2455,13 @@ __global__ void __launch_bounds__(256) k_iota_u32(uint32_t* p, uint64_t n) {
 
 // FGPU_DEBUG_NEED_DROP=1 (tests): after the flags kernel, forget the evaluation of about half of the windows whose tests came out
 // false -- need bit and NbJCheckKmer bits cleared -- so that the walk has to evaluate them itself wherever it scans them.  =2: see below.
+// FGPU_DEBUG_WALK_STALL_US (tests): the walk stream held up for that long before every batch's walk, so that the pure stage gets as far ahead of
+// the walk as the host lets it -- a bounded wait on the constant 100 MHz clock
+__global__ void k_debug_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 __global__ void __launch_bounds__(256) k_debug_need_drop(uint64_t n_words, uint64_t* __restrict__ ff, uint64_t* __restrict__ fb,
                                                          uint64_t* need, uint64_t* cf0, uint64_t* cf1, uint64_t* cb0, uint64_t* cb1, int mode,
                                                          const uint64_t* __restrict__ pm, const uint32_t* __restrict__ kh) {
@@ -2925,6 +2932,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
     ctx->launch_stream = walk_stream;
     if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(walk_stream, bb.pure_done, 0));
+    const int stall_us = getenv("FGPU_DEBUG_WALK_STALL_US") ? std::min(100000, std::max(0, atoi(getenv("FGPU_DEBUG_WALK_STALL_US")))) : 0;
+    if (stall_us) FGPU_LAUNCH("debug_stall", k_debug_stall, 1, 1, (unsigned long long)stall_us * 100ULL);
     if (ctx->refresh_snapshot) {
         // batches that were prepared before their turn (multi-GPU shards; scan_prepare / scan_walk_prepared) carry snapshot planes of a table
         // that has since been replaced or walked on by an unknown number of batches: made again here, behind the previous batch's walk

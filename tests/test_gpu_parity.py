@@ -242,6 +242,30 @@ def test_scan_prepare_then_walk_equals_scan_batch(name):
     assert sorted(api.junction_lines(keys, recs, c.k)) == sorted(c.junction_lines())
 
 
+def test_streaming_scan_after_a_prepared_shard_does_not_outrun_its_walk(monkeypatch):
+    """A context that has walked a prepared shard keeps that shard's buffers (one set per batch).  A streaming scan afterwards must still
+    reuse the buffers of two batches ago and wait for that walk: taken first in, first out, the deep pool let the pure stage run ahead of the
+    walk by more batches than the created-key lists cover -- snapshot planes without keys that exist, a wrong map (round 5: config 4's first
+    50 M reads streamed after a 60 M-read prepared shard came out with 9 887 records too many).  The walk stream is held up 3 ms per batch
+    here (FGPU_DEBUG_WALK_STALL_US) so that the pure stage of these small batches WOULD run ahead as far as the host lets it."""
+    bases, offs = _random_case(30000, 100, 31, 40000, 0.01, 77, 0.0, 3)
+    k, E, S = 31, 2_000_000, 400_000
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    ctx = api.Context(k, tai, nh)
+    ctx.bloom_upload(L.BLOO2, b2.bits())
+    ctx.scan_begin()
+    for part in chunks(bases, offs, 24):
+        ctx.scan_prepare(part)
+    ctx.scan_walk_prepared()
+    st = ctx.scan_end()
+    assert st["n_junctions"] == osc.stats()["n_junctions"]
+    monkeypatch.setenv("FGPU_DEBUG_WALK_STALL_US", "3000")
+    sc = api.ReadScanner(ctx)
+    sst = sc.scanReads(chunks(bases, offs, 24))
+    _scan_equals_oracle(sc, sst, osc)
+
+
 def test_load_then_scan_end_to_end_on_device():
     """bloo2 stays resident between the passes (no upload), as in the CLI."""
     c = Case("c1_k21")
