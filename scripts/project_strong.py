@@ -97,6 +97,10 @@ for N in Ns:
             acc2 |= b.bloom_tensor(L.BLOO2)
             del reads, batches
         pres = None
+    # the reduced filters are the whole run's: checked against the oracle's digests (tests/golden/fullsize.json) before pass 2 uses them
+    import hashlib
+    d1, d2 = (hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in (running, acc2))
+    filters_ok = d1 == fx.get("bloo1_sha256") and d2 == fx.get("bloo2_sha256")
     # ---- pass 2: rank 0 streams; rank r prepares on the hint (rank 0's table after a quarter of its reads), then imports, walks, exports
     t_pure, t_hop, recs = [], [], []
     table, n_table, stats, hint = None, 0, None, None
@@ -160,5 +164,5 @@ for N in Ns:
     print(f"N={N}: per rank {per} reads | pass 1 ({'own load + fix-up' if fixup else 'presence + load'}): {min(t_first):.0f}-{max(t_first):.0f} ms + {min(t_second):.0f}-{max(t_second):.0f} ms + exchanges {exch:.0f} ms = {p1:.0f} ms | "
           f"pass 2: rank 0 scan {t_scan0:.0f} ms, others' pure stage {min(t_pure) if t_pure else 0:.0f}-{max(t_pure) if t_pure else 0:.0f} ms, hops (send + import + walk + export) "
           f"{' '.join(f'{recs[r - 1] * 32 / LINK / 1e6:.0f}+{t_hop[r - 1][0]:.0f}+{t_hop[r - 1][1]:.0f}' for r in range(1, N))} = {hops:.0f} ms | step {step:.0f} ms = {kmers / step * 1e3:.3g} k-mers/s "
-          f"(records {recs[-1]}, junctions of the last rank's stats {stats['n_junctions']})", flush=True)
+          f"(records {recs[-1]}, junctions of the last rank's stats {stats['n_junctions']}; bloo1 and bloo2 of the shards' pass 1 {'EQUAL' if filters_ok else 'DIFFER FROM'} the oracle's digests)", flush=True)
 print(f"(links priced at {LINK:.0f} GB/s per direction; the one-GPU step of the same workload is the bench line's full_size.config4)")
