@@ -264,6 +264,16 @@ def test_streaming_scan_after_a_prepared_shard_does_not_outrun_its_walk(monkeypa
     sc = api.ReadScanner(ctx)
     sst = sc.scanReads(chunks(bases, offs, 24))
     _scan_equals_oracle(sc, sst, osc)
+    # ... and inside ONE scan: the first half prepared and walked, the second half streamed behind it
+    parts = chunks(bases, offs, 24)
+    ctx.scan_begin()
+    for part in parts[:12]:
+        ctx.scan_prepare(part)
+    ctx.scan_walk_prepared()
+    for part in parts[12:]:
+        ctx.scan_batch(part)
+    sst = ctx.scan_end()
+    _scan_equals_oracle(ctx, sst, osc)
 
 
 def test_load_then_scan_end_to_end_on_device():
