@@ -777,7 +777,7 @@ def main():
                         missing.append(n)
                     continue
                 tot += b * c / args.steps
-            for n in ("k_walk_register", "k_walk_link", "k_walk", "k_walk_cluster", "k_walk_reset_uf"):   # the walk stage is timed as one entry
+            for n in ("k_walk_register", "k_walk_link", "k_walk", "k_walk_dyn", "k_walk_cluster", "k_walk_reset_uf"):   # the walk stage is timed as one entry
                 if n in pl and "walk_stage" in ktimes:
                     tot += pl[n] * sst["walk_windows"]
             res["pipeline_measured"] = {"hbm_bytes_per_step": tot, "GBps": tot / (elapsed_timed / steps_timed) / 1e9, "frac_of_hbm_peak": tot / (elapsed_timed / steps_timed) / 1e9 / HBM_PEAK_GBPS,

@@ -3005,7 +3005,11 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             // has seen counted; being wrong only picks the dearer of two exact ways.
             // (earlier batches: records counted between their walks' issue times; this batch: at most ~3 creations per piece walked so far)
             const uint64_t delta_est = ctx->delta_ring_keys + (uint64_t)(3.0 * (double)bb.n_pieces * (double)lo / (double)T);
-            const bool refresh_window = !ctx->refresh_snapshot && delta_est > (pos_end - lo) / 4;
+            // (FGPU_REFRESH_DIV: the 4 below.  Swept in round 5 on configs 2, 5 and 4 at full size: 1, 2, 4 within noise of each other, 16 and more --
+            // planes made again more readily -- slower everywhere: config 4's walk stage 1 202 -> 1 258 / 1 343 ms, config 2's step 119.7 -> 122.1 / 125.7 ms;
+            // profiles/r05_refresh_div_sweep.txt)
+            static const uint64_t refresh_div = getenv("FGPU_REFRESH_DIV") ? std::max(1, atoi(getenv("FGPU_REFRESH_DIV"))) : 4;
+            const bool refresh_window = !ctx->refresh_snapshot && delta_est > (pos_end - lo) / refresh_div;
             if (refresh_window) {
                 const uint64_t w_first = lo >> 6, w_last = std::min<uint64_t>(bb.n_words, (pos_end + 63) / 64);
                 FGPU_LAUNCH("walk_lookup", k_need_lookup, fgpu_grid((w_last - w_first) * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, w_last,

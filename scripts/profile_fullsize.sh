@@ -1,18 +1,21 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of BASELINE config 4's whole workload on one GPU (one bench step; GPU box).  Output under gpurun_out/prof_config4/.
+# rocprofv3 kernel statistics of one of BASELINE's full-size configurations on one GPU (bench.py's full-size leg: two steps; GPU box).
+#   gpurun --timeout 900 -- 'bash scripts/profile_fullsize.sh config5 r05'      -> gpurun_out/prof_<config>/<tag>_rocprofv3_kernel_stats_<config>.csv
+cfg=${1:-config5}
+tag=${2:-r05}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/prof_config4
+out=$root/gpurun_out/prof_$cfg
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --reads 200000000 --genome 400000000 --estimated-kmers 1000000000 --singletons 200000000 --batch-reads 2500000 --steps 1 --warmup 1 --no-cpu --no-ceilings --no-host-leg > "$out/bench.json" 2> "$out/bench.err"
+timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/scripts/fullsize_step.py" "$cfg" > "$out/step.json" 2> "$out/step.err"
 echo "rc=$?"
 find "$out" \( -name "*kernel_trace.csv" -o -name "*.db" \) -delete
 python3 - <<PY
 import csv, glob
 f = glob.glob("$out/**/*kernel_stats.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "k_" in r["Name"] and "at::" not in r["Name"] and "rocprim" not in r["Name"]]
-w = csv.writer(open("$out/r04_rocprofv3_kernel_stats_config4.csv", "w"))
+w = csv.writer(open("$out/${tag}_rocprofv3_kernel_stats_${cfg}.csv", "w"))
 w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
 for r in rows:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
