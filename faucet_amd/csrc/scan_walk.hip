@@ -2976,7 +2976,8 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // coverage data -- must not pay for the launch of the thousands of empty blocks the largest window would need
         const uint64_t max_pieces = std::min<uint64_t>((hi - lo) / (uint64_t)(ctx->fd.k + 1) + 2, ctx->wmax);
         const unsigned walk_grid_w = fgpu_blocks(max_pieces, 64);
-        const unsigned cluster_grid = std::min(256u, fgpu_blocks(max_pieces, 256));
+        static const unsigned cluster_cap = getenv("FGPU_CLUSTER_GRID") ? (unsigned)std::max(1, atoi(getenv("FGPU_CLUSTER_GRID"))) : 256u;
+        const unsigned cluster_grid = std::min(cluster_cap, fgpu_blocks(max_pieces, 256));
         const unsigned piece_blocks_ko = fgpu_blocks(max_pieces, 256);
 #ifdef FGPU_KO_ONE_XCD
         const unsigned ko_grid = 4096;
@@ -3028,7 +3029,13 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             }
             const unsigned word_blocks = fgpu_blocks((pos_end - (lo & ~63ULL) + 63) / 64, 256);
             const unsigned piece_blocks = fgpu_blocks(max_pieces, 256);
-            FGPU_LAUNCH("walk_lookup", k_walk_register, word_blocks + piece_blocks + 64, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, ctx->counters,
+            // the delta's share of the grid by its size: 64 blocks took a batch's worth of created keys (millions per window while a large map is
+            // being built: config 4's first shards) 500 dependent atomics per thread, the kernel's tail.  One block per 1024 keys: walk stage of
+            // config 4 1 216 -> 1 150-1 177 ms, config 5 298 -> 278-282 ms, the steps' wall time within noise (the pure stage beside it bounds pass 2);
+            // config 2 unchanged (its delta never exceeds 64 blocks' worth).  profiles/r05_walk_grid_sweep.txt
+            static const unsigned delta_per_block = getenv("FGPU_DELTA_PER_BLOCK") ? (unsigned)std::max(1, atoi(getenv("FGPU_DELTA_PER_BLOCK"))) : 1024u;
+            const unsigned delta_blocks = refresh_window ? 64u : (unsigned)std::min<uint64_t>(4096, std::max<uint64_t>(64, delta_est / delta_per_block));
+            FGPU_LAUNCH("walk_lookup", k_walk_register, word_blocks + piece_blocks + delta_blocks, 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, ctx->counters,
                         word_blocks, piece_blocks, ds);
         }
         uint32_t* const roots_state = ctx->cl_roots;               // [0] leaders listed, [1] handed out; the list follows (16 words in)
