@@ -386,6 +386,12 @@ class Context:
         self._c(self.lib.fgpu_diag_ovw(self.h, out))
         return dict(zip(("pieces", "rounds", "windows", "fallback_windows", "kept_piece_rounds", "table_overflow_windows"), (int(v) for v in out)))
 
+    def diag_ovw_tables(self):
+        """event tables of the optimistic walk: the most entries a round of the last scan held, and the entries per table as they stand"""
+        hw, cap = C.c_uint64(), C.c_uint64()
+        self._c(self.lib.fgpu_diag_ovw_tables(self.h, C.byref(hw), C.byref(cap)))
+        return {"high_water": int(hw.value), "capacity": int(cap.value)}
+
     def stage3_set_junctions(self, keys, recs):
         """the junction map Stage 3's walks look into (keys as JunctionMap keys them; records as junctions() returns them)"""
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

@@ -1331,6 +1331,13 @@ int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[6]) {
     return FGPU_OK;
 }
 
+int fgpu_diag_ovw_tables(fgpu_ctx* ctx, uint64_t* high_water, uint64_t* capacity) {
+    if (!ctx || !high_water || !capacity) return FGPU_ERR_ARG;
+    *high_water = ctx->counters_host->ovw_fill;          // as of the scan's last synchronising call
+    *capacity = 1ULL << ctx->ovw_ev_log2;
+    return FGPU_OK;
+}
+
 int fgpu_kernel_times(fgpu_ctx* ctx, fgpu_kernel_time* out, int cap) {
     if (!ctx) return 0;
     if (fgpu_prof_collect(ctx) != FGPU_OK) return 0;

@@ -177,6 +177,7 @@ struct DevCounters {
     unsigned long long ko_overflows;    // windows whose large clusters did not fit the key-ordered / optimistic walks' tables
     unsigned long long ovw_kept;        // optimistic walk: piece-rounds in which a piece kept its log (no earlier piece had changed what it reads)
     unsigned long long ovw[4];          // optimistic walk of large clusters: pieces walked, rounds run, windows settled, windows left to the key-ordered walk
+    unsigned long long ovw_fill;        // ... the most event-table entries a round of any window has held (k_ovw_commit counts them): the host grows the tables on it
     unsigned long long late_n[3];       // ([2] noted positions the check has passed over: every one of [0], once)
     unsigned long long late[2 * FGPU_LATE_CAP];
 };
@@ -260,6 +261,8 @@ struct fgpu_ctx {
     // three presence filters used in turn, the list of pieces; allocated when a scan first meets a large cluster
     DevBuf ovw_ev, ovw_filt, ovw_log, ovw_res, ovw_list, ovw_state, ovw_longp, ovw_marks;
     uint32_t ovw_epoch = 0;            // epoch of the newest events (1..255; the tables are wiped when it wraps)
+    int ovw_ev_log2 = 23;              // entries per event table (FGPU_OVW_EV_LOG2 sets the size a context starts with; grown when a round has filled a quarter)
+    int ovw_ev_log2_alloc = 0;         // ... the size the buffers were last made for
     int ovw_rounds = 12;               // rounds issued per window (FGPU_OVW_ROUNDS; 0 = the key-ordered walk takes every large cluster)
     uint32_t ko_hk_cap = 0, ko_occ_cap = 0;
     uint32_t walk_ko = 64;             // clusters of at least this many pieces are walked in k-mer order instead of piece order (0 = never); FGPU_WALK_KO

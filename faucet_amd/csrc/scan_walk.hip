@@ -1536,7 +1536,8 @@ struct OvwTables {
     uint32_t mark_mask;
     uint32_t* list;            // window-local indices of the pieces walked this way (k_ko_prepare)
     uint32_t list_cap;
-    uint32_t* state;           // [0] pieces listed, [1] failed (overflow), [2] rounds run, [3] some cluster holds a long piece, [8 + r] some log changed in round r
+    uint32_t* state;           // [0] pieces listed, [1] failed (overflow), [2] rounds run, [3] some cluster holds a long piece, [5] blocks of k_ovw_commit done,
+                               // [6], [7] entries of the window's rounds found in the two event tables, [8 + r] some log changed in round r
     uint32_t* longp;           // per root: the cluster holds a piece of more than 128 windows
 };
 
@@ -2291,8 +2292,28 @@ __device__ __forceinline__ void ovw_apply(uint64_t* rec_addr, uint32_t tn, uint3
 // the settled logs are applied; the counters of the settled paths are added up
 __global__ void __launch_bounds__(64) k_ovw_commit(Planes pl, FdParams fp, JTable jt, const uint32_t* __restrict__ root, const uint32_t* __restrict__ count,
                                                    const WinDesc* __restrict__ wdp, uint64_t piece_seq_base, KoTables kt, OvwTables ot, int rounds,
-                                                   DevCounters* cnt, int count_followers) {
+                                                   DevCounters* cnt, int count_followers, const unsigned long long* __restrict__ ev_keys, uint64_t ev_entries,
+                                                   uint64_t epoch_first) {
     if ((kt.state[1] & 1u) || kt.state[3] == 0) return;
+    {   // How full did the event tables get?  The two tables hold what the window's last two posting rounds left (every round posts all events
+        // again); counted here, behind the rounds, and kept as a maximum over the scan: the host grows the tables before a window overflows them
+        // (an overflow is exact -- the window goes to the key-ordered walk -- and slow)
+        unsigned n0 = 0, n1 = 0;
+        for (uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; a < ev_entries; a += (uint64_t)gridDim.x * blockDim.x) {
+            n0 += (ev_keys[a] >> 56) >= epoch_first ? 1u : 0u;
+            n1 += (ev_keys[2 * ev_entries + a] >> 56) >= epoch_first ? 1u : 0u;
+        }
+        for (int o = 32; o > 0; o >>= 1) { n0 += __shfl_down(n0, o, 64); n1 += __shfl_down(n1, o, 64); }
+        if (fd_lane() == 0) {
+            if (n0) atomicAdd(&ot.state[6], n0);
+            if (n1) atomicAdd(&ot.state[7], n1);
+            __threadfence();
+            if (atomicAdd(&ot.state[5], 1u) + 1u == gridDim.x * (blockDim.x / 64)) {
+                const unsigned a = atomicAdd(&ot.state[6], 0u), b = atomicAdd(&ot.state[7], 0u);
+                atomicMax(&cnt->ovw_fill, (unsigned long long)(a > b ? a : b));
+            }
+        }
+    }
     const int settled = ovw_settled_round(ot.state, rounds);
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // processed, skipped, jcheck, no_juncs, created, filled, walked, rounds
     if (settled >= 0) {
@@ -2728,6 +2749,7 @@ int fgpu_scan_alloc(fgpu_ctx* ctx) {
     // ... and the rule by weight: clusters whose pieces hold 128 lk positions and more between them (three pieces inside a repeat, thirty ordinary ones)
     ctx->walk_ko_weight = (ctx->prm.flags & FGPU_FLAG_KEY_ORDER_FROM_START) ? 128u : 0u;
     if (const char* e = getenv("FGPU_WALK_KO_WEIGHT")) ctx->walk_ko_weight = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("FGPU_OVW_EV_LOG2")) ctx->ovw_ev_log2 = std::min(27, std::max(8, atoi(e)));   // entries per event table to start with
     if (const char* e = getenv("FGPU_OVW_ROUNDS")) ctx->ovw_rounds = std::max(0, atoi(e));   // 0: the key-ordered walk takes every large cluster
     // (round 4: four times round 3's sizes -- the optimistic walk lets windows of repeat-rich data grow to 10^5 pieces of large clusters and more)
     ctx->ko_hk_cap = 1u << 22;
@@ -3111,13 +3133,29 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                              ctx->counters_host->walk_parallel * 256 > ctx->counters_host->walked_pieces);
         OvwTables ot;
         memset(&ot, 0, sizeof(ot));
-        constexpr int kEvLog2 = 23, kFiltLog2 = 24, kMarkLog2 = 22;
+        {   // the event tables follow what the scan has shown (weak 9 of VERDICT r4): once a round of some window has filled a quarter of a table,
+            // the next windows get tables eight times that round's entries -- before a window overflows them and is left to the key-ordered walk
+            const uint64_t fill = ctx->counters_host->ovw_fill;
+            int want = ctx->ovw_ev_log2;
+            while (want < 27 && fill * 4 > (1ULL << want)) want++;
+            if (want != ctx->ovw_ev_log2) {
+                while (want < 27 && fill * 8 > (1ULL << want)) want++;
+                if (ctx->ovw_ev.p) {     // rounds of the window before may still be reading the tables that are about to be replaced
+                    FGPU_HIP(fgpu_sync_stream(ctx, walk_stream));
+                    if (ctx->ostream) FGPU_HIP(fgpu_sync_stream(ctx, ctx->ostream));
+                }
+                ctx->ovw_ev_log2 = want;
+            }
+        }
+        const int kEvLog2 = ctx->ovw_ev_log2, kFiltLog2 = kEvLog2 + 1;
+        constexpr int kMarkLog2 = 22;
         const uint32_t filt_words = 1u << (kFiltLog2 - 5);
         const uint32_t list_cap = (uint32_t)std::min<uint64_t>(ctx->wmax, 1u << 20);
         uint32_t* ovw_filt = nullptr;
         if (ovw_on) {
             int rc;
-            const bool fresh = !ctx->ovw_ev.p;
+            const bool fresh = !ctx->ovw_ev.p || ctx->ovw_ev_log2_alloc != kEvLog2;     // (grown since the last window: other table boundaries, wipe)
+            ctx->ovw_ev_log2_alloc = kEvLog2;
             if ((rc = fgpu_ensure(ctx, &ctx->ovw_ev, 4ULL * 8 * (1ULL << kEvLog2))) || (rc = fgpu_ensure(ctx, &ctx->ovw_filt, 3ULL * 4 * filt_words)) ||
                 (rc = fgpu_ensure(ctx, &ctx->ovw_log, 2ULL * ctx->ko_occ_cap * sizeof(uint4))) || (rc = fgpu_ensure(ctx, &ctx->ovw_res, 32ULL * list_cap)) ||
                 (rc = fgpu_ensure(ctx, &ctx->ovw_marks, 3ULL * 4 * (1ULL << kMarkLog2))) ||
@@ -3168,6 +3206,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                 ev.fshift = 32 - kFiltLog2;
                 return ev;
             };
+            const uint64_t epoch_first = (uint64_t)ctx->ovw_epoch + 1;
             for (int r = 0; r < ovw_rounds; r++) {
                 ctx->ovw_epoch++;
                 ot.cur = table(r, ctx->ovw_epoch);
@@ -3181,7 +3220,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                             (const uint32_t*)ctx->bloo2, ctx->counters);
             }
             FGPU_LAUNCH("walk_ovw", k_ovw_commit, ovw_grid, 64, pl, ctx->fd, jt, (const uint32_t*)ctx->cl_fill, (const uint32_t*)cl_count, (const WinDesc*)ctx->wdesc,
-                        seq_base, kt, ot, ovw_rounds, ctx->counters, ovw_followers);
+                        seq_base, kt, ot, ovw_rounds, ctx->counters, ovw_followers, (const unsigned long long*)evb, (uint64_t)1 << kEvLog2, epoch_first);
         }
         if (ovw_on && ovw_stream != walk_stream) {
             FGPU_HIP(hipEventRecord(ctx->ev_settled, ovw_stream));

@@ -474,6 +474,11 @@ int fgpu_diag_long_pairs(fgpu_ctx* ctx, uint64_t out[6]);
  * [3] windows it left to the key-ordered walk (rounds that did not settle, full tables), [4] piece-rounds in which a piece kept its log (no
  * earlier piece had changed what it reads), [5] windows whose large clusters outgrew the tables of both walks (walked by cluster) */
 int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[6]);
+/* ... and how full its event tables got: *high_water = the most entries a round of any window of the scan held, *capacity = entries per table as
+ * they stand.  The library grows the tables (x 2 up to 2^27 entries, 32 bytes each) once a round has filled a quarter, so that coverage of many
+ * hundred-fold inside repeats does not first overflow them (exact either way: an overflowing window goes to the key-ordered walk, slowly).
+ * FGPU_OVW_EV_LOG2 = log2 of the entries a context starts with (default 23). */
+int fgpu_diag_ovw_tables(fgpu_ctx* ctx, uint64_t* high_water, uint64_t* capacity);
 /* Where the last load pass settled its occurrences (measurement: which kernel performs the reference's bloo2 sets): *in_mark = occurrences
  * whose bits were all in the carried-in state and that the marking kernel itself routed to bloo2, *pending = occurrences left to the
  * first-set-time resolution.  Valid after fgpu_load_end, until the next pass begins. */

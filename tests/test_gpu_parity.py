@@ -215,6 +215,36 @@ def test_large_clusters_walked_optimistically_settle_or_are_handed_over(rounds, 
         ctx.close()
 
 
+def test_event_tables_of_the_optimistic_walk_grow_before_they_overflow(monkeypatch):
+    """The event tables are sized by what the scan shows (fgpu_diag_ovw_tables): started at 2^10 entries on the twenty-copy repeat set, the first
+    windows overflow them -- exact: they are handed to the key-ordered walk -- and report how many entries a round held; the next windows get
+    tables eight times that.  Same map and counters as the oracle either way; with the default 2^23 entries nothing grows."""
+    monkeypatch.setenv("FGPU_WALK_KO", "16")
+    monkeypatch.setenv("FGPU_WALK_KO_ALWAYS", "1")
+    g = synth.make_genome(150_000, 91, repeats=20, repeat_len=300)
+    r = synth.make_reads(g, 60_000, 100, 0.01, 92)
+    bases, offs = po.reads_from_matrix(r)
+    k, E, S = 31, 2_000_000, 500_000
+    tai, nh = api.load_filter_shape(E, S)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh, 1, 100)
+    for start in ("10", None):
+        if start:
+            monkeypatch.setenv("FGPU_OVW_EV_LOG2", start)
+        else:
+            monkeypatch.delenv("FGPU_OVW_EV_LOG2")
+        ctx = api.Context(k, tai, nh, walk_window_span=1 << 16)
+        ctx.bloom_upload(L.BLOO2, b2.bits())
+        sc = api.ReadScanner(ctx)
+        sst = sc.scanReads(chunks(bases, offs, 6))
+        _scan_equals_oracle(sc, sst, osc)
+        t, d = ctx.diag_ovw_tables(), ctx.diag_ovw()
+        assert t["high_water"] > 0 and d["pieces"] > 1000, (t, d)
+        if start:
+            assert t["capacity"] > 1 << 10 and t["capacity"] >= 4 * t["high_water"], (t, d)
+        else:
+            assert t["capacity"] == 1 << 23 and d["fallback_windows"] == 0, (t, d)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_scan_eager_flags_mode_gives_the_same_result(name):
     c = Case(name)
