@@ -41,7 +41,7 @@ proj = "\n".join(["| N | reads per rank | pass 1 (slowest rank) + exchanges | ra
                   "|---|---|---|---|---|---|---|---|"] + [r_ for _, r_ in sorted(rows)])
 doc_path = os.path.join(ROOT, "DESIGN.md")
 doc = open(doc_path).read()
-for name, text in (("TABLE1", table1), ("TABLE2", table2), ("SUMMARY", "\n".join("* " + ln for ln in lines)), ("PROJTABLE", proj), ("PROJ8", f"{x8:.1f}" if x8 else "?")):
+for name, text in (("TABLE1", table1), ("TABLE2", table2), ("SUMMARY", "\n".join("* " + ln for ln in lines)), ("PROJTABLE", proj), ("PROJ8", f"{x8:.2f}" if x8 else "?")):
     inline = name == "PROJ8"
     pat = re.compile(r"<!-- %s -->.*?<!-- /%s -->" % (name, name), re.S)
     rep = f"<!-- {name} -->{text}<!-- /{name} -->" if inline else f"<!-- {name} -->\n{text}\n<!-- /{name} -->"
