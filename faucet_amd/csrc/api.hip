@@ -440,6 +440,13 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
         unsigned n = 1, d = 1;
         if (sscanf(sweep_env, "%u/%u", &n, &d) == 2 && d > 0) { ctx->sweep_num = n; ctx->sweep_den = d; }
     }
+    {   // a sweep streams tai x 4 bytes whatever the epoch holds: not before the epoch's accesses are tai / 16 (FGPU_SWEEP_MIN_FRAC; 0 = no such
+        // bar, rounds 1-4).  The first sweeps of a pass on large filters came after a quarter-size ramp batch and brought the carry almost nothing:
+        // one rank's own load of config 4 on 8 GPUs 350 -> 337 ms (6 sweeps -> 4), configs 2, 4, 5 whole unchanged (profiles/r05_sweep_policy.txt)
+        const char* e = getenv("FGPU_SWEEP_MIN_FRAC");
+        const double frac = e ? atof(e) : 16.0;
+        ctx->sweep_min = frac > 0.0 ? (uint64_t)((double)ctx->prm.tai / frac / (double)std::max(1, ctx->prm.n_hash)) : 0;
+    }
     if (!ctx->rec_layout) FGPU_HIP(hipMemsetAsync(ctx->first, 0xFF, ctx->prm.tai * 4, ctx->stream));   // (records: k_rec_init, fgpu_load_pair_begin)
     fgpu_resident_reset(ctx, true);
     if (!keep_carry) FGPU_HIP(hipMemsetAsync(ctx->bloo1, 0, ctx->bloom_bytes, ctx->stream));

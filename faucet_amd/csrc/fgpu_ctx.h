@@ -216,6 +216,7 @@ struct fgpu_ctx {
     uint32_t cur_tb = 0;             // time base of the batch being loaded
     bool pass_empty_carry = true;
     uint64_t pass_batches = 0;       // batches of the pass (all of them must be resident for fgpu_load_fixup)
+    uint64_t sweep_min = 0;                  // ... and not before an epoch holds this many positions (FGPU_SWEEP_MIN_FRAC: a sweep streams all of first[])
     uint32_t sweep_num = 1, sweep_den = 1;   // sweep when epoch_positions >= swept_positions * num / den (FGPU_SWEEP_RATIO=num/den)
     bool carry_by_set = false;       // large filters: the carry is updated by re-hashing the new k-mers instead of sweeping first[]
     uint32_t* bloo2 = nullptr;

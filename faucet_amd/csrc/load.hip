@@ -794,7 +794,8 @@ int fgpu_stage_load(fgpu_ctx* ctx) {
     // carry := carry | bits set during this batch -- or later: the carry may lag behind (see fgpu_load_sweep)
     if (!ctx->carry_by_set) {
         ctx->epoch_positions += span;
-        if (ctx->epoch_positions * ctx->sweep_den >= ctx->swept_positions * ctx->sweep_num && (rc = fgpu_load_sweep(ctx))) return rc;
+        if (ctx->epoch_positions * ctx->sweep_den >= ctx->swept_positions * ctx->sweep_num && ctx->epoch_positions >= ctx->sweep_min &&
+            (rc = fgpu_load_sweep(ctx))) return rc;
     }
     return fgpu_resident_keep(ctx);
 }
