@@ -375,6 +375,12 @@ class Context:
         self._c(self.lib.fgpu_scan_long_pairs_download(self.h, out.ctypes.data if tai else None, len(out) if tai else 0, C.byref(e), C.byref(ne)))
         return out, int(e.value), int(ne.value)
 
+    def scan_pairs_devptr(self, which: int):
+        """(device pointer, bytes) of a pair filter as it stands while a scan is open: 0 the short one, 1 the long one"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._c(self.lib.fgpu_scan_pairs_devptr(self.h, int(which), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def diag_long_pairs(self):
         out = (C.c_uint64 * 6)()
         self._c(self.lib.fgpu_diag_long_pairs(self.h, out))

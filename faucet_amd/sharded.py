@@ -353,8 +353,21 @@ class _HintReceiver:
             self._advance()
 
 
+def _move_pair_filters(backend, rank: int, send: bool):
+    """Both pair filters travel with the junction table (src/ReadScanner.cpp:208-225, 317-343): the short one only collects adds, the long one is
+    check-then-insert in file order -- what shard r ends with is what shard r + 1 starts from.  Shards begin at even records (the caller's
+    cut), so no first end waits across a cut."""
+    for t in getattr(backend, "pair_tensors", lambda: [])():
+        if send:
+            _send(t, rank + 1)
+        else:
+            _recv(t, rank - 1)
+
+
 def scan_sharded(backend, batches, rank: int, world: int):
     """Returns (stats, is_last): on the last rank the stats are the whole run's and backend.junctions() is the final map.
+    A backend whose pair filters are on (GpuShard.pairs_setup before the call) has them handed from shard to shard with the table; the
+    pair counts of the shards are the caller's to add up (backend.pair_counts()).
 
     The ranks behind the first one have no junction table while they run their pure stage, and with an empty table every junction test
     of every position is evaluated (105-116 ms per 10 M reads instead of ~50).  So the first rank shows them its table once it has
@@ -405,6 +418,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
         n_in = int(h[0])
         buf = backend.scratch(max(n_in, 1) * L.TABLE_ENTRY_BYTES, tag="table_in")
         _recv(buf, rank - 1)
+        backend.fence()                                    # (scan_begin emptied the pair filters on the context's stream: not after they land)
+        _move_pair_filters(backend, rank, send=False)
         backend.fence()
         CLOCK.mark("pass2_wait_for_table")                 # (the host waits here: the chain of walks of the lower ranks)
         carried = dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]]))
@@ -419,6 +434,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
         hdr[1:1 + len(_STAT_NAMES)] = torch.tensor([stats[n] for n in _STAT_NAMES], dtype=torch.int64)
         _send(hdr, rank + 1)
         _send(buf, rank + 1)
+        _move_pair_filters(backend, rank, send=True)
         CLOCK.mark("pass2_send")
     return stats, rank == world - 1
 
@@ -493,12 +509,18 @@ def run_in_turn(make_backend, shards, protocol: str = "presence", after_load=Non
     hint = [None, 0]
     table, n_table, stats = None, 0, None
     last = None
+    pair_state = None                # the pair filters as the previous shard left them (pass 2; only with a backend whose filters are on)
     for r in range(world):
         b = make_backend()
         b.clear_filters()
         b.bloom_tensor(L.BLOO2).copy_(acc2)      # what the OR-allreduce leaves on every rank
         b.fence()
         b.scan_begin()
+        if pair_state is not None:
+            b.fence()                # (scan_begin empties the filters on the context's stream: not after the copies)
+            for dst, src in zip(b.pair_tensors(), pair_state):
+                dst.copy_(src)
+            b.fence()
         if r == 0:
             total, done, marks = sum(_n_reads(x) for x in shards[0]), 0, []
             for x in shards[0]:
@@ -526,6 +548,8 @@ def run_in_turn(make_backend, shards, protocol: str = "presence", after_load=Non
             n_table, buf = b.export_table()
             b.fence()
             table = buf[:max(n_table, 1) * L.TABLE_ENTRY_BYTES].clone()
+            if getattr(b, "pair_tensors", None) and b.pair_tensors():
+                pair_state = [t.clone() for t in b.pair_tensors()]
             close(b)
         else:
             last = b
@@ -620,6 +644,31 @@ class GpuShard:
 
     def load_fixup(self, prefix):
         return self.ctx.load_fixup(prefix.data_ptr())
+
+    def pairs_setup(self, short=None, long=None, count_only=False):
+        """the pair filters of the scans to come: short / long = (tai, n_hash) or None; count_only: the paired-end loop's two counts without
+        the long filter (--no_cleaning).  The context needs record_stops."""
+        self._pairs = [bool(short), bool(long)]
+        self.ctx.scan_short_pairs(short[0], short[1], lists_to_host=False) if short else self.ctx.scan_short_pairs(0, 0, lists_to_host=False)
+        if long:
+            self.ctx.scan_long_pairs(long[0], long[1], 2)
+        else:
+            self.ctx.scan_long_pairs(0, 0, 1 if count_only else 0)
+        self._long_tai = long[0] if long else 0
+
+    def pair_tensors(self):
+        """the filters that are on, as device tensors (valid from scan_begin on): what travels from shard to shard"""
+        out = []
+        for which, on in enumerate(getattr(self, "_pairs", [False, False])):
+            if on:
+                ptr, nbytes = self.ctx.scan_pairs_devptr(which)
+                out.append(torch.as_tensor(_DevView(ptr, nbytes), device=self.device))
+        return out
+
+    def pair_counts(self):
+        """(empty, not empty) pair counts of THIS shard's scan, after scan_end"""
+        _, e, ne = self.ctx.scan_long_pairs_download(0)
+        return e, ne
 
     def scan_begin(self):
         self.ctx.scan_begin()

@@ -776,6 +776,47 @@ def test_long_pair_filter_on_the_device_equals_the_oracles(n_chunks):
     _scan_equals_oracle(ctx, sst, osc)
 
 
+@pytest.mark.parametrize("cuts", [(0, 6002, 24000, 40000), (0, 0, 13000, 13000, 40000), (0, 2, 4, 6, 39998, 40000)])
+def test_python_host_hands_both_pair_filters_from_shard_to_shard(cuts):
+    """faucet_amd/sharded.py (the host of `bench.py --gpus N`): the pair filters travel with the junction table as they do in the C++ host
+    (shard_host.h): the short one collects adds, the long one is check-then-insert in file order, shards begin at even records, the pair
+    counts of the shards add up.  Ranks in turn in one process (run_in_turn), every shard in batches that cut pairs in two; shards of a
+    single pair and empty shards among them."""
+    import torch
+    from faucet_amd import sharded
+    k, E, S = 21, 400_000, 150_000
+    bases, offs = _pairs_in_repeats(20_000, 5)
+    assert len(offs) - 1 == cuts[-1]
+    tai, nh = api.load_filter_shape(E, S)
+    b2, short, long_, osc = _paired_oracle(bases, offs, k, tai, nh, E)
+    ost = osc.stats()
+    dev = torch.device("cuda", 0)
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        inner = sorted({lo, hi, lo + (hi - lo) // 3 | 1 if hi - lo > 3 else hi, lo + 2 * (hi - lo) // 3 if hi - lo > 3 else hi})   # odd cuts inside
+        inner = [x for x in inner if lo <= x <= hi]
+        shards.append([api.ReadBatch(bases, offs[a:b + 1].copy()) for a, b in zip(inner[:-1], inner[1:]) if b > a])
+    counts = []
+
+    def make():
+        g = sharded.GpuShard(api.Context(k, tai, nh, record_stops=True), dev)
+        g.pairs_setup(short=(short.tai, short.n_hash), long=(long_.tai, long_.n_hash))
+        return g
+
+    def after_scan(r, stats, backend):
+        counts.append(backend.pair_counts())
+
+    for protocol in ("fixup", "presence"):
+        counts.clear()
+        lst, sst, last = sharded.run_in_turn(make, shards, protocol, None, after_scan)
+        assert (sum(c[0] for c in counts), sum(c[1] for c in counts)) == (ost["empty_count"], ost["not_empty_count"])
+        assert np.array_equal(last.ctx.scan_short_pairs_download(short.tai), short.bits())
+        bits, _, _ = last.ctx.scan_long_pairs_download(long_.tai)
+        assert bits.any() and np.array_equal(bits, long_.bits())
+        _scan_equals_oracle(last.ctx, sst, osc)
+        last.close()
+
+
 def test_long_pair_filter_with_ragged_reads_and_empty_records():
     """reads with N (several pieces per read, lists spliced over the pieces), empty records between them (each still toggles firstEnd) and
     batches without a single valid piece"""
