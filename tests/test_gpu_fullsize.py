@@ -228,8 +228,9 @@ def test_config5_two_hash_high_error_150bp():
     assert np.array_equal(keys, okeys) and np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["linked"], orecs["linked"])
 
 
-@pytest.mark.parametrize("ranks,per_rank,torch_stream", [(2, 2_000_000, False), (3, 700_000, False), (3, 700_000, True)])
-def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank, torch_stream):
+@pytest.mark.parametrize("ranks,per_rank,torch_stream,pairs", [(2, 2_000_000, False, False), (3, 700_000, False, False), (3, 700_000, True, False),
+                                                               (3, 400_000, False, True), (2, 400_000, True, True)])
+def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank, torch_stream, pairs):
     """bench.py's multi-GPU path (sharded.py over GpuShard) in real separate processes, one per rank, all on this GPU with gloo as
     the transport (scripts/two_rank_check.py): result identical to one context fed all shards in file order.  With the library on a
     stream of its own every exchange is fenced on the host (two fences were missing until late in round 2: one run in ten came out with a
@@ -242,6 +243,8 @@ def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank, torch_str
     env = dict(os.environ, GLOO_SOCKET_IFNAME="lo")      # one node: gloo must not look the host name up to find an interface
     if torch_stream:                                     # the library on torch's stream and no host fence, as bench.py runs N > 1
         env["FAUCET_TORCH_STREAM"] = "1"
+    if pairs:                                            # both pair filters on, travelling with the table (round 5)
+        env["FAUCET_CHECK_PAIRS"] = "1"
     r = None
     for attempt in range(2):
         with socket.socket() as s:
