@@ -392,6 +392,15 @@ class Context:
         self._c(self.lib.fgpu_diag_ovw(self.h, out))
         return dict(zip(("pieces", "rounds", "windows", "fallback_windows", "kept_piece_rounds", "table_overflow_windows"), (int(v) for v in out)))
 
+    def scan_refresh_prepared(self):
+        """the in-map planes of every prepared batch made again against the preview in the table (after a fresher import_hint)"""
+        self._c(self.lib.fgpu_scan_refresh_prepared(self.h))
+
+    def diag_prepared_refresh(self):
+        out = (C.c_uint64 * 4)()
+        self._c(self.lib.fgpu_diag_prepared_refresh(self.h, out))
+        return dict(zip(("batches_in_full", "batches_merged", "new_keys", "mismatching_words"), (int(v) for v in out)))
+
     def diag_ovw_tables(self):
         """event tables of the optimistic walk: the most entries a round of the last scan held, and the entries per table as they stand"""
         hw, cap = C.c_uint64(), C.c_uint64()

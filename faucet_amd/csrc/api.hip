@@ -629,6 +629,10 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->have_import = false;
     ctx->journal_max_read_len = 0;
     ctx->hint_in_table = false;
+    ctx->hint_gen = 0;
+    ctx->hint_n = ctx->hint_max_seq = 0;
+    ctx->delta_ready = false;
+    ctx->delta_keys = ctx->refresh_full = ctx->refresh_delta = ctx->refresh_mismatch = 0;
     // calibrated upwards window by window; a context that has scanned before starts a quarter below where that scan ended up
     const uint64_t start_span = std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4);
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
@@ -856,6 +860,7 @@ static int scan_replay(fgpu_ctx* ctx) {
     ctx->scan_imported = 0;
     ctx->delta_next = 0;
     ctx->hint_in_table = false;
+    ctx->delta_ready = false;            // (the replay makes every batch's planes from scratch against the table as it stands)
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
                                                  : std::min<uint64_t>(std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4), ctx->max_span);
     ctx->calib_left = 16;
@@ -975,7 +980,27 @@ int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
         return fgpu_scan_prepare(ctx, reads);
     }
     if (rc) { ctx->pool.push_back(b); return rc; }
+    b->planes_gen = ctx->hint_in_table ? ctx->hint_gen : 0;      // what this batch's snapshot planes speak of
     ctx->prepared.push_back(b);
+    return FGPU_OK;
+}
+
+// Read shards: a FRESHER preview has taken the place of the one the batches were prepared against (fgpu_scan_import_hint again: the table the
+// shard below was handed, one hop before this shard's own arrives) -- the snapshot planes of every prepared batch are made again against it,
+// off the chain of walks.  When the real table arrives it differs from this preview by the keys ONE shard created, and the walk only has to
+// look for those (fgpu_scan_import_table).
+int fgpu_scan_refresh_prepared(fgpu_ctx* ctx) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ctx->phase != 2) { ctx->err = "scan_refresh_prepared outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
+    if (!ctx->hint_in_table) { ctx->err = "scan_refresh_prepared without a preview in the table (fgpu_scan_import_hint)"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    for (BatchBufs* b : ctx->prepared) {
+        if (b->planes_gen == ctx->hint_gen) continue;
+        if (int rc = fgpu_scan_refresh_planes(ctx, b)) return rc;
+        b->planes_gen = ctx->hint_gen;
+    }
+    ctx->launch_stream = ctx->stream;
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     return FGPU_OK;
 }
 
@@ -1172,9 +1197,30 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
     if (ctx->phase != 2) { ctx->err = "import_table outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
     int rc = sync_all(ctx);
     if (rc) return rc;
+    ctx->delta_ready = false;
     if (ctx->hint_in_table) {   // the preview has done its work (the prepared batches' planes): the real table takes its place
         if ((rc = fgpu_scan_clear_table(ctx))) return rc;
         ctx->hint_in_table = false;
+        // If every prepared batch's planes speak of the newest preview and this table is a LATER STATE of it (the caller's promise, checked by
+        // counting: the entries with a creation stamp beyond the preview's are exactly the surplus), the walk merges the new keys into the planes
+        // through a filter of just those keys instead of probing the whole table's filter at every position again (22 -> ~7 ms per 25 M reads).
+        static const bool no_delta = getenv("FGPU_NO_DELTA_REFRESH") != nullptr;
+        bool all = ctx->hint_gen != 0 && !ctx->prepared.empty() && !no_delta && n_entries >= ctx->hint_n;
+        for (BatchBufs* b : ctx->prepared) all = all && b->planes_gen == ctx->hint_gen;
+        const uint64_t surplus = all ? n_entries - ctx->hint_n : 0;
+        if (all && surplus <= (1ULL << 23)) {
+            uint64_t bits = 1ULL << 20;      // (room for what this shard's own batches will add: they join the filter as they are walked)
+            while (bits < 32 * surplus) bits <<= 1;
+            if ((rc = fgpu_ensure(ctx, &ctx->delta_filter, bits / 8))) return rc;
+            FGPU_HIP(hipMemsetAsync(ctx->delta_filter.p, 0, bits / 8, ctx->stream));
+            uint64_t max_seq = 0, newer = 0;
+            if ((rc = fgpu_scan_import_probe(ctx, dev_buf, n_entries, ctx->hint_max_seq, (uint32_t*)ctx->delta_filter.p, bits, &max_seq, &newer))) return rc;
+            if (newer == surplus) {
+                ctx->delta_ready = true;
+                ctx->delta_filter_bits = bits;
+                ctx->delta_keys = newer;
+            }
+        }
     }
     if ((rc = fgpu_scan_reserve(ctx, ctx->counters_host->n_junctions + ctx->scan_imported + n_entries))) return rc;
     rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries);
@@ -1200,16 +1246,22 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
 int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries) {
     if (!ctx || (n_entries && !dev_buf)) return FGPU_ERR_ARG;
     if (ctx->phase != 2) { ctx->err = "import_hint outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
-    if (ctx->scan_windows || ctx->scan_imported || ctx->hint_in_table) {
+    if (ctx->scan_windows || ctx->scan_imported) {
         ctx->err = "import_hint comes before any walk and before the real table (batches prepared earlier have simply seen an empty table)";
         return FGPU_ERR_STATE;
     }
     int rc = sync_all(ctx);
     if (rc) return rc;
+    if (ctx->hint_in_table && (rc = fgpu_scan_clear_table(ctx))) return rc;      // a fresher preview takes the place of an older one
     if ((rc = fgpu_scan_reserve(ctx, n_entries))) return rc;
     if ((rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries))) return rc;
+    uint64_t newer = 0;
+    ctx->hint_max_seq = 0;
+    if ((rc = fgpu_scan_import_probe(ctx, dev_buf, n_entries, ~0ULL, nullptr, 0, &ctx->hint_max_seq, &newer))) return rc;
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     ctx->hint_in_table = true;
+    ctx->hint_n = n_entries;
+    ctx->hint_gen++;
     return FGPU_OK;
 }
 
@@ -1335,6 +1387,15 @@ int fgpu_diag_ovw(fgpu_ctx* ctx, uint64_t out[6]) {
     for (int i = 0; i < 4; i++) out[i] = ctx->counters_host->ovw[i];   // as of the scan's last synchronising call (fgpu_scan_end)
     out[4] = ctx->counters_host->ovw_kept;
     out[5] = ctx->counters_host->ko_overflows;
+    return FGPU_OK;
+}
+
+int fgpu_diag_prepared_refresh(fgpu_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return FGPU_ERR_ARG;
+    out[0] = ctx->refresh_full;
+    out[1] = ctx->refresh_delta;
+    out[2] = ctx->delta_keys;
+    out[3] = ctx->refresh_mismatch;
     return FGPU_OK;
 }
 

@@ -66,6 +66,7 @@ struct BatchBufs {
     hipEvent_t pure_done = nullptr;   // main stream: planes of this batch are complete
     hipEvent_t walk_done = nullptr;   // walk stream: the walk has finished with this batch's buffers
     bool walk_pending = false;
+    uint32_t planes_gen = 0;       // read shards: the preview (fgpu_scan_import_hint, counted from 1) the snapshot planes nF / nB speak of; 0 = an empty table
 };
 
 // Planes of a load batch kept in HBM for the scan pass over the same reads: codes/bad identify the batch (the scan compares
@@ -281,6 +282,16 @@ struct fgpu_ctx {
     uint64_t scan_piece_base = 0;    // pieces walked by earlier batches (creation stamps)
     uint64_t scan_imported = 0;      // junction records imported from a previous shard
     bool hint_in_table = false;      // fgpu_scan_import_hint: the table holds a preview, not the state to walk on
+    // ... the newest preview: its number within the scan, its entries, the largest creation stamp (piece number) among them.  If every prepared
+    // batch's planes speak of it when the real table arrives, only the keys created SINCE have to be looked for (fgpu_scan_import_table):
+    uint32_t hint_gen = 0;
+    uint64_t hint_n = 0, hint_max_seq = 0;
+    DevBuf delta_filter;             // presence filter of the keys of the imported table that are newer than the preview (two bits of one word per key)
+    uint64_t delta_filter_bits = 0;
+    bool delta_ready = false;        // the walk of the prepared batches merges the new keys into their planes instead of making the planes again
+    uint64_t delta_keys = 0;         // (diagnostics: keys in the filter; batches whose planes were made again in full / merged)
+    uint64_t refresh_full = 0, refresh_delta = 0, refresh_mismatch = 0;
+    unsigned long long* import_probe = nullptr;   // device: [0] largest piece number among the entries of the last import, [1] entries newer than the preview
     uint64_t scan_grown = 0;         // times the junction table was rehashed into a larger one
 
     DevCounters* counters = nullptr;      // device
@@ -462,6 +473,8 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_stage_scan_need(fgpu_ctx* ctx);
 int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b);
+int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, uint64_t after_seq, uint32_t* dfilter, uint64_t dfilter_bits,
+                           uint64_t* max_seq, uint64_t* n_newer);
 int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx);
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);
 int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out);

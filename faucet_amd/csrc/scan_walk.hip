@@ -2540,6 +2540,48 @@ __global__ void __launch_bounds__(256) k_need_lookup(const uint64_t* __restrict_
     }
 }
 
+// the two bits of a key in the filter of NEW keys (fgpu_scan_import_table; k_refresh_lookup probes it with the same rule): one word, two bits
+__device__ __forceinline__ uint64_t delta_word(uint32_t h32, uint64_t bits_mask) {
+    return ((((uint64_t)(h32 * 0x9E3779B1u) << 16) ^ (uint64_t)(h32 >> 7)) & bits_mask) >> 5;
+}
+__device__ __forceinline__ uint32_t delta_bits(uint32_t h32) { return (1u << (h32 & 31)) | (1u << ((h32 >> 22) & 31)); }
+
+// The same planes made AGAIN for a batch whose hash plane exists (prepared batches of a read shard, right before their walk: the table has been
+// replaced since the pure stage made them): the hash is read back instead of being extracted, mixed and written a second time (4 bytes per
+// position of stores), the k-mer is only taken out where the filter says it may be in the map.  merge: the planes keep the bits they have
+// (a filter of the keys that are NEW since the planes were made -- the table only grows).
+__global__ void __launch_bounds__(256) k_refresh_lookup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm, uint64_t n_words,
+                                                        FdParams fp, JTable jt, const uint32_t* __restrict__ filter, uint64_t filter_mask,
+                                                        uint64_t* __restrict__ nF, uint64_t* __restrict__ nB, const uint32_t* __restrict__ kh, int merge) {
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool inF = false, inB = false;
+        if ((pm[p >> 6] >> (p & 63)) & 1ULL) {
+            const uint32_t h32 = kh[p];
+            const uint64_t hb = ((((uint64_t)(h32 * 0x9E3779B1u) << 16) ^ (uint64_t)(h32 >> 7)) & filter_mask);
+            const bool maybe = merge ? (filter[hb >> 5] & delta_bits(h32)) == delta_bits(h32) : (((filter[hb >> 5] >> (hb & 31)) & 1u) != 0);
+            if (maybe) {
+                const uint64_t km = fd_kmer_at(codes, p, fp.k);
+                const uint64_t rc = fd_revcomp(km, fp.k);
+                const uint64_t canon = km < rc ? km : rc;
+                const uint32_t present = jt_present_snapshot(jt, canon);
+                inF = (present >> (km == canon ? 0 : 1)) & 1u;
+                inB = (present >> (rc == canon ? 0 : 1)) & 1u;
+            }
+        }
+        const uint64_t mF = __ballot(inF), mB = __ballot(inB);
+        if (fd_lane() == 0) {
+            if (merge) { if (mF) nF[p >> 6] |= mF; if (mB) nB[p >> 6] |= mB; }
+            else { nF[p >> 6] = mF; nB[p >> 6] = mB; }
+        }
+    }
+}
+
+__global__ void k_dbg_diff(const uint64_t* a, const uint64_t* b, uint64_t n, unsigned long long* out, int slot) {
+    unsigned long long d = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+    if (d) atomicAdd(&out[slot], d);
+}
 __device__ __forceinline__ void need_mark(unsigned long long* need, uint64_t a, uint64_t z) {   // positions [a, z)
     while (a < z) {
         uint64_t wi = a >> 6;
@@ -2695,6 +2737,46 @@ __global__ void __launch_bounds__(256) k_gather_sorted(const ExportEntry* in, co
     for (int c = 0; c < 4; c++) r.cov[c] = e.rec[5 + c];
     for (int c = 0; c < 5; c++) { r.dist[c] = e.rec[c]; r.linked[c] = (e.rec[9] >> c) & 1; }
     recs[i] = r;
+}
+
+// the keys a batch of this shard has just created join the filter of new keys: the batches behind it were prepared before ANY of this shard was
+// walked, and their planes are only merged with what the filter names (the full refresh sees the table as it stands; this is its equal)
+__global__ void __launch_bounds__(256) k_delta_filter_add(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ count, uint32_t* dfilter,
+                                                          uint64_t dmask) {
+    const uint64_t n = *count;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t h32 = list[i];
+        atomicOr(&dfilter[delta_word(h32, dmask)], delta_bits(h32));
+    }
+}
+
+// what an import has to know about its entries beyond putting them into the table: the largest creation stamp (piece number) among them, and --
+// when a preview is being replaced by a later state of the same table -- which keys are newer than the preview: counted, and put into the filter
+__global__ void __launch_bounds__(256) k_import_probe(const ExportEntry* in, uint64_t n, FdParams fp, uint64_t after_seq, uint32_t* dfilter,
+                                                      uint64_t dmask, unsigned long long* out) {
+    unsigned long long mx = 0, newer = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const ExportEntry e = in[i];
+        const unsigned long long seq = e.stamp >> STAMP_SHIFT;
+        mx = seq > mx ? seq : mx;
+        if (seq > after_seq) {
+            newer++;
+            if (dfilter) {
+                const uint64_t rc = fd_revcomp(e.key, fp.k);
+                const uint32_t h32 = jt_h32(e.key < rc ? e.key : rc);
+                atomicOr(&dfilter[delta_word(h32, dmask)], delta_bits(h32));
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_down(mx, o, 64);
+        mx = t > mx ? t : mx;
+        newer += __shfl_down(newer, o, 64);
+    }
+    if (fd_lane() == 0) {
+        if (mx) atomicMax(&out[0], mx);
+        if (newer) atomicAdd(&out[1], newer);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_import(JTable jt, FdParams fp, const ExportEntry* in, uint64_t n, DevCounters* cnt) {
@@ -2895,8 +2977,8 @@ int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b) {
     if (!b->n_pieces || !b->T) return FGPU_OK;
     JTable jt = make_jt(ctx);
     ctx->launch_stream = ctx->stream;
-    FGPU_LAUNCH("need_lookup", k_need_lookup, fgpu_grid(b->n_words * 64, 256), 256, (const uint64_t*)b->codes.p, (const uint64_t*)b->pm.p, b->n_words,
-                ctx->fd, jt, (uint64_t*)b->nF.p, (uint64_t*)b->nB.p, (uint32_t*)b->kh.p, (uint64_t)0);
+    FGPU_LAUNCH("need_lookup", k_refresh_lookup, fgpu_grid(b->n_words * 64, 256), 256, (const uint64_t*)b->codes.p, (const uint64_t*)b->pm.p, b->n_words,
+                ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, (uint64_t*)b->nF.p, (uint64_t*)b->nB.p, (const uint32_t*)b->kh.p, 0);
     if (b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
     return FGPU_OK;
 }
@@ -2960,8 +3042,40 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         // batches that were prepared before their turn (multi-GPU shards; scan_prepare / scan_walk_prepared) carry snapshot planes of a table
         // that has since been replaced or walked on by an unknown number of batches: made again here, behind the previous batch's walk
         // (the preview -- need plane and junction tests -- stays what it was: it is checked by the walk, not trusted)
-        FGPU_LAUNCH("walk_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
-                    ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p, (uint64_t)0);
+        static const bool old_refresh = getenv("FGPU_REFRESH_OLD") != nullptr;      // measurement aid: the pure stage's kernel, as until round 5
+        if (old_refresh)
+            FGPU_LAUNCH("walk_lookup", k_need_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
+                        ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p, (uint64_t)0);
+        else if (ctx->delta_ready && bb.planes_gen == ctx->hint_gen) {
+            // the planes speak of the newest preview and the table is a later state of it: only the keys created since are looked for and merged in
+            if (ctx->delta_keys || ctx->refresh_delta)      // (nothing new in the table and nothing walked yet: the planes stand)
+                FGPU_LAUNCH("walk_lookup", k_refresh_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
+                            ctx->fd, jt, (const uint32_t*)ctx->delta_filter.p, ctx->delta_filter_bits - 1, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p,
+                            (const uint32_t*)bb.kh.p, 1);
+            ctx->refresh_delta++;
+            if (getenv("FGPU_DEBUG_DELTA_CHECK")) {      // tests: the merged planes against planes made again in full, word by word
+                uint64_t *cF = nullptr, *cB = nullptr;
+                unsigned long long* out = nullptr;
+                FGPU_HIP(hipMalloc(&cF, bb.n_words * 8));
+                FGPU_HIP(hipMalloc(&cB, bb.n_words * 8));
+                FGPU_HIP(hipMalloc(&out, 32));
+                FGPU_HIP(hipMemsetAsync(out, 0, 32, walk_stream));
+                hipLaunchKernelGGL(k_refresh_lookup, dim3(fgpu_grid(bb.n_words * 64, 256)), dim3(256), 0, walk_stream, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
+                                   bb.n_words, ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, cF, cB, (const uint32_t*)bb.kh.p, 0);
+                hipLaunchKernelGGL(k_dbg_diff, dim3(64), dim3(256), 0, walk_stream, (const uint64_t*)cF, (const uint64_t*)bb.nF.p, bb.n_words, out, 0);
+                hipLaunchKernelGGL(k_dbg_diff, dim3(64), dim3(256), 0, walk_stream, (const uint64_t*)cB, (const uint64_t*)bb.nB.p, bb.n_words, out, 1);
+                unsigned long long h[4] = {0, 0, 0, 0};
+                FGPU_HIP(hipMemcpyAsync(h, out, 32, hipMemcpyDeviceToHost, walk_stream));
+                FGPU_HIP(hipStreamSynchronize(walk_stream));
+                ctx->refresh_mismatch += h[0] + h[1];
+                if (h[0] + h[1]) fprintf(stderr, "[fgpu] merged in-map planes differ from planes made again: batch %llu, %llu + %llu words\n", (unsigned long long)bb.seq, h[0], h[1]);
+                (void)hipFree(cF); (void)hipFree(cB); (void)hipFree(out);
+            }
+        } else {
+            FGPU_LAUNCH("walk_lookup", k_refresh_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
+                        ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (const uint32_t*)bb.kh.p, 0);
+            ctx->refresh_full++;
+        }
     }
     if (ctx->record_stops) {
         const uint64_t wb = (bb.n_words + FGPU_PADW) * 8;
@@ -3312,6 +3426,9 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             }
         }
     }
+    if (ctx->delta_ready)      // (read shards, planes merged instead of made again: see k_delta_filter_add)
+        FGPU_LAUNCH("walk_delta", k_delta_filter_add, 256, 256, (const uint32_t*)mine_list.list.p, (const unsigned long long*)mine_list.count.p,
+                    (uint32_t*)ctx->delta_filter.p, ctx->delta_filter_bits - 1);
     ctx->delta_next++;
     ctx->window_span = span_now;
     ctx->prof_suppress = false;
@@ -3542,6 +3659,22 @@ int fgpu_scan_export_impl(fgpu_ctx* ctx, void* dev_entries, uint64_t cap_entries
 int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n) {
     if (!n) return FGPU_OK;
     FGPU_LAUNCH("import", k_import, fgpu_blocks(n, 256), 256, make_jt(ctx), ctx->fd, (const ExportEntry*)dev_entries, n, ctx->counters);
+    return FGPU_OK;
+}
+
+int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, uint64_t after_seq, uint32_t* dfilter, uint64_t dfilter_bits,
+                           uint64_t* max_seq, uint64_t* n_newer) {
+    *max_seq = *n_newer = 0;
+    if (!n) return FGPU_OK;
+    if (!ctx->import_probe) FGPU_HIP(hipMalloc(&ctx->import_probe, 16));
+    FGPU_HIP(hipMemsetAsync(ctx->import_probe, 0, 16, ctx->stream));
+    FGPU_LAUNCH("import", k_import_probe, (unsigned)std::min<uint64_t>(fgpu_blocks(n, 256), 4096), 256, (const ExportEntry*)dev_entries, n, ctx->fd, after_seq, dfilter,
+                dfilter_bits ? dfilter_bits - 1 : 0, ctx->import_probe);
+    unsigned long long out[2] = {0, 0};
+    FGPU_HIP(hipMemcpyAsync(out, ctx->import_probe, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
+    *max_seq = out[0];
+    *n_newer = out[1];
     return FGPU_OK;
 }
 

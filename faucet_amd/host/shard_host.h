@@ -203,6 +203,9 @@ public:
         const bool short_pairs = !o_.no_cleaning && o_.short_tai, long_filter = o_.paired_ends && !o_.no_cleaning && o_.long_tai;
         hint_ = Announce();
         chain_.assign((size_t)n, Announce());
+        late_.assign((size_t)n, Announce());
+        const char* late_env = getenv("FAUCET_LATE_HINT");
+        const bool late_hints = !(late_env && late_env[0] == '0');
         std::vector<uint64_t> empty((size_t)n, 0), not_empty((size_t)n, 0);
         fgpu_scan_stats last_stats;
         memset(&last_stats, 0, sizeof(last_stats));
@@ -215,8 +218,8 @@ public:
             RANK_CHECK(fgpu_scan_begin(c));
             fgpu_scan_stats st;
             memset(&st, 0, sizeof(st));
-            void *hint_buf = nullptr, *table_in = nullptr, *table_out = nullptr;
-            struct FreeAll { fgpu_ctx* c; void** p[3]; ~FreeAll() { for (void** q : p) if (*q) fgpu_device_free(c, *q); } } free_all{c, {&hint_buf, &table_in, &table_out}};
+            void *hint_buf = nullptr, *table_in = nullptr, *table_out = nullptr, *late_buf = nullptr;
+            struct FreeAll { fgpu_ctx* c; void** p[4]; ~FreeAll() { for (void** q : p) if (*q) fgpu_device_free(c, *q); } } free_all{c, {&hint_buf, &table_in, &table_out, &late_buf}};
             if (r == 0) {
                 // the first shard has nothing to wait for: it streams (pure stage of batch b + 1 beside the walk of batch b, lazy junction tests).
                 // Once a quarter of it is walked the others are shown its table -- an earlier state of the very table they will be handed, which is
@@ -257,12 +260,27 @@ public:
                     return fgpu_scan_prepare(c, b);
                 }, nullptr));
                 if (!have_hint) RANK_TRY(take_hint(true, false));   // the send is received even when it came too late to be of use
+                if (late_hints && r > 1) {
+                    // the table the rank below has just been HANDED, passed on at once: a preview one shard older than the table this rank will get.
+                    // The planes of the prepared batches are made again against it while the rank below walks; the walk then only looks for the
+                    // keys that rank created (fgpu_scan_refresh_prepared, faucet_gpu.h)
+                    uint64_t n_late = 0;
+                    if (!announced(&late_[(size_t)r], true, &n_late, nullptr)) { err_[(size_t)r] = "the run was aborted while this rank waited for the fresher preview"; return FGPU_ERR_STATE; }
+                    RANK_CHECK(fgpu_device_alloc(c, std::max<uint64_t>(n_late, 1) * FGPU_TABLE_ENTRY_BYTES, &late_buf));
+                    GROUP_CHECK(fgpu_group_recv(group_, r, r - 1, late_buf, n_late * FGPU_TABLE_ENTRY_BYTES));
+                    RANK_CHECK(fgpu_scan_import_hint(c, late_buf, n_late));
+                    RANK_CHECK(fgpu_scan_refresh_prepared(c));
+                }
                 const double t1 = now_ms();
                 uint64_t n_in = 0;
                 fgpu_scan_stats carried;
                 if (!announced(&chain_[(size_t)r], true, &n_in, &carried)) { err_[(size_t)r] = "the run was aborted while this rank waited for the junction table"; return FGPU_ERR_STATE; }
                 RANK_CHECK(fgpu_device_alloc(c, std::max<uint64_t>(n_in, 1) * FGPU_TABLE_ENTRY_BYTES, &table_in));
                 GROUP_CHECK(fgpu_group_recv(group_, r, r - 1, table_in, n_in * FGPU_TABLE_ENTRY_BYTES));
+                if (late_hints && r + 1 < n) {                       // pass it on before walking on it: the copy runs beside the walk
+                    GROUP_CHECK(fgpu_group_send_async(group_, r, r + 1, table_in, n_in * FGPU_TABLE_ENTRY_BYTES));
+                    announce(&late_[(size_t)r + 1], n_in, nullptr);
+                }
                 RANK_TRY(move_pair_filters(r, short_pairs, long_filter, false));
                 const double t2 = now_ms();
                 RANK_CHECK(fgpu_scan_import_table(c, table_in, n_in, &carried));   // (takes the place of the preview)
@@ -282,7 +300,7 @@ public:
             } else {
                 last_stats = st;
             }
-            if (r == 0 && n > 1) GROUP_CHECK(fgpu_group_flush(group_, 0));
+            if (n > 1 && (r == 0 || (late_hints && r + 1 < n))) GROUP_CHECK(fgpu_group_flush(group_, r));      // (asynchronous sends: the previews)
             RANK_CHECK(fgpu_synchronize(c));
             return FGPU_OK;
         });
@@ -410,6 +428,7 @@ private:
     std::atomic<bool> aborted_{false};
     Announce hint_;
     std::vector<Announce> chain_;
+    std::vector<Announce> late_;      // the table a rank was handed, passed on to the rank above as a fresher preview
 };
 
 }  // namespace faucet_host

@@ -94,6 +94,12 @@ def _send(t, dst):
     dist.send(_staging.out(t) if _staged(t) else t, dst=dst)
 
 
+def _isend(t, dst):
+    """a send the caller does not wait for now: (request, the tensor that has to outlive it)"""
+    src = _staging.out(t) if _staged(t) else t
+    return dist.isend(src, dst=dst), src
+
+
 def _recv(t, src):
     if _staged(t):
         h = _staging.landing(t)
@@ -293,6 +299,10 @@ def load_sharded_presence(backend, batches, rank: int, world: int):
 # batches prepared without one: with the 2-rank shapes the pure stage of a later rank takes 91.8 ms behind a hint taken at 10 %, 75.0 ms
 # at 25 % (117 without); 25 % arrives ~20 ms into the scan, 10 % ~8 ms (scripts/rank_stage_times.py, HINT_AFTER=...)
 HINT_AFTER = 0.25
+# Round 5: a rank that is handed the junction table passes it on at once, as a FRESHER PREVIEW, to the rank above, which makes the in-map planes of
+# its prepared batches again against it while this rank walks; when its own table arrives it differs from that preview by what ONE shard created,
+# and its walk looks only for those keys (faucet_gpu.h, fgpu_scan_refresh_prepared): 22 -> ~7 ms of every hop from the third rank on.
+LATE_HINT = os.environ.get("FAUCET_LATE_HINT", "1") != "0"      # (has to be the same on every rank)
 
 
 def _n_reads(b):
@@ -412,12 +422,27 @@ def scan_sharded(backend, batches, rank: int, world: int):
             rx.finish()                                    # the collective is completed even when it came too late to be of use
         CLOCK.mark("pass2_pure_stage")
     hdr = backend.header_tensor()
+    late = LATE_HINT and hasattr(backend, "refresh_prepared")
+    forwarded = None
+    if rank > 1 and late:
+        # the table the rank below has just been handed: a preview one shard older than the table this rank will get
+        _recv(hdr, rank - 1)
+        n_late = int(hdr.cpu().tolist()[0])
+        late_buf = backend.scratch(max(n_late, 1) * L.TABLE_ENTRY_BYTES, tag="table_late")
+        _recv(late_buf, rank - 1)
+        backend.fence()
+        backend.import_hint(late_buf, n_late)
+        backend.refresh_prepared()
+        CLOCK.mark("pass2_late_hint")
     if rank > 0:
         _recv(hdr, rank - 1)
         h = hdr.cpu().tolist()
         n_in = int(h[0])
         buf = backend.scratch(max(n_in, 1) * L.TABLE_ENTRY_BYTES, tag="table_in")
         _recv(buf, rank - 1)
+        if late and rank < world - 1:                      # pass it on before walking on it (the sends complete beside the walk)
+            fhdr = hdr.clone()
+            forwarded = [_isend(fhdr, rank + 1), _isend(buf, rank + 1)]
         backend.fence()                                    # (scan_begin emptied the pair filters on the context's stream: not after they land)
         _move_pair_filters(backend, rank, send=False)
         backend.fence()
@@ -425,6 +450,9 @@ def scan_sharded(backend, batches, rank: int, world: int):
         carried = dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]]))
         stats = backend.walk_shard(batches, buf, n_in, carried)   # import (replaces the hint) + ordered walk of this shard + scan_end
         CLOCK.mark("pass2_import_and_walk")
+    if forwarded:
+        for req, keep in forwarded:
+            req.wait()
     if rank < world - 1:
         n_out, buf = backend.export_table()
         backend.fence()
@@ -509,6 +537,7 @@ def run_in_turn(make_backend, shards, protocol: str = "presence", after_load=Non
     hint = [None, 0]
     table, n_table, stats = None, 0, None
     last = None
+    older = None                     # the table the previous rank was handed (what it passes on as a fresher preview)
     pair_state = None                # the pair filters as the previous shard left them (pass 2; only with a backend whose filters are on)
     for r in range(world):
         b = make_backend()
@@ -540,8 +569,12 @@ def run_in_turn(make_backend, shards, protocol: str = "presence", after_load=Non
             b.import_hint(hint[0], hint[1])
             for batch in shards[r]:
                 b.scan_prepare(batch)
+            if r > 1 and LATE_HINT and hasattr(b, "refresh_prepared"):      # the table the rank below was handed, as scan_sharded passes it on
+                b.import_hint(older[0], older[1])
+                b.refresh_prepared()
             carried = {n: int(stats[n]) for n in _STAT_NAMES}
             stats = b.walk_shard(shards[r], table, n_table, carried)
+            older = (table, n_table)
         if after_scan:
             after_scan(r, stats, b)
         if r < world - 1:
@@ -688,6 +721,9 @@ class GpuShard:
 
     def import_hint(self, buf, n):
         self.ctx.import_hint(buf.data_ptr(), n)
+
+    def refresh_prepared(self):
+        self.ctx.scan_refresh_prepared()
 
     def walk_shard(self, batches, buf, n, carried):
         """the handed-over table takes the place of the preview, then the ordered walk of the prepared batches"""

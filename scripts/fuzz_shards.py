@@ -57,7 +57,17 @@ for seed in range(lo, hi):
             def after_load(rk, stats, t1, t2):
                 seen.append((rk, np.array_equal(t1.cpu().numpy(), after[rk][0]), np.array_equal(t2.cpu().numpy(), after[rk][1])))
 
-            lst, sst, last = sharded.run_in_turn(lambda: sharded.GpuShard(api.Context(k, tai, nh, j=j), dev), shards, protocol, after_load, None)
+            merged = [0, 0]
+
+            def after_scan(rk, stats, backend):      # (with FGPU_DEBUG_DELTA_CHECK=1 the library compares merged in-map planes with planes made again)
+                d = backend.ctx.diag_prepared_refresh()
+                merged[0] += d["batches_merged"]
+                merged[1] += d["mismatching_words"]
+
+            lst, sst, last = sharded.run_in_turn(lambda: sharded.GpuShard(api.Context(k, tai, nh, j=j), dev), shards, protocol, after_load, after_scan)
+            assert merged[1] == 0, (protocol, "merged planes differ from planes made again", merged)
+            total_merged = globals().get("total_merged", 0) + merged[0]
+            globals()["total_merged"] = total_merged
             keys, recs = last.ctx.junctions()
             last.close()
             assert all(x[1] and x[2] for x in seen) and len(seen) == world, (protocol, "filters after a shard", seen)
@@ -68,5 +78,5 @@ for seed in range(lo, hi):
     except Exception as e:   # noqa: BLE001
         bad += 1
         print("seed", seed, "FAILED", repr(e)[:500], flush=True)
-print("done, seeds", lo, "to", hi - 1, "failures:", bad)
+print("done, seeds", lo, "to", hi - 1, "failures:", bad, "| batches whose planes were merged with the new keys:", globals().get("total_merged", 0))
 sys.exit(1 if bad else 0)

@@ -79,12 +79,16 @@ def show(i):
         hint[0] = (buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n)
 
 
+older = None
 stats0 = timed("rank 0: streaming scan of its shard", lambda: b.scan_stream(batches0, after_batch=show) if HOP == 1 else None)
 if HOP > 1:       # the table a later rank is handed: shards 0 .. HOP - 1 scanned one after the other by this one context (the same map, the same counters)
     for x in batches0:
         ctx.scan_batch(x)
         show(len(batches0))
     for r in range(1, HOP):
+        if r == HOP - 1:      # the table rank HOP - 1 is handed: what it passes on to rank HOP as a fresher preview (round 5)
+            n_o, buf_o = b.export_table(tag="older")
+            older = (buf_o[:max(n_o, 1) * L.TABLE_ENTRY_BYTES].clone(), n_o)
         del batches0, reads0
         reads0, batches0 = batches_of(r)
         for x in batches0:
@@ -103,6 +107,9 @@ for rep in range(2):
     b.scan_begin()
     b.import_hint(hint[0][0], hint[0][1])
     timed(f"rank {HOP}: pure stage on the preview", lambda: [b.scan_prepare(x) for x in batches1])
+    if HOP > 1 and sharded.LATE_HINT and older is not None:
+        timed(f"rank {HOP}: fresher preview ({older[1]} records) imported, planes of the prepared batches made again (off the chain)",
+              lambda: (b.import_hint(older[0], older[1]), b.refresh_prepared()))
     carried = {n: int(stats0[n]) for n in sharded._STAT_NAMES}
     timed(f"rank {HOP}: import of {n0} records + walk of the prepared shard (the hop)", lambda: b.walk_shard(batches1, table0, n0, carried))
     timed(f"rank {HOP}: export", lambda: b.export_table())

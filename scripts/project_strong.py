@@ -20,6 +20,7 @@ from faucet_amd import api, sharded  # noqa: E402
 from faucet_amd import synth_det as sd  # noqa: E402
 
 LINK = float(os.environ.get("LINK_GBPS", "50"))
+LATE = sharded.LATE_HINT          # FAUCET_LATE_HINT=0: as until round 5
 WARM = int(os.environ.get("WARM", "2"))        # every stage runs WARM times, the last one is the one reported (a rank of a bench run is warm: the timed steps follow warm-up steps)
 Ns = [int(a) for a in sys.argv[1:]] or [2, 4, 8]
 fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fullsize.json")))[os.environ.get("FIXTURE", "config4")]
@@ -102,7 +103,8 @@ for N in Ns:
     d1, d2 = (hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in (running, acc2))
     filters_ok = d1 == fx.get("bloo1_sha256") and d2 == fx.get("bloo2_sha256")
     # ---- pass 2: rank 0 streams; rank r prepares on the hint (rank 0's table after a quarter of its reads), then imports, walks, exports
-    t_pure, t_hop, recs = [], [], []
+    t_pure, t_hop, recs, t_late, n_merged = [], [], [], [], []
+    older = None
     table, n_table, stats, hint = None, 0, None, None
     t_scan0 = 0.0
     for r in range(N):
@@ -140,12 +142,19 @@ for N in Ns:
             else:
                 b.import_hint(hint[0], hint[1])
                 _, ms_pure = timed(lambda: [b.scan_prepare(x) for x in batches])
+                ms_late = 0.0
+                if r > 1 and LATE:      # the table the rank below was handed, passed on as a fresher preview: planes made again off the chain
+                    _, ms_late = timed(lambda: (b.import_hint(older[0], older[1]), b.refresh_prepared()))
                 carried = {n: int(prev_stats[n]) for n in sharded._STAT_NAMES}
                 (stats), ms_walk = timed(lambda: b.walk_shard(batches, table, n_table, carried))
+                merged = ctx.diag_prepared_refresh()
             (res), ms_exp = timed(lambda: b.export_table())
         if r > 0:
             t_pure.append(ms_pure)
             t_hop.append([ms_walk, ms_exp])
+            t_late.append(ms_late)
+            n_merged.append(merged["batches_merged"])
+            older = (table, n_table)
         else:
             exp0 = ms_exp
         n_table, buf = res
@@ -164,5 +173,6 @@ for N in Ns:
     print(f"N={N}: per rank {per} reads | pass 1 ({'own load + fix-up' if fixup else 'presence + load'}): {min(t_first):.0f}-{max(t_first):.0f} ms + {min(t_second):.0f}-{max(t_second):.0f} ms + exchanges {exch:.0f} ms = {p1:.0f} ms | "
           f"pass 2: rank 0 scan {t_scan0:.0f} ms, others' pure stage {min(t_pure) if t_pure else 0:.0f}-{max(t_pure) if t_pure else 0:.0f} ms, hops (send + import + walk + export) "
           f"{' '.join(f'{recs[r - 1] * 32 / LINK / 1e6:.0f}+{t_hop[r - 1][0]:.0f}+{t_hop[r - 1][1]:.0f}' for r in range(1, N))} = {hops:.0f} ms | step {step:.0f} ms = {kmers / step * 1e3:.3g} k-mers/s "
+          f"| fresher previews (off the chain): {' '.join(f'{x:.0f}' for x in t_late)} ms, batches whose planes the walk merged: {sum(n_merged)} "
           f"(records {recs[-1]}, junctions of the last rank's stats {stats['n_junctions']}; bloo1 and bloo2 of the shards' pass 1 {'EQUAL' if filters_ok else 'DIFFER FROM'} the oracle's digests)", flush=True)
 print(f"(links priced at {LINK:.0f} GB/s per direction; the one-GPU step of the same workload is the bench line's full_size.config4)")

@@ -777,13 +777,14 @@ def test_long_pair_filter_on_the_device_equals_the_oracles(n_chunks):
 
 
 @pytest.mark.parametrize("cuts", [(0, 6002, 24000, 40000), (0, 0, 13000, 13000, 40000), (0, 2, 4, 6, 39998, 40000)])
-def test_python_host_hands_both_pair_filters_from_shard_to_shard(cuts):
+def test_python_host_hands_both_pair_filters_from_shard_to_shard(cuts, monkeypatch):
     """faucet_amd/sharded.py (the host of `bench.py --gpus N`): the pair filters travel with the junction table as they do in the C++ host
     (shard_host.h): the short one collects adds, the long one is check-then-insert in file order, shards begin at even records, the pair
     counts of the shards add up.  Ranks in turn in one process (run_in_turn), every shard in batches that cut pairs in two; shards of a
     single pair and empty shards among them."""
     import torch
     from faucet_amd import sharded
+    monkeypatch.setenv("FGPU_DEBUG_DELTA_CHECK", "1")      # (round 5: a shard's planes merged with the new keys; this data found what the first version missed)
     k, E, S = 21, 400_000, 150_000
     bases, offs = _pairs_in_repeats(20_000, 5)
     assert len(offs) - 1 == cuts[-1]
@@ -805,6 +806,7 @@ def test_python_host_hands_both_pair_filters_from_shard_to_shard(cuts):
 
     def after_scan(r, stats, backend):
         counts.append(backend.pair_counts())
+        assert backend.ctx.diag_prepared_refresh()["mismatching_words"] == 0
 
     for protocol in ("fixup", "presence"):
         counts.clear()
@@ -1627,6 +1629,80 @@ def test_load_fixup_refuses_passes_it_cannot_speak_for():
         with pytest.raises(api.FaucetGpuError, match="load_fixup needs"):
             ctx.load_fixup(prefix.data_ptr())
         ctx.close()
+
+
+def test_a_fresher_preview_lets_the_walk_look_only_for_the_keys_created_since(monkeypatch):
+    """fgpu_scan_import_hint a second time + fgpu_scan_refresh_prepared (round 5): shard C prepares against an early preview, is then shown the table
+    shard B was HANDED (= A's final table) and makes its planes again against it, and when B's final table arrives its walk merges the keys B
+    created into the planes through a filter of just those keys (fgpu_diag_prepared_refresh says so).  Records, creation order and counters are
+    the oracle's -- also when the "fresher preview" is NOT an earlier state of the table that arrives (the count of newer entries does not fit:
+    the planes are made again in full), when nothing was refreshed, and with the short cut switched off."""
+    import torch
+    monkeypatch.setenv("FGPU_DEBUG_DELTA_CHECK", "1")      # the merged planes are compared with planes made again in full, batch by batch
+    k, G = 21, 30_000
+    bases, offs = _random_case(15_000, 100, k, G, 0.012, 911, 0.002, 3)
+    tai, nh = api.load_filter_shape(20 * G, 4 * G)
+    b1, b2, lst, osc = oracle_run((bases, offs), k, tai, nh)
+    n = len(offs) - 1
+    cut = [0, n // 3, 2 * n // 3, n]
+    parts = [[api.ReadBatch(bases, offs[x:y + 1].copy()) for x, y in ((lo, (lo + hi) // 2), ((lo + hi) // 2, hi))] for lo, hi in zip(cut[:-1], cut[1:])]
+    ctxs = [api.Context(k, tai, nh) for _ in range(3)]
+    for ctx in ctxs:
+        ctx.bloom_upload(L.BLOO2, b2.bits())
+
+    def export(ctx):
+        m = ctx.table_entries()
+        buf = torch.empty(max(m, 1) * L.TABLE_ENTRY_BYTES, dtype=torch.uint8, device="cuda")
+        assert ctx.export_table(buf.data_ptr(), buf.numel()) == m
+        torch.cuda.synchronize()
+        return m, buf
+
+    a, b, c = ctxs
+    a.scan_begin()
+    a.scan_batch(parts[0][0])
+    n_early, early = export(a)
+    a.scan_batch(parts[0][1])
+    st_a = a.scan_end()
+    n_a, t_a = export(a)
+    b.scan_begin()
+    b.import_table(t_a.data_ptr(), n_a, carried=st_a)
+    for p in parts[1]:
+        b.scan_batch(p)
+    st_b = b.scan_end()
+    n_b, t_b = export(b)
+    assert 0 < n_early < n_a < n_b
+    okeys, orecs = osc.junctions("creation")
+    ost = osc.stats()
+
+    def run_c(late, refresh=True):
+        c.scan_begin()
+        c.import_hint(early.data_ptr(), n_early)
+        for p in parts[2]:
+            c.scan_prepare(p)
+        if late is not None:
+            c.import_hint(late[1].data_ptr(), late[0])
+            if refresh:
+                c.scan_refresh_prepared()
+        c.import_table(t_b.data_ptr(), n_b, carried=st_b)
+        c.scan_walk_prepared()
+        st = c.scan_end()
+        keys, recs = c.junctions()
+        for key in ("n_junctions", "nb_jcheck_kmer", "nb_no_juncs", "nb_processed", "nb_skipped", "reads_no_errors"):
+            assert st[key] == ost[key], key
+        assert np.array_equal(keys, okeys) and np.array_equal(recs["dist"], orecs["dist"]) and np.array_equal(recs["cov"], orecs["cov"])
+        return c.diag_prepared_refresh()
+
+    d = run_c((n_a, t_a))
+    assert d == {"batches_in_full": 0, "batches_merged": 2, "new_keys": n_b - n_a, "mismatching_words": 0}, d
+    d = run_c(None)                                         # no fresher preview: the planes speak of the early one, the surplus is A's rest + B's
+    assert d["batches_merged"] == 2 and d["new_keys"] == n_b - n_early and d["mismatching_words"] == 0, d
+    d = run_c((n_a, t_a), refresh=False)                    # shown but not refreshed: the planes do not speak of the newest preview
+    assert d["batches_in_full"] == 2 and d["batches_merged"] == 0, d
+    # a "preview" that is not an earlier state of the table that arrives: B's own final table with half of its entries dropped from the FRONT
+    # (old entries missing, all the new ones there) -- as many entries as A's table, but the newer-than-the-preview count does not fit
+    bogus = t_b[(n_b - n_a) * L.TABLE_ENTRY_BYTES:].clone()
+    d = run_c((n_a, bogus))
+    assert d["batches_in_full"] == 2 and d["batches_merged"] == 0, d
 
 
 def test_table_hint_lets_a_later_shard_prepare_lazily_and_never_enters_the_result():

@@ -98,6 +98,10 @@ class OracleShard:
         # the oracle has no preview to feed; what matters here is that the hint is a state of rank 0's table and never part of a result
         self.hint = buf.numpy()[: n * L.TABLE_ENTRY_BYTES].view(ENTRY).copy()
 
+    def refresh_prepared(self):
+        # (round 5: a rank passes the table it is handed on as a fresher preview; the oracle prepares nothing ahead, the check below is the point)
+        self.late_hints = getattr(self, "late_hints", 0) + 1
+
     def walk_shard(self, batches, buf, n, carried):
         self.import_table(buf, n, carried)
         if getattr(self, "hint", None) is not None and len(self.hint):   # the hint is an EARLIER state of the first shard's table
