@@ -490,6 +490,8 @@ def test_config4_as_eight_shards_in_file_order_equals_the_oracle_after_every_ran
     and the OR of bloo2 as slice-wise ORs on the device; the junction table handed from rank to rank, the hint from rank 0).  After EVERY
     rank the filters, the junction map and the counters are the sequential run's at that shard boundary = the oracle's checkpoint."""
     from faucet_amd import sharded
+    if protocol == "presence":            # (round 5) in one of the three runs the library compares the planes it MERGED with the new keys against planes made again
+        monkeypatch.setenv("FGPU_DEBUG_DELTA_CHECK", "1")
     if protocol == "fixup_planes":        # the fix-up's own pass with the fail planes (what shards beyond 2^32 positions take) instead of the shard-long clock
         monkeypatch.setenv("FAUCET_SHARD_PLANES", "1")
         protocol = "fixup"
@@ -516,7 +518,12 @@ def test_config4_as_eight_shards_in_file_order_equals_the_oracle_after_every_ran
         assert _sha_dev(bloo2) == ck["bloo2_sha256"], f"bloo2 after shard {r} ({protocol})"
         checked["load"] += 1
 
+    merged = []
+
     def after_scan(r, stats, backend):
+        d = backend.ctx.diag_prepared_refresh()
+        merged.append(d["batches_merged"])
+        assert d["mismatching_words"] == 0, (r, d)
         ck = scan_ck.get(cuts[r + 1])
         if ck is None:
             return
@@ -529,6 +536,7 @@ def test_config4_as_eight_shards_in_file_order_equals_the_oracle_after_every_ran
 
     lst, sst, last = sharded.run_in_turn(lambda: sharded.GpuShard(api.Context(c["k"], tai, nh), dev), shards, protocol, after_load, after_scan)
     last.close()
+    assert merged[0] == 0 and all(m > 0 for m in merged[2:]), merged      # from the third rank on the walk merges the new keys into the planes (a fresher preview came first)
     assert checked["load"] >= min(1, len(load_ck)) and checked["scan"] >= min(1, len(scan_ck))
     if "bloo2_sha256" in fx:         # the whole fixture is there: every shard boundary was compared
         assert checked == {"load": world, "scan": world}
