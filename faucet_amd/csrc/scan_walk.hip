@@ -3666,12 +3666,12 @@ int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, u
                            uint64_t* max_seq, uint64_t* n_newer) {
     *max_seq = *n_newer = 0;
     if (!n) return FGPU_OK;
-    if (!ctx->import_probe) FGPU_HIP(hipMalloc(&ctx->import_probe, 16));
-    FGPU_HIP(hipMemsetAsync(ctx->import_probe, 0, 16, ctx->stream));
+    if (int rc = fgpu_ensure(ctx, &ctx->import_probe, 16)) return rc;
+    FGPU_HIP(hipMemsetAsync(ctx->import_probe.p, 0, 16, ctx->stream));
     FGPU_LAUNCH("import", k_import_probe, (unsigned)std::min<uint64_t>(fgpu_blocks(n, 256), 4096), 256, (const ExportEntry*)dev_entries, n, ctx->fd, after_seq, dfilter,
-                dfilter_bits ? dfilter_bits - 1 : 0, ctx->import_probe);
+                dfilter_bits ? dfilter_bits - 1 : 0, (unsigned long long*)ctx->import_probe.p);
     unsigned long long out[2] = {0, 0};
-    FGPU_HIP(hipMemcpyAsync(out, ctx->import_probe, 16, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(out, ctx->import_probe.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     *max_seq = out[0];
     *n_newer = out[1];
