@@ -25,8 +25,11 @@ def _run(c, tmp_path, gpus, extra=(), env=None, tag="out"):
         with open(inp, "wb") as f:
             f.write(c.reads_text())
     prefix = str(tmp_path / f"{tag}_{gpus}")
+    # (round 5) from the third shard on a walk merges the keys created since its fresher preview into its planes: the library compares them with
+    # planes made again, word by word, and says so on stderr if they ever differ
     r = subprocess.run([CLI, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix, "-gpus", str(gpus)] + c.meta["args"] + list(extra),
-                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, FGPU_DEBUG_DELTA_CHECK="1", **(env or {})))
+    assert "merged in-map planes differ" not in r.stderr, r.stderr[-2000:]
     return prefix, r
 
 

@@ -40,11 +40,14 @@ def test_cli_equals_the_compiled_reference_on_a_random_run(seed, tmp_path, cli_e
         d = tmp_path / tag
         d.mkdir()
         # (unbuffered stdout: the reference may crash in its contig-graph stage, after the files and the counters this test is about)
+        # (with -gpus N: the library checks the in-map planes a shard's walk MERGES with the new keys against planes made again, FGPU_DEBUG_DELTA_CHECK)
         r = subprocess.run(["stdbuf", "-o0", exe, "-read_load_file", path, "-read_scan_file", path, "-file_prefix", str(d / "out")] + args +
-                           (list(cli_extra) if tag == "gpu" else []), capture_output=True, text=True, errors="replace", timeout=600)
+                           (list(cli_extra) if tag == "gpu" else []), capture_output=True, text=True, errors="replace", timeout=600,
+                           env=dict(os.environ, FGPU_DEBUG_DELTA_CHECK="1") if tag == "gpu" and cli_extra else None)
         outs[tag] = (r, d)
     (rr, dr), (rg, dg) = outs["ref"], outs["gpu"]
     assert rg.returncode == (0 if "--no_cleaning" in args else 3), rg.stderr[-2000:]      # (the reference goes on into its contig graph and may crash there)
+    assert "merged in-map planes differ" not in rg.stderr, rg.stderr[-2000:]
     mine = sorted(os.listdir(dg))
     assert any(f.endswith(".bloom") for f in mine) and any(f.endswith(".junctions") for f in mine)
     for f in mine:                                   # every file this build writes, the reference wrote too, with the same bytes
