@@ -633,6 +633,8 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->hint_n = ctx->hint_max_seq = 0;
     ctx->delta_ready = false;
     ctx->delta_keys = ctx->refresh_full = ctx->refresh_delta = ctx->refresh_mismatch = 0;
+    ctx->dbg_stall_us = getenv("FGPU_DEBUG_WALK_STALL_US") ? std::min(100000, std::max(0, atoi(getenv("FGPU_DEBUG_WALK_STALL_US")))) : 0;
+    ctx->dbg_delta_check = getenv("FGPU_DEBUG_DELTA_CHECK") != nullptr;
     // calibrated upwards window by window; a context that has scanned before starts a quarter below where that scan ended up
     const uint64_t start_span = std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4);
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)

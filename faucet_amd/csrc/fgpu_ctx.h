@@ -291,6 +291,8 @@ struct fgpu_ctx {
     bool delta_ready = false;        // the walk of the prepared batches merges the new keys into their planes instead of making the planes again
     uint64_t delta_keys = 0;         // (diagnostics: keys in the filter; batches whose planes were made again in full / merged)
     uint64_t refresh_full = 0, refresh_delta = 0, refresh_mismatch = 0;
+    int dbg_stall_us = 0;            // FGPU_DEBUG_WALK_STALL_US, FGPU_DEBUG_DELTA_CHECK: read once per scan (fgpu_scan_begin), not from the walk's inner calls
+    bool dbg_delta_check = false;
     DevBuf import_probe;             // device: [0] largest piece number among the entries of the last import, [1] entries newer than the preview
     uint64_t scan_grown = 0;         // times the junction table was rehashed into a larger one
 

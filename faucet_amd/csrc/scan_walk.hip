@@ -3036,7 +3036,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     hipStream_t walk_stream = no_overlap ? ctx->stream : ctx->wstream;
     ctx->launch_stream = walk_stream;
     if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(walk_stream, bb.pure_done, 0));
-    const int stall_us = getenv("FGPU_DEBUG_WALK_STALL_US") ? std::min(100000, std::max(0, atoi(getenv("FGPU_DEBUG_WALK_STALL_US")))) : 0;
+    const int stall_us = ctx->dbg_stall_us;
     if (stall_us) FGPU_LAUNCH("debug_stall", k_debug_stall, 1, 1, (unsigned long long)stall_us * 100ULL);
     if (ctx->refresh_snapshot) {
         // batches that were prepared before their turn (multi-GPU shards; scan_prepare / scan_walk_prepared) carry snapshot planes of a table
@@ -3053,7 +3053,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                             ctx->fd, jt, (const uint32_t*)ctx->delta_filter.p, ctx->delta_filter_bits - 1, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p,
                             (const uint32_t*)bb.kh.p, 1);
             ctx->refresh_delta++;
-            if (getenv("FGPU_DEBUG_DELTA_CHECK")) {      // tests: the merged planes against planes made again in full, word by word
+            if (ctx->dbg_delta_check) {      // tests (FGPU_DEBUG_DELTA_CHECK=1): the merged planes against planes made again in full, word by word
                 uint64_t *cF = nullptr, *cB = nullptr;
                 unsigned long long* out = nullptr;
                 FGPU_HIP(hipMalloc(&cF, bb.n_words * 8));

@@ -19,6 +19,8 @@ dev = torch.device("cuda", 0)
 bad = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(40_000 + seed)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("seed", seed, flush=True)
     try:
         k = int(rng.choice([15, 21, 27, 31]))
         G = int(rng.integers(1500, 9000))
