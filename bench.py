@@ -476,6 +476,27 @@ def config3_cli_leg(device):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the PARENT of the N ranks.  It has made no GPU call
+    (importing torch and counting devices does not start the HIP runtime), starts `python -m torch.distributed.run` as a CHILD (never exec),
+    relays the ranks' output -- rank 0's ONE JSON line on stdout -- and returns the child's exit code."""
+    share = os.environ.get("FAUCET_SHARE_GPU", "0") == "1"
+    seen = torch.cuda.device_count()
+    if not share and seen < n:
+        sys.stderr.write(f"bench.py --gpus {n}: only {seen} GPU(s) visible on this node (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); "
+                         f"nothing was started.  (FAUCET_SHARE_GPU=1 FAUCET_DIST_BACKEND=gloo runs the N ranks on one device: functional check only)\n")
+        return 2
+    import socket
+    with socket.socket() as s:              # a free port of this host: two benches side by side must not meet
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,6 +528,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true",
                     help="timed steps WITHOUT HIP events around every kernel (A/B of what FGPU_FLAG_PROFILE costs; no roofline / kernel times in the line)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL prints its version banner there) go to stderr
     json_fd = os.dup(1)
@@ -668,10 +692,15 @@ def main():
     if prof_steps:
         ctx.profile_enable(False)
     all_stage_ms = all_checks = None
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    hbm = {"rank": rank, "device": local_rank, "used_bytes_after_the_steps": int(total_b - free_b), "total_bytes": int(total_b),
+           "torch_peak_allocated_bytes": int(torch.cuda.max_memory_allocated(device))}
+    all_hbm = [hbm]
     if world > 1:
-        all_stage_ms, all_checks = [None] * world, [None] * world
+        all_stage_ms, all_checks, all_hbm = [None] * world, [None] * world, [None] * world
         dist.all_gather_object(all_stage_ms, stage_ms)
         dist.all_gather_object(all_checks, checks)
+        dist.all_gather_object(all_hbm, hbm)
     else:
         all_stage_ms, all_checks = ([stage_ms] if force_sharded else None), [checks]
 
@@ -692,6 +721,10 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": L_, "k": k, "tai": tai, "n_hash": nh, "batch_reads": args.batch_reads,
                    "sharding": "reads in file order; slice-wise prefix-OR(bloo1) + OR-allreduce(bloo2) over RCCL send/recv; walk handed rank to rank" if world > 1 else "single GPU"},
         "kmers_per_step": kmers_total, "lazy_flag_fallbacks": len(FALLBACKS),
+        # what the ranks talked through: the size of the process group's communicator (backend nccl = RCCL), and every rank's HBM in use once the
+        # steps are over (the library keeps its pools between steps: the device-wide figure is the run's high-water mark but for transient buffers)
+        "rccl_ranks": (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0),
+        "dist_backend": (dist.get_backend() if dist.is_initialized() else None), "hbm_per_rank": all_hbm,
         "outputs": {"junctions": int(sst["n_junctions"]) if world == 1 else None, "to_bloo2_rank0": int(lst["to_bloo2"]),
                     "walk_windows_rank0": int(sst["walk_windows"]), "walk_followers_rank0": int(sst["walk_followers"]),
                     "walk_max_cluster_rank0": int(sst["walk_max_cluster"]), "walk_key_ordered_pieces_rank0": int(sst["walk_parallel"]),

@@ -174,7 +174,8 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-    lib = C.CDLL(LIB_PATH)
+    # FAUCET_GPU_LIB: another build of the SAME library (host code under AddressSanitizer: scripts/asan_gpu_fuzz.sh); never a fallback
+    lib = C.CDLL(os.environ.get("FAUCET_GPU_LIB") or LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res

@@ -104,27 +104,43 @@ NEIGHBOR_DTYPE = np.dtype([("kmer", "<u8"), ("dist", "<i4"), ("len", "<i4"), ("n
                            ("reserved2", "<i4")])   # fgpu_neighbor
 
 
+class _PinnedMemory:
+    """The owner of one fgpu_host_alloc block: the ONLY place that frees it, and only when the last reference is gone -- the HostBuffer
+    that made it, or any numpy view handed out over it (every view's base chain ends in a ctypes array that holds this object)."""
+
+    def __init__(self, lib, nbytes):
+        self.lib = lib
+        self.ptr = lib.fgpu_host_alloc(nbytes)
+        if not self.ptr:
+            raise FaucetGpuError("fgpu_host_alloc failed")
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            self.lib.fgpu_host_free(ptr)
+
+
 class HostBuffer:
-    """Page-locked host memory (fgpu_host_alloc) seen as numpy arrays: device-to-host copies into it run at link speed and
-    asynchronously.  The memory lives as long as this object; views must not outlive it."""
+    """Page-locked host memory (fgpu_host_alloc) seen as numpy arrays: device-to-host copies into it run at link speed and asynchronously.
+    Views keep the memory alive (a view that outlived its buffer pointed into hipHostFree'd memory): free() and __del__ only
+    drop THIS object's reference, the block goes back when the last view is gone too."""
 
     def __init__(self, nbytes: int):
         self.lib = L.load()
         self.nbytes = int(nbytes)
-        self.ptr = self.lib.fgpu_host_alloc(max(self.nbytes, 1))
-        if not self.ptr:
-            raise FaucetGpuError("fgpu_host_alloc failed")
+        self._mem = _PinnedMemory(self.lib, max(self.nbytes, 1))
+        self.ptr = self._mem.ptr
         self._raw = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+        self._raw._owner = self._mem          # numpy view -> .base = this ctypes array -> the block's owner
 
     def view(self, dtype=np.uint8, count=None) -> np.ndarray:
-        a = np.frombuffer(self._raw, dtype=dtype, count=-1 if count is None else count)
-        return a
+        if self._raw is None:
+            raise FaucetGpuError("HostBuffer.view() after free()")
+        return np.frombuffer(self._raw, dtype=dtype, count=-1 if count is None else count)
 
     def free(self):
-        if getattr(self, "ptr", None):
-            self._raw = None
-            self.lib.fgpu_host_free(self.ptr)
-            self.ptr = None
+        """give this object's reference up; the memory itself is released once no view of it is left"""
+        self._raw = self._mem = self.ptr = None
 
     def __del__(self):
         self.free()
@@ -209,8 +225,7 @@ class Context:
             self._pinned = {}
         b = self._pinned.get(tag)
         if b is None or b.nbytes < nbytes:
-            if b is not None:
-                b.free()
+            # a tagged buffer is never regrown in place: the old block stays with whoever still holds a view of it (HostBuffer)
             b = self._pinned[tag] = HostBuffer(nbytes + nbytes // 4)
         return b
 

@@ -428,7 +428,10 @@ int fgpu_load_begin(fgpu_ctx* ctx, int keep_carry) {
     static const char* carry_env = getenv("FGPU_CARRY_MODE");   // "sweep" / "set": measurement aid
     ctx->carry_by_set = carry_env ? carry_env[0] == 's' && carry_env[1] == 'e' : ctx->prm.tai == (1ULL << 31);
     ctx->shard_times = (keep_carry & FGPU_LOAD_SHARD_TIMES) != 0;
-    ctx->shard_planes = (keep_carry & FGPU_LOAD_SHARD_PLANES) != 0 && !ctx->shard_times;
+    // ONE predicate for the fail planes: they exist for at most 4 hash functions (load.hip MISS_PLANES).  With more the flag is
+    // accepted and the pass is a plain load -- nothing is sized for or copied from planes that are never made -- and fgpu_load_fixup answers
+    // FGPU_ERR_STATE as faucet_gpu.h says (hosts then take the presence protocol: sharded.fixup_possible, shard_host.h)
+    ctx->shard_planes = (keep_carry & FGPU_LOAD_SHARD_PLANES) != 0 && !ctx->shard_times && ctx->prm.n_hash <= 4;
     ctx->fixup_ready = false;
     ctx->pass_positions = ctx->pass_batches = 0;
     ctx->pass_empty_carry = !(keep_carry & FGPU_LOAD_KEEP_CARRY);
@@ -505,7 +508,7 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     ctx->load_mark_pending = ctx->counters_host->mark_pending;
     ctx->load_stats.unambiguous_reads = ctx->counters_host->segments;
     if (stats) *stats = ctx->load_stats;
-    ctx->fixup_ready = (ctx->shard_times || (ctx->shard_planes && ctx->fd.n_hash <= 4)) && ctx->pass_empty_carry &&
+    ctx->fixup_ready = (ctx->shard_times || ctx->shard_planes) && ctx->pass_empty_carry &&
                        ctx->resident_count == ctx->pass_batches && !(ctx->prm.flags & FGPU_FLAG_MERCY);
     return FGPU_OK;
 }

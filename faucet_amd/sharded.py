@@ -652,10 +652,19 @@ class GpuShard:
         ptr, nbytes = self.ctx.bloom_devptr(which)
         self.ctx.bitmap_or(ptr, src.data_ptr(), nbytes)
 
+    def _one_clock(self, batches):
+        """does the fix-up protocol's own pass run on ONE 32-bit clock (True) or with fail planes (False)?  One rule for load() and
+        fixup_possible(): the planes cover four hash functions, so FAUCET_SHARD_PLANES=1 (tests: planes at any size) only
+        forces them where they exist."""
+        pos = [getattr(b, "n_positions", None) for b in batches]
+        fits = all(p is not None for p in pos) and sum(pos) + 64 * len(pos) < 0xFFF00000
+        if fits and os.environ.get("FAUCET_SHARD_PLANES", "0") == "1" and getattr(self.ctx, "n_hash", 0) <= 4:
+            return False
+        return fits
+
     def load(self, batches, keep_carry, shard_times=False):
         # the fix-up protocol's own pass: on one clock where the shard's positions fit 32 bits (costs nothing), else with the fail planes
-        pos = [getattr(b, "n_positions", None) for b in batches]
-        short = all(p is not None for p in pos) and sum(pos) + 64 * len(pos) < 0xFFF00000 and os.environ.get("FAUCET_SHARD_PLANES", "0") != "1"
+        short = self._one_clock(batches)
         self.ctx.load_begin(keep_carry=keep_carry, shard_times=shard_times and short, shard_planes=shard_times and not short)
         for b in batches:
             self.ctx.load_batch(b)
@@ -666,7 +675,7 @@ class GpuShard:
         pos = [getattr(b, "n_positions", None) for b in batches]
         if any(p is None for p in pos) or getattr(self.ctx, "mercy", False):    # --mercy: fgpu_load_end leaves no fix-up state
             return False
-        short = sum(pos) + 64 * len(pos) < 0xFFF00000    # one 32-bit clock for the shard; beyond: fail planes, which cover four hash functions
+        short = self._one_clock(batches)                 # one 32-bit clock for the shard; beyond: fail planes, which cover four hash functions
         if not short and getattr(self.ctx, "n_hash", 0) > 4:
             return False
         free, total = torch.cuda.mem_get_info(self.device)

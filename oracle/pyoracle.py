@@ -16,6 +16,8 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("FAUCET_ORACLE_LIB"):          # a sanitizer build of the same source (scripts/asan_oracle_fuzz.sh)
+        return os.environ["FAUCET_ORACLE_LIB"]
     src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("faucet_oracle.cpp", "faucet_oracle.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)

@@ -127,3 +127,74 @@ def test_replayed_dump_order_equals_the_containers(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_views_of_a_host_buffer_keep_its_memory_alive(monkeypatch):
+    """VERDICT r5 (weak 1): `HostBuffer.view()` handed out arrays over page-locked memory that `free()`, a regrown tagged buffer or
+    `Context.close()` released under them.  Now the block has ONE owner that every view references: it goes back exactly once, after the
+    last view.  (Host logic only: the allocator is a counting stand-in, no device.)"""
+    import ctypes as C
+    import gc
+
+    import numpy as np
+
+    from faucet_amd import _lib as L
+    from faucet_amd import api
+
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes, libc.free.argtypes = C.c_void_p, [C.c_size_t], [C.c_void_p]
+    live, freed = set(), []
+
+    class FakeLib:
+        @staticmethod
+        def fgpu_host_alloc(n):
+            p = libc.malloc(n)
+            live.add(p)
+            return p
+
+        @staticmethod
+        def fgpu_host_free(p):
+            assert p in live, "freed twice, or never allocated"
+            live.discard(p)
+            freed.append(p)
+            libc.free(p)
+
+        @staticmethod
+        def fgpu_destroy(h):
+            pass
+
+    monkeypatch.setattr(L, "load", lambda: FakeLib)
+    hb = api.HostBuffer(4096)
+    block = hb.ptr
+    v = hb.view(np.uint32)
+    v[:] = 7
+    part = v[10:20]
+    hb.free()                                     # the object lets go; the views still stand on live memory
+    hb.free()
+    assert not freed and int(part.sum()) == 70
+    with pytest.raises(api.FaucetGpuError):
+        hb.view()
+    del v
+    gc.collect()
+    assert not freed                              # a slice of a view holds the block as well
+    del part
+    gc.collect()
+    assert freed == [block] and not live
+    # a context's tagged buffer that has to grow leaves the old block to the views of it; close() drops the context's references only
+    ctx = api.Context.__new__(api.Context)
+    ctx.lib, ctx.h = FakeLib, None
+    small = ctx._pinned_buffer("out", 100)
+    old_view = small.view(np.uint8, 100)
+    first = small.ptr
+    del small
+    big = ctx._pinned_buffer("out", 10_000)
+    assert big.ptr != first and first in live
+    keep = big.view(np.uint8, 10)
+    second = big.ptr
+    del big
+    ctx.close()
+    gc.collect()
+    assert first in live and second in live
+    del old_view, keep
+    gc.collect()
+    assert not live and sorted(freed) == sorted([block, first, second])

@@ -268,8 +268,9 @@ def test_ranks_in_separate_processes_sharing_this_gpu(ranks, per_rank, torch_str
     assert "RESULT PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def _bench_line(args, env, nproc=0, timeout=600):
-    """one run of bench.py (plain, or under torch.distributed.run with `nproc` ranks); returns the parsed JSON line"""
+def _bench_line(args, env, nproc=0, timeout=600, self_launch=0):
+    """one run of bench.py (plain, or under torch.distributed.run with `nproc` ranks, or -- self_launch=N -- as the driver starts it: plain
+    `python bench.py --gpus N`, which starts its own ranks as child processes); returns the parsed JSON line"""
     import socket
     import sys
     with socket.socket() as sk:
@@ -278,8 +279,9 @@ def _bench_line(args, env, nproc=0, timeout=600):
     cmd = [sys.executable]
     if nproc:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(max(nproc, 1))] + args
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env))
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(max(nproc, self_launch, 1))] + args
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")} if self_launch else dict(os.environ)
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=timeout, env=dict(base, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -294,6 +296,7 @@ def test_bench_sharded_path_over_rccl_gives_config2s_digests():
     d = _bench_line(["--scaling", "strong", "--fixture", "config2", "--batch-reads", "1000000", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-ceilings",
                      "--no-host-leg", "--no-full-size", "--no-profile"], {"FAUCET_FORCE_SHARDED": "1"})
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["kmers_per_step"] == FULL["config2"]["kmers"]
+    assert d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl" and d["hbm_per_rank"][0]["used_bytes_after_the_steps"] > 0
     chk = d["outputs_check"]
     for key in ("bloo2_equals_the_oracles", "junction_keys_equal_the_oracles", "junction_records_equal_the_oracles", "scan_counters_equal_the_oracles"):
         assert chk[key] is True, (key, chk)
@@ -308,7 +311,9 @@ def test_bench_strong_scaling_three_ranks_equal_one():
     size = ["--scaling", "strong", "--fixture", "config2", "--reads", "3000000", "--genome", "6000000", "--estimated-kmers", "30000000", "--singletons", "6000000",
             "--batch-reads", "250000", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-ceilings", "--no-host-leg", "--no-full-size", "--no-profile"]
     one = _bench_line(size, {})
-    three = _bench_line(size, {"FAUCET_SHARE_GPU": "1", "FAUCET_DIST_BACKEND": "gloo", "GLOO_SOCKET_IFNAME": "lo"}, nproc=3)
+    # (round 6) started the way the driver starts N = 1: no launcher around it -- the parent spawns its ranks before any GPU call
+    three = _bench_line(size, {"FAUCET_SHARE_GPU": "1", "FAUCET_DIST_BACKEND": "gloo", "GLOO_SOCKET_IFNAME": "lo"}, self_launch=3)
+    assert three["n_gpus"] == 3 and three["rccl_ranks"] == 0 and three["dist_backend"] == "gloo" and len(three["hbm_per_rank"]) == 3
     assert one["scaling"] == three["scaling"] == "strong" and one["kmers_per_step"] == three["kmers_per_step"] == 3_000_000 * 70
     a, b = one["outputs_check"], three["outputs_check"]
     for key in ("bloo2_sha256", "junction_keys_sha256", "junction_records_sha256", "junctions"):

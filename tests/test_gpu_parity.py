@@ -446,6 +446,22 @@ def test_state_machine_errors():
         api.Context(32, 1 << 19, 3)
     with pytest.raises(api.FaucetGpuError):
         api.Context(21, 1000, 3)
+    # fail planes exist for at most four hash functions.  A pass begun with FGPU_LOAD_SHARD_PLANES on a five-function context is a
+    # plain load (it ran into a copy from planes that were never made), gives the plain load's filters, and the fix-up says STATE
+    lines = [b"ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGATCGATTAGCTAGCTAGGCTAGCTAGGATCGATCGAT", b"TTGACCAGTAGGACCATTGACGATTAGGCAGATTACAGGATTTACAGGCATTACAGAC"] * 50
+    five, plain = api.Context(21, 1 << 19, 5), api.Context(21, 1 << 19, 5)
+    batch = api.ReadBatch.from_lines(lines)
+    five.load_begin(shard_planes=True)
+    five.load_batch(batch)
+    five.load_end()
+    plain.load_begin()
+    plain.load_batch(batch)
+    plain.load_end()
+    for which in (L.BLOO1, L.BLOO2):
+        assert np.array_equal(five.bloom_download(which), plain.bloom_download(which))
+    prefix, _ = plain.bloom_devptr(L.BLOO1)
+    with pytest.raises(api.FaucetGpuError):
+        five.load_fixup(prefix)
 
 
 def test_ceiling_diagnostics_run_and_reject_bad_arguments():
