@@ -356,6 +356,19 @@ def cli_leg(reads, args, kmers, want_junctions, variants=()):
 
 
 
+def _fullsize_traffic(config, kernel):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) of `kernel` on a full-size configuration, from the committed counter passes; None if absent"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ks = json.load(f)["full_size"][config]["kernels"]
+        for n, v in ks.items():
+            if n.split("<")[0] == kernel:
+                return float(v["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def full_size_leg(name, device, batch_reads):
     """One of BASELINE.json's other configurations at its FULL size as one cold step (load + scan, reads resident in HBM, junctions and
     bloo2 back in host memory), on the reads of the committed parity fixture (tests/golden/fullsize.json: faucet_amd/synth_det.py's
@@ -394,6 +407,11 @@ def full_size_leg(name, device, batch_reads):
             achieved = 64.0 * nh * (kmers / lm[0]) / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "load_mark", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "avg_launch_ms": avg_ms, "launches": lm[0], "algorithmic_bytes_per_kmer": 64.0 * nh, "kmers_per_launch": kmers / lm[0]}
+            # the counters' view of the same kernel on this configuration (round 6: scripts/profile_fullsize.sh <config> r06 pmc -> profiles/pmc_traffic.json)
+            traffic = _fullsize_traffic(name, "k_load_mark")
+            roof["traffic"] = traffic
+            roof["frac_measured_traffic"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if traffic else None
+            roof["traffic_over_algorithmic"] = traffic / (64.0 * nh * kmers / lm[0]) if traffic else None
         steps.append({"seconds": dt, "value": kmers / dt, "counters_equal_the_oracles": all(same.values()),
                       "differing": sorted(k2 for k2, v in same.items() if not v), "kernel_ms": {n: round(ms, 1) for n, (cnt, ms) in kt}, "roofline_load_mark": roof,
                       "junction_tests_run_by_the_walk": int(sst["flags_filled"]), "late_junction_tests": ctx.diag_late_flags(),
@@ -939,7 +957,7 @@ def main():
         try:
             rl = res["full_size"]["config4"]["second_step"]["roofline_load_mark"]
             if rl:
-                res["roofline_large"] = dict(rl, workload="BASELINE config 4 whole on one GPU (2 x 1 GiB filters), second step of the context", traffic=None)
+                res["roofline_large"] = dict(rl, workload="BASELINE config 4 whole on one GPU (2 x 1 GiB filters), second step of the context")
         except (KeyError, TypeError):
             pass
     emit(json.dumps(res))

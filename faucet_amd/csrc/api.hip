@@ -106,7 +106,17 @@ int fgpu_prof_collect(fgpu_ctx* ctx) {
 
 static int check_errors(fgpu_ctx* ctx) {
     // device-side error flags (table overflow) are surfaced at the synchronising calls
-    if (ctx->counters_host->error_flags & 1ULL) { ctx->err = "junction table full: raise fgpu_params.junction_capacity"; return FGPU_ERR_CAPACITY; }
+    if (ctx->counters_host->error_flags & 1ULL) {
+        // A batch created more records than the table had room for (it is kept below a quarter full BETWEEN batches).  While the scan's batches
+        // are all in the journal the library absorbs that itself (round 6): the next entry point scans the journal again
+        // on a table four times the size (scan_replay) -- the reference's unordered_map simply grows (utils/JunctionMap.h:61).
+        if (ctx->journal_on && ctx->phase == 2 && !ctx->in_replay && ctx->jcap < (1ULL << 31)) {
+            ctx->lazy_failed = ctx->capacity_failed = true;
+            return FGPU_OK;
+        }
+        ctx->err = "junction table full: raise fgpu_params.junction_capacity";
+        return FGPU_ERR_CAPACITY;
+    }
     if (ctx->counters_host->error_flags & 2ULL) { ctx->err = "window table full"; return FGPU_ERR_CAPACITY; }
     if (ctx->counters_host->error_flags & 32ULL) { ctx->err = "fgpu_reads.total_bases does not match the batch's offsets"; return FGPU_ERR_ARG; }
     // FGPU_DEBUG_LAZY_FAIL=1 pretends the self-check of the lazy flags fired (tests of the callers' fall-back to eager flags)
@@ -513,6 +523,13 @@ int fgpu_load_end(fgpu_ctx* ctx, fgpu_load_stats* stats) {
     return FGPU_OK;
 }
 
+int fgpu_load_fixup_state(fgpu_ctx* ctx, int* ready, uint64_t* resident_budget_bytes) {
+    if (!ctx) return FGPU_ERR_ARG;
+    if (ready) *ready = ctx->phase == 0 && ctx->fixup_ready ? 1 : 0;
+    if (resident_budget_bytes) *resident_budget_bytes = ctx->resident_budget;
+    return FGPU_OK;
+}
+
 int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stats) {
     if (!ctx || !prefix_dev) return FGPU_ERR_ARG;
     if (ctx->phase != 0) { ctx->err = "load_fixup while a pass is open"; return FGPU_ERR_STATE; }
@@ -620,7 +637,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->delta_next = 0;
     journal_recycle(ctx);
     ctx->journal_on = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
-    ctx->eager_scan = ctx->lazy_failed = false;
+    ctx->eager_scan = ctx->lazy_failed = ctx->capacity_failed = false;
     ctx->late_acc[0] = ctx->late_acc[1] = ctx->late_acc[2] = 0;
     ctx->stops_delivered = 0;
     ctx->lp_applied_seq = 0;
@@ -834,7 +851,32 @@ static int journal_add(fgpu_ctx* ctx, BatchBufs* b, const fgpu_reads* reads) {
 
 // Reset the junction map and scan every journalled batch again with all junction tests evaluated.  On return everything the journal holds
 // has been walked; batches that were only prepared are walked as well (their turn has come: this is only reached from a walk or after one).
+static int scan_replay_once(fgpu_ctx* ctx);
 static int scan_replay(fgpu_ctx* ctx) {
+    for (int attempt = 0;; attempt++) {
+        const bool for_room = ctx->capacity_failed;
+        ctx->capacity_failed = false;
+        if (for_room) {
+            int rc = sync_all(ctx);
+            if (!rc) rc = fgpu_scan_regrow_empty(ctx, ctx->jcap * 4);
+            if (rc) { ctx->lazy_failed = false; return rc; }
+            ctx->capacity_replays++;
+        }
+        int rc = scan_replay_once(ctx);
+        // the replay itself ran out of room (its batches are walked with the table kept below a quarter full between them, so this takes a
+        // single batch that creates more than three times what the whole table held): once more, larger again
+        if (rc == FGPU_ERR_CAPACITY && (ctx->counters_host->error_flags & 1ULL) && ctx->jcap < (1ULL << 31) && attempt < 6) {
+            ctx->capacity_failed = true;
+            continue;
+        }
+        // The journal still holds every batch of the scan: it stays on, so that a later batch that outgrows the table is absorbed as well (the
+        // scan is eager from here on and cannot fail the lazy way again)
+        if (!rc && for_room) ctx->journal_on = true;
+        return rc;
+    }
+}
+
+static int scan_replay_once(fgpu_ctx* ctx) {
     ctx->in_replay = true;
     ctx->journal_on = false;
     ctx->eager_scan = true;
@@ -919,6 +961,7 @@ static int scan_replay(fgpu_ctx* ctx) {
         ctx->pool.push_back(b);
     }
     ctx->cur = &ctx->bb_default;
+    if (!rc) rc = pull_counters(ctx);     // (still in_replay: an overflow of the last walks is reported here, to scan_replay, not flagged for later)
     ctx->in_replay = false;
     ctx->scan_replays++;
     return rc;
@@ -1218,9 +1261,10 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
             while (bits < 32 * surplus) bits <<= 1;
             if ((rc = fgpu_ensure(ctx, &ctx->delta_filter, bits / 8))) return rc;
             FGPU_HIP(hipMemsetAsync(ctx->delta_filter.p, 0, bits / 8, ctx->stream));
-            uint64_t max_seq = 0, newer = 0;
-            if ((rc = fgpu_scan_import_probe(ctx, dev_buf, n_entries, ctx->hint_max_seq, (uint32_t*)ctx->delta_filter.p, bits, &max_seq, &newer))) return rc;
-            if (newer == surplus) {
+            uint64_t max_seq = 0, newer = 0, digest[2] = {0, 0};
+            if ((rc = fgpu_scan_import_probe(ctx, dev_buf, n_entries, ctx->hint_max_seq, (uint32_t*)ctx->delta_filter.p, bits, &max_seq, &newer, digest))) return rc;
+            // a later state of the preview: as many newer entries as the surplus, AND the others are the preview's keys (their digest)
+            if (newer == surplus && digest[0] == ctx->hint_digest[0] && digest[1] == ctx->hint_digest[1]) {
                 ctx->delta_ready = true;
                 ctx->delta_filter_bits = bits;
                 ctx->delta_keys = newer;
@@ -1262,7 +1306,7 @@ int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries
     if ((rc = fgpu_scan_import_impl(ctx, dev_buf, n_entries))) return rc;
     uint64_t newer = 0;
     ctx->hint_max_seq = 0;
-    if ((rc = fgpu_scan_import_probe(ctx, dev_buf, n_entries, ~0ULL, nullptr, 0, &ctx->hint_max_seq, &newer))) return rc;
+    if ((rc = fgpu_scan_import_probe(ctx, dev_buf, n_entries, ~0ULL, nullptr, 0, &ctx->hint_max_seq, &newer, ctx->hint_digest))) return rc;
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     ctx->hint_in_table = true;
     ctx->hint_n = n_entries;

@@ -286,6 +286,7 @@ struct fgpu_ctx {
     // batch's planes speak of it when the real table arrives, only the keys created SINCE have to be looked for (fgpu_scan_import_table):
     uint32_t hint_gen = 0;
     uint64_t hint_n = 0, hint_max_seq = 0;
+    uint64_t hint_digest[2] = {0, 0};   // XOR / sum of the preview's mixed keys: the real table's not-newer entries must give the same (k_import_probe)
     DevBuf delta_filter;             // presence filter of the keys of the imported table that are newer than the preview (two bits of one word per key)
     uint64_t delta_filter_bits = 0;
     bool delta_ready = false;        // the walk of the prepared batches merges the new keys into their planes instead of making the planes again
@@ -293,7 +294,7 @@ struct fgpu_ctx {
     uint64_t refresh_full = 0, refresh_delta = 0, refresh_mismatch = 0;
     int dbg_stall_us = 0;            // FGPU_DEBUG_WALK_STALL_US, FGPU_DEBUG_DELTA_CHECK: read once per scan (fgpu_scan_begin), not from the walk's inner calls
     bool dbg_delta_check = false;
-    DevBuf import_probe;             // device: [0] largest piece number among the entries of the last import, [1] entries newer than the preview
+    DevBuf import_probe;             // device: [0] largest piece number among the entries of the last import, [1] entries newer than the preview, [2] [3] digest of the others
     uint64_t scan_grown = 0;         // times the junction table was rehashed into a larger one
 
     DevCounters* counters = nullptr;      // device
@@ -329,6 +330,8 @@ struct fgpu_ctx {
     bool eager_scan = false;              // the rest of this scan evaluates every junction test (after a replay, or beyond the journal's budget)
     bool lazy_failed = false;             // a synchronising call has seen the lazy-flag check fire: replay at the next entry point
     bool in_replay = false;
+    bool capacity_failed = false;         // ... because a batch outgrew the junction table: the replay starts on a table four times the size
+    uint64_t capacity_replays = 0;        // (fgpu_diag_scan_replays counts them with the others; this is how many of them were for room)
     // the short pair filter on the device (fgpu_scan_short_pairs): scan_forward's addPair rules applied to every piece's list as it is harvested
     uint32_t* short_pf = nullptr;
     uint64_t short_pf_tai = 0;
@@ -476,7 +479,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_stage_scan_need(fgpu_ctx* ctx);
 int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, uint64_t after_seq, uint32_t* dfilter, uint64_t dfilter_bits,
-                           uint64_t* max_seq, uint64_t* n_newer);
+                           uint64_t* max_seq, uint64_t* n_newer, uint64_t digest[2]);
 int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx);
 int fgpu_util_count_segments(fgpu_ctx* ctx, int minlen);
 int fgpu_util_popcount(fgpu_ctx* ctx, const void* dev, uint64_t nbytes, unsigned long long* dev_out);
@@ -494,3 +497,4 @@ int fgpu_scan_reset(fgpu_ctx* ctx);
 int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap);
 int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records);
 int fgpu_scan_clear_table(fgpu_ctx* ctx);
+int fgpu_scan_regrow_empty(fgpu_ctx* ctx, uint64_t new_cap);

@@ -2754,11 +2754,19 @@ __global__ void __launch_bounds__(256) k_delta_filter_add(const uint32_t* __rest
 // when a preview is being replaced by a later state of the same table -- which keys are newer than the preview: counted, and put into the filter
 __global__ void __launch_bounds__(256) k_import_probe(const ExportEntry* in, uint64_t n, FdParams fp, uint64_t after_seq, uint32_t* dfilter,
                                                       uint64_t dmask, unsigned long long* out) {
-    unsigned long long mx = 0, newer = 0;
+    // out[2], out[3]: a digest (XOR and sum of the mixed keys) of the entries that are NOT newer -- of a preview: of all its keys.  A table that is
+    // a later state of a preview holds the preview's keys with their stamps, so its not-newer entries give the preview's digest (the
+    // count alone could agree by coincidence for a table that is NOT such a state, e.g. after the sender replayed its scan)
+    unsigned long long mx = 0, newer = 0, dx = 0, dsum = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const ExportEntry e = in[i];
         const unsigned long long seq = e.stamp >> STAMP_SHIFT;
         mx = seq > mx ? seq : mx;
+        if (seq <= after_seq) {
+            const unsigned long long m = fd_mix(e.key ^ 0x9E3779B97F4A7C15ULL);
+            dx ^= m;
+            dsum += m;
+        }
         if (seq > after_seq) {
             newer++;
             if (dfilter) {
@@ -2772,10 +2780,14 @@ __global__ void __launch_bounds__(256) k_import_probe(const ExportEntry* in, uin
         const unsigned long long t = __shfl_down(mx, o, 64);
         mx = t > mx ? t : mx;
         newer += __shfl_down(newer, o, 64);
+        dx ^= __shfl_down(dx, o, 64);
+        dsum += __shfl_down(dsum, o, 64);
     }
     if (fd_lane() == 0) {
         if (mx) atomicMax(&out[0], mx);
         if (newer) atomicAdd(&out[1], newer);
+        if (dx) atomicXor(&out[2], dx);
+        if (dsum) atomicAdd(&out[3], dsum);
     }
 }
 
@@ -2915,6 +2927,25 @@ int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap) {
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));   // the walk stream starts on the new table
     ctx->scan_grown++;
     return FGPU_OK;
+}
+
+// A batch outgrew the table (error bit 1): the scan's attempt is void and is made again from the journal -- on a table with new_cap slots, EMPTY
+// (nothing of the void attempt is kept).  Both streams idle.  The reference's unordered_map just grows (utils/JunctionMap.h:61).
+int fgpu_scan_regrow_empty(fgpu_ctx* ctx, uint64_t new_cap) {
+    if (new_cap <= ctx->jcap) return FGPU_OK;
+    uint64_t* nk = nullptr; uint8_t* nr = nullptr; uint64_t* ns = nullptr; uint32_t* nf = nullptr;
+    if (hipMalloc(&nk, new_cap * 8) != hipSuccess || hipMalloc(&nr, new_cap * 32) != hipSuccess || hipMalloc(&ns, new_cap * 16) != hipSuccess ||
+        hipMalloc(&nf, new_cap * 2 / 8) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(nk); hipFree(nr); hipFree(ns); hipFree(nf);
+        ctx->err = "junction table full, and no memory to grow it to " + std::to_string(new_cap) + " slots";
+        return FGPU_ERR_NOMEM;
+    }
+    hipFree(ctx->jkeys); hipFree(ctx->jrecs); hipFree(ctx->jstamps); hipFree(ctx->jfilter);
+    ctx->jkeys = nk; ctx->jrecs = nr; ctx->jstamps = ns; ctx->jfilter = nf;
+    ctx->jcap = new_cap;
+    ctx->scan_grown++;
+    return fgpu_scan_clear_table(ctx);
 }
 
 // empty junction table (a preview is being replaced by the real state); both streams idle
@@ -3663,18 +3694,21 @@ int fgpu_scan_import_impl(fgpu_ctx* ctx, const void* dev_entries, uint64_t n) {
 }
 
 int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, uint64_t after_seq, uint32_t* dfilter, uint64_t dfilter_bits,
-                           uint64_t* max_seq, uint64_t* n_newer) {
+                           uint64_t* max_seq, uint64_t* n_newer, uint64_t digest[2]) {
     *max_seq = *n_newer = 0;
+    digest[0] = digest[1] = 0;
     if (!n) return FGPU_OK;
-    if (int rc = fgpu_ensure(ctx, &ctx->import_probe, 16)) return rc;
-    FGPU_HIP(hipMemsetAsync(ctx->import_probe.p, 0, 16, ctx->stream));
+    if (int rc = fgpu_ensure(ctx, &ctx->import_probe, 32)) return rc;
+    FGPU_HIP(hipMemsetAsync(ctx->import_probe.p, 0, 32, ctx->stream));
     FGPU_LAUNCH("import", k_import_probe, (unsigned)std::min<uint64_t>(fgpu_blocks(n, 256), 4096), 256, (const ExportEntry*)dev_entries, n, ctx->fd, after_seq, dfilter,
                 dfilter_bits ? dfilter_bits - 1 : 0, (unsigned long long*)ctx->import_probe.p);
-    unsigned long long out[2] = {0, 0};
-    FGPU_HIP(hipMemcpyAsync(out, ctx->import_probe.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long out[4] = {0, 0, 0, 0};
+    FGPU_HIP(hipMemcpyAsync(out, ctx->import_probe.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
     *max_seq = out[0];
     *n_newer = out[1];
+    digest[0] = out[2];
+    digest[1] = out[3];
     return FGPU_OK;
 }
 

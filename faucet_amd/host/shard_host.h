@@ -72,7 +72,7 @@ do {                                                \
 
 class ShardedRun {
 public:
-    explicit ShardedRun(const ShardOptions& o) : o_(o), ctx_((size_t)o.n_ranks, nullptr), err_((size_t)o.n_ranks), bufs_((size_t)o.n_ranks) {}
+    explicit ShardedRun(const ShardOptions& o) : o_(o), ctx_((size_t)o.n_ranks, nullptr), err_((size_t)o.n_ranks), bufs_((size_t)o.n_ranks) { graveyard_.resize((size_t)std::max(o.n_ranks, 1)); }
     ~ShardedRun() { close(); }
     ShardedRun(const ShardedRun&) = delete;
     ShardedRun& operator=(const ShardedRun&) = delete;
@@ -111,6 +111,12 @@ public:
 
     void close() {
         if (group_) { fgpu_group_destroy(group_); group_ = nullptr; }
+        // exchange buffers of a pass that FAILED: freed only here, behind fgpu_group_destroy, which has synchronised every rank's stream -- a peer's
+        // copy may still have been reading them when their rank gave up
+        for (size_t r = 0; r < graveyard_.size() && r < ctx_.size(); r++) {
+            for (void* p : graveyard_[r]) if (ctx_[r]) fgpu_device_free(ctx_[r], p);
+            graveyard_[r].clear();
+        }
         for (size_t r = 0; r < ctx_.size(); r++) {
             if (ctx_[r]) { fgpu_destroy(ctx_[r]); ctx_[r] = nullptr; }
             for (int i = 0; i < 2; i++) if (bufs_[r].p[i]) { fgpu_host_free(bufs_[r].p[i]); bufs_[r].p[i] = nullptr; }
@@ -126,45 +132,70 @@ public:
         }
         uint64_t largest = 0;
         for (int r = 0; r < o_.n_ranks; r++) largest = std::max(largest, cuts[(size_t)r + 1] - cuts[(size_t)r]);
-        // the fix-up protocol keeps the shard's batches in HBM (8 bits per base with the fail planes; the library gives them an eighth of the
-        // device) and covers four hash functions; --mercy leaves no fix-up state (fgpu_load_end)
+        // the fix-up protocol keeps the shard's batches in HBM (about a byte per base with the fail planes) within what the library sets aside for
+        // resident batches -- asked of every context, not assumed -- and covers four hash functions; --mercy leaves no fix-up state
+        uint64_t budget = ~0ULL;
+        for (int r = 0; r < o_.n_ranks; r++) {
+            uint64_t b = 0;
+            if (fgpu_load_fixup_state(ctx_[(size_t)r], nullptr, &b) != FGPU_OK) b = 0;
+            budget = std::min(budget, b);
+        }
         const char* force_planes = getenv("FAUCET_SHARD_PLANES");
-        const bool short_shards = largest < 0xFFF00000ULL - (1ULL << 24) && !(force_planes && force_planes[0] == '1');   // a shard's positions (<= its bytes) fit one 32-bit clock
-        bool fixup = !o_.mercy && (short_shards || o_.prm.n_hash <= 4) && largest < (24ULL << 30);
+        const bool short_shards = largest < 0xFFF00000ULL - (1ULL << 24) && !(force_planes && force_planes[0] == '1' && o_.prm.n_hash <= 4);   // a shard's positions (<= its bytes) fit one 32-bit clock
+        bool fixup = !o_.mercy && (short_shards || o_.prm.n_hash <= 4) && largest + (64ULL << 20) < budget;
         if (const char* e = getenv("FAUCET_SHARD_PROTOCOL")) {
             if (!strcmp(e, "presence")) fixup = false;
             else if (!strcmp(e, "fixup") && !fixup) { error_ = "FAUCET_SHARD_PROTOCOL=fixup: a shard is too large to stay in HBM, more than 4 hash functions, or --mercy is on"; return FGPU_ERR_ARG; }
         }
+        const char* dbg_not_ready = getenv("FAUCET_DEBUG_FIXUP_NOT_READY");      // tests: this rank's own load "did not stay resident"
         std::vector<fgpu_load_stats> st((size_t)o_.n_ranks);
         float w1 = 0, w2 = 0;
         const uint64_t nbytes = o_.prm.tai / 8;
+        std::atomic<bool> fixup_done{fixup};
         int rc = run_ranks([&](int r) -> int {
             fgpu_ctx* c = ctx_[(size_t)r];
             const double t0 = now_ms();
             void *b1 = nullptr, *b2 = nullptr, *prefix = nullptr;
             RANK_CHECK(fgpu_device_alloc(c, nbytes, &prefix));
-            struct FreePrefix { fgpu_ctx* c; void* p; ~FreePrefix() { fgpu_device_free(c, p); } } free_prefix{c, prefix};
-            if (fixup) {
+            Deferred free_prefix(this, r, &prefix, nullptr, nullptr, nullptr);
+            bool use_fixup = fixup;
+            double t1 = t0;
+            if (use_fixup) {
                 RANK_CHECK(fgpu_load_begin(c, short_shards ? FGPU_LOAD_SHARD_TIMES : FGPU_LOAD_SHARD_PLANES));
                 RANK_TRY(for_each_batch(r, path, cuts, [&](const fgpu_reads* b) { return fgpu_load_batch(c, b); }, nullptr));
                 RANK_CHECK(fgpu_load_end(c, &st[(size_t)r]));
-                const double t1 = now_ms();
+                t1 = now_ms();
+                // Can every rank complete its pass by the fix-up?  (A batch that did not stay resident -- over the budget, or no memory at that
+                // moment -- leaves fgpu_load_fixup nothing to work on.)  The ranks agree: if one cannot, ALL run the presence protocol instead --
+                // a pass more, the same filters -- rather than the run dying after a full pass 1.
+                int ready = 0;
+                RANK_CHECK(fgpu_load_fixup_state(c, &ready, nullptr));
+                if (dbg_not_ready && atoi(dbg_not_ready) == r) ready = 0;
+                if (!vote(ready != 0)) {
+                    if (aborted_) { err_[(size_t)r] = "the run was aborted (another rank failed)"; return FGPU_ERR_STATE; }
+                    use_fixup = false;
+                    fixup_done = false;
+                    tell(r, "pass 1: own load %.1f ms; a rank cannot complete it by the fix-up: the presence protocol instead", t1 - t0);
+                }
+            }
+            if (use_fixup) {
                 RANK_CHECK(fgpu_bloom_devptr(c, FGPU_BLOO1, &b1, nullptr));
                 GROUP_CHECK(fgpu_group_exclusive_prefix_or(group_, r, b1, prefix, nbytes));
                 if (r > 0) RANK_CHECK(fgpu_load_fixup(c, prefix, &st[(size_t)r]));
                 tell(r, "pass 1: own load %.1f ms, prefix-OR exchange + fix-up %.1f ms", t1 - t0, now_ms() - t1);
             } else {
+                const double t1p = now_ms();
                 RANK_CHECK(fgpu_load_begin(c, 0));             // (empties both filters)
                 RANK_CHECK(fgpu_load_end(c, nullptr));
                 RANK_TRY(for_each_batch(r, path, cuts, [&](const fgpu_reads* b) { return fgpu_presence_batch(c, b); }, nullptr));
-                const double t1 = now_ms();
+                const double t2p = now_ms();
                 RANK_CHECK(fgpu_bloom_devptr(c, FGPU_BLOO1, &b1, nullptr));
                 GROUP_CHECK(fgpu_group_exclusive_prefix_or(group_, r, b1, prefix, nbytes));
                 RANK_CHECK(fgpu_device_copy(c, b1, prefix, nbytes));      // the carried-in bloo1 of this shard
                 RANK_CHECK(fgpu_load_begin(c, FGPU_LOAD_KEEP_CARRY));
                 RANK_TRY(for_each_batch(r, path, cuts, [&](const fgpu_reads* b) { return fgpu_load_batch(c, b); }, nullptr));
                 RANK_CHECK(fgpu_load_end(c, &st[(size_t)r]));
-                tell(r, "pass 1: presence pass %.1f ms, prefix-OR exchange + ordered load %.1f ms", t1 - t0, now_ms() - t1);
+                tell(r, "pass 1: presence pass %.1f ms, prefix-OR exchange + ordered load %.1f ms", t2p - t1p, now_ms() - t2p);
             }
             const double t2 = now_ms();
             RANK_CHECK(fgpu_bloom_devptr(c, FGPU_BLOO2, &b2, nullptr));
@@ -176,6 +207,7 @@ public:
                 RANK_CHECK(fgpu_synchronize(c));
             }
             tell(r, "pass 1: OR-allreduce of bloo2 %.1f ms (to the device's completion)", now_ms() - t2);
+            free_prefix.ok = true;
             return FGPU_OK;
         });
         if (rc != FGPU_OK) return rc;
@@ -188,7 +220,7 @@ public:
         }
         out->w1 = w1;
         out->w2 = w2;
-        out->fixup = fixup;
+        out->fixup = fixup_done;
         return FGPU_OK;
     }
 
@@ -219,7 +251,7 @@ public:
             fgpu_scan_stats st;
             memset(&st, 0, sizeof(st));
             void *hint_buf = nullptr, *table_in = nullptr, *table_out = nullptr, *late_buf = nullptr;
-            struct FreeAll { fgpu_ctx* c; void** p[4]; ~FreeAll() { for (void** q : p) if (*q) fgpu_device_free(c, *q); } } free_all{c, {&hint_buf, &table_in, &table_out, &late_buf}};
+            Deferred free_all(this, r, &hint_buf, &table_in, &table_out, &late_buf);
             if (r == 0) {
                 // the first shard has nothing to wait for: it streams (pure stage of batch b + 1 beside the walk of batch b, lazy junction tests).
                 // Once a quarter of it is walked the others are shown its table -- an earlier state of the very table they will be handed, which is
@@ -302,6 +334,7 @@ public:
             }
             if (n > 1 && (r == 0 || (late_hints && r + 1 < n))) GROUP_CHECK(fgpu_group_flush(group_, r));      // (asynchronous sends: the previews)
             RANK_CHECK(fgpu_synchronize(c));
+            free_all.ok = true;
             return FGPU_OK;
         });
         if (rc != FGPU_OK) return rc;
@@ -313,6 +346,38 @@ public:
 
 private:
     struct Bufs { char* p[2] = {nullptr, nullptr}; };
+    // device buffers of one rank's pass: freed at once when the pass ended well (everything that touched them has been waited for), else left to close()
+    struct Deferred {
+        ShardedRun* run;
+        int r;
+        void** p[4];
+        bool ok;
+        Deferred(ShardedRun* run_, int r_, void** a, void** b, void** c, void** d) : run(run_), r(r_), ok(false) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+        Deferred(const Deferred&) = delete;
+        ~Deferred() {
+            for (void** q : p) {
+                if (!q || !*q) continue;
+                if (ok) fgpu_device_free(run->ctx_[(size_t)r], *q);
+                else { std::lock_guard<std::mutex> g(run->m_); run->graveyard_[(size_t)r].push_back(*q); }
+            }
+        }
+    };
+    // every rank arrives with its answer; true iff all said yes (false as well when the run has been aborted meanwhile)
+    bool vote(bool mine) {
+        std::unique_lock<std::mutex> g(m_);
+        const uint64_t gen = vote_gen_;
+        vote_all_ = vote_all_ && mine;
+        if (++vote_count_ == o_.n_ranks) {
+            vote_result_ = vote_all_;
+            vote_count_ = 0;
+            vote_all_ = true;
+            vote_gen_++;
+            cv_.notify_all();
+            return vote_result_;
+        }
+        cv_.wait(g, [&] { return vote_gen_ != gen || aborted_; });
+        return vote_gen_ != gen ? vote_result_ : false;
+    }
     // what one rank tells another through host memory (the ranks share a process): a count, the scan's counters.  The bytes themselves
     // travel device to device (fgpu_group_send / _recv).
     struct Announce {
@@ -429,6 +494,10 @@ private:
     Announce hint_;
     std::vector<Announce> chain_;
     std::vector<Announce> late_;      // the table a rank was handed, passed on to the rank above as a fresher preview
+    std::vector<std::vector<void*>> graveyard_{64};
+    int vote_count_ = 0;
+    bool vote_all_ = true, vote_result_ = false;
+    uint64_t vote_gen_ = 0;
 };
 
 }  // namespace faucet_host

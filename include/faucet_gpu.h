@@ -52,8 +52,11 @@ typedef struct {
     int32_t  flags;             /* FGPU_FLAG_* */
     uint64_t junction_capacity; /* INITIAL slots of the device junction table, power of two; 0 = default (tai / 32).  The table is
                                  * rehashed into a larger one between batches whenever it is more than a quarter full (the
-                                 * reference's unordered_map grows the same way); a single batch that outgrows it ends the scan
-                                 * with FGPU_ERR_CAPACITY: hand over smaller batches or start larger. */
+                                 * reference's unordered_map grows the same way, utils/JunctionMap.h:61).  A single batch that outgrows
+                                 * it is absorbed by the library while the scan's batches are in its journal (see fgpu_scan_set_eager:
+                                 * the journal is scanned again on a table four times the size; fgpu_diag_scan_replays counts it); only a
+                                 * scan without a journal -- FGPU_FLAG_EAGER_FLAGS, fgpu_scan_set_eager(1), or beyond the journal's
+                                 * budget of an eighth of the device memory -- ends with FGPU_ERR_CAPACITY there. */
     uint64_t max_batch_bases;   /* largest batch (bases + one separator per read); 0 = default 2^30 */
     void*    stream;            /* hipStream_t to run on, or NULL for a private stream */
     uint64_t walk_window_span;  /* stream positions per scheduling window of the ordered walk; 0 = adaptive.
@@ -185,6 +188,12 @@ int fgpu_presence_batch(fgpu_ctx* ctx, const fgpu_reads* reads);
  * those occurrences to bloo2, to the planes the scan reuses and to stats->to_bloo2; bloo1 |= prefix.  FGPU_ERR_STATE when the pass was not
  * begun that way or a batch was not kept. */
 int fgpu_load_fixup(fgpu_ctx* ctx, const void* prefix_dev, fgpu_load_stats* stats);
+/* What a host needs to CHOOSE between the two protocols of pass 1 and to fall back from one to the other (shard_host.h had a
+ * constant of its own and no way back).  *ready (may be NULL): 1 iff fgpu_load_fixup can complete the load pass that has just ended -- 0 when
+ * a batch was not kept resident (budget, or no memory at that moment), the pass was not begun as a shard's, or --mercy: the ranks then
+ * agree to run the presence protocol instead (every rank the same).  *resident_budget_bytes (may be NULL): device bytes this context keeps
+ * load batches resident in; a shard's batches need about one byte per base (codes, bad, sure, and up to four fail planes). */
+int fgpu_load_fixup_state(fgpu_ctx* ctx, int* ready, uint64_t* resident_budget_bytes);
 
 /* filters: raw bit arrays, tai/8 bytes, exactly the .bloom file body (utils/Bloom.cpp:571-587) */
 int fgpu_bloom_download(fgpu_ctx* ctx, int which, uint8_t* host_out, uint64_t nbytes);

@@ -8,6 +8,17 @@ out=$root/gpurun_out/prof_$cfg
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
+if [ "${3:-}" = "pmc" ]; then
+  # round 6: the two counter passes of the same program, each in its own run (never with a trace domain); the summary goes into
+  # profiles/pmc_traffic.json under full_size.<config> (scripts/pmc_fullsize_summary.py)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 800 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -o run -- python3 "$root/scripts/fullsize_step.py" "$cfg" > "$out/step_$c.json" 2> "$out/step_$c.err"
+    echo "$c rc=$?"
+  done
+  python3 "$root/scripts/pmc_fullsize_summary.py" "$out" "$cfg"
+  find "$out" \( -name "*counter_collection.csv" -o -name "*.db" \) -delete
+  exit 0
+fi
 timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/scripts/fullsize_step.py" "$cfg" > "$out/step.json" 2> "$out/step.err"
 echo "rc=$?"
 find "$out" \( -name "*kernel_trace.csv" -o -name "*.db" \) -delete

@@ -416,6 +416,12 @@ int fgpu_scan_download_junctions(fgpu_ctx* c, uint64_t* keys, fgpu_junction* rec
 // ---- the rest of the ABI is not needed by the stub's callers ------------------------------------------------------------------------------
 #define STUB_UNSUPPORTED(c) fail(c, FGPU_ERR_STATE, "not in the test stub (tests/stub/faucet_gpu_stub.cpp)")
 int fgpu_load_fixup(fgpu_ctx* c, const void*, fgpu_load_stats*) { return STUB_UNSUPPORTED(c); }
+int fgpu_load_fixup_state(fgpu_ctx* c, int* ready, uint64_t* budget) {     // (the stand-in keeps nothing resident: hosts take the presence protocol)
+    if (!c) return FGPU_ERR_ARG;
+    if (ready) *ready = 0;
+    if (budget) *budget = 0;
+    return FGPU_OK;
+}
 int fgpu_scan_set_eager(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_profile_enable(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_diag_host_waits(fgpu_ctx* c, uint64_t* waits, double* ms) { if (!c || !waits) return FGPU_ERR_ARG; *waits = 0; if (ms) *ms = 0; return FGPU_OK; }

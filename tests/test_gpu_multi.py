@@ -79,6 +79,20 @@ def test_both_pass1_protocols_and_small_chunks(protocol, extra, tmp_path):
         _same_files(c, prefix)
 
 
+def test_a_rank_that_cannot_complete_its_pass_by_the_fixup_sends_all_ranks_to_the_presence_protocol(tmp_path):
+    """a shard whose batches did not all stay resident (over the budget of fgpu_load_fixup_state, or no memory at that moment) left
+    `faucet -gpus N` dead after a full pass 1.  The ranks now vote after their own loads; one "no" (forced here on rank 1) and every rank runs the
+    presence protocol instead: one pass more, the reference's files."""
+    for case in ("ragged_k31", "pe_repeats_k25"):
+        c = Case(case)
+        where = tmp_path / case
+        where.mkdir()
+        prefix, r = _run(c, where, 3, ["-chunk_mb", "1"], env={"FAUCET_DEBUG_FIXUP_NOT_READY": "1", "FGPU_CLI_TIMES": "1"}, tag="fallback")
+        assert r.returncode == (0 if c.no_cleaning else 3), r.stdout[-2000:] + r.stderr[-3000:]
+        assert "the presence protocol instead" in r.stderr and "pass 1 (shards, presence protocol)" in r.stderr
+        _same_files(c, prefix)
+
+
 def test_more_shards_than_records_and_refusals(tmp_path):
     """8 shards of a 30-record file leave shards empty; pipes and -batch_reads are refused loudly (a shard is a byte range of a regular file)"""
     c = Case("c1_k21")
