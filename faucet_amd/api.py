@@ -191,6 +191,12 @@ class Context:
         self._c(self.lib.fgpu_load_fixup(self.h, prefix_dev_ptr, C.byref(st)))
         return st.as_dict()
 
+    def load_fixup_state(self):
+        """(can fgpu_load_fixup complete the load pass that has just ended?, bytes the context keeps load batches resident in)"""
+        ready, budget = C.c_int(0), C.c_uint64(0)
+        self._c(self.lib.fgpu_load_fixup_state(self.h, C.byref(ready), C.byref(budget)))
+        return bool(ready.value), int(budget.value)
+
     def load_batch(self, batch: ReadBatch):
         s = batch.c_struct()
         self._c(self.lib.fgpu_load_batch(self.h, C.byref(s)))

@@ -260,6 +260,11 @@ def load_sharded_fixup(backend, batches, rank: int, world: int):
     CLOCK.mark("pass1_begin")
     stats = backend.load(batches, keep_carry=False, shard_times=True)
     CLOCK.mark("pass1_own_load")
+    # can every rank complete its pass by the fix-up (all batches stayed resident)?  One "no" and ALL ranks run the presence protocol instead
+    # (a pass more, the same filters) -- as host/shard_host.h does; backends without the query are taken at their word
+    ready = getattr(backend, "fixup_ready", lambda: True)()
+    if world > 1 and not _agree(bool(ready), getattr(backend, "device", None)):
+        return load_sharded_presence(backend, batches, rank, world)
     b1 = backend.bloom_tensor(L.BLOO1)
     prefix = backend.scratch(b1.numel(), tag="prefix")
     exclusive_prefix_or(backend, b1, prefix, rank, world)
@@ -678,8 +683,13 @@ class GpuShard:
         short = self._one_clock(batches)                 # one 32-bit clock for the shard; beyond: fail planes, which cover four hash functions
         if not short and getattr(self.ctx, "n_hash", 0) > 4:
             return False
-        free, total = torch.cuda.mem_get_info(self.device)
-        return sum(pos) + (64 << 20) < total // 8        # 8 bits per position kept in HBM (codes, bad, sure, four fail planes): an eighth of the device
+        return sum(pos) + (64 << 20) < self.ctx.load_fixup_state()[1]     # 8 bits per position kept in HBM (codes, bad, sure, four fail planes) within the library's budget
+
+    def fixup_ready(self):
+        """after the own load of the fix-up protocol: did every batch stay resident (fgpu_load_fixup_state)?"""
+        if os.environ.get("FAUCET_DEBUG_FIXUP_NOT_READY", "") == str(dist.get_rank() if dist.is_initialized() else 0):
+            return False
+        return self.ctx.load_fixup_state()[0]
 
     def or_tensor(self, dst, src):
         self.ctx.bitmap_or(dst.data_ptr(), src.data_ptr(), dst.numel())

@@ -64,6 +64,10 @@ class OracleShard:
         self.asked = True
         return True
 
+    def fixup_ready(self):
+        # protocol "fallback": the last rank's own load "did not stay resident" -- the ranks vote and ALL take the presence protocol
+        return not (self.protocol == "fallback" and dist.get_rank() == dist.get_world_size() - 1)
+
     def or_tensor(self, dst, src):
         dst.numpy()[:] |= src.numpy()
 
@@ -154,7 +158,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, name, out_dir, protocol):
-    os.environ["FAUCET_SHARD_PROTOCOL"] = protocol
+    os.environ["FAUCET_SHARD_PROTOCOL"] = "auto" if protocol == "fallback" else protocol
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: no host-name look-up for the interface
@@ -168,7 +172,7 @@ def _worker(rank, world, port, name, out_dir, protocol):
     tai, nh, _, _ = po.sizing_from_cli(c.E, c.S)
     be = OracleShard(c.k, tai, nh, c.j, c.spacer, protocol)
     sharded.load_sharded(be, mine, rank, world)
-    assert getattr(be, "fixed_up", False) == (protocol != "presence" and rank > 0)      # auto: the fix-up protocol wherever every rank can run it
+    assert getattr(be, "fixed_up", False) == (protocol not in ("presence", "fallback") and rank > 0)      # auto: the fix-up protocol wherever every rank can run it
     np.save(os.path.join(out_dir, f"bloo2_{rank}.npy"), be.b2.bits().copy())
     st, last = sharded.scan_sharded(be, mine, rank, world)
     if last:
@@ -182,7 +186,7 @@ def _worker(rank, world, port, name, out_dir, protocol):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("protocol", ["fixup", "presence", "auto"])
+@pytest.mark.parametrize("protocol", ["fixup", "presence", "auto", "fallback"])
 @pytest.mark.parametrize("name,world", [("c1_k21", 2), ("ragged_k31", 2), ("j2_spacer20_k15", 3)])
 def test_sharded_protocol_matches_single_process(name, world, protocol, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), protocol), nprocs=world, join=True)
