@@ -58,7 +58,7 @@ def build(force: bool = False, jobs: int = 6) -> str:
     if force or _newer(LIB, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     main = os.path.join(HERE, "host", "faucet_main.cpp")
-    if os.path.exists(main) and (force or _newer(CLI, [main, LIB] + [os.path.join(HERE, "host", h) for h in ("junction_order.h", "shard_host.h", "text_source.h")] + hdrs)):
+    if os.path.exists(main) and (force or _newer(CLI, [main, LIB] + [os.path.join(HERE, "host", h) for h in ("junction_order.h", "shard_host.h", "text_source.h", "pair_loop.h")] + hdrs)):
         _run(["g++", "-std=c++11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), main, "-o", CLI,
               "-L", HERE, "-lfaucet_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib", "-lpthread"])
     return LIB

@@ -381,12 +381,16 @@ int fgpu_scan_long_pairs(fgpu_ctx* ctx, uint64_t tai, int32_t n_hash, int32_t mo
     if (!ctx->record_stops) { ctx->err = "fgpu_scan_long_pairs needs FGPU_FLAG_RECORD_STOPS"; return FGPU_ERR_STATE; }
     if (mode == FGPU_LONG_PAIRS_FILTER) {
         if (!tai || (tai & (tai - 1)) || tai < 128 || n_hash < 1 || n_hash > 32) { ctx->err = "fgpu_scan_long_pairs: tai must be a power of two >= 128, n_hash 1..32"; return FGPU_ERR_ARG; }
-        hipError_t e = hipMalloc(&lp.bits, tai / 8);
+        // FGPU_DEBUG_LONG_PAIRS_NOMEM=1 (tests): as if the filter's working state -- 4 bytes per bit -- did not fit, so that the hosts' way on can be tested
+        static const bool dbg_nomem = getenv("FGPU_DEBUG_LONG_PAIRS_NOMEM") != nullptr;
+        hipError_t e = dbg_nomem ? hipErrorOutOfMemory : hipMalloc(&lp.bits, tai / 8);
         if (e == hipSuccess) e = hipMalloc(&lp.first, tai * 4);
         if (e != hipSuccess) {
             if (lp.bits) hipFree(lp.bits);
             lp.bits = nullptr;
-            ctx->err = std::string("fgpu_scan_long_pairs: hipMalloc of the filter and its first-set times (4 bytes per bit) failed: ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            ctx->err = std::string("fgpu_scan_long_pairs: hipMalloc of the filter and its first-set times (4 bytes per bit) failed: ") + hipGetErrorString(e) +
+                       " -- hosts run the loop themselves over fgpu_scan_take_stops' lists then (host/pair_loop.h)";
             return FGPU_ERR_NOMEM;
         }
         lp.tai = tai;

@@ -33,6 +33,7 @@
 
 #include "faucet_gpu.h"
 #include "junction_order.h"
+#include "pair_loop.h"
 #include "shard_host.h"
 #include "text_source.h"
 
@@ -764,10 +765,36 @@ int main(int argc, char** argv) {
             int rc = device_short_pairs ? fgpu_scan_short_pairs(ctx, short_pf.tai, short_pf.n_hash, 0) : FGPU_OK;
             if (rc != FGPU_OK) return failed("fgpu_scan_short_pairs", rc);
             // scanReads' paired-end loop (src/ReadScanner.cpp:317-343): on the device, from the same lists, in file order
+            bool host_long_pairs = false;
             if (o.paired_ends) {
                 rc = o.no_cleaning ? fgpu_scan_long_pairs(ctx, 0, 0, FGPU_LONG_PAIRS_COUNT) : fgpu_scan_long_pairs(ctx, long_pf.tai, long_pf.n_hash, FGPU_LONG_PAIRS_FILTER);
+                if (rc == FGPU_ERR_NOMEM && !o.no_cleaning) {
+                    // the device cannot hold the filter's working state (4 bytes per filter bit; --high_cov sizes the filter at E / 2 x 9 bits,
+                    // src/Faucet.cpp:279-280): the loop runs HERE instead, over the lists the device hands out (pair_loop.h) -- the reference
+                    // has no such limit, so neither has the command line
+                    fprintf(stderr, "note: the long pair filter (%llu bits) does not fit the device's fixed-point form; the paired-end loop runs on the host\n",
+                            (unsigned long long)long_pf.tai);
+                    host_long_pairs = true;
+                    rc = fgpu_scan_long_pairs(ctx, 0, 0, FGPU_LONG_PAIRS_OFF);
+                    if (rc == FGPU_OK && device_short_pairs) rc = fgpu_scan_short_pairs(ctx, short_pf.tai, short_pf.n_hash, 1);   // (the lists come to the host)
+                }
                 if (rc != FGPU_OK) return failed("fgpu_scan_long_pairs", rc);
             }
+            faucet_host::HostLongPairs hlp(long_pf.bits.data(), long_pf.tai, long_pf.n_hash, o.k, true);
+            std::vector<fgpu_stop> stops;
+            std::vector<uint64_t> batch_reads;
+            auto take_lists = [&](bool all) -> int {     // one batch's lists (after a batch call: the batch before it), or all that are left
+                for (;;) {
+                    uint64_t n_stops = 0;
+                    int64_t seq = -1;
+                    int trc = fgpu_scan_take_stops(ctx, stops.data(), stops.size(), &n_stops, &seq);
+                    if (trc == FGPU_ERR_CAPACITY) { stops.resize((size_t)(n_stops + n_stops / 4 + 16)); continue; }
+                    if (trc != FGPU_OK) return failed("fgpu_scan_take_stops", trc);
+                    if (seq < 0) return 0;
+                    hlp.batch(stops.data(), n_stops, batch_reads[(size_t)seq]);
+                    if (!all) return 0;
+                }
+            };
             rc = fgpu_scan_begin(ctx);
             if (rc != FGPU_OK) return failed("fgpu_scan_begin", rc);
             uint64_t scanned = 0;
@@ -777,6 +804,10 @@ int main(int argc, char** argv) {
                 const auto t_scan = std::chrono::steady_clock::now();
                 if ((rc = fgpu_scan_batch(ctx, &r)) != FGPU_OK) return failed("fgpu_scan_batch", rc);
                 clk.scan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count();
+                if (host_long_pairs) {
+                    batch_reads.push_back(r.n_reads);
+                    if (batch_reads.size() > 1) { const int trc = take_lists(false); if (trc) return trc; }
+                }
                 scanned += r.n_reads;
                 fprintf(stdout, "\rreads scanned: %lld", (long long)scanned);
                 fflush(stdout);
@@ -786,6 +817,12 @@ int main(int argc, char** argv) {
             clk.take_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_end).count();
             if (device_short_pairs && (rc = fgpu_scan_short_pairs_download(ctx, short_pf.bits.data(), short_pf.bits.size())) != FGPU_OK)
                 return failed("fgpu_scan_short_pairs_download", rc);
+            if (host_long_pairs) {
+                const int trc = take_lists(true);
+                if (trc) return trc;
+                empty_count = hlp.empty_count;
+                not_empty_count = hlp.not_empty_count;
+            } else
             if (o.paired_ends) {
                 rc = o.no_cleaning ? fgpu_scan_long_pairs_download(ctx, nullptr, 0, &empty_count, &not_empty_count)
                                    : fgpu_scan_long_pairs_download(ctx, long_pf.bits.data(), long_pf.bits.size(), &empty_count, &not_empty_count);

@@ -23,6 +23,7 @@
 #include "../utils/Kmer.h"
 #include "../utils/JuncPairs.h"
 #include "faucet_gpu.h"
+#include "pair_loop.h"      // faucet_amd/host: scanReads' paired-end loop over the device's lists, where the device cannot hold the long pair filter's working state
 #include "shard_host.h"     // faucet_amd/host: the two passes over several GPUs from this one process (one host thread per device)
 
 extern int j;               // src/Faucet.h:15
@@ -215,16 +216,63 @@ void gpu_scan_paired(JunctionMap* junctionMap, std::string read_scan_file, bool 
     if (g_run) return gpu_scan_sharded(junctionMap, read_scan_file, no_cleaning ? NULL : short_pair_filter, filters ? long_pair_filter : NULL, true);
     if (short_pair_filter && !no_cleaning)
         GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 0));
-    if (filters) GPU_CHECK(fgpu_scan_long_pairs(g_ctx, long_pair_filter->tai, long_pair_filter->getNumHash(), FGPU_LONG_PAIRS_FILTER));
-    else GPU_CHECK(fgpu_scan_long_pairs(g_ctx, 0, 0, FGPU_LONG_PAIRS_COUNT));
+    bool host_loop = false;
+    if (filters) {
+        const int lrc = fgpu_scan_long_pairs(g_ctx, long_pair_filter->tai, long_pair_filter->getNumHash(), FGPU_LONG_PAIRS_FILTER);
+        if (lrc == FGPU_ERR_NOMEM) {
+            // The device form of the loop keeps 4 bytes of HBM per filter bit; a filter it cannot hold (--high_cov: E / 2 x 9 bits,
+            // src/Faucet.cpp:279-280) is filled HERE, by the reference's own loop (src/ReadScanner.cpp:317-343) over the lists the device hands out
+            // (fgpu_scan_take_stops; host/pair_loop.h), straight into long_pair_filter's bit array
+            fprintf(stderr, "note: the long pair filter does not fit the device's fixed-point form; the paired-end loop runs on the host\n");
+            host_loop = true;
+            GPU_CHECK(fgpu_scan_long_pairs(g_ctx, 0, 0, FGPU_LONG_PAIRS_OFF));
+            if (short_pair_filter) GPU_CHECK(fgpu_scan_short_pairs(g_ctx, short_pair_filter->tai, short_pair_filter->getNumHash(), 1));   // (lists to the host)
+        } else if (lrc != FGPU_OK) {
+            gpu_die("fgpu_scan_long_pairs", lrc);
+        }
+    } else {
+        GPU_CHECK(fgpu_scan_long_pairs(g_ctx, 0, 0, FGPU_LONG_PAIRS_COUNT));
+    }
     fgpu_scan_stats st;
-    const int rc = gpu_scan_pass(read_scan_file, fastq, &st);
+    uint64_t empty_count = 0, not_empty_count = 0;
+    int rc;
+    if (host_loop) {
+        faucet_host::HostLongPairs hlp((uint8_t*)long_pair_filter->blooma, long_pair_filter->tai, long_pair_filter->getNumHash(), sizeKmer, true);
+        std::vector<fgpu_stop> stops;
+        std::vector<uint64_t> batch_reads;
+        auto take_lists = [&](bool all) -> int {
+            for (;;) {
+                uint64_t n_stops = 0;
+                int64_t seq = -1;
+                const int trc = fgpu_scan_take_stops(g_ctx, stops.data(), stops.size(), &n_stops, &seq);
+                if (trc == FGPU_ERR_CAPACITY) { stops.resize((size_t)(n_stops + n_stops / 4 + 16)); continue; }
+                if (trc != FGPU_OK || seq < 0) return trc;
+                hlp.batch(stops.data(), n_stops, batch_reads[(size_t)seq]);
+                if (!all) return FGPU_OK;
+            }
+        };
+        rc = fgpu_scan_begin(g_ctx);
+        if (rc == FGPU_OK)
+            rc = for_each_batch(read_scan_file, fastq, [&](const fgpu_reads* r) -> int {
+                const int brc = fgpu_scan_batch(g_ctx, r);
+                if (brc != FGPU_OK) return brc;
+                batch_reads.push_back(r->n_reads);
+                return batch_reads.size() > 1 ? take_lists(false) : FGPU_OK;
+            });
+        const int end_rc = fgpu_scan_end(g_ctx, &st);
+        if (rc == FGPU_OK) rc = end_rc;
+        if (rc == FGPU_OK) rc = take_lists(true);
+        empty_count = hlp.empty_count;
+        not_empty_count = hlp.not_empty_count;
+    } else {
+        rc = gpu_scan_pass(read_scan_file, fastq, &st);
+    }
     if (rc != FGPU_OK) gpu_die("paired-end junction scan", rc);
     if (short_pair_filter && !no_cleaning)
         GPU_CHECK(fgpu_scan_short_pairs_download(g_ctx, short_pair_filter->blooma, short_pair_filter->tai / 8));
-    uint64_t empty_count = 0, not_empty_count = 0;
-    GPU_CHECK(fgpu_scan_long_pairs_download(g_ctx, filters ? long_pair_filter->blooma : NULL, filters ? long_pair_filter->tai / 8 : 0, &empty_count,
-                                            &not_empty_count));
+    if (!host_loop)
+        GPU_CHECK(fgpu_scan_long_pairs_download(g_ctx, filters ? long_pair_filter->blooma : NULL, filters ? long_pair_filter->tai / 8 : 0, &empty_count,
+                                                &not_empty_count));
     gpu_fill_junction_map(junctionMap);
     printf("Empty count: %d, not empty count: %d\n", (int)empty_count, (int)not_empty_count);
     gpu_print_scan_summary(st);

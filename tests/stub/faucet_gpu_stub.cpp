@@ -246,6 +246,10 @@ int fgpu_scan_long_pairs(fgpu_ctx* c, uint64_t tai, int32_t n_hash, int32_t mode
     c->long_mode = mode;
     if (mode == FGPU_LONG_PAIRS_FILTER) {
         if (!tai || (tai & (tai - 1)) || n_hash < 1) return fail(c, FGPU_ERR_ARG, "bad long pair filter shape");
+        if (getenv("FGPU_DEBUG_LONG_PAIRS_NOMEM")) {      // (the product's knob: "the filter's working state does not fit the device" -- the hosts' own loop takes over)
+            c->long_mode = FGPU_LONG_PAIRS_OFF;
+            return fail(c, FGPU_ERR_NOMEM, "stub: fgpu_scan_long_pairs told to fail (FGPU_DEBUG_LONG_PAIRS_NOMEM)");
+        }
         c->long_pf = fo_bloom_new(tai, n_hash);
     }
     return FGPU_OK;

@@ -72,6 +72,22 @@ def test_reference_with_the_binding_linked_in_ends_like_the_pure_reference(linke
         assert want and want == got, line
 
 
+@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31"])
+def test_the_bindings_own_paired_end_loop_ends_like_the_pure_reference(linked, case, tmp_path):
+    """fgpu_scan_long_pairs answers FGPU_ERR_NOMEM (forced) -- the binding runs the reference's paired-end loop itself over the
+    device's lists (host/pair_loop.h) into the reference's long_pair_filter, and the reference's Stage 3 ends as it does on its own passes"""
+    c, outs = run_both(linked, case, tmp_path, env_bound={"FGPU_DEBUG_LONG_PAIRS_NOMEM": "1"})
+    (rp, dp), (rb, db) = outs["pure"], outs["bound"]
+    assert rb.returncode == rp.returncode, (rp.returncode, rb.returncode, rb.stdout[-1500:], rb.stderr[-1500:])
+    assert "the paired-end loop runs on the host" in rb.stderr
+    files = sorted(os.listdir(dp))
+    assert files == sorted(os.listdir(db)) and any(f.endswith(".long_pair_filter") for f in files)
+    for f in files:
+        assert normalised(str(dp / f)) == normalised(str(db / f)), f
+    counts = lambda out: [ln[ln.index("Empty count:"):] for ln in out.splitlines() if "Empty count:" in ln]      # noqa: E731
+    assert counts(rp.stdout) and counts(rp.stdout) == counts(rb.stdout)
+
+
 @pytest.mark.parametrize("gpus", [2, 3])
 @pytest.mark.parametrize("case", ["se_cleaning_k21", "pe_repeats_k25", "mercy_k21"])
 def test_the_linked_binding_over_read_shards_ends_like_the_pure_reference(linked, case, gpus, tmp_path):

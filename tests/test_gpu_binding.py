@@ -50,6 +50,27 @@ def test_reference_stage3_runs_on_the_gpu_passes_and_ends_like_the_pure_referenc
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/faucet_ref_gpu was not built (it needs the reference tree: make -C oracle ref_gpu)")
+@pytest.mark.parametrize("case", [c for c in sorted(WANT) if c.startswith("pe_")])
+def test_the_paired_end_loop_on_the_host_over_the_devices_lists(case, tmp_path):
+    """VERDICT r5 item 6b on the device: the long pair filter's fixed-point form "does not fit" (FGPU_DEBUG_LONG_PAIRS_NOMEM) -- the binding runs the
+    reference's loop over the lists the DEVICE hands out (fgpu_scan_take_stops) and every file, Stage 3's included, is the pure reference's"""
+    c = Case(case)
+    inp = str(tmp_path / ("reads.fq" if c.fastq else "reads.fa"))
+    with open(inp, "wb") as f:
+        f.write(c.reads_text())
+    r = subprocess.run([EXE, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", str(tmp_path / "out")] + c.meta["args"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, FGPU_DEBUG_LONG_PAIRS_NOMEM="1"))
+    want = WANT[case]
+    assert r.returncode == want["exit"], (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    assert ("the paired-end loop runs on the host" in r.stderr) == ("--no_cleaning" not in c.meta["args"])
+    got = {f: hashlib.sha256(normalised(str(tmp_path / f))).hexdigest() for f in sorted(os.listdir(tmp_path)) if f.startswith("out.")}
+    for f, d in want["files"].items():
+        assert got[f] == d, f
+    for line in want["summary"]:
+        assert line in r.stdout.splitlines(), line
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/faucet_ref_gpu was not built (it needs the reference tree: make -C oracle ref_gpu)")
 @pytest.mark.parametrize("gpus", [2, 3])
 @pytest.mark.parametrize("case", sorted(WANT))
 def test_reference_stage3_on_gpu_passes_over_read_shards(case, gpus, tmp_path):

@@ -41,6 +41,28 @@ def _check(r, want_rc):
     assert r.returncode == want_rc, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31"])
+@pytest.mark.parametrize("extra", [["-chunk_mb", "1"], ["-batch_reads", "333"]], ids=["chunks_1MB", "host_getline"])
+def test_the_paired_end_loop_on_the_host_writes_the_reference_files(cli, extra, case, tmp_path):
+    """where the device cannot hold the long pair filter's working state (fgpu_scan_long_pairs: FGPU_ERR_NOMEM, forced here) the
+    command line runs scanReads' paired-end loop itself (host/pair_loop.h) over the lists fgpu_scan_take_stops hands out, batch by batch -- a first
+    end whose mate opens the next batch included: the same four files and pair counts, clean under both sanitizers."""
+    exe, _ = cli
+    c = Case(case)
+    inp = str(tmp_path / ("reads.fq" if c.fastq else "reads.fa"))
+    with open(inp, "wb") as f:
+        f.write(c.reads_text())
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + c.meta["args"] + extra,
+                       capture_output=True, text=True, env=dict(_env(), FGPU_DEBUG_LONG_PAIRS_NOMEM="1"), timeout=600)
+    _check(r, 3)
+    assert "the paired-end loop runs on the host" in r.stderr
+    for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
+        with open(prefix + "." + ext, "rb") as f, gzip.open(os.path.join(c.dir, f"out.{ext}.gz"), "rb") as g:
+            assert f.read() == g.read(), ext
+    assert f"Empty count: {c.counters['empty_count']}, not empty count: {c.counters['not_empty_count']}" in r.stdout
+
+
 @pytest.mark.parametrize("case", ["pe_fastq_k21", "pe_repeats_k25", "pe_fasta_highcov_k31", "pe_mercy_k21", "pe_twohash_k27"])
 @pytest.mark.parametrize("extra", [[], ["-chunk_mb", "1"], ["-batch_reads", "333"]], ids=["chunks_64MB", "chunks_1MB", "host_getline"])
 def test_paired_end_fastq_with_cleaning_is_clean_and_equals_the_reference(cli, extra, case, tmp_path):
