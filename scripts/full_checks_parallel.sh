@@ -9,3 +9,5 @@ python scripts/full_oracle_check.py 5000000 7 77 8000 > "$out/repeats.log" 2>&1 
 python scripts/full_oracle_check.py 3000000 5 55 0 150 0.05 two_hash > "$out/config5_shape.log" 2>&1 &
 while [ -n "$(jobs -r)" ]; do sleep 30; echo "[$(date +%T)] still running: $(jobs -r | wc -l)"; done
 for f in config2 seeds_102_5002 repeats config5_shape; do echo "--- $f"; grep -v amdgpu.ids "$out/$f.log" | tail -4; done
+# ... and the variants of the suite's full-size / multi-variant checks that the driver-run `pytest -m gpu` leaves out (tests/conftest.py: marker `slow`)
+python -m pytest tests -q -m "gpu and slow" > "$out/slow_variants.log" 2>&1; echo "--- slow variants"; tail -3 "$out/slow_variants.log"

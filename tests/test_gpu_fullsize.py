@@ -488,7 +488,7 @@ def test_config4_full_size_equals_the_oracle(config4):
 
 
 @needs_config4
-@pytest.mark.parametrize("protocol", ["presence", "fixup", "fixup_planes"])
+@pytest.mark.parametrize("protocol", [pytest.param("presence", marks=pytest.mark.slow), "fixup", pytest.param("fixup_planes", marks=pytest.mark.slow)])
 def test_config4_as_eight_shards_in_file_order_equals_the_oracle_after_every_rank(config4, protocol, monkeypatch):
     """The same reads as the 8 contiguous shards of the 8-GPU layout through the sharded pipeline's own steps (faucet_amd/sharded.py,
     run_in_turn: one process, the ranks' contexts made in turn so that 8 x 32 GiB of first-set times never coexist; the exclusive prefix-OR

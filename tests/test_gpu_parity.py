@@ -763,7 +763,7 @@ def _pairs_in_repeats(n_pairs, seed):
     return po.reads_from_matrix(np.ascontiguousarray(r))
 
 
-@pytest.mark.parametrize("n_chunks", [1, 4, 7])
+@pytest.mark.parametrize("n_chunks", [pytest.param(1, marks=pytest.mark.slow), 4, pytest.param(7, marks=pytest.mark.slow)])
 def test_long_pair_filter_on_the_device_equals_the_oracles(n_chunks):
     """fgpu_scan_long_pairs: scanReads' paired-end loop (src/ReadScanner.cpp:317-343; check with Bloom::containsPair, insert with addPair, in
     file order) on the device.  Both pair filters and the two pair counts equal the oracle's whatever the batching -- 7 chunks of an odd
@@ -792,7 +792,8 @@ def test_long_pair_filter_on_the_device_equals_the_oracles(n_chunks):
     _scan_equals_oracle(ctx, sst, osc)
 
 
-@pytest.mark.parametrize("cuts", [(0, 6002, 24000, 40000), (0, 0, 13000, 13000, 40000), (0, 2, 4, 6, 39998, 40000)])
+@pytest.mark.parametrize("cuts", [pytest.param((0, 6002, 24000, 40000), marks=pytest.mark.slow), (0, 0, 13000, 13000, 40000),
+                                  pytest.param((0, 2, 4, 6, 39998, 40000), marks=pytest.mark.slow)])
 def test_python_host_hands_both_pair_filters_from_shard_to_shard(cuts, monkeypatch):
     """faucet_amd/sharded.py (the host of `bench.py --gpus N`): the pair filters travel with the junction table as they do in the C++ host
     (shard_host.h): the short one collects adds, the long one is check-then-insert in file order, shards begin at even records, the pair
