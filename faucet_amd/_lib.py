@@ -76,6 +76,7 @@ SIGNATURES = {
     "fgpu_presence_batch": (C.c_int, [_vp, _P(Reads)]),
     "fgpu_load_fixup": (C.c_int, [_vp, _vp, _P(LoadStats)]),
     "fgpu_load_fixup_state": (C.c_int, [_vp, _P(C.c_int), _P(C.c_uint64)]),
+    "fgpu_scan_dump_order": (C.c_int, [_vp, _P(C.c_uint64), _P(C.c_uint64), C.c_uint64, C.c_uint64, _P(C.c_uint32)]),
     "fgpu_bloom_download": (C.c_int, [_vp, C.c_int, _vp, _u64]),
     "fgpu_bloom_download_begin": (C.c_int, [_vp, C.c_int, _vp, _u64]),
     "fgpu_bloom_download_wait": (C.c_int, [_vp]),

@@ -643,6 +643,7 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     journal_recycle(ctx);
     ctx->journal_on = !(ctx->prm.flags & FGPU_FLAG_EAGER_FLAGS) && !ctx->eager_runtime;
     ctx->eager_scan = ctx->lazy_failed = ctx->capacity_failed = false;
+    ctx->dl_keys_n = 0;
     ctx->late_acc[0] = ctx->late_acc[1] = ctx->late_acc[2] = 0;
     ctx->stops_delivered = 0;
     ctx->lp_applied_seq = 0;
@@ -1233,6 +1234,14 @@ int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* r
 }
 
 int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries) { return fgpu_scan_junction_count(ctx, n_entries); }
+
+int fgpu_scan_dump_order(fgpu_ctx* ctx, const uint64_t* rehash_counts, const uint64_t* rehash_buckets, uint64_t n_rehashes, uint64_t n, uint32_t* order) {
+    if (!ctx || !rehash_counts || !rehash_buckets || !n_rehashes || (n && !order)) return FGPU_ERR_ARG;
+    if (ctx->phase != 0) { ctx->err = "fgpu_scan_dump_order while a pass is open"; return FGPU_ERR_STATE; }
+    if (!ctx->dl_keys_n || n > ctx->dl_keys_n) { ctx->err = "fgpu_scan_dump_order works on the keys of the last fgpu_scan_download_junctions (at most that many)"; return FGPU_ERR_STATE; }
+    FGPU_HIP(hipSetDevice(ctx->prm.device));
+    return fgpu_scan_dump_order_impl(ctx, (const uint64_t*)ctx->dl_keys.p, rehash_counts, rehash_buckets, n_rehashes, n, order);
+}
 
 int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries) {
     if (!ctx || !dev_buf || !n_entries) return FGPU_ERR_ARG;

@@ -364,6 +364,7 @@ struct fgpu_ctx {
     uint64_t s3_mask = 0, s3_count = 0;
     bool s3_ready = false;
     DevBuf dl_entries, dl_stamps, dl_stamps_sorted, dl_idx, dl_idx_sorted, dl_keys, dl_recs, dl_tmp;   // junction download scratch
+    uint64_t dl_keys_n = 0;               // junction keys in creation order that dl_keys holds since the last fgpu_scan_download_junctions (0: none)
     hipStream_t copy_stream = nullptr;    // fgpu_bloom_download_begin: a device-to-host copy next to the kernels
     hipEvent_t copy_after = nullptr;      // main stream: everything the copy has to wait for
     bool copy_pending = false;
@@ -497,4 +498,5 @@ int fgpu_scan_reset(fgpu_ctx* ctx);
 int fgpu_scan_grow(fgpu_ctx* ctx, uint64_t new_cap);
 int fgpu_scan_reserve(fgpu_ctx* ctx, uint64_t records);
 int fgpu_scan_clear_table(fgpu_ctx* ctx);
+int fgpu_scan_dump_order_impl(fgpu_ctx* ctx, const uint64_t* d_keys, const uint64_t* counts, const uint64_t* buckets, uint64_t n_phases, uint64_t n, uint32_t* order_host);
 int fgpu_scan_regrow_empty(fgpu_ctx* ctx, uint64_t new_cap);

@@ -3712,6 +3712,71 @@ int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, u
     return FGPU_OK;
 }
 
+// ---- the reference's dump order on the device (host/junction_order.h: the closed form of what std::unordered_map does to its node list) -----
+namespace {
+// stretch j of the insertion sequence: position t holds node list[t] (t < c: the list as the last rehash found it) or node t itself (t >= c:
+// inserted since); its bucket is key % B.  first[b] = the earliest position of bucket b.
+__global__ void __launch_bounds__(256) k_dump_first(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ list, uint64_t c, uint64_t m, uint64_t B,
+                                                    uint32_t* __restrict__ bucket, uint32_t* first) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t node = t < c ? list[t] : (uint32_t)t;
+        const uint32_t b = (uint32_t)(keys[node] % B);
+        bucket[t] = b;
+        atomicMin(&first[b], (uint32_t)t);
+    }
+}
+// sort key: (first time of the node's bucket, own time), both descending
+__global__ void __launch_bounds__(256) k_dump_key(const uint32_t* __restrict__ list, uint64_t c, uint64_t m, const uint32_t* __restrict__ bucket,
+                                                  const uint32_t* __restrict__ first, uint64_t* __restrict__ sortkey, uint32_t* __restrict__ node_out) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (uint64_t)gridDim.x * blockDim.x) {
+        node_out[t] = t < c ? list[t] : (uint32_t)t;
+        sortkey[t] = ((uint64_t)(0xFFFFFFFFu - first[bucket[t]]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)t);
+    }
+}
+}  // namespace
+
+// order_host[i] = index (in creation order) of the i-th junction of the reference's dump; d_keys: the junction keys in creation order on the device
+int fgpu_scan_dump_order_impl(fgpu_ctx* ctx, const uint64_t* d_keys, const uint64_t* counts, const uint64_t* buckets, uint64_t n_phases, uint64_t n,
+                              uint32_t* order_host) {
+    if (!n) return FGPU_OK;
+    uint64_t max_b = 1;
+    for (uint64_t j = 0; j < n_phases; j++) max_b = std::max(max_b, buckets[j]);
+    DevBuf list_a, list_b, bucket, first, key_a, key_b, tmp;
+    struct FreeAll { DevBuf* b[7]; ~FreeAll() { for (DevBuf* x : b) if (x->p) (void)hipFree(x->p); } } free_all{{&list_a, &list_b, &bucket, &first, &key_a, &key_b, &tmp}};
+    auto alloc = [&](DevBuf& b, uint64_t bytes) -> int {
+        if (hipMalloc(&b.p, bytes) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; ctx->err = "fgpu_scan_dump_order: out of device memory"; return FGPU_ERR_NOMEM; }
+        b.bytes = bytes;
+        return FGPU_OK;
+    };
+    int rc;
+    if ((rc = alloc(list_a, n * 4)) || (rc = alloc(list_b, n * 4)) || (rc = alloc(bucket, n * 4)) || (rc = alloc(first, max_b * 4)) || (rc = alloc(key_a, n * 8)) ||
+        (rc = alloc(key_b, n * 8)))
+        return rc;
+    size_t tmp_bytes = 0;
+    FGPU_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)key_a.p, (uint64_t*)key_b.p, (uint32_t*)list_a.p, (uint32_t*)list_b.p, n, 0, 64, ctx->stream));
+    if ((rc = alloc(tmp, tmp_bytes + 16))) return rc;
+    uint32_t* list = (uint32_t*)list_a.p;      // the list as the last stretch left it
+    uint32_t* other = (uint32_t*)list_b.p;
+    bool any = false;
+    for (uint64_t j = 0; j < n_phases; j++) {
+        const uint64_t c = counts[j], m = j + 1 < n_phases ? counts[j + 1] : n, B = buckets[j];
+        if (m == 0) continue;
+        if (c > m || m > n || !B) { ctx->err = "fgpu_scan_dump_order: rehash counts must ascend to n, bucket counts must not be zero"; return FGPU_ERR_ARG; }
+        FGPU_HIP(hipMemsetAsync(first.p, 0xFF, B * 4, ctx->stream));
+        hipLaunchKernelGGL(k_dump_first, dim3(fgpu_grid(m, 256)), dim3(256), 0, ctx->stream, d_keys, (const uint32_t*)list, c, m, B, (uint32_t*)bucket.p, (uint32_t*)first.p);
+        hipLaunchKernelGGL(k_dump_key, dim3(fgpu_grid(m, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)list, c, m, (const uint32_t*)bucket.p, (const uint32_t*)first.p,
+                           (uint64_t*)key_a.p, other);
+        // (`other` holds the nodes in sequence order now; sorted into `list`)
+        size_t tb = tmp_bytes;
+        FGPU_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t*)key_a.p, (uint64_t*)key_b.p, other, list, m, 0, 64, ctx->stream));
+        any = true;
+    }
+    if (!any) { ctx->err = "fgpu_scan_dump_order: empty schedule"; return FGPU_ERR_ARG; }
+    FGPU_HIP(hipMemcpyAsync(order_host, list, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
+    return FGPU_OK;
+}
+
 // creation-ordered download: export, radix-sort the stamps (rocPRIM; not a hot step), gather
 int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* recs_host, uint64_t cap, uint64_t* n_out) {
     uint64_t n_max = ctx->scan_stats.n_junctions;
@@ -3746,5 +3811,6 @@ int fgpu_scan_download_impl(fgpu_ctx* ctx, uint64_t* keys_host, fgpu_junction* r
     FGPU_HIP(hipMemcpyAsync(keys_host, d_keys, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipMemcpyAsync(recs_host, d_recs, n * sizeof(fgpu_junction), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
+    ctx->dl_keys_n = n;              // dl_keys holds the keys in creation order (fgpu_scan_dump_order works from them)
     return FGPU_OK;
 }

@@ -385,15 +385,41 @@ int write_scan_outputs(const Options& o, fgpu_ctx* ctx, const fgpu_scan_stats& s
     std::vector<fgpu_junction> recs(n ? n : 1);
     CHECK(fgpu_scan_download_junctions(ctx, keys.data(), recs.data(), keys.size(), &n));
     clk.mark("  junction download");
-    // the reference's dump order = the iteration order of its container after these insertions (junction_order.h)
+    // the reference's dump order = the iteration order of its container after these insertions (junction_order.h).  Round 6: computed on the DEVICE
+    // from the closed form of what the container does to its node list (fgpu_scan_dump_order: one radix sort per stretch between rehashes; the host
+    // replay was 5.7 s of a 9.5 s run at config 5's 2.95e7 junctions) -- after the device has shown, on a prefix of these very keys, that it agrees
+    // with the host's replay, which has shown that it agrees with a real container.  Anything else falls back to the replay, or to the container.
     std::vector<uint32_t> order;
-    if (DumpOrder::agrees_with_the_container(keys.data(), (size_t)std::min<uint64_t>(n, 50000))) {
-        order = DumpOrder::of(keys.data(), (size_t)n);
-    } else {   // a standard library that links its nodes another way: ask the container itself
-        std::unordered_map<uint64_t, uint32_t> container;
-        for (uint64_t i = 0; i < n; i++) container.insert(std::pair<uint64_t, uint32_t>(keys[i], (uint32_t)i));
-        for (const auto& kv : container) order.push_back(kv.second);
+    const size_t prefix = (size_t)std::min<uint64_t>(n, 50000);
+    const bool replay_ok = DumpOrder::agrees_with_the_container(keys.data(), prefix);
+    bool on_device = false;
+    if (replay_ok && n) {
+        auto device_order = [&](size_t m, std::vector<uint32_t>* out) -> bool {
+            const std::vector<DumpOrder::Rehash> sch = DumpOrder::schedule(m);
+            std::vector<uint64_t> counts, buckets;
+            for (const DumpOrder::Rehash& r : sch) { counts.push_back(r.count); buckets.push_back(r.buckets); }
+            out->assign(m, 0);
+            return fgpu_scan_dump_order(ctx, counts.data(), buckets.data(), counts.size(), m, out->data()) == FGPU_OK;
+        };
+        std::vector<uint32_t> head;
+        if (device_order(prefix, &head) && head == DumpOrder::of(keys.data(), prefix) && device_order((size_t)n, &order)) on_device = true;
+        if (on_device && getenv("FAUCET_DEBUG_DUMP_ORDER_CHECK")) {     // (tests, measurements: the whole order against the host replay)
+            const bool same = order == DumpOrder::of(keys.data(), (size_t)n);
+            fprintf(stderr, "[cli] dump order of %llu junctions on the device %s the host replay's\n", (unsigned long long)n, same ? "equals" : "DIFFERS FROM");
+            if (!same) return 2;
+        }
     }
+    if (!on_device) {
+        if (replay_ok) {
+            order = DumpOrder::of(keys.data(), (size_t)n);
+        } else {   // a standard library that links its nodes another way: ask the container itself
+            order.clear();
+            std::unordered_map<uint64_t, uint32_t> container;
+            for (uint64_t i = 0; i < n; i++) container.insert(std::pair<uint64_t, uint32_t>(keys[i], (uint32_t)i));
+            for (const auto& kv : container) order.push_back(kv.second);
+        }
+    }
+    if (clk.on) fprintf(stderr, "[cli]   dump order %s\n", on_device ? "on the device (fgpu_scan_dump_order)" : replay_ok ? "by the host replay" : "by the container");
     clk.mark("  dump order");
     // JunctionMap::writeToFile (utils/JunctionMap.cpp:579-596) first counts the junctions that are solid at thresholds 0..4
     // (Junction::isSolid, utils/Junction.cpp:38-46: more than one of the four extensions with that much coverage)

@@ -14,10 +14,21 @@
 //     restated here; the hash of a 64-bit integer is the integer.
 // Keys must be distinct (the device's are).  `agrees_with_the_container` checks the replay against a real std::unordered_map on a prefix
 // of the keys; the CLI runs it before trusting the replay and falls back to the container if it ever fails (another standard library).
+//
+// Round 6: the replay is one dependent cache miss after the other -- 5.7 s for config 5's 29.5 M junctions, 60 % of the command line's wall time
+// there (profiles/r06_cli_large.txt).  But the two rules have a CLOSED FORM.  Between two rehashes the list is: the buckets' groups in the
+// order in which the buckets FIRST received a node, latest first; inside a group the nodes latest first.  I.e. insert the sequence S into an
+// empty table of B buckets and the list is S sorted by (first time of the node's bucket, descending; own time, descending).  A rehash
+// re-inserts the list as it stands into the new buckets by the same rules, so with rehashes at counts c_1 < c_2 < ... (to B_1, B_2, ... buckets)
+//     L_j = sorted( L_(j-1) followed by the nodes c_j .. c_(j+1) - 1,  by B_j )        and the dump order is the last L.
+// The sizes double, so all the sorts together are about 2 n elements: `schedule` asks the library's policy object WHEN it rehashes and to how
+// many buckets (no container, no memory traffic), `of_sorted` does the sorts on the host (the check below and the tests), and the device does
+// them for the command line (fgpu_scan_dump_order: radix sorts, milliseconds for 3e7 junctions).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -40,7 +51,42 @@ public:
         size_t at = 0;
         for (const auto& kv : real)
             if (at >= order.size() || order[at++] != kv.second) return false;
-        return at == order.size();
+        return at == order.size() && of_sorted(keys, n) == order;      // ... and the closed form (what the device computes) gives the same
+    }
+
+    // WHEN the container rehashes while n keys are inserted one by one, and to how many buckets: {nodes present, buckets from then on}, the
+    // first entry being the empty container's {0, 1}.  Asked of the library's own policy object, insertion by insertion as the container asks
+    // (bits/hashtable.h, _M_insert_unique_node); a call is a comparison unless it rehashes.
+    struct Rehash { uint64_t count, buckets; };
+    static std::vector<Rehash> schedule(size_t n) {
+        std::__detail::_Prime_rehash_policy policy;
+        std::vector<Rehash> out(1, Rehash{0, 1});
+        size_t buckets = 1;
+        for (size_t count = 0; count < n; count++) {
+            const std::pair<bool, size_t> grow = policy._M_need_rehash(buckets, count, 1);
+            if (grow.first) { buckets = grow.second; out.push_back(Rehash{(uint64_t)count, (uint64_t)buckets}); }
+        }
+        return out;
+    }
+    // the closed form on the host: one sort per stretch between rehashes
+    static std::vector<uint32_t> of_sorted(const uint64_t* keys, size_t n) {
+        const std::vector<Rehash> sch = schedule(n);
+        std::vector<uint32_t> list, seq, first;
+        std::vector<uint64_t> sortkey;
+        for (size_t j = 0; j < sch.size(); j++) {
+            const size_t c = (size_t)sch[j].count, m = j + 1 < sch.size() ? (size_t)sch[j + 1].count : n, B = (size_t)sch[j].buckets;
+            if (m == 0) continue;                                        // (the empty container's first rehash: nothing to relink)
+            seq.assign(list.begin(), list.end());                        // the list as it stands (c nodes) ...
+            for (size_t t = c; t < m; t++) seq.push_back((uint32_t)t);   // ... followed by the nodes inserted until the next rehash
+            first.assign(B, 0xFFFFFFFFu);
+            for (size_t t = m; t-- > 0;) first[keys[seq[t]] % B] = (uint32_t)t;
+            sortkey.resize(m);
+            for (size_t t = 0; t < m; t++) sortkey[t] = ((uint64_t)(0xFFFFFFFFu - first[keys[seq[t]] % B]) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)t);
+            std::sort(sortkey.begin(), sortkey.end());
+            list.resize(m);
+            for (size_t i = 0; i < m; i++) list[i] = seq[0xFFFFFFFFu - (uint32_t)sortkey[i]];
+        }
+        return list;
     }
 
 private:

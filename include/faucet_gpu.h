@@ -304,6 +304,16 @@ int fgpu_scan_download_junctions(fgpu_ctx* ctx, uint64_t* keys, fgpu_junction* r
 /* Multi-GPU hand-over of the ordered state between consecutive read shards: export on rank r
  * (device buffer of n_entries * FGPU_TABLE_ENTRY_BYTES), import on rank r+1 before its first scan_batch. */
 int fgpu_scan_table_entries(fgpu_ctx* ctx, uint64_t* n_entries);
+/* The ORDER in which the reference dumps its junctions (JunctionMap::writeToFile, utils/JunctionMap.cpp:579-596: the iteration order of its
+ * std::unordered_map, utils/JunctionMap.h:61), computed on the device for the keys of the last fgpu_scan_download_junctions -- which are in
+ * creation order = the reference's insertion order.  The container's node list has a closed form (host/junction_order.h): between two rehashes
+ * the nodes stand sorted by (first insertion into their bucket, own insertion), both latest first, and a rehash re-inserts the list as it
+ * stands -- one radix sort per stretch, about 2 n elements in all.  The caller supplies WHEN its standard library rehashes and to how many
+ * buckets (DumpOrder::schedule: asked of the library's own policy object): rehash_counts[j] nodes are present when the table goes to
+ * rehash_buckets[j] buckets, first entry {0, buckets of the empty container}; the hash of a 64-bit key is the key (libstdc++).  order[i] =
+ * index in creation order of the i-th junction dumped, for the first n keys (n <= the downloaded count; a prefix lets a host check the device
+ * against its own container before trusting it).  Replaces a host-side replay that took 5.7 s for 2.95e7 junctions. */
+int fgpu_scan_dump_order(fgpu_ctx* ctx, const uint64_t* rehash_counts, const uint64_t* rehash_buckets, uint64_t n_rehashes, uint64_t n, uint32_t* order);
 int fgpu_scan_export_table(fgpu_ctx* ctx, void* dev_buf, uint64_t buf_bytes, uint64_t* n_entries);
 int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries, const fgpu_scan_stats* carried);
 /* A PREVIEW of the table a later shard will be handed: an earlier state of the same ordered table (what the first shard has built

@@ -83,7 +83,8 @@ for _ in range(2):
         sys.exit(1)
     ph = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[cli\] (pass [12][^\d]*?)\s+([0-9.]+) ms", r.stderr)}
     waits = re.search(r"pass 2: the host waited for the device (\d+) times, ([0-9.]+) ms", r.stderr)
-    runs.append({"seconds": dt, "pass_ms": ph, "pass2_host_waits": int(waits.group(1)) if waits else None})
+    runs.append({"seconds": dt, "pass_ms": ph, "pass2_host_waits": int(waits.group(1)) if waits else None,
+                 "phase_clock": [ln.strip() for ln in r.stderr.splitlines() if ln.startswith("[cli]")]})
 best = min(runs, key=lambda x: x["seconds"])
 mj = re.search(r"Distinct junctions: (\d+)", r.stdout)
 kmers = n * (L_ - c["k"] + 1)
@@ -100,7 +101,7 @@ out = {"config": name, "input_bytes": size, "kmers": kmers, "seconds": best["sec
        "pinned_h2d_GBps_this_box": h2d, "pass2_host_waits": best["pass2_host_waits"], "both_runs_seconds": [x["seconds"] for x in runs],
        "junctions": int(mj.group(1)) if mj else None, "junctions_equal_the_oracles": bool(mj) and int(mj.group(1)) == int(fx["counters"]["n_junctions"]),
        "bloom_equals_the_oracles": bloom_sha.hexdigest() == fx["bloo2_sha256"],
-       "resident_step_seconds": resident,
+       "resident_step_seconds": resident, "phase_clock": best["phase_clock"],
        "device_share_of_the_passes": resident / ((p1 + p2) / 1e3) if resident and p1 and p2 else None,
        "note": "wall time of the whole `faucet` process on a FASTA file in tmpfs (start-up, both passes, .bloom and .junctions written), best of two runs; "
                "device_share = the resident-input step of the same workload (bench line, full_size) / (pass 1 + pass 2): the rest is the device waiting for text"}

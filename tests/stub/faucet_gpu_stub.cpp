@@ -17,6 +17,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/faucet_gpu.h"
@@ -414,6 +415,21 @@ int fgpu_scan_download_junctions(fgpu_ctx* c, uint64_t* keys, fgpu_junction* rec
     static_assert(sizeof(fgpu_junction) == sizeof(fo_junction), "record layouts");
     fo_scan_get_junctions(c->sc, 1, keys, (fo_junction*)recs, cap);
     *n_out = n;
+    return FGPU_OK;
+}
+
+// the reference's dump order: here from the container itself (the product computes it on the device from the caller's rehash schedule)
+int fgpu_scan_dump_order(fgpu_ctx* c, const uint64_t* counts, const uint64_t* buckets, uint64_t n_rehashes, uint64_t n, uint32_t* order) {
+    if (!c || !counts || !buckets || !n_rehashes || (n && !order) || !c->sc) return FGPU_ERR_ARG;
+    const uint64_t have = fo_scan_get_junctions(c->sc, 1, NULL, NULL, 0);
+    if (n > have) return fail(c, FGPU_ERR_STATE, "more keys than junctions");
+    std::vector<uint64_t> keys(have ? have : 1);
+    std::vector<fo_junction> recs(have ? have : 1);
+    fo_scan_get_junctions(c->sc, 1, keys.data(), recs.data(), have);
+    std::unordered_map<uint64_t, uint32_t> real;
+    for (uint64_t i = 0; i < n; i++) real.insert(std::pair<uint64_t, uint32_t>(keys[i], (uint32_t)i));
+    uint64_t at = 0;
+    for (const auto& kv : real) order[at++] = kv.second;
     return FGPU_OK;
 }
 
