@@ -245,11 +245,11 @@ typedef std::unordered_map<uint64_t, Junction> JunctionTable;
 //   "<kmer> d0 d1 d2 d3 d4  c0 c1 c2 c3 <sum>  l0 l1 l2 l3 l4 \n"
 // in the order given (indices into keys / recs), formatted by hand: a million lines, a few threads, each its own stretch of the order.
 int write_junctions(const std::string& path, const uint64_t* keys, const fgpu_junction* recs, const std::vector<uint32_t>& order, int k) {
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
     const size_t kLine = (size_t)k + 1 + 5 * 4 + 1 + 4 * 4 + 5 + 1 + 5 * 2 + 1;   // longest line: three digits and a blank per byte field
-    auto format = [&](size_t from, size_t to, std::vector<char>& buf) {
-        buf.resize((to - from) * kLine);
+    auto format = [&](size_t from, size_t to, std::vector<char>& buf) -> size_t {      // returns the bytes written into buf (sized once per thread, never re-zeroed)
+        if (buf.size() < (to - from) * kLine) buf.resize((to - from) * kLine);
         char* w = buf.data();
         auto put_uint = [&](unsigned v) {
             if (v >= 1000) *w++ = (char)('0' + v / 1000);
@@ -274,26 +274,50 @@ int write_junctions(const std::string& path, const uint64_t* keys, const fgpu_ju
             for (int i = 0; i < 5; i++) { *w++ = j.linked[i] ? '1' : '0'; *w++ = ' '; }
             *w++ = '\n';
         }
-        buf.resize((size_t)(w - buf.data()));
+        return (size_t)(w - buf.data());
     };
-    const size_t kThreads = 4, kRound = 1u << 20;   // lines per thread and round
-    std::vector<char> bufs[kThreads];
-    for (size_t base = 0; base < order.size(); base += kThreads * kRound) {
-        std::thread workers[kThreads];
-        size_t used = 0;
-        for (size_t t = 0; t < kThreads; t++) {
-            const size_t from = std::min(order.size(), base + t * kRound), to = std::min(order.size(), from + kRound);
-            if (from == to) break;
-            used = t + 1;
-            if (t) workers[t] = std::thread(format, from, to, std::ref(bufs[t]));
-            else format(from, to, bufs[0]);
+    // Round 6 (profiles/r06_cli_large.txt: 1.25 s for config 5's 2.95e7 lines, formatting and writing in turn): the order is cut into chunks that
+    // the threads take one after the other; a chunk's place in the file is known as soon as every chunk before it has been FORMATTED (its size), and
+    // it is then written there (pwrite) while other chunks are still being formatted or written -- formatting and writing overlap, both in parallel.
+    const size_t kChunk = getenv("FAUCET_DEBUG_DUMP_CHUNK") ? (size_t)std::max(1, atoi(getenv("FAUCET_DEBUG_DUMP_CHUNK"))) : (size_t)1 << 18;   // (tests: many small chunks)
+    const size_t n_chunks = (order.size() + kChunk - 1) / kChunk;
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 4), n_chunks));
+    std::vector<uint64_t> offset(n_chunks + 1, 0);
+    std::mutex m;
+    std::condition_variable cv;
+    size_t known = 0, next = 0;          // offset[0 .. known] are final; next chunk to hand out
+    bool failed = false;
+    auto worker = [&]() {
+        std::vector<char> buf;
+        for (;;) {
+            size_t i;
+            { std::lock_guard<std::mutex> g(m); if (next >= n_chunks || failed) return; i = next++; }
+            const size_t bytes = format(i * kChunk, std::min(order.size(), (i + 1) * kChunk), buf);
+            uint64_t at;
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv.wait(g, [&] { return known == i || failed; });      // (chunks are handed out in order: chunk i - 1 is being formatted or done)
+                if (failed) return;
+                at = offset[i];
+                offset[i + 1] = at + bytes;
+                known = i + 1;
+            }
+            cv.notify_all();
+            size_t done = 0;
+            while (done < bytes) {
+                const ssize_t w = pwrite(fd, buf.data() + done, bytes - done, (off_t)(at + done));
+                if (w <= 0) { std::lock_guard<std::mutex> g(m); failed = true; break; }
+                done += (size_t)w;
+            }
+            if (failed) { cv.notify_all(); return; }
         }
-        for (size_t t = 0; t < used; t++) {
-            if (workers[t].joinable()) workers[t].join();
-            if (fwrite(bufs[t].data(), 1, bufs[t].size(), f) != bufs[t].size()) { fprintf(stderr, "cannot write %s\n", path.c_str()); fclose(f); return 2; }
-        }
-    }
-    fclose(f);
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < n_threads; t++) th.emplace_back(worker);
+    worker();
+    for (std::thread& t : th) t.join();
+    const bool bad = failed || close(fd) != 0;
+    if (bad) { fprintf(stderr, "cannot write %s\n", path.c_str()); return 2; }
     return 0;
 }
 

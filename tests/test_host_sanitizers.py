@@ -54,7 +54,7 @@ def test_the_paired_end_loop_on_the_host_writes_the_reference_files(cli, extra, 
         f.write(c.reads_text())
     prefix = str(tmp_path / "out")
     r = subprocess.run([exe, "-read_load_file", inp, "-read_scan_file", inp, "-file_prefix", prefix] + c.meta["args"] + extra,
-                       capture_output=True, text=True, env=dict(_env(), FGPU_DEBUG_LONG_PAIRS_NOMEM="1"), timeout=600)
+                       capture_output=True, text=True, env=dict(_env(), FGPU_DEBUG_LONG_PAIRS_NOMEM="1", FAUCET_DEBUG_DUMP_CHUNK="37"), timeout=600)   # (and the .junctions dump in many chunks: eight threads format and pwrite them side by side)
     _check(r, 3)
     assert "the paired-end loop runs on the host" in r.stderr
     for ext in ("bloom", "junctions", "short_pair_filter", "long_pair_filter"):
