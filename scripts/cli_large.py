@@ -72,7 +72,7 @@ torch.cuda.empty_cache()
 
 exe = os.path.join(ROOT, "faucet_amd", "faucet")
 cmd = [exe, "-read_load_file", path, "-read_scan_file", path, "-size_kmer", str(c["k"]), "-max_read_length", str(L_), "-estimated_kmers", str(c["E"]),
-       "-singletons", str(c["S"]), "--no_cleaning", "-file_prefix", os.path.join(d, "out")]
+       "-singletons", str(c["S"]), "--no_cleaning", "-file_prefix", os.path.join(d, "out")] + os.environ.get("CLI_EXTRA", "").split()
 runs = []
 for _ in range(2):
     t2 = time.perf_counter()
@@ -95,7 +95,7 @@ bloom_sha = hashlib.sha256()
 with open(os.path.join(d, "out.bloom"), "rb") as f:
     for blk in iter(lambda: f.read(1 << 24), b""):
         bloom_sha.update(blk)
-out = {"config": name, "input_bytes": size, "kmers": kmers, "seconds": best["seconds"], "value": kmers / best["seconds"], "unit": "k-mers/s",
+out = {"config": name, "extra_arguments": os.environ.get("CLI_EXTRA", ""), "input_bytes": size, "kmers": kmers, "seconds": best["seconds"], "value": kmers / best["seconds"], "unit": "k-mers/s",
        "pass_ms": best["pass_ms"], "load_scan_value": kmers / ((p1 + p2) / 1e3) if p1 and p2 else None,
        "text_GBps": {"pass 1": size / (p1 / 1e3) / 1e9 if p1 else None, "pass 2": size / (p2 / 1e3) / 1e9 if p2 else None},
        "pinned_h2d_GBps_this_box": h2d, "pass2_host_waits": best["pass2_host_waits"], "both_runs_seconds": [x["seconds"] for x in runs],

@@ -1,6 +1,6 @@
 """Fills DESIGN.md's generated parts from the committed bench line and the strong-scaling projection: the text between `<!-- NAME -->` and `<!-- /NAME -->`
 markers is replaced (TABLE1: one number per configuration; TABLE2: roofline / pipeline / cpu rows; SUMMARY: per-kernel lines of section 7; PROJTABLE: section 5).
-    python scripts/design_fill.py profiles/r05_bench_config2.json profiles/r05_project_strong.txt"""
+    python scripts/design_fill.py profiles/r06_bench_config2.json profiles/r06_project_strong.txt"""
 import json
 import os
 import re
@@ -19,7 +19,8 @@ pa, pm, cpu = d.get("pipeline_ab64", {}), d.get("pipeline_measured", {}), d.get(
 table2 = "\n".join([
     f"| roofline, dominant kernel `k_load_mark` | {r['avg_launch_ms']:.3f} ms per launch of {r['kmers_per_launch']:.3g} k-mers: **{r['frac']:.3f}** of the 8 TB/s peak on the sectors it needs (192 B per k-mer), "
     f"{r['frac_measured_traffic']:.3f} by the counters (FETCH+WRITE, `profiles/pmc_traffic.json`), {r['frac_reference_accesses']:.3f} on the reference's separate-array accesses; on config 4's 2 x 1 GiB filters "
-    f"(`roofline_large`) {rl.get('avg_launch_ms', 0):.2f} ms per {rl.get('kmers_per_launch', 0):.3g} k-mers: **{rl.get('frac', 0):.3f}** |",
+    f"(`roofline_large`) {rl.get('avg_launch_ms', 0):.2f} ms per {rl.get('kmers_per_launch', 0):.3g} k-mers: **{rl.get('frac', 0):.3f}**, {rl.get('frac_measured_traffic') or 0:.3f} by ITS counters "
+    f"({rl.get('traffic_over_algorithmic') or 0:.2f} x the algorithmic bytes) |",
     f"| pipeline | AB64 {pa.get('bytes_per_kmer', 0):.0f} B per k-mer -> {pa.get('achieved_GBps', 0) / 1e3:.2f} TB/s = {100 * pa.get('frac_of_hbm_peak', 0):.1f} % of peak; {pa.get('bit_accesses_per_s', 0):.3g} of the reference's counted bit "
     f"accesses per second = {100 * pa.get('frac_of_random_access_ceiling', 0):.0f} % of the device's measured random-access ceiling; by counters {pm.get('hbm_bytes_per_step', 0) / 1e9:.0f} GB per step = "
     f"{pm.get('GBps', 0) / 1e3:.2f} TB/s = {100 * pm.get('frac_of_hbm_peak', 0):.0f} % |",

@@ -34,6 +34,12 @@ for name, label in (("config5", "5 (50 M × 150 bp, 5 % errors, two hash functio
     f = fs.get(name)
     if f and "value" in f:
         print(f"| {label} | {f['seconds']:.3f} | **{f['value']:.3g}** | `full_size.{name}` (second step of the context; counters equal the oracle's: {f['counters_equal_the_oracles']}) |")
+import os
+for name, label in (("config5", "5 as an 8.05 GB FASTA file through the `faucet` process"), ("config4", "4 as a 22.2 GB FASTA file through the `faucet` process")):
+    path = os.path.join(os.path.dirname(os.path.abspath(src)), f"r06_cli_large_{name}.json")
+    if os.path.exists(path):
+        c = json.load(open(path))
+        print(f"| {label} (start-up, both passes, `.bloom` and `.junctions` of {c['junctions']:.3g} records written) | {c['seconds']:.2f} | {c['value']:.3g} | `profiles/r06_cli_large_{name}.json` (`scripts/cli_large.py`; passes alone: {c['load_scan_value']:.3g}) |")
 print()
 print("per kernel per step (ms, `kernel_ms_per_step_rank0`, from the bracketed steps): " + ", ".join(f"`{n}` {v:.1f}" for n, v in list(k.items())[:11]))
 print(f"roofline ({r['kernel']}): {r['avg_launch_ms']:.3f} ms per launch of {r['kmers_per_launch']:.3g} k-mers, frac {r['frac']:.3f} (sectors needed), "

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_config2.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_config2.json")).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "k-mers/s"
     for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -31,6 +31,9 @@ def test_committed_bench_line_has_the_contract_keys():
     # round 5: the same kernel on the large filters rides along, the timing method is stated, the C++ host over two read shards writes the same files
     rl = d["roofline_large"]
     assert rl["kernel"] == "load_mark" and 0 < rl["frac"] < r["frac"] and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9
+    # round 6: ... with ITS counters (profiles/pmc_traffic.json, full_size.config4): traffic close to the algorithmic bytes, no wasted re-reads
+    assert rl["traffic"] and 1.0 <= rl["traffic_over_algorithmic"] < 1.5 and abs(rl["frac_measured_traffic"] - rl["traffic"] / (rl["avg_launch_ms"] * 1e-3) / 1e9 / rl["peak"]) < 1e-9
+    assert d["rccl_ranks"] == 0 and d["hbm_per_rank"][0]["used_bytes_after_the_steps"] > 0
     assert d["ms_per_step_with_events"] > 0 and "without" in d["timing_method"].lower()
     g2 = f["gpus2_one_device"]
     assert all(g2["files_equal_the_single_device_runs"].values()) and g2["seconds"] > 0
@@ -70,11 +73,11 @@ def test_batch_bounds_cover_the_reads_once_in_order():
 
 
 def test_design_md_quotes_the_committed_bench_line():
-    """DESIGN.md's number tables are printed from profiles/r05_bench_config2.json by scripts/design_tables.py (one number per
+    """DESIGN.md's number tables are printed from profiles/r06_bench_config2.json by scripts/design_tables.py (one number per
     configuration, one source): every generated table row and summary line has to be in the document as it is printed today."""
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_tables.py"), os.path.join("profiles", "r05_bench_config2.json")],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_tables.py"), os.path.join("profiles", "r06_bench_config2.json")],
                          capture_output=True, text=True, cwd=ROOT, check=True).stdout
     doc = open(os.path.join(ROOT, "DESIGN.md")).read()
     rows = [ln for ln in out.splitlines() if ln.strip() and not set(ln) <= set("|- ")]
