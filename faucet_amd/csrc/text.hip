@@ -20,15 +20,35 @@
 
 namespace {
 
+// 0x80 in every byte of x that equals '\n' (exact: no borrow between bytes), gathered into 8 bits, lowest byte first
+__device__ __forceinline__ uint32_t nl_mask8(uint64_t x) {
+    const uint64_t t = x ^ 0x0A0A0A0A0A0A0A0AULL;                                                     // zero bytes <=> newlines
+    const uint64_t y = ~(((t & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | t | 0x7F7F7F7F7F7F7F7FULL);   // 0x80 where the byte is zero
+    return (uint32_t)(((y >> 7) * 0x0102040810204080ULL) >> 56);
+}
+
+// One lane per 64 bytes of text = one word of the newline plane: four 16-byte loads, the byte compares as SWAR arithmetic.  (Round 6: one lane
+// per BYTE and a ballot -- the kernel of rounds 1-5 -- ran at 41 GB/s beside the pass's kernels, 0.38 s of config 5's 1.4 s of passes through the
+// command line: profiles/r06_cli_large.txt.)  `aligned`: text is 16-byte aligned and readable up to n_words * 64 (the library's own copy of a
+// host chunk); else -- a caller's device buffer -- bytes are read one by one and never past n.
 __global__ void __launch_bounds__(256) k_text_newlines(const unsigned char* __restrict__ text, uint64_t n, uint64_t n_words,
-                                                       uint64_t* __restrict__ nl, uint32_t* __restrict__ count) {
-    const uint64_t total = n_words * 64;
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t m = __ballot(p < n && text[p] == '\n');
-        if (fd_lane() == 0) {
-            nl[p >> 6] = m;
-            count[p >> 6] = (uint32_t)__popcll(m);
+                                                       uint64_t* __restrict__ nl, uint32_t* __restrict__ count, int aligned) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t m = 0;
+        if (aligned) {
+            const uint4* p = (const uint4*)(text + w * 64);
+            const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+            m = (uint64_t)nl_mask8((uint64_t)a.x | ((uint64_t)a.y << 32)) | ((uint64_t)nl_mask8((uint64_t)a.z | ((uint64_t)a.w << 32)) << 8) |
+                ((uint64_t)nl_mask8((uint64_t)b.x | ((uint64_t)b.y << 32)) << 16) | ((uint64_t)nl_mask8((uint64_t)b.z | ((uint64_t)b.w << 32)) << 24) |
+                ((uint64_t)nl_mask8((uint64_t)c.x | ((uint64_t)c.y << 32)) << 32) | ((uint64_t)nl_mask8((uint64_t)c.z | ((uint64_t)c.w << 32)) << 40) |
+                ((uint64_t)nl_mask8((uint64_t)d.x | ((uint64_t)d.y << 32)) << 48) | ((uint64_t)nl_mask8((uint64_t)d.z | ((uint64_t)d.w << 32)) << 56);
+            if ((w + 1) * 64 > n) m &= (1ULL << (n - w * 64)) - 1;            // (the bytes behind the text are whatever the buffer held)
+        } else {
+            const uint64_t lo = w * 64, hi = lo + 64 < n ? lo + 64 : n;
+            for (uint64_t q = lo; q < hi; q++) m |= (uint64_t)(text[q] == '\n') << (q - lo);
         }
+        nl[w] = m;
+        count[w] = (uint32_t)__popcll(m);
     }
 }
 
@@ -142,7 +162,9 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     uint64_t* nl = (uint64_t*)ts.nl.p;
     uint32_t* count = (uint32_t*)ts.rank.p;
     uint32_t* rank = count + n_words + 1;
-    FGPU_LAUNCH("text_newlines", k_text_newlines, fgpu_grid(n_words * 64, 256), 256, d_text, nbytes, n_words, nl, count);
+    // (the library's own copy of a host chunk is 256-byte aligned and cap + 64 bytes long; a caller's device text is taken byte by byte unless aligned AND not the tail)
+    const int aligned = (!text_on_device && ((uintptr_t)d_text & 15) == 0) ? 1 : 0;
+    FGPU_LAUNCH("text_newlines", k_text_newlines, fgpu_grid(n_words, 256), 256, d_text, nbytes, n_words, nl, count, aligned);
     size_t tmp_bytes = 0, tmp2 = 0;
     FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count, rank, 0u, n_words, rocprim::plus<uint32_t>(), st));
     FGPU_HIP(rocprim::exclusive_scan(nullptr, tmp2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, n_words * 64 / 2 + 2, rocprim::plus<uint64_t>(), st));

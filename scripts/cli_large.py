@@ -105,5 +105,17 @@ out = {"config": name, "extra_arguments": os.environ.get("CLI_EXTRA", ""), "inpu
        "device_share_of_the_passes": resident / ((p1 + p2) / 1e3) if resident and p1 and p2 else None,
        "note": "wall time of the whole `faucet` process on a FASTA file in tmpfs (start-up, both passes, .bloom and .junctions written), best of two runs; "
                "device_share = the resident-input step of the same workload (bench line, full_size) / (pass 1 + pass 2): the rest is the device waiting for text"}
+if os.environ.get("CLI_ROCPROF") == "1":      # one more run under rocprofv3 --stats: what the device spends per kernel with text as the input
+    import csv
+    import glob
+    pd = os.path.join(d, "prof")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pd, "-o", "cli", "--"] + cmd, capture_output=True, text=True,
+                   env=dict(os.environ, FGPU_CLI_TIDY="1", TMPDIR="/tmp"), cwd="/tmp")
+    fs = glob.glob(os.path.join(pd, "**", "*kernel_stats.csv"), recursive=True)
+    if fs:
+        rows = list(csv.DictReader(open(fs[0])))
+        out["kernels_ms"] = [[r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48], int(r["Calls"]), round(int(r["TotalDurationNs"]) / 1e6, 1)]
+                             for r in rows[:22]]
+        out["kernels_total_ms"] = round(sum(int(r["TotalDurationNs"]) for r in rows) / 1e6, 1)
 print(json.dumps(out))
 shutil.rmtree(d, ignore_errors=True)
