@@ -322,6 +322,22 @@ def test_bench_strong_scaling_three_ranks_equal_one():
     assert "pass2_wait_for_table" in dict(three["rank_stage_ms"][2]) and "pass2_send" in dict(three["rank_stage_ms"][0])
 
 
+def test_bench_falls_back_to_gloo_when_the_run_over_rccl_fails():
+    """RCCL with N > 1 ranks has never run where this was built; `python bench.py --gpus N` must not lose a first contact with an N-GPU node to
+    the transport.  Forced here: two ranks told to share this one GPU over `nccl` -- RCCL refuses two ranks on one device (or, at worst, never
+    comes up: the parent's limit ends that) -- and the parent runs the same pipeline over gloo, says so in the line, and the outputs are the
+    one-GPU run's."""
+    size = ["--scaling", "strong", "--fixture", "config2", "--reads", "2000000", "--genome", "4000000", "--estimated-kmers", "20000000", "--singletons", "4000000",
+            "--batch-reads", "250000", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-ceilings", "--no-host-leg", "--no-full-size", "--no-profile"]
+    one = _bench_line(size, {})
+    two = _bench_line(size, {"FAUCET_SHARE_GPU": "1", "GLOO_SOCKET_IFNAME": "lo", "FAUCET_BENCH_RANKS_TIMEOUT": "120"}, self_launch=2)
+    assert two["n_gpus"] == 2 and two["dist_backend"] == "gloo" and two["rccl_ranks"] == 0
+    assert two["transport_fallback"] and "nccl" in two["transport_fallback"]
+    assert one["transport_fallback"] is None
+    for key in ("bloo2_sha256", "junction_keys_sha256", "junction_records_sha256", "junctions"):
+        assert one["outputs_check"][key] == two["outputs_check"][key], key
+
+
 @pytest.mark.skipif("config5" not in FULL, reason="tests/golden/fullsize.json has no config5 entry yet (make_fullsize.py config5: ~1.5 h of one core)")
 def test_config5_full_size_equals_the_oracle():
     """BASELINE config 5 at its FULL size -- 50 M reads of 150 bases, 5 % errors, S/E = 0.5 so that the reference's own sizing gives two
