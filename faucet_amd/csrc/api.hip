@@ -353,7 +353,7 @@ void fgpu_destroy(fgpu_ctx* ctx) {
         hipStreamSynchronize(ctx->tstream);
         hipStreamDestroy(ctx->tstream);
     }
-    for (int i = 0; i < 2; i++) if (ctx->ev_text_mark[i]) hipEventDestroy(ctx->ev_text_mark[i]);
+    for (int i = 0; i < FGPU_TEXT_SETS; i++) if (ctx->ev_text_mark[i]) hipEventDestroy(ctx->ev_text_mark[i]);
     for (int i = 0; i < 2; i++) if (ctx->ev_stage_free[i]) hipEventDestroy(ctx->ev_stage_free[i]);
     if (ctx->ev_text_done) hipEventDestroy(ctx->ev_text_done);
     if (ctx->wstream) hipStreamSynchronize(ctx->wstream);

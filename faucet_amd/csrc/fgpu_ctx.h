@@ -183,6 +183,10 @@ struct DevCounters {
     unsigned long long late[2 * FGPU_LATE_CAP];
 };
 
+// (three sets since round 6: with two, the split of chunk c + 1 could only begin when batch c - 1 had finished, and the batch cut out of it was queued
+// with at most a fraction of batch c left to run.  Measured through the command line on config 4's 22 GB: pass 1 1.73 -> 1.75 s, pass 2 1.53 -> 1.43 s,
+// both inside the box's run-to-run spread: the passes are bound by the device's own work, not by the hand-over -- kept because it costs 150 MB)
+constexpr int FGPU_TEXT_SETS = 3;
 struct TextSet { DevBuf buf, nl, rank, tmp, rec; };
 
 // host wall clock in ms (FGPU_DEBUG_HOST)
@@ -368,15 +372,15 @@ struct fgpu_ctx {
     hipStream_t copy_stream = nullptr;    // fgpu_bloom_download_begin: a device-to-host copy next to the kernels
     hipEvent_t copy_after = nullptr;      // main stream: everything the copy has to wait for
     bool copy_pending = false;
-    // fgpu_text_split: the text and the batch that points into it, two sets used in turn, on a stream of their own
-    TextSet text[2];
+    // fgpu_text_split: the text and the batch that points into it, FGPU_TEXT_SETS sets used in turn, on a stream of their own
+    TextSet text[FGPU_TEXT_SETS];
     uint64_t text_calls = 0;
     uint64_t text_reserve = 0;          // fgpu_text_reserve: the largest chunk of text the caller will hand to fgpu_text_split
     uint64_t text_last_bytes = 0;       // bytes of the chunk the last fgpu_text_split cut
     double ensure_scale = 1.0;          // reserve / bytes of the chunk in hand: per-batch buffers that have to grow are sized for the largest chunk at
                                         // once (a scan's first chunks are a quarter of the later ones: 97 re-allocations, each a wait, in config 3's pass 2)
     hipStream_t tstream = nullptr;
-    hipEvent_t ev_text_mark[2] = {nullptr, nullptr};   // main stream, at the beginning of each call
+    hipEvent_t ev_text_mark[FGPU_TEXT_SETS] = {nullptr, nullptr, nullptr};   // main stream, at the beginning of each call
     hipEvent_t ev_text_done = nullptr;                 // text stream, at the end of each call (the main stream waits for it)
     DevBuf host_stage[4];                              // host batches: {bases, offsets} x 2 staging sets (pack.hip)
     hipEvent_t ev_stage_free[2] = {nullptr, nullptr};   // main stream: the call that used the set has been queued completely

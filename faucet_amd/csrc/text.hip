@@ -96,15 +96,20 @@ void fgpu_touch_text() {
     (void)hipFuncGetAttributes(&attr, (const void*)k_text_lengths);
 }
 
-// The split runs on its own stream with two alternating sets of buffers: while the main stream works on the batch cut out of the previous
+// The split runs on its own stream with three sets of buffers used in turn (two until round 6): while the main stream works on the batch cut out of the previous
 // chunk, this chunk is copied to the device and cut, and the host waits for the text stream only.  (On the main stream -- round 1 -- every
 // chunk waited for the batch before it, the device idled during the copy, and a 1.1 GB file took 2.4 times the kernels' time per pass.)
 int fgpu_text_streams(fgpu_ctx* ctx) {
     if (ctx->tstream) return FGPU_OK;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < FGPU_TEXT_SETS; i++)
         if (!ctx->ev_text_mark[i]) FGPU_HIP(hipEventCreateWithFlags(&ctx->ev_text_mark[i], hipEventDisableTiming));
     if (!ctx->ev_text_done) FGPU_HIP(hipEventCreateWithFlags(&ctx->ev_text_done, hipEventDisableTiming));
-    FGPU_HIP(hipStreamCreateWithFlags(&ctx->tstream, hipStreamNonBlocking));   // last: its presence says the events are there
+    // High priority (round 6): the host WAITS for this stream before it can queue the batch, and the pass's kernels on the main stream are fixed
+    // grids of long-lived blocks -- at equal priority the newline kernel's blocks are dispatched as those retire, 0.9 ms per 64 MB chunk where
+    // the kernel alone needs 0.03 (rocprofv3 of `faucet` on config 4's 22 GB: 598 ms in 666 launches, beside the pass, not in front of it)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    FGPU_HIP(hipStreamCreateWithPriority(&ctx->tstream, hipStreamNonBlocking, hi));   // last: its presence says the events are there
     return FGPU_OK;
 }
 
@@ -128,13 +133,14 @@ extern "C" int fgpu_text_split(fgpu_ctx* ctx, const char* text, uint64_t nbytes,
     if (nbytes == 0) return FGPU_OK;
     int rc;
     if ((rc = fgpu_text_streams(ctx))) return rc;
-    // Set c & 1 was last read by the batch of call c - 2, which was queued before call c - 1 began: the mark call c - 1 left on the main
-    // stream.  Text that is on the device already was written in main-stream order by the caller: this call's own mark.
+    // Set c % 3 was last read by the batch of call c - 3, which was queued before call c - 2 began: the mark call c - 2 left on the main
+    // stream -- so this chunk is cut while the batches of calls c - 2 and c - 1 run, and the main stream has a whole batch queued behind the one
+    // it works on.  Text that is on the device already was written in main-stream order by the caller: this call's own mark.
     const uint64_t c = ctx->text_calls++;
-    TextSet& ts = ctx->text[c & 1];
-    FGPU_HIP(hipEventRecord(ctx->ev_text_mark[c & 1], ctx->stream));
-    if (text_on_device) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_text_mark[c & 1], 0));
-    else if (c) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_text_mark[(c - 1) & 1], 0));
+    TextSet& ts = ctx->text[c % FGPU_TEXT_SETS];
+    FGPU_HIP(hipEventRecord(ctx->ev_text_mark[c % FGPU_TEXT_SETS], ctx->stream));
+    if (text_on_device) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_text_mark[c % FGPU_TEXT_SETS], 0));
+    else if (c >= FGPU_TEXT_SETS - 1) FGPU_HIP(hipStreamWaitEvent(ctx->tstream, ctx->ev_text_mark[(c - (FGPU_TEXT_SETS - 1)) % FGPU_TEXT_SETS], 0));
     struct OnStream {   // kernels of this call go to the text stream
         fgpu_ctx* c;
         hipStream_t saved;
