@@ -110,6 +110,7 @@ SIGNATURES = {
     "fgpu_diag_ovw_tables": (C.c_int, [_vp, _P(_u64), _P(_u64)]),
     "fgpu_scan_refresh_prepared": (C.c_int, [_vp]),
     "fgpu_diag_prepared_refresh": (C.c_int, [_vp, _P(_u64)]),
+    "fgpu_diag_sparse_link": (C.c_int, [_vp, _P(_u64)]),
     "fgpu_probe_hash": (C.c_int, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "fgpu_probe_contains": (C.c_int, [_vp, C.c_int, _vp, _u64, _vp]),
     "fgpu_probe_jcheck": (C.c_int, [_vp, _vp, _u64, _vp]),

@@ -422,6 +422,12 @@ class Context:
         self._c(self.lib.fgpu_diag_prepared_refresh(self.h, out))
         return dict(zip(("batches_in_full", "batches_merged", "new_keys", "mismatching_words"), (int(v) for v in out)))
 
+    def diag_sparse_link(self):
+        """windows of prepared batches (read shards) whose link pass visited candidate positions only / every position"""
+        out = (C.c_uint64 * 2)()
+        self._c(self.lib.fgpu_diag_sparse_link(self.h, out))
+        return {"windows_sparse": int(out[0]), "windows_in_full": int(out[1])}
+
     def diag_ovw_tables(self):
         """event tables of the optimistic walk: the most entries a round of the last scan held, and the entries per table as they stand"""
         hw, cap = C.c_uint64(), C.c_uint64()

@@ -659,8 +659,10 @@ int fgpu_scan_begin(fgpu_ctx* ctx) {
     ctx->hint_n = ctx->hint_max_seq = 0;
     ctx->delta_ready = false;
     ctx->delta_keys = ctx->refresh_full = ctx->refresh_delta = ctx->refresh_mismatch = 0;
+    ctx->sparse_links = ctx->full_links = 0;
     ctx->dbg_stall_us = getenv("FGPU_DEBUG_WALK_STALL_US") ? std::min(100000, std::max(0, atoi(getenv("FGPU_DEBUG_WALK_STALL_US")))) : 0;
     ctx->dbg_delta_check = getenv("FGPU_DEBUG_DELTA_CHECK") != nullptr;
+    ctx->no_sparse_link = getenv("FGPU_NO_SPARSE_LINK") != nullptr;      // measurement aid: no candidate planes, every window of a prepared batch linked in full
     // calibrated upwards window by window; a context that has scanned before starts a quarter below where that scan ended up
     const uint64_t start_span = std::max<uint64_t>(1ULL << 18, ctx->settled_span / 4);
     ctx->window_span = ctx->prm.walk_window_span ? std::min<uint64_t>(std::max<uint64_t>(ctx->prm.walk_window_span, 64), ctx->max_span)
@@ -1035,6 +1037,7 @@ int fgpu_scan_prepare(fgpu_ctx* ctx, const fgpu_reads* reads) {
     }
     if (rc) { ctx->pool.push_back(b); return rc; }
     b->planes_gen = ctx->hint_in_table ? ctx->hint_gen : 0;      // what this batch's snapshot planes speak of
+    b->cand_gen = 0;
     ctx->prepared.push_back(b);
     return FGPU_OK;
 }
@@ -1048,10 +1051,16 @@ int fgpu_scan_refresh_prepared(fgpu_ctx* ctx) {
     if (ctx->phase != 2) { ctx->err = "scan_refresh_prepared outside scan_begin/scan_end"; return FGPU_ERR_STATE; }
     if (!ctx->hint_in_table) { ctx->err = "scan_refresh_prepared without a preview in the table (fgpu_scan_import_hint)"; return FGPU_ERR_STATE; }
     FGPU_HIP(hipSetDevice(ctx->prm.device));
+    const bool no_sparse = ctx->no_sparse_link;
     for (BatchBufs* b : ctx->prepared) {
-        if (b->planes_gen == ctx->hint_gen) continue;
-        if (int rc = fgpu_scan_refresh_planes(ctx, b)) return rc;
-        b->planes_gen = ctx->hint_gen;
+        if (b->planes_gen != ctx->hint_gen) {
+            if (int rc = fgpu_scan_refresh_planes(ctx, b)) return rc;
+            b->planes_gen = ctx->hint_gen;
+            b->cand_gen = 0;
+        }
+        // ... and, while this rank still waits, the plane that lets its walk link a window by visiting candidates only (round 6, k_walk_link_sparse)
+        if (!no_sparse && b->cand_gen != ctx->hint_gen)
+            if (int rc = fgpu_scan_build_cand(ctx, b)) return rc;
     }
     ctx->launch_stream = ctx->stream;
     FGPU_HIP(fgpu_sync_stream(ctx, ctx->stream));
@@ -1459,6 +1468,13 @@ int fgpu_diag_prepared_refresh(fgpu_ctx* ctx, uint64_t out[4]) {
     out[1] = ctx->refresh_delta;
     out[2] = ctx->delta_keys;
     out[3] = ctx->refresh_mismatch;
+    return FGPU_OK;
+}
+
+int fgpu_diag_sparse_link(fgpu_ctx* ctx, uint64_t out[2]) {
+    if (!ctx || !out) return FGPU_ERR_ARG;
+    out[0] = ctx->sparse_links;
+    out[1] = ctx->full_links;
     return FGPU_OK;
 }
 

@@ -46,6 +46,8 @@ struct BatchBufs {
     // pass 2 planes (1 bit per stream position, LSB first)
     DevBuf valid, pm, ps, ff, fb, cf0, cf1, cb0, cb1, inF, inB;
     DevBuf lk;                     // walk: positions whose k-mer is a registered candidate of the current window
+    DevBuf cand;                   // read shards: positions the link pass of ANY window of this batch can find, made off the chain (k_walk_link_sparse)
+    uint32_t cand_gen = 0;         // the preview (hint_gen) `cand` was made against; 0 = none
     DevBuf nF, nB, need;           // lazy flags: in-map snapshot planes of the pure stage, positions whose flags get evaluated
     DevBuf kh;                     // uint32 per stream position: hash of the canonical k-mer (positions inside pieces; see jt_h32)
     DevBuf cr;                     // walk: positions at which this batch's walk created a junction record
@@ -296,8 +298,11 @@ struct fgpu_ctx {
     bool delta_ready = false;        // the walk of the prepared batches merges the new keys into their planes instead of making the planes again
     uint64_t delta_keys = 0;         // (diagnostics: keys in the filter; batches whose planes were made again in full / merged)
     uint64_t refresh_full = 0, refresh_delta = 0, refresh_mismatch = 0;
+    DevBuf cand_filter;              // scratch of fgpu_scan_build_cand: the hashes of one batch's candidates (2^27 bits)
+    uint64_t sparse_links = 0, full_links = 0;   // (diagnostics: windows of prepared batches linked by the candidate plane / in full)
     int dbg_stall_us = 0;            // FGPU_DEBUG_WALK_STALL_US, FGPU_DEBUG_DELTA_CHECK: read once per scan (fgpu_scan_begin), not from the walk's inner calls
     bool dbg_delta_check = false;
+    bool no_sparse_link = false;     // FGPU_NO_SPARSE_LINK, read once per scan
     DevBuf import_probe;             // device: [0] largest piece number among the entries of the last import, [1] entries newer than the preview, [2] [3] digest of the others
     uint64_t scan_grown = 0;         // times the junction table was rehashed into a larger one
 
@@ -483,6 +488,7 @@ int fgpu_stage_scan_pure(fgpu_ctx* ctx, uint64_t* n_pieces);
 int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces);
 int fgpu_stage_scan_need(fgpu_ctx* ctx);
 int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b);
+int fgpu_scan_build_cand(fgpu_ctx* ctx, BatchBufs* b);
 int fgpu_scan_import_probe(fgpu_ctx* ctx, const void* dev_entries, uint64_t n, uint64_t after_seq, uint32_t* dfilter, uint64_t dfilter_bits,
                            uint64_t* max_seq, uint64_t* n_newer, uint64_t digest[2]);
 int fgpu_stage_scan_debug_drop(fgpu_ctx* ctx);

@@ -380,6 +380,96 @@ __global__ void __launch_bounds__(256) k_walk_link(Planes pl, FdParams fp, WTabl
     }
 }
 
+// ---- B': the link pass of a PREPARED batch of a read shard, by a candidate plane made off the chain (round 6) --------------------------
+// On the chain of hand-overs a prepared batch pays two per-position passes over its hash plane: k_refresh_lookup (the keys created since the
+// preview, merged into the in-map planes through a small filter) and k_walk_link (every position against the window table).  The second one
+// asks a question whose answer is almost entirely known BEFORE the table arrives: the keys a window registers are
+//   (a) candidates by the planes as the preview left them (in the map, flagged), by the pieces' shapes (fake junction, spacer rule): static;
+//   (b) positions whose in-map bit the merge has just set: their k-mer is in the filter of new keys;
+//   (c) keys this batch's own earlier windows created (the delta list): only for windows with lo > 0.
+// So while the rank waits (fgpu_scan_refresh_prepared) every prepared batch gets a plane `cand`: positions whose hash is in a filter of all
+// hashes of kind (a) -- a superset of the positions k_walk_link would find for them, whatever the window --, the merge ORs in the positions
+// that hit the filter of new keys (a superset for (b): every position with the hash of such a key hits it too), and the link pass of a
+// window with lo == 0 visits the set bits only.  Windows with lo > 0 are linked in full.  FGPU_DEBUG_DELTA_CHECK=1 runs the full pass behind
+// the sparse one and compares the lk planes word by word.
+constexpr int CAND_FILTER_LOG2 = 27;
+__device__ __forceinline__ uint32_t cand_bit(uint32_t h32) { return (h32 * 0xC2B2AE35u) >> (32 - CAND_FILTER_LOG2); }
+
+__global__ void __launch_bounds__(256) k_cand_mark(const uint64_t* __restrict__ pm, const uint64_t* __restrict__ inF, const uint64_t* __restrict__ inB,
+                                                   const uint64_t* __restrict__ ff, const uint64_t* __restrict__ fb, const uint32_t* __restrict__ kh,
+                                                   uint64_t n_words, const uint2* __restrict__ pieces, uint64_t n_pieces, FdParams fp,
+                                                   uint32_t* __restrict__ filt, unsigned word_blocks) {
+    if (blockIdx.x < word_blocks) {
+        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)word_blocks * blockDim.x) {
+            unsigned long long m = pm[w] & (inF[w] | inB[w] | ff[w] | fb[w]);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t cb = cand_bit(kh[w * 64 + (uint64_t)b]);
+                atomicOr(&filt[cb >> 5], 1u << (cb & 31));
+            }
+        }
+    } else {   // the pieces' own candidates, as k_walk_register takes them
+        const uint64_t stride = (uint64_t)(gridDim.x - word_blocks) * blockDim.x;
+        for (uint64_t i = (uint64_t)(blockIdx.x - word_blocks) * blockDim.x + threadIdx.x; i < n_pieces; i += stride) {
+            const uint2 pc = pieces[i];
+            const uint32_t len = pc.y + (uint32_t)fp.k - 1;
+            uint32_t cb = cand_bit(kh[pc.x + (len / 2 - (uint32_t)fp.k / 2)]);
+            atomicOr(&filt[cb >> 5], 1u << (cb & 31));
+            for (uint32_t q = (uint32_t)fp.max_spacer - 1; q < pc.y; q++) {
+                cb = cand_bit(kh[pc.x + q]);
+                atomicOr(&filt[cb >> 5], 1u << (cb & 31));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cand_probe(const uint64_t* __restrict__ pm, const uint32_t* __restrict__ kh, uint64_t n_words,
+                                                    const uint32_t* __restrict__ filt, uint64_t* __restrict__ cand) {
+    const uint64_t total = n_words * 64;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool hit = false;
+        if ((pm[p >> 6] >> (p & 63)) & 1ULL) {
+            const uint32_t cb = cand_bit(kh[p]);
+            hit = (filt[cb >> 5] >> (cb & 31)) & 1u;
+        }
+        const uint64_t m = __ballot(hit);
+        if (fd_lane() == 0) cand[p >> 6] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_walk_link_sparse(Planes pl, FdParams fp, WTable wt, uint32_t* parent, uint64_t lo, uint64_t hi,
+                                                          uint64_t pos_end, uint32_t* roots_state, const uint64_t* __restrict__ cand, uint64_t* lk_out) {
+    const WinDesc wd = make_window(pl, lo, hi);
+    if (roots_state && blockIdx.x == 0 && threadIdx.x == 0) { roots_state[0] = 0; roots_state[1] = 0; }
+    const uint64_t w0 = wd.lo >> 6, w1 = (pos_end + 63) >> 6;
+    for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned long long m = cand[w] & pl.pm[w];
+        if (w == w0) m &= ~0ULL << (wd.lo & 63);
+        if ((w + 1) * 64 > pos_end) m &= (1ULL << (pos_end & 63)) - 1;
+        unsigned long long out = 0;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint64_t p = w * 64 + (uint64_t)b;
+            const uint32_t h = pl.kh[p];
+            uint64_t slot = 0;
+            uint32_t owner = wt_owner(wt, h, slot);
+            if (owner == U_INF) continue;
+            uint32_t li;
+            uint2 pc;
+            if (!piece_in_window(pl, wd, p, li, pc)) continue;
+            out |= 1ULL << b;
+            if (owner == W_NO_OWNER) {
+                const unsigned long long mine = (unsigned long long)(wt.epoch | ((uint64_t)h << W_OWNER_BITS) | (uint64_t)li);
+                owner = (uint32_t)(atomicMin((unsigned long long*)&wt.keys[slot], mine) & W_OWNER_MASK);
+            }
+            if (owner != li && owner != W_NO_OWNER) uf_union(parent, li, owner);
+        }
+        lk_out[w] = out;
+    }
+}
+
 // ---- C: clusters -> member lists ---------------------------------------------------------------------
 // One pass over the pieces of the window (the union-find is final: every union happened in the kernels before):
 // flat root of every piece, and every follower pushes itself onto its root's singly linked list.  No scan, no
@@ -2552,15 +2642,18 @@ __device__ __forceinline__ uint32_t delta_bits(uint32_t h32) { return (1u << (h3
 // (a filter of the keys that are NEW since the planes were made -- the table only grows).
 __global__ void __launch_bounds__(256) k_refresh_lookup(const uint64_t* __restrict__ codes, const uint64_t* __restrict__ pm, uint64_t n_words,
                                                         FdParams fp, JTable jt, const uint32_t* __restrict__ filter, uint64_t filter_mask,
-                                                        uint64_t* __restrict__ nF, uint64_t* __restrict__ nB, const uint32_t* __restrict__ kh, int merge) {
+                                                        uint64_t* __restrict__ nF, uint64_t* __restrict__ nB, const uint32_t* __restrict__ kh, int merge,
+                                                        uint64_t* __restrict__ cand) {
+    // cand (merge only, may be null): the candidate plane of the sparse link pass gains every position that hits the filter of new keys
     const uint64_t total = n_words * 64;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
-        bool inF = false, inB = false;
+        bool inF = false, inB = false, hitC = false;
         if ((pm[p >> 6] >> (p & 63)) & 1ULL) {
             const uint32_t h32 = kh[p];
             const uint64_t hb = ((((uint64_t)(h32 * 0x9E3779B1u) << 16) ^ (uint64_t)(h32 >> 7)) & filter_mask);
             const bool maybe = merge ? (filter[hb >> 5] & delta_bits(h32)) == delta_bits(h32) : (((filter[hb >> 5] >> (hb & 31)) & 1u) != 0);
             if (maybe) {
+                hitC = true;
                 const uint64_t km = fd_kmer_at(codes, p, fp.k);
                 const uint64_t rc = fd_revcomp(km, fp.k);
                 const uint64_t canon = km < rc ? km : rc;
@@ -2570,6 +2663,10 @@ __global__ void __launch_bounds__(256) k_refresh_lookup(const uint64_t* __restri
             }
         }
         const uint64_t mF = __ballot(inF), mB = __ballot(inB);
+        if (cand) {
+            const uint64_t mC = __ballot(hitC);
+            if (fd_lane() == 0 && mC) cand[p >> 6] |= mC;
+        }
         if (fd_lane() == 0) {
             if (merge) { if (mF) nF[p >> 6] |= mF; if (mB) nB[p >> 6] |= mB; }
             else { nF[p >> 6] = mF; nB[p >> 6] = mB; }
@@ -3009,8 +3106,30 @@ int fgpu_scan_refresh_planes(fgpu_ctx* ctx, BatchBufs* b) {
     JTable jt = make_jt(ctx);
     ctx->launch_stream = ctx->stream;
     FGPU_LAUNCH("need_lookup", k_refresh_lookup, fgpu_grid(b->n_words * 64, 256), 256, (const uint64_t*)b->codes.p, (const uint64_t*)b->pm.p, b->n_words,
-                ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, (uint64_t*)b->nF.p, (uint64_t*)b->nB.p, (const uint32_t*)b->kh.p, 0);
+                ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, (uint64_t*)b->nF.p, (uint64_t*)b->nB.p, (const uint32_t*)b->kh.p, 0, (uint64_t*)nullptr);
     if (b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));
+    return FGPU_OK;
+}
+
+// Read shards (fgpu_scan_refresh_prepared, off the chain): the candidate plane of a prepared batch against the planes as they stand -- see
+// k_walk_link_sparse.  Two passes: the hashes of every candidate position and of the pieces' own candidates into a filter, then every position
+// against that filter.
+int fgpu_scan_build_cand(fgpu_ctx* ctx, BatchBufs* b) {
+    b->cand_gen = 0;
+    if (!b->n_pieces || !b->T) return FGPU_OK;
+    int rc;
+    const uint64_t wb = (b->n_words + FGPU_PADW) * 8;
+    if ((rc = fgpu_ensure_b(ctx, &b->cand, wb)) || (rc = fgpu_ensure(ctx, &ctx->cand_filter, (1ULL << CAND_FILTER_LOG2) / 8))) return rc;
+    ctx->launch_stream = ctx->stream;
+    FGPU_HIP(hipMemsetAsync(ctx->cand_filter.p, 0, (1ULL << CAND_FILTER_LOG2) / 8, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(b->cand.p, 0, wb, ctx->stream));
+    const unsigned word_blocks = std::min(fgpu_blocks(b->n_words, 256), 2048u), piece_blocks = std::min(fgpu_blocks(b->n_pieces, 256), 2048u);
+    FGPU_LAUNCH("cand_plane", k_cand_mark, word_blocks + piece_blocks, 256, (const uint64_t*)b->pm.p, (const uint64_t*)b->nF.p, (const uint64_t*)b->nB.p,
+                (const uint64_t*)b->ff.p, (const uint64_t*)b->fb.p, (const uint32_t*)b->kh.p, b->n_words, (const uint2*)b->pieces.p, b->n_pieces, ctx->fd,
+                (uint32_t*)ctx->cand_filter.p, word_blocks);
+    FGPU_LAUNCH("cand_plane", k_cand_probe, fgpu_grid(b->n_words * 64, 256), 256, (const uint64_t*)b->pm.p, (const uint32_t*)b->kh.p, b->n_words,
+                (const uint32_t*)ctx->cand_filter.p, (uint64_t*)b->cand.p);
+    b->cand_gen = ctx->hint_gen;
     return FGPU_OK;
 }
 
@@ -3069,6 +3188,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     if (bb.pure_done) FGPU_HIP(hipStreamWaitEvent(walk_stream, bb.pure_done, 0));
     const int stall_us = ctx->dbg_stall_us;
     if (stall_us) FGPU_LAUNCH("debug_stall", k_debug_stall, 1, 1, (unsigned long long)stall_us * 100ULL);
+    bool cand_ok = false;      // this batch's candidate plane covers every position its windows' link passes can find (see k_walk_link_sparse)
     if (ctx->refresh_snapshot) {
         // batches that were prepared before their turn (multi-GPU shards; scan_prepare / scan_walk_prepared) carry snapshot planes of a table
         // that has since been replaced or walked on by an unknown number of batches: made again here, behind the previous batch's walk
@@ -3079,10 +3199,12 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                         ctx->fd, jt, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (uint32_t*)bb.kh.p, (uint64_t)0);
         else if (ctx->delta_ready && bb.planes_gen == ctx->hint_gen) {
             // the planes speak of the newest preview and the table is a later state of it: only the keys created since are looked for and merged in
+            // (and the candidate plane of the sparse link pass, made against the same preview, gains the positions that hit the filter: k_walk_link_sparse)
+            cand_ok = !ctx->no_sparse_link && bb.cand.p && bb.cand_gen == ctx->hint_gen;      // (FGPU_NO_SPARSE_LINK: every window in full, as until round 6)
             if (ctx->delta_keys || ctx->refresh_delta)      // (nothing new in the table and nothing walked yet: the planes stand)
                 FGPU_LAUNCH("walk_lookup", k_refresh_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
                             ctx->fd, jt, (const uint32_t*)ctx->delta_filter.p, ctx->delta_filter_bits - 1, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p,
-                            (const uint32_t*)bb.kh.p, 1);
+                            (const uint32_t*)bb.kh.p, 1, cand_ok ? (uint64_t*)bb.cand.p : (uint64_t*)nullptr);
             ctx->refresh_delta++;
             if (ctx->dbg_delta_check) {      // tests (FGPU_DEBUG_DELTA_CHECK=1): the merged planes against planes made again in full, word by word
                 uint64_t *cF = nullptr, *cB = nullptr;
@@ -3092,7 +3214,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
                 FGPU_HIP(hipMalloc(&out, 32));
                 FGPU_HIP(hipMemsetAsync(out, 0, 32, walk_stream));
                 hipLaunchKernelGGL(k_refresh_lookup, dim3(fgpu_grid(bb.n_words * 64, 256)), dim3(256), 0, walk_stream, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p,
-                                   bb.n_words, ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, cF, cB, (const uint32_t*)bb.kh.p, 0);
+                                   bb.n_words, ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, cF, cB, (const uint32_t*)bb.kh.p, 0, (uint64_t*)nullptr);
                 hipLaunchKernelGGL(k_dbg_diff, dim3(64), dim3(256), 0, walk_stream, (const uint64_t*)cF, (const uint64_t*)bb.nF.p, bb.n_words, out, 0);
                 hipLaunchKernelGGL(k_dbg_diff, dim3(64), dim3(256), 0, walk_stream, (const uint64_t*)cB, (const uint64_t*)bb.nB.p, bb.n_words, out, 1);
                 unsigned long long h[4] = {0, 0, 0, 0};
@@ -3104,7 +3226,7 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
             }
         } else {
             FGPU_LAUNCH("walk_lookup", k_refresh_lookup, fgpu_grid(bb.n_words * 64, 256), 256, (const uint64_t*)bb.codes.p, (const uint64_t*)bb.pm.p, bb.n_words,
-                        ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (const uint32_t*)bb.kh.p, 0);
+                        ctx->fd, jt, (const uint32_t*)jt.filter, jt.filter_mask, (uint64_t*)bb.nF.p, (uint64_t*)bb.nB.p, (const uint32_t*)bb.kh.p, 0, (uint64_t*)nullptr);
             ctx->refresh_full++;
         }
     }
@@ -3207,7 +3329,32 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
         }
         uint32_t* const roots_state = ctx->cl_roots;               // [0] leaders listed, [1] handed out; the list follows (16 words in)
         uint32_t* const root_list = ctx->cl_roots + 16;
-        FGPU_LAUNCH("walk_link", k_walk_link, std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, roots_state);
+        if (cand_ok && lo == 0) {      // (lo > 0: the window registers what this batch's earlier windows created -- positions the plane does not know)
+            const uint64_t link_words = ((pos_end + 63) >> 6) - (lo >> 6);
+            FGPU_LAUNCH("walk_link", k_walk_link_sparse, std::min(fgpu_blocks(link_words, 256), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, roots_state,
+                        (const uint64_t*)bb.cand.p, (uint64_t*)bb.lk.p);
+            ctx->sparse_links++;
+            if (ctx->dbg_delta_check) {      // tests: the full pass behind it (its unions are the same ones again), the two lk planes word by word
+                uint64_t* copy = nullptr;
+                unsigned long long* out = nullptr;
+                FGPU_HIP(hipMalloc(&copy, link_words * 8));
+                FGPU_HIP(hipMalloc(&out, 32));
+                FGPU_HIP(hipMemsetAsync(out, 0, 32, walk_stream));
+                FGPU_HIP(hipMemcpyAsync(copy, (const uint64_t*)bb.lk.p + (lo >> 6), link_words * 8, hipMemcpyDeviceToDevice, walk_stream));
+                hipLaunchKernelGGL(k_walk_link, dim3(std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u)), dim3(256), 0, walk_stream, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end,
+                                   (uint32_t*)nullptr);
+                hipLaunchKernelGGL(k_dbg_diff, dim3(64), dim3(256), 0, walk_stream, (const uint64_t*)copy, (const uint64_t*)bb.lk.p + (lo >> 6), link_words, out, 0);
+                unsigned long long h[4] = {0, 0, 0, 0};
+                FGPU_HIP(hipMemcpyAsync(h, out, 32, hipMemcpyDeviceToHost, walk_stream));
+                FGPU_HIP(hipStreamSynchronize(walk_stream));
+                ctx->refresh_mismatch += h[0];
+                if (h[0]) fprintf(stderr, "[fgpu] sparse link pass: %llu lk words differ from the full pass's, batch %llu window at %llu\n", h[0], (unsigned long long)bb.seq, (unsigned long long)lo);
+                (void)hipFree(copy); (void)hipFree(out);
+            }
+        } else {
+            FGPU_LAUNCH("walk_link", k_walk_link, std::min(fgpu_blocks(pos_end - (lo & ~63ULL), 1024), 4096u), 256, pl, ctx->fd, wt, uf_parent, lo, hi, pos_end, roots_state);
+            if (ctx->refresh_snapshot) ctx->full_links++;
+        }
         // The key-ordered walk costs four small launches per window whether or not the window holds a large cluster, so it is switched on by
         // what the scan has shown so far: the largest cluster among the windows whose counters the host has seen (every batch's pure stage
         // brings them along).  Data without such clusters never pays; data with them walks its first batch by cluster.  Either way the

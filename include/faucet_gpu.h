@@ -334,6 +334,13 @@ int fgpu_scan_import_hint(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entries
  * behind them were prepared before any of the shard was walked. */
 int fgpu_scan_refresh_prepared(fgpu_ctx* ctx);
 int fgpu_diag_prepared_refresh(fgpu_ctx* ctx, uint64_t out[4]);
+/* Round 6: fgpu_scan_refresh_prepared also makes, for every prepared batch, the plane of positions a link pass of the walk can find at all
+ * (their hash is a candidate's by the planes as the preview left them); the merge of the new keys adds the positions that hit the filter of new
+ * keys, and the walk links a window by visiting those positions only instead of probing the window table at every position (18 -> 3 ms per
+ * 25 M reads on the chain; windows that follow another window of their batch are linked in full).  FGPU_NO_SPARSE_LINK=1: every window in full.
+ * fgpu_diag_sparse_link (after fgpu_scan_end): [0] windows of prepared batches linked by the plane, [1] in full; FGPU_DEBUG_DELTA_CHECK=1 runs
+ * the full pass behind every sparse one and counts differing lk words into fgpu_diag_prepared_refresh's [3]. */
+int fgpu_diag_sparse_link(fgpu_ctx* ctx, uint64_t out[2]);
 #define FGPU_TABLE_ENTRY_BYTES 32
 
 /* The two pair filters as they stand on the device while a scan is open (after fgpu_scan_begin, which empties them): which = 0 the short

@@ -46,19 +46,30 @@ def timed(name, fn):
 
 
 # pass 1 of the two shards the way the library does it (fix-up protocol where it can), so that bloo2 and the kept planes are a rank's own
+# (FULL_BLOO2=1: pass 1 of ALL N shards, so that bloo2 -- and with it the number of junctions, the size of the table and the walk's work -- is the
+# whole run's, as in scripts/project_strong.py; the default, two shards, is quicker and gives a table a third of the size)
 prefix = None
 b2 = None
-for r in (0, 1):
+running = None
+prefixes = {}
+for r in range(N if os.environ.get("FULL_BLOO2") == "1" else 2):
     reads, batches = batches_of(r)
     b.clear_filters()
     b.load(batches, keep_carry=False, shard_times=True)
     if r == 0:
-        prefix = b.bloom_tensor(L.BLOO1).clone()
+        running = b.bloom_tensor(L.BLOO1).clone()
         b2 = b.bloom_tensor(L.BLOO2).clone()
     else:
-        b.load_fixup(prefix)
+        prefixes[r] = running.clone() if r == HOP else None
+        mine1 = b.bloom_tensor(L.BLOO1).clone()
+        b.load_fixup(running)
         b2 |= b.bloom_tensor(L.BLOO2)
+        running |= mine1
+        del mine1
     del reads, batches
+prefix = prefixes.get(HOP)
+if prefix is None:      # (HOP beyond the shards loaded: the OR of what was loaded -- only the kept planes of the hop's own load differ)
+    prefix = running
 hint = [None]
 reads0, batches0 = batches_of(0)
 b.clear_filters()

@@ -447,6 +447,7 @@ int fgpu_profile_enable(fgpu_ctx* c, int) { return c ? FGPU_OK : FGPU_ERR_ARG; }
 int fgpu_diag_host_waits(fgpu_ctx* c, uint64_t* waits, double* ms) { if (!c || !waits) return FGPU_ERR_ARG; *waits = 0; if (ms) *ms = 0; return FGPU_OK; }
 int fgpu_scan_refresh_prepared(fgpu_ctx* c) { return c ? FGPU_OK : FGPU_ERR_ARG; }   // (the stub prepares nothing ahead: its walk sees the table as it stands)
 int fgpu_diag_prepared_refresh(fgpu_ctx* c, uint64_t out[4]) { if (!c || !out) return FGPU_ERR_ARG; out[0] = out[1] = out[2] = out[3] = 0; return FGPU_OK; }
+int fgpu_diag_sparse_link(fgpu_ctx* c, uint64_t out[2]) { if (!c || !out) return FGPU_ERR_ARG; out[0] = out[1] = 0; return FGPU_OK; }
 int fgpu_diag_ovw_tables(fgpu_ctx* c, uint64_t* hw, uint64_t* cap) { if (!c || !hw || !cap) return FGPU_ERR_ARG; *hw = 0; *cap = 1ULL << 23; return FGPU_OK; }
 int fgpu_diag_ovw(fgpu_ctx* c, uint64_t out[6]) { if (!c || !out) return FGPU_ERR_ARG; memset(out, 0, 6 * sizeof(uint64_t)); return FGPU_OK; }
 int fgpu_stage3_set_junctions(fgpu_ctx* c, const uint64_t*, const fgpu_junction*, uint64_t) { return STUB_UNSUPPORTED(c); }

@@ -1744,10 +1744,20 @@ def test_a_fresher_preview_lets_the_walk_look_only_for_the_keys_created_since(mo
 
     d = run_c((n_a, t_a))
     assert d == {"batches_in_full": 0, "batches_merged": 2, "new_keys": n_b - n_a, "mismatching_words": 0}, d
+    # round 6: the refresh also made the batches' candidate planes, and the walk linked every first window of a batch by them (the debug knob
+    # above ran the full link pass behind each and compared the lk planes: "mismatching_words")
+    sl = c.diag_sparse_link()
+    assert sl["windows_sparse"] >= 2, sl
     d = run_c(None)                                         # no fresher preview: the planes speak of the early one, the surplus is A's rest + B's
     assert d["batches_merged"] == 2 and d["new_keys"] == n_b - n_early and d["mismatching_words"] == 0, d
+    assert c.diag_sparse_link()["windows_sparse"] == 0      # (no refresh call, no candidate planes: every window linked in full)
     d = run_c((n_a, t_a), refresh=False)                    # shown but not refreshed: the planes do not speak of the newest preview
     assert d["batches_in_full"] == 2 and d["batches_merged"] == 0, d
+    assert c.diag_sparse_link()["windows_sparse"] == 0
+    monkeypatch.setenv("FGPU_NO_SPARSE_LINK", "1")          # the short cut off: same records
+    d = run_c((n_a, t_a))
+    assert d["batches_merged"] == 2 and d["mismatching_words"] == 0 and c.diag_sparse_link()["windows_sparse"] == 0, d
+    monkeypatch.delenv("FGPU_NO_SPARSE_LINK")
     # a "preview" that is not an earlier state of the table that arrives: B's own final table with half of its entries dropped from the FRONT
     # (old entries missing, all the new ones there) -- as many entries as A's table, but the newer-than-the-preview count does not fit
     bogus = t_b[(n_b - n_a) * L.TABLE_ENTRY_BYTES:].clone()
