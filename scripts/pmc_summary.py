@@ -74,6 +74,12 @@ def main():
         if "k_diag_random" in k and n_acc:
             cal[k] = {"fetch_bytes_per_access": 1024.0 * (v["fetch_KB_per_launch"] or 0) / n_acc, "write_bytes_per_access": 1024.0 * (v["write_KB_per_launch"] or 0) / n_acc}
     out["calibration"] = cal
+    try:      # (the counters of configs 4 and 5 at full size are another script's: scripts/pmc_fullsize_summary.py)
+        old = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+        if "full_size" in old:
+            out["full_size"] = old["full_size"]
+    except (OSError, ValueError):
+        pass
     with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k in ("calibration",)}, indent=1))
