@@ -3256,8 +3256,16 @@ int fgpu_stage_scan_walk(fgpu_ctx* ctx, uint64_t n_pieces) {
     const int stage_tok = fgpu_prof_begin(ctx, "walk_stage");
     ctx->prof_suppress = !ctx->prof_walk_detail;
     uint64_t span_now = span;
+    // A prepared batch with a candidate plane is one window when the controller's span would cut it into two or three: only a batch's FIRST
+    // window is linked by the plane (the later ones register what the earlier ones created and are linked in full), and the walk itself is no
+    // slower on the whole batch (hop of config 4 on 8 shards, 23 windows -> 14: k_walk_dyn 22.3 -> 22.6 ms, the link passes 12.7 -> 8.7, the hop
+    // 69.1 -> 64.9 ms: profiles/r06_hop_sparse_link.txt).  The controller's own span is left as it is (it goes on voting from the counters; once it
+    // asks for less than half a batch this rule no longer applies).  FGPU_NO_WHOLE_BATCH=1: off (measurement aid).
+    static const bool no_whole = getenv("FGPU_NO_WHOLE_BATCH") != nullptr;
+    const bool whole_batch = cand_ok && !no_whole && !ctx->prm.walk_window_span && ctx->calib_left <= 0 && span * 2 >= T && span < T && T <= ctx->max_span &&
+                             bb.n_pieces <= ctx->wmax;
     for (uint64_t lo = 0, step = 0; lo < T; lo += step) {
-        step = span_now;
+        step = whole_batch ? T : span_now;
         const uint64_t hi = std::min<uint64_t>(T, lo + step);
         const uint64_t pos_end = std::min<uint64_t>(T, hi + ext);
         const int parity = (int)(ctx->scan_windows & 1);

@@ -23,7 +23,7 @@ dev = torch.device("cuda", 0)
 tai, nh = api.load_filter_shape(c["E"], c["S"])
 genome = sd.make_genome(c["genome"], c["genome_seed"], dev)
 per = c["reads"] // N
-ctx = api.Context(c["k"], tai, nh, profile=True)
+ctx = api.Context(c["k"], tai, nh, profile=True, walk_window_span=int(os.environ.get("FAUCET_WALK_SPAN", "0")))
 b = sharded.GpuShard(ctx, dev, stream_ordered=False)
 
 
