@@ -269,9 +269,30 @@ public:
                     shown = true;
                     return FGPU_OK;
                 };
+                // Round 6: the rank above this one has nobody to pass it a table, so it is shown a second, later state of this one (after 7/10 of the
+                // shard): its planes and candidate planes are made against a table a few million keys short of the one it is handed, and its
+                // hop is the short one of every later rank (fgpu_scan_refresh_prepared).  Sent without waiting: the scan goes on beside the copy.
+                bool shown_late = n == 1 || !late_hints;
+                const uint64_t late_at = (cuts[1] - cuts[0]) / 10 * 7;
+                auto show_late = [&]() -> int {
+                    uint64_t n_entries = 0;
+                    RANK_CHECK(fgpu_scan_table_entries(c, &n_entries));
+                    RANK_CHECK(fgpu_device_alloc(c, std::max<uint64_t>(n_entries, 1) * FGPU_TABLE_ENTRY_BYTES, &late_buf));
+                    uint64_t got = 0;
+                    RANK_CHECK(fgpu_scan_export_table(c, late_buf, std::max<uint64_t>(n_entries, 1) * FGPU_TABLE_ENTRY_BYTES, &got));
+                    GROUP_CHECK(fgpu_group_send_async(group_, 0, 1, late_buf, got * FGPU_TABLE_ENTRY_BYTES));
+                    announce(&late_[1], got, nullptr);
+                    shown_late = true;
+                    return FGPU_OK;
+                };
                 RANK_TRY(for_each_batch(r, path, cuts, [&](const fgpu_reads* b) { return fgpu_scan_batch(c, b); },
-                                        [&](uint64_t bytes_done) -> int { return !shown && bytes_done >= quarter ? show() : FGPU_OK; }));
+                                        [&](uint64_t bytes_done) -> int {
+                                            if (!shown && bytes_done >= quarter) { const int src = show(); if (src != FGPU_OK) return src; }
+                                            if (shown && !shown_late && bytes_done >= late_at) return show_late();
+                                            return FGPU_OK;
+                                        }));
                 if (!shown) RANK_TRY(show());                 // (a shard without batches still owes the others their preview)
+                if (!shown_late) RANK_TRY(show_late());
                 RANK_CHECK(fgpu_scan_end(c, &st));
                 tell(r, "pass 2: first shard streamed in %.1f ms", now_ms() - t0);
             } else {
@@ -292,8 +313,9 @@ public:
                     return fgpu_scan_prepare(c, b);
                 }, nullptr));
                 if (!have_hint) RANK_TRY(take_hint(true, false));   // the send is received even when it came too late to be of use
-                if (late_hints && r > 1) {
-                    // the table the rank below has just been HANDED, passed on at once: a preview one shard older than the table this rank will get.
+                if (late_hints && r >= 1) {
+                    // the table the rank below has just been HANDED, passed on at once: a preview one shard older than the table this rank will get
+                    // (the rank above the first one: the first rank's own table after 7/10 of its shard).
                     // The planes of the prepared batches are made again against it while the rank below walks; the walk then only looks for the
                     // keys that rank created (fgpu_scan_refresh_prepared, faucet_gpu.h)
                     uint64_t n_late = 0;

@@ -308,6 +308,10 @@ HINT_AFTER = 0.25
 # its prepared batches again against it while this rank walks; when its own table arrives it differs from that preview by what ONE shard created,
 # and its walk looks only for those keys (faucet_gpu.h, fgpu_scan_refresh_prepared): 22 -> ~7 ms of every hop from the third rank on.
 LATE_HINT = os.environ.get("FAUCET_LATE_HINT", "1") != "0"      # (has to be the same on every rank)
+# Round 6: the rank above the first one has nobody to pass it a table, so the FIRST rank shows it a second, later state of its own table (after
+# LATE_AFTER of its reads): that rank's planes and candidate planes are then made against a table a few million keys short of the one it is handed,
+# and its hop is the short one every later rank has (config 4 on 8 shards: 94 -> 72 ms; the rest of the first shard's scan is the time it has).
+LATE_AFTER = 0.7
 
 
 def _n_reads(b):
@@ -392,13 +396,17 @@ def scan_sharded(backend, batches, rank: int, world: int):
     backend.scan_begin()
     hinting = world > 1
     hint_hdr = backend.header_tensor()[:1] if hinting else None
+    late = LATE_HINT and hasattr(backend, "refresh_prepared")
+    late_reqs = []
     if rank == 0:
-        total, done, sent = sum(_n_reads(b) for b in batches), 0, [False]
-        marks = []
+        total, done, sent, sent_late = sum(_n_reads(b) for b in batches), 0, [False], [False]
+        marks, marks_late = [], []
         for b in batches:
             done += _n_reads(b)
             marks.append(done >= HINT_AFTER * total)
+            marks_late.append(done >= LATE_AFTER * total)
         hint_index = marks.index(True) if True in marks else len(batches) - 1
+        late_index = marks_late.index(True) if True in marks_late else len(batches) - 1
 
         def show(i):
             if hinting and not sent[0] and i >= hint_index:
@@ -408,6 +416,15 @@ def scan_sharded(backend, batches, rank: int, world: int):
                 hint_hdr[0] = n
                 _bcast(hint_hdr, 0, rank)
                 _bcast(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 0, rank)
+            if hinting and late and not sent_late[0] and i >= late_index:
+                # the fresher preview of the rank above (round 6): sent without waiting -- the scan goes on beside the copy
+                sent_late[0] = True
+                n, buf = backend.export_table(tag="table_late_out")
+                backend.fence()
+                lhdr = backend.header_tensor()
+                lhdr[0] = n
+                late_reqs.append(_isend(lhdr, 1))
+                late_reqs.append(_isend(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 1))
 
         # the first shard has nothing to wait for: it streams (pure stage of batch b+1 overlapped with the walk of batch b, lazy
         # junction tests), which puts the table on its way ~50 ms per 10 M reads earlier than prepare-all + walk
@@ -427,10 +444,10 @@ def scan_sharded(backend, batches, rank: int, world: int):
             rx.finish()                                    # the collective is completed even when it came too late to be of use
         CLOCK.mark("pass2_pure_stage")
     hdr = backend.header_tensor()
-    late = LATE_HINT and hasattr(backend, "refresh_prepared")
     forwarded = None
-    if rank > 1 and late:
-        # the table the rank below has just been handed: a preview one shard older than the table this rank will get
+    if rank >= 1 and late:
+        # the table the rank below has just been handed: a preview one shard older than the table this rank will get (the rank above the
+        # first one: the first rank's own table after LATE_AFTER of its reads)
         _recv(hdr, rank - 1)
         n_late = int(hdr.cpu().tolist()[0])
         late_buf = backend.scratch(max(n_late, 1) * L.TABLE_ENTRY_BYTES, tag="table_late")
@@ -455,9 +472,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
         carried = dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]]))
         stats = backend.walk_shard(batches, buf, n_in, carried)   # import (replaces the hint) + ordered walk of this shard + scan_end
         CLOCK.mark("pass2_import_and_walk")
-    if forwarded:
-        for req, keep in forwarded:
-            req.wait()
+    for req, keep in (forwarded or []) + late_reqs:
+        req.wait()
     if rank < world - 1:
         n_out, buf = backend.export_table()
         backend.fence()
@@ -561,20 +577,31 @@ def run_in_turn(make_backend, shards, protocol: str = "presence", after_load=Non
                 done += _n_reads(x)
                 marks.append(done >= HINT_AFTER * total)
             hint_index = marks.index(True) if True in marks else len(shards[0]) - 1
+            done, marks_late = 0, []
+            for x in shards[0]:
+                done += _n_reads(x)
+                marks_late.append(done >= LATE_AFTER * total)
+            late_index = marks_late.index(True) if True in marks_late else len(shards[0]) - 1
+            late0 = [None]
 
             def show(i, b=b):
                 if hint[0] is None and i >= hint_index:
                     n, buf = b.export_table(tag="table_hint_out")
                     b.fence()
                     hint[0], hint[1] = buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n
+                if late0[0] is None and i >= late_index and world > 1 and LATE_HINT and hasattr(b, "refresh_prepared"):
+                    n, buf = b.export_table(tag="table_late_out")      # (round 6: the second rank's fresher preview, as scan_sharded sends it)
+                    b.fence()
+                    late0[0] = (buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n)
 
             stats = b.scan_stream(shards[0], after_batch=show)
             show(len(shards[0]))
+            older = late0[0]
         else:
             b.import_hint(hint[0], hint[1])
             for batch in shards[r]:
                 b.scan_prepare(batch)
-            if r > 1 and LATE_HINT and hasattr(b, "refresh_prepared"):      # the table the rank below was handed, as scan_sharded passes it on
+            if older is not None and LATE_HINT and hasattr(b, "refresh_prepared"):      # the table the rank below was handed (rank 1: the first rank's late state), as scan_sharded passes it on
                 b.import_hint(older[0], older[1])
                 b.refresh_prepared()
             carried = {n: int(stats[n]) for n in _STAT_NAMES}

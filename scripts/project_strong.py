@@ -127,23 +127,29 @@ for N in Ns:
         for rep in range(WARM):
             b.scan_begin()
             if r == 0:
-                total, done, marks = per, 0, []
+                total, done, marks, marks_late = per, 0, [], []
                 for x in batches:
                     done += x.n_reads
                     marks.append(done >= sharded.HINT_AFTER * total)
-                hi = marks.index(True)
+                    marks_late.append(done >= sharded.LATE_AFTER * total)
+                hi, hi_late = marks.index(True), marks_late.index(True)
                 hint = None
+                late0 = None
                 def show(i):
-                    global hint
+                    global hint, late0
                     if hint is None and i >= hi:
                         n, buf = b.export_table(tag="hint")
                         hint = (buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n)
+                    if late0 is None and i >= hi_late and LATE and N > 1:      # (round 6: the second rank's fresher preview; its export is inside rank 0's timed scan)
+                        n, buf = b.export_table(tag="late0")
+                        late0 = (buf[:max(n, 1) * L.TABLE_ENTRY_BYTES].clone(), n)
                 stats, t_scan0 = timed(lambda: b.scan_stream(batches, after_batch=show))
+                older = late0
             else:
                 b.import_hint(hint[0], hint[1])
                 _, ms_pure = timed(lambda: [b.scan_prepare(x) for x in batches])
                 ms_late = 0.0
-                if r > 1 and LATE:      # the table the rank below was handed, passed on as a fresher preview: planes made again off the chain
+                if r >= 1 and LATE and older is not None:      # the table the rank below was handed (rank 1: rank 0's table after LATE_AFTER of its reads), passed on as a fresher preview: planes made again off the chain
                     _, ms_late = timed(lambda: (b.import_hint(older[0], older[1]), b.refresh_prepared()))
                 carried = {n: int(prev_stats[n]) for n in sharded._STAT_NAMES}
                 (stats), ms_walk = timed(lambda: b.walk_shard(batches, table, n_table, carried))
