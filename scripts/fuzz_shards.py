@@ -64,7 +64,10 @@ for seed in range(lo, hi):
             def after_scan(rk, stats, backend):      # (with FGPU_DEBUG_DELTA_CHECK=1 the library compares merged in-map planes with planes made again)
                 d = backend.ctx.diag_prepared_refresh()
                 merged[0] += d["batches_merged"]
-                merged[1] += d["mismatching_words"]
+                merged[1] += d["mismatching_words"]      # (round 6: also lk words in which a sparse link pass differed from the full pass run behind it)
+                sl = backend.ctx.diag_sparse_link()
+                globals()["total_sparse"] = globals().get("total_sparse", 0) + sl["windows_sparse"]
+                globals()["total_full"] = globals().get("total_full", 0) + sl["windows_in_full"]
 
             lst, sst, last = sharded.run_in_turn(lambda: sharded.GpuShard(api.Context(k, tai, nh, j=j), dev), shards, protocol, after_load, after_scan)
             assert merged[1] == 0, (protocol, "merged planes differ from planes made again", merged)
@@ -80,5 +83,6 @@ for seed in range(lo, hi):
     except Exception as e:   # noqa: BLE001
         bad += 1
         print("seed", seed, "FAILED", repr(e)[:500], flush=True)
-print("done, seeds", lo, "to", hi - 1, "failures:", bad, "| batches whose planes were merged with the new keys:", globals().get("total_merged", 0))
+print("done, seeds", lo, "to", hi - 1, "failures:", bad, "| batches whose planes were merged with the new keys:", globals().get("total_merged", 0),
+      "| windows of prepared batches linked by the candidate plane:", globals().get("total_sparse", 0), "in full:", globals().get("total_full", 0))
 sys.exit(1 if bad else 0)
