@@ -533,10 +533,10 @@ def launch_ranks(n):
             return None
 
     # RCCL with more than one rank has never run where this was built (one GPU per box).  So that a first contact with an N-GPU node
-    # is not lost to a transport problem, a run over RCCL that fails or hangs (FAUCET_BENCH_RANKS_TIMEOUT seconds, default 600; 0 = no limit) is
+    # is not lost to a transport problem, a run over RCCL that fails or hangs (FAUCET_BENCH_RANKS_TIMEOUT seconds, default 450: a run of 8 ranks takes about 2 minutes with a cold start; 0 = no limit) is
     # followed by ONE run of the same protocol over gloo (device buffers staged through page-locked host memory), with few steps and the reason in
     # the line (`transport_fallback`): a functional record of the N-rank pipeline, not the xGMI number.  FAUCET_BENCH_NO_FALLBACK=1: off.
-    limit = float(os.environ.get("FAUCET_BENCH_RANKS_TIMEOUT", "600"))
+    limit = float(os.environ.get("FAUCET_BENCH_RANKS_TIMEOUT", "450"))
     rc = attempt(sys.argv[1:], env, limit)
     if rc == 0 or env.get("FAUCET_DIST_BACKEND", "nccl") != "nccl" or os.environ.get("FAUCET_BENCH_NO_FALLBACK") == "1":
         return 1 if rc is None else rc
