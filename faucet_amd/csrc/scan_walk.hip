@@ -3129,6 +3129,7 @@ int fgpu_scan_build_cand(fgpu_ctx* ctx, BatchBufs* b) {
                 (uint32_t*)ctx->cand_filter.p, word_blocks);
     FGPU_LAUNCH("cand_plane", k_cand_probe, fgpu_grid(b->n_words * 64, 256), 256, (const uint64_t*)b->pm.p, (const uint32_t*)b->kh.p, b->n_words,
                 (const uint32_t*)ctx->cand_filter.p, (uint64_t*)b->cand.p);
+    if (b->pure_done) FGPU_HIP(hipEventRecord(b->pure_done, ctx->stream));      // (the walk waits for this event: the plane is part of what it reads)
     b->cand_gen = ctx->hint_gen;
     return FGPU_OK;
 }

@@ -328,6 +328,15 @@ def _bcast(t, src, rank):
         dist.broadcast(t, src=src)
 
 
+def _bcast_async(t, src, rank):
+    """the SENDER's side of a broadcast it does not wait for: (request, the tensor that has to outlive it).  The first rank shows its table in the
+    middle of its scan; the receivers post the second of the two broadcasts only when their host has looked at the first (between two of their
+    batches), and a broadcast the sender's stream waited for would hold its scan up for that long."""
+    assert rank == src
+    h = _staging.out(t) if _staged(t) else t
+    return dist.broadcast(h, src=src, async_op=True), h
+
+
 class _HintReceiver:
     """the two broadcasts of the hint (count, then entries) posted asynchronously and looked at between batches"""
 
@@ -397,7 +406,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
     hinting = world > 1
     hint_hdr = backend.header_tensor()[:1] if hinting else None
     late = LATE_HINT and hasattr(backend, "refresh_prepared")
-    late_reqs = []
+    pending_sends = []
     if rank == 0:
         total, done, sent, sent_late = sum(_n_reads(b) for b in batches), 0, [False], [False]
         marks, marks_late = [], []
@@ -414,8 +423,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
                 n, buf = backend.export_table(tag="table_hint_out")   # its own buffer: the broadcast may still be reading it at the final export
                 backend.fence()
                 hint_hdr[0] = n
-                _bcast(hint_hdr, 0, rank)
-                _bcast(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 0, rank)
+                pending_sends.append(_bcast_async(hint_hdr, 0, rank))      # (round 6: not waited for here -- the scan goes on beside the broadcasts)
+                pending_sends.append(_bcast_async(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 0, rank))
             if hinting and late and not sent_late[0] and i >= late_index:
                 # the fresher preview of the rank above (round 6): sent without waiting -- the scan goes on beside the copy
                 sent_late[0] = True
@@ -423,8 +432,8 @@ def scan_sharded(backend, batches, rank: int, world: int):
                 backend.fence()
                 lhdr = backend.header_tensor()
                 lhdr[0] = n
-                late_reqs.append(_isend(lhdr, 1))
-                late_reqs.append(_isend(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 1))
+                pending_sends.append(_isend(lhdr, 1))
+                pending_sends.append(_isend(buf[:max(n, 1) * L.TABLE_ENTRY_BYTES], 1))
 
         # the first shard has nothing to wait for: it streams (pure stage of batch b+1 overlapped with the walk of batch b, lazy
         # junction tests), which puts the table on its way ~50 ms per 10 M reads earlier than prepare-all + walk
@@ -472,7 +481,7 @@ def scan_sharded(backend, batches, rank: int, world: int):
         carried = dict(zip(_STAT_NAMES, [int(x) for x in h[1:1 + len(_STAT_NAMES)]]))
         stats = backend.walk_shard(batches, buf, n_in, carried)   # import (replaces the hint) + ordered walk of this shard + scan_end
         CLOCK.mark("pass2_import_and_walk")
-    for req, keep in (forwarded or []) + late_reqs:
+    for req, keep in (forwarded or []) + pending_sends:
         req.wait()
     if rank < world - 1:
         n_out, buf = backend.export_table()
