@@ -1281,7 +1281,10 @@ int fgpu_scan_import_table(fgpu_ctx* ctx, const void* dev_buf, uint64_t n_entrie
         const uint64_t surplus = all ? n_entries - ctx->hint_n : 0;
         if (all && surplus <= (1ULL << 23)) {
             uint64_t bits = 1ULL << 20;      // (room for what this shard's own batches will add: they join the filter as they are walked)
-            while (bits < 32 * surplus) bits <<= 1;
+            // (32 bits of filter per new key, swept in round 6 on config 4's hop, FGPU_DELTA_FILTER_MULT = 8 / 16 / 32 / 64: the merge 16.4 / 14.4 / 13.0 / 13.9 ms, the
+            // link by the candidate plane -- which takes the filter's hits -- 11.6 / 9.7 / 8.7 / 8.2 ms, the hop 71.1 / 67.6 / 64.8 / 66.0 ms: false hits cost more than cache misses)
+            static const uint64_t mult = getenv("FGPU_DELTA_FILTER_MULT") ? (uint64_t)std::max(2, atoi(getenv("FGPU_DELTA_FILTER_MULT"))) : 32;
+            while (bits < mult * surplus) bits <<= 1;
             if ((rc = fgpu_ensure(ctx, &ctx->delta_filter, bits / 8))) return rc;
             FGPU_HIP(hipMemsetAsync(ctx->delta_filter.p, 0, bits / 8, ctx->stream));
             uint64_t max_seq = 0, newer = 0, digest[2] = {0, 0};
