@@ -12,6 +12,8 @@ lo = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 bad = 0
 for seed in range(lo, hi):
+    if (seed - lo) % 20 == 0:
+        print("at seed", seed, "failures so far:", bad, flush=True)      # (gpurun takes seven silent minutes for a hang)
     with tempfile.TemporaryDirectory() as td:
         try:
             T.test_cli_equals_the_compiled_reference_on_a_random_run(seed, pathlib.Path(td))
