@@ -114,7 +114,7 @@ b.load(batches1, keep_carry=False, shard_times=True)
 b.load_fixup(prefix)
 b.bloom_tensor(L.BLOO2).copy_(b2)
 ctx.synchronize()
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
     b.scan_begin()
     b.import_hint(hint[0][0], hint[0][1])
     timed(f"rank {HOP}: pure stage on the preview", lambda: [b.scan_prepare(x) for x in batches1])

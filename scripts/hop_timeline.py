@@ -52,3 +52,8 @@ starts = sorted((s, n) for s, e, n, _ in hop)
 for g, at in big:
     nxt = next((n for s, n in starts if s >= at + g), "?")
     print(f"    gap {g / 1e3:8.1f} us after {ends.get(at, '?'):28s} before {nxt}")
+
+# HOP_DUMP=n: the first n dispatches of the hop one by one (start since the hop's beginning, duration, queue, kernel)
+n_dump = int(os.environ.get("HOP_DUMP", "0"))
+for st, en, name, q in hop[:n_dump]:
+    print(f"    {(st - t0) / 1e3:9.1f} us  +{(en - st) / 1e3:8.1f} us  q{q}  {name}")
